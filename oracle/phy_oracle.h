@@ -1,0 +1,80 @@
+/* TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, scalar) of the reference hot path -- srsRAN_Project 23.5 upper-PHY channel coding,
+ * OFDM and DM-RS channel estimation -- used as the parity checker for the HIP kernels.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load this library; the product path (libmiphy.so) never does.
+ *
+ * Parity pinning: every function is checked against (1) the reference itself, compiled in place into
+ * oracle/_ref/libref_capi.so (tests/test_oracle_vs_ref.py, runs where /root/reference exists) and (2) the golden
+ * fixtures in tests/golden/ that were generated from the reference by oracle/gen_golden.py (run everywhere).
+ */
+#ifndef PHY_ORACLE_H
+#define PHY_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* CRC polynomial ids (order of crc_generator_poly, include/srsran/phy/upper/channel_coding/crc_calculator.h:31-38). */
+enum { ORC_CRC24A = 0, ORC_CRC24B = 1, ORC_CRC24C = 2, ORC_CRC16 = 3, ORC_CRC11 = 4, ORC_CRC6 = 5 };
+
+/* CRC of a bit sequence (one bit per byte; only bit 0 of each byte is used). */
+uint32_t orc_crc_bits(int poly, const uint8_t* bits, unsigned nbits);
+/* CRC of the first nbits of an MSB-first packed buffer. */
+uint32_t orc_crc_packed(int poly, const uint8_t* bytes, unsigned nbits);
+
+/* LDPC encoder. in: bg_K*Z bytes, one bit per byte, filler = 254. out: out_len <= N_short*Z bytes. */
+int orc_ldpc_encode(int bg, int Z, const uint8_t* in, uint8_t* out, unsigned out_len);
+
+/* LDPC decoder (AVX2 arithmetic rule of the reference).
+ * Returns: iterations (>=1) when crc_poly >= 0 and the CRC matched after that iteration; 0 otherwise ("nullopt").
+ * out_packed: bg_K*Z bits MSB-first. If all input LLRs are zero: out = all ones when crc_poly < 0, untouched
+ * otherwise. soft_out (optional, may be NULL): final soft bits, N_full*Z bytes. */
+int orc_ldpc_decode(int           bg,
+                    int           Z,
+                    const int8_t* llr,
+                    unsigned      in_len,
+                    unsigned      nof_filler,
+                    int           crc_poly,
+                    unsigned      max_iter,
+                    uint8_t*      out_packed,
+                    int8_t*       soft_out);
+
+/* Rate matcher. in: N bytes (one bit/byte, filler 254 allowed). out: E bytes. mod = bits per symbol (1,2,4,6,8). */
+int orc_ldpc_rate_match(int rv, int mod, unsigned Nref, unsigned nof_filler, const uint8_t* in, unsigned N, uint8_t* out, unsigned E);
+/* Rate dematcher (AVX2 combine rule: saturating add clamped to +-120). out: N bytes, in/out. */
+int orc_ldpc_rate_dematch(int rv, int mod, unsigned Nref, unsigned nof_filler, int new_data, const int8_t* in, unsigned E, int8_t* out, unsigned N);
+
+/* Transport-block segmentation parameters (TS 38.212 5.2.2 + 5.4.2.1 as restated by the reference segmenter). */
+typedef struct {
+  unsigned tbs;            /* TB size, bits (no CRC) */
+  unsigned nof_tb_crc_bits;
+  unsigned nof_cbs;
+  unsigned Z;
+  unsigned K;              /* segment length = bg_K*Z */
+  unsigned N;              /* full codeblock length (3K or 5K) */
+  unsigned cb_info_bits;   /* information bits per segment (TB bits incl. TB CRC share, excl. CB CRC) */
+  unsigned nof_cb_crc_bits;/* 24 when nof_cbs > 1, else 0 */
+  unsigned nof_filler_bits;
+  unsigned zero_pad;       /* zero padding bits in last CB */
+  unsigned nof_short_segments;
+  unsigned E[52];          /* rate-matched length per CB */
+  unsigned cw_offset[52];
+  unsigned crc_poly;       /* CRC checked by the decoder for each CB */
+} orc_segmentation_t;
+int orc_ldpc_segmentation(unsigned tbs, int bg, int mod, unsigned nof_layers, unsigned nof_ch_symbols, orc_segmentation_t* s);
+
+/* PDSCH encoder: tb packed bytes -> codeword (one bit per byte), length nof_ch_symbols*mod. */
+int orc_pdsch_encode(int bg, int rv, int mod, unsigned Nref, unsigned nof_layers, unsigned nof_ch_symbols,
+                     const uint8_t* tb, unsigned tb_bytes, uint8_t* codeword);
+
+/* PUSCH decoder: one (re)transmission. softbuf: nof_cbs * N int8 (in/out), cb_crc: nof_cbs flags (in/out),
+ * cb_msgs: nof_cbs * ceil(K/8) bytes decoded messages (in/out). Returns tb_crc_ok; iters_minmax[2]. */
+int orc_pusch_decode(int bg, int rv, int mod, unsigned Nref, unsigned nof_layers, unsigned nof_ch_symbols,
+                     unsigned tb_bytes, int new_data, const int8_t* llrs, unsigned max_iter, int early_stop,
+                     int8_t* softbuf, uint8_t* cb_crc, uint8_t* cb_msgs, uint8_t* tb_out, int* iters_minmax);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

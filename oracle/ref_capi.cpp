@@ -1,0 +1,396 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into, loaded by or called from the product path.
+//
+// C API over the *reference's own classes* (srsRAN_Project 23.5, compiled in place from
+// /root/reference by oracle/build_ref.sh into oracle/_ref/).  Every function instantiates the
+// reference implementation through the reference's public factories / headers and forwards
+// plain pointers, so Python (ctypes) can
+//   * generate the golden fixtures under tests/golden/ (oracle/gen_golden.py),
+//   * validate the C restatement in oracle/phy_oracle.c,
+//   * serve as `cpu_baseline.kind = "reference"` in bench.py (AVX2 path, timed on host cores).
+// Nothing here re-implements an algorithm.
+#include "srsran/phy/generic_functions/dft_processor.h"
+#include "srsran/phy/upper/channel_coding/channel_coding_factories.h"
+#include "srsran/phy/upper/channel_processors/channel_processor_factories.h"
+#include "srsran/phy/upper/rx_softbuffer_pool.h"
+#include "srsran/phy/upper/unique_rx_softbuffer.h"
+#include "srsran/srsvec/bit.h"
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+// Internal reference headers (graph tables are not exported through include/).
+#include "lib/phy/upper/channel_coding/ldpc/ldpc_graph_impl.h"
+#include "lib/phy/upper/channel_coding/ldpc/ldpc_luts_impl.h"
+
+using namespace srsran;
+
+namespace {
+
+const char* impl_name(int impl)
+{
+  switch (impl) {
+    case 0:
+      return "generic";
+    case 1:
+      return "avx2";
+    case 2:
+      return "avx512";
+    default:
+      return "auto";
+  }
+}
+
+crc_generator_poly to_poly(int p)
+{
+  switch (p) {
+    case 0:
+      return crc_generator_poly::CRC24A;
+    case 1:
+      return crc_generator_poly::CRC24B;
+    case 2:
+      return crc_generator_poly::CRC24C;
+    case 3:
+      return crc_generator_poly::CRC16;
+    case 4:
+      return crc_generator_poly::CRC11;
+    default:
+      return crc_generator_poly::CRC6;
+  }
+}
+
+codeblock_metadata make_meta(int bg, int Z, int rv, int mod, unsigned Nref, unsigned nof_filler, unsigned nof_crc_bits)
+{
+  codeblock_metadata m          = {};
+  m.tb_common.base_graph        = (bg == 1) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+  m.tb_common.lifting_size      = static_cast<ldpc::lifting_size_t>(Z);
+  m.tb_common.rv                = rv;
+  m.tb_common.mod               = static_cast<modulation_scheme>(mod);
+  m.tb_common.Nref              = Nref;
+  m.cb_specific.nof_filler_bits = nof_filler;
+  m.cb_specific.nof_crc_bits    = nof_crc_bits;
+  return m;
+}
+
+double now_s()
+{
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+extern "C" {
+
+int ref_capi_version()
+{
+  return 2;
+}
+
+// ---------------------------------------------------------------- LDPC graph tables (TS 38.212 Tables 5.3.2-2/-3)
+// out[m*68+n] = shift (already reduced mod Z) or 0xffff.
+void ref_ldpc_get_graph(int bg, int Z, uint16_t* out)
+{
+  ldpc::BG_matrix_t g = ldpc::get_graph((bg == 1) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2,
+                                        static_cast<ldpc::lifting_size_t>(Z));
+  for (unsigned m = 0; m != ldpc::MAX_BG_M; ++m) {
+    for (unsigned n = 0; n != ldpc::MAX_BG_N_FULL; ++n) {
+      out[m * ldpc::MAX_BG_N_FULL + n] = g[m][n];
+    }
+  }
+}
+
+// out[m*20+e] = variable node index or 0xffff.
+void ref_ldpc_get_adjacency(int bg, uint16_t* out)
+{
+  const ldpc::BG_adjacency_matrix_t* a =
+      ldpc::get_adjacency_matrix((bg == 1) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2);
+  for (unsigned m = 0; m != ldpc::MAX_BG_M; ++m) {
+    for (unsigned e = 0; e != ldpc::MAX_BG_CHECK_EDGES; ++e) {
+      out[m * ldpc::MAX_BG_CHECK_EDGES + e] = (*a)[m][e];
+    }
+  }
+}
+
+int ref_ldpc_lifting_index(int Z)
+{
+  return ldpc::get_lifting_index(static_cast<ldpc::lifting_size_t>(Z));
+}
+
+// ---------------------------------------------------------------- CRC
+// bits: one bit per byte. Returns checksum.
+uint32_t ref_crc_bits(int poly, const uint8_t* bits, unsigned nbits, int impl_lut)
+{
+  auto f   = create_crc_calculator_factory_sw(impl_lut ? "lut" : "auto");
+  auto crc = f->create(to_poly(poly));
+  return crc->calculate_bit(span<const uint8_t>(bits, nbits));
+}
+
+// ---------------------------------------------------------------- LDPC encoder
+// in: bg_K*Z bytes (one bit per byte, fillers = 254); out: out_len bytes.
+int ref_ldpc_encode(int bg, int Z, const uint8_t* in, unsigned in_len, uint8_t* out, unsigned out_len, int impl)
+{
+  auto f = create_ldpc_encoder_factory_sw(impl_name(impl));
+  if (!f) {
+    return -1;
+  }
+  auto enc = f->create();
+  if (!enc) {
+    return -1;
+  }
+  codeblock_metadata m = make_meta(bg, Z, 0, 1, 0, 0, 24);
+  enc->encode(span<uint8_t>(out, out_len), span<const uint8_t>(in, in_len), m.tb_common);
+  return 0;
+}
+
+// ---------------------------------------------------------------- LDPC decoder
+// llr: in_len int8; out_bits: packed MSB-first, bg_K*Z bits. crc_poly < 0 -> no CRC (nullptr).
+// Returns number of iterations if the CRC matched (early stop), 0 if nullopt.
+struct ref_ldpc_decoder_handle {
+  std::unique_ptr<ldpc_decoder>   dec;
+  std::unique_ptr<crc_calculator> crc[6];
+};
+
+void* ref_ldpc_decoder_create(int impl)
+{
+  auto f = create_ldpc_decoder_factory_sw(impl_name(impl));
+  if (!f) {
+    return nullptr;
+  }
+  auto h = new ref_ldpc_decoder_handle;
+  h->dec = f->create();
+  if (!h->dec) {
+    delete h;
+    return nullptr;
+  }
+  auto cf = create_crc_calculator_factory_sw("auto");
+  for (int p = 0; p != 6; ++p) {
+    h->crc[p] = cf->create(to_poly(p));
+  }
+  return h;
+}
+
+void ref_ldpc_decoder_destroy(void* hv)
+{
+  delete static_cast<ref_ldpc_decoder_handle*>(hv);
+}
+
+int ref_ldpc_decode(void*         hv,
+                    int           bg,
+                    int           Z,
+                    const int8_t* llr,
+                    unsigned      in_len,
+                    unsigned      nof_filler,
+                    unsigned      nof_crc_bits,
+                    int           crc_poly,
+                    unsigned      max_iter,
+                    uint8_t*      out_packed)
+{
+  auto*                       h = static_cast<ref_ldpc_decoder_handle*>(hv);
+  unsigned                    K = ((bg == 1) ? 22 : 10) * Z;
+  ldpc_decoder::configuration cfg;
+  cfg.block_conf                    = make_meta(bg, Z, 0, 1, 0, nof_filler, nof_crc_bits);
+  cfg.algorithm_conf.max_iterations = max_iter;
+  dynamic_bit_buffer out(K);
+  optional<unsigned> r = h->dec->decode(out,
+                                        span<const log_likelihood_ratio>(reinterpret_cast<const log_likelihood_ratio*>(llr), in_len),
+                                        (crc_poly < 0) ? nullptr : h->crc[crc_poly].get(),
+                                        cfg);
+  std::memcpy(out_packed, out.get_buffer().data(), (K + 7) / 8);
+  return r.has_value() ? static_cast<int>(r.value()) : 0;
+}
+
+// Times `reps` decodes of `n_cb` codeblocks (laid out back to back, in_len each); returns seconds.
+double ref_ldpc_decode_time(void*         hv,
+                            int           bg,
+                            int           Z,
+                            const int8_t* llr,
+                            unsigned      in_len,
+                            unsigned      n_cb,
+                            unsigned      nof_filler,
+                            int           crc_poly,
+                            unsigned      max_iter,
+                            unsigned      reps,
+                            uint8_t*      out_packed)
+{
+  unsigned Kb = (((bg == 1) ? 22 : 10) * Z + 7) / 8;
+  double   t0 = now_s();
+  for (unsigned r = 0; r != reps; ++r) {
+    for (unsigned i = 0; i != n_cb; ++i) {
+      ref_ldpc_decode(hv, bg, Z, llr + size_t(i) * in_len, in_len, nof_filler, 24, crc_poly, max_iter, out_packed + size_t(i) * Kb);
+    }
+  }
+  return now_s() - t0;
+}
+
+// ---------------------------------------------------------------- LDPC rate matcher / dematcher
+int ref_ldpc_rate_match(int            bg,
+                        int            Z,
+                        int            rv,
+                        int            mod,
+                        unsigned       Nref,
+                        unsigned       nof_filler,
+                        const uint8_t* in,
+                        unsigned       in_len,
+                        uint8_t*       out,
+                        unsigned       out_len)
+{
+  auto               rm = create_ldpc_rate_matcher_factory_sw()->create();
+  codeblock_metadata m  = make_meta(bg, Z, rv, mod, Nref, nof_filler, 24);
+  rm->rate_match(span<uint8_t>(out, out_len), span<const uint8_t>(in, in_len), m);
+  return 0;
+}
+
+// out is in/out (soft buffer), length full_length.
+int ref_ldpc_rate_dematch(int           bg,
+                          int           Z,
+                          int           rv,
+                          int           mod,
+                          unsigned      Nref,
+                          unsigned      nof_filler,
+                          int           new_data,
+                          const int8_t* in,
+                          unsigned      in_len,
+                          int8_t*       out,
+                          unsigned      out_len,
+                          int           impl)
+{
+  auto f = create_ldpc_rate_dematcher_factory_sw(impl_name(impl));
+  if (!f) {
+    return -1;
+  }
+  auto rdm = f->create();
+  if (!rdm) {
+    return -1;
+  }
+  codeblock_metadata m = make_meta(bg, Z, rv, mod, Nref, nof_filler, 24);
+  rdm->rate_dematch(span<log_likelihood_ratio>(reinterpret_cast<log_likelihood_ratio*>(out), out_len),
+                    span<const log_likelihood_ratio>(reinterpret_cast<const log_likelihood_ratio*>(in), in_len),
+                    new_data != 0,
+                    m);
+  return 0;
+}
+
+// ---------------------------------------------------------------- PDSCH encoder (segment + encode + rate match)
+// tb: packed bytes; codeword: one bit per byte, nof_ch_symbols*Qm.
+int ref_pdsch_encode(int            bg,
+                     int            rv,
+                     int            mod,
+                     unsigned       Nref,
+                     unsigned       nof_layers,
+                     unsigned       nof_ch_symbols,
+                     const uint8_t* tb,
+                     unsigned       tb_bytes,
+                     uint8_t*       codeword,
+                     unsigned       cw_len,
+                     int            impl)
+{
+  auto                                  crcf = create_crc_calculator_factory_sw("auto");
+  pdsch_encoder_factory_sw_configuration c;
+  c.encoder_factory      = create_ldpc_encoder_factory_sw(impl_name(impl));
+  c.rate_matcher_factory = create_ldpc_rate_matcher_factory_sw();
+  c.segmenter_factory    = create_ldpc_segmenter_tx_factory_sw(crcf);
+  auto             enc   = create_pdsch_encoder_factory_sw(c)->create();
+  segmenter_config cfg;
+  cfg.base_graph     = (bg == 1) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+  cfg.rv             = rv;
+  cfg.mod            = static_cast<modulation_scheme>(mod);
+  cfg.Nref           = Nref;
+  cfg.nof_layers     = nof_layers;
+  cfg.nof_ch_symbols = nof_ch_symbols;
+  enc->encode(span<uint8_t>(codeword, cw_len), span<const uint8_t>(tb, tb_bytes), cfg);
+  return 0;
+}
+
+// ---------------------------------------------------------------- PUSCH decoder (segment + dematch + decode + CRC)
+struct ref_pusch_decoder_handle {
+  std::unique_ptr<pusch_decoder>      dec;
+  std::unique_ptr<rx_softbuffer_pool> pool;
+};
+
+void* ref_pusch_decoder_create(int impl)
+{
+  auto                                   crcf = create_crc_calculator_factory_sw("auto");
+  pusch_decoder_factory_sw_configuration c;
+  c.crc_factory       = crcf;
+  c.decoder_factory   = create_ldpc_decoder_factory_sw(impl_name(impl));
+  c.dematcher_factory = create_ldpc_rate_dematcher_factory_sw(impl_name(impl));
+  c.segmenter_factory = create_ldpc_segmenter_rx_factory_sw();
+  if (!c.decoder_factory || !c.dematcher_factory) {
+    return nullptr;
+  }
+  auto h = new ref_pusch_decoder_handle;
+  h->dec = create_pusch_decoder_factory_sw(c)->create();
+  rx_softbuffer_pool_config pc;
+  pc.max_codeblock_size   = ldpc::MAX_CODEBLOCK_SIZE;
+  pc.max_softbuffers      = 4;
+  pc.max_nof_codeblocks   = 4 * 64;
+  pc.expire_timeout_slots = 100000;
+  h->pool                 = create_rx_softbuffer_pool(pc);
+  return h;
+}
+
+void ref_pusch_decoder_destroy(void* hv)
+{
+  delete static_cast<ref_pusch_decoder_handle*>(hv);
+}
+
+// Decodes a sequence of `nof_tx` (re)transmissions of one TB (same HARQ process). llrs holds nof_tx codewords of
+// cw_len each, rvs[nof_tx]. Outputs, per transmission: tb_crc_ok, nof_codeblocks, min/max iterations, and the TB bytes.
+int ref_pusch_decode(void*          hv,
+                     int            bg,
+                     int            mod,
+                     unsigned       Nref,
+                     unsigned       nof_layers,
+                     unsigned       nof_ch_symbols,
+                     unsigned       tb_bytes,
+                     unsigned       nof_tx,
+                     const int*     rvs,
+                     const int8_t*  llrs,
+                     unsigned       cw_len,
+                     unsigned       max_iter,
+                     int            early_stop,
+                     uint8_t*       tb_out,      // nof_tx * tb_bytes
+                     int*           tb_crc_ok,   // nof_tx
+                     int*           iters_minmax // nof_tx * 2
+)
+{
+  auto*                    h = static_cast<ref_pusch_decoder_handle*>(hv);
+  rx_softbuffer_identifier id;
+  id.rnti          = 0x1234;
+  id.harq_ack_id   = 3;
+  unsigned nof_cbs = ldpc::compute_nof_codeblocks(units::bits(tb_bytes * 8),
+                                                  (bg == 1) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2);
+  slot_point slot(1, 0);
+  for (unsigned t = 0; t != nof_tx; ++t) {
+    unique_rx_softbuffer sb = h->pool->reserve_softbuffer(slot, id, nof_cbs);
+    if (!sb.is_valid()) {
+      return -1;
+    }
+    pusch_decoder::configuration cfg;
+    cfg.segmenter_cfg.base_graph     = (bg == 1) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+    cfg.segmenter_cfg.rv             = rvs[t];
+    cfg.segmenter_cfg.mod            = static_cast<modulation_scheme>(mod);
+    cfg.segmenter_cfg.Nref           = Nref;
+    cfg.segmenter_cfg.nof_layers     = nof_layers;
+    cfg.segmenter_cfg.nof_ch_symbols = nof_ch_symbols;
+    cfg.nof_ldpc_iterations          = max_iter;
+    cfg.use_early_stop               = early_stop != 0;
+    cfg.new_data                     = (t == 0);
+    pusch_decoder_result res;
+    std::vector<uint8_t> tb(tb_bytes, 0);
+    h->dec->decode(tb,
+                   res,
+                   &sb.get(),
+                   span<const log_likelihood_ratio>(reinterpret_cast<const log_likelihood_ratio*>(llrs) + size_t(t) * cw_len, cw_len),
+                   cfg);
+    std::memcpy(tb_out + size_t(t) * tb_bytes, tb.data(), tb_bytes);
+    tb_crc_ok[t]            = res.tb_crc_ok ? 1 : 0;
+    iters_minmax[2 * t]     = res.ldpc_decoder_stats.get_nof_observations() ? (int)res.ldpc_decoder_stats.get_min() : 0;
+    iters_minmax[2 * t + 1] = res.ldpc_decoder_stats.get_nof_observations() ? (int)res.ldpc_decoder_stats.get_max() : 0;
+  }
+  // Release the buffer for the next call.
+  h->pool->run_slot(slot + 200000);
+  return (int)nof_cbs;
+}
+
+} // extern "C"

@@ -1,0 +1,251 @@
+"""ctypes bindings for the CPU oracle (oracle/libphy_oracle.so) and, when built, for the reference
+itself (oracle/_ref/libref_capi.so).  TEST INFRASTRUCTURE: imported by tests/, bench.py (cpu_baseline) and
+__graft_entry__.smoke() only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+u8p = C.POINTER(C.c_uint8)
+i8p = C.POINTER(C.c_int8)
+vp = C.c_void_p
+
+
+def _p(a):
+    return a.ctypes.data_as(vp)
+
+
+class Segmentation(C.Structure):
+    _fields_ = [
+        ("tbs", C.c_uint), ("nof_tb_crc_bits", C.c_uint), ("nof_cbs", C.c_uint), ("Z", C.c_uint), ("K", C.c_uint),
+        ("N", C.c_uint), ("cb_info_bits", C.c_uint), ("nof_cb_crc_bits", C.c_uint), ("nof_filler_bits", C.c_uint),
+        ("zero_pad", C.c_uint), ("nof_short_segments", C.c_uint), ("E", C.c_uint * 52), ("cw_offset", C.c_uint * 52),
+        ("crc_poly", C.c_uint),
+    ]
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        so = os.path.join(ORACLE_DIR, "libphy_oracle.so")
+        if not os.path.exists(so):
+            build_oracle()
+        _oracle = C.CDLL(so)
+        _oracle.orc_crc_bits.restype = C.c_uint32
+        _oracle.orc_crc_packed.restype = C.c_uint32
+    return _oracle
+
+
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libref_capi.so"))
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libref_capi.so"))
+        _ref.ref_crc_bits.restype = C.c_uint32
+        _ref.ref_ldpc_decoder_create.restype = vp
+        _ref.ref_pusch_decoder_create.restype = vp
+        _ref.ref_ldpc_decode_time.restype = C.c_double
+    return _ref
+
+
+BG_K = {1: 22, 2: 10}
+BG_NS = {1: 66, 2: 50}
+BG_NF = {1: 68, 2: 52}
+ALL_Z = sorted(a * 2 ** j for a in (2, 3, 5, 7, 9, 11, 13, 15) for j in range(8) if a * 2 ** j <= 384)
+CRC24A, CRC24B, CRC24C, CRC16, CRC11, CRC6 = range(6)
+CRC_ORDER = [24, 24, 24, 16, 11, 6]
+
+
+# ---------------------------------------------------------------------------------------------- oracle wrappers
+def o_crc_bits(poly, bits):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    return int(oracle().orc_crc_bits(poly, _p(bits), C.c_uint(bits.size)))
+
+
+def o_ldpc_encode(bg, Z, msg, out_len):
+    msg = np.ascontiguousarray(msg, dtype=np.uint8)
+    assert msg.size == BG_K[bg] * Z
+    out = np.zeros(out_len, dtype=np.uint8)
+    rc = oracle().orc_ldpc_encode(bg, Z, _p(msg), _p(out), C.c_uint(out_len))
+    assert rc == 0, rc
+    return out
+
+
+def o_ldpc_decode(bg, Z, llr, nof_filler=0, crc_poly=-1, max_iter=6, want_soft=False, out_init=None):
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    K = BG_K[bg] * Z
+    out = np.zeros((K + 7) // 8, dtype=np.uint8) if out_init is None else out_init.copy()
+    soft = np.zeros(BG_NF[bg] * Z, dtype=np.int8) if want_soft else None
+    it = oracle().orc_ldpc_decode(bg, Z, _p(llr), C.c_uint(llr.size), C.c_uint(nof_filler), crc_poly,
+                                  C.c_uint(max_iter), _p(out), _p(soft) if want_soft else None)
+    assert it >= 0, it
+    return (it, out, soft) if want_soft else (it, out)
+
+
+def o_rate_match(rv, mod, Nref, nof_filler, cb, E):
+    cb = np.ascontiguousarray(cb, dtype=np.uint8)
+    out = np.zeros(E, dtype=np.uint8)
+    rc = oracle().orc_ldpc_rate_match(rv, mod, C.c_uint(Nref), C.c_uint(nof_filler), _p(cb), C.c_uint(cb.size), _p(out), C.c_uint(E))
+    assert rc == 0
+    return out
+
+
+def o_rate_dematch(rv, mod, Nref, nof_filler, new_data, llr, softbuf):
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    out = np.ascontiguousarray(softbuf, dtype=np.int8).copy()
+    rc = oracle().orc_ldpc_rate_dematch(rv, mod, C.c_uint(Nref), C.c_uint(nof_filler), int(new_data), _p(llr),
+                                        C.c_uint(llr.size), _p(out), C.c_uint(out.size))
+    assert rc == 0
+    return out
+
+
+def o_segmentation(tbs, bg, mod, nof_layers, nof_ch_symbols):
+    s = Segmentation()
+    rc = oracle().orc_ldpc_segmentation(C.c_uint(tbs), bg, mod, C.c_uint(nof_layers), C.c_uint(nof_ch_symbols), C.byref(s))
+    assert rc == 0, rc
+    return s
+
+
+def o_pdsch_encode(bg, rv, mod, Nref, nof_layers, nof_ch_symbols, tb):
+    tb = np.ascontiguousarray(tb, dtype=np.uint8)
+    cw = np.zeros(nof_ch_symbols * mod, dtype=np.uint8)
+    rc = oracle().orc_pdsch_encode(bg, rv, mod, C.c_uint(Nref), C.c_uint(nof_layers), C.c_uint(nof_ch_symbols), _p(tb),
+                                   C.c_uint(tb.size), _p(cw))
+    assert rc > 0, rc
+    return cw
+
+
+class OraclePuschDecoder:
+    """Stateful (HARQ) wrapper around orc_pusch_decode."""
+
+    def __init__(self, bg, mod, Nref, nof_layers, nof_ch_symbols, tb_bytes):
+        self.args = (bg, mod, Nref, nof_layers, nof_ch_symbols, tb_bytes)
+        s = o_segmentation(tb_bytes * 8, bg, mod, nof_layers, nof_ch_symbols)
+        self.seg = s
+        self.softbuf = np.zeros(s.nof_cbs * s.N, dtype=np.int8)
+        self.cb_crc = np.zeros(s.nof_cbs, dtype=np.uint8)
+        self.cb_msgs = np.zeros(s.nof_cbs * ((s.K + 7) // 8), dtype=np.uint8)
+
+    def decode(self, llrs, rv, new_data, max_iter=6, early_stop=True):
+        bg, mod, Nref, nl, nsym, tb_bytes = self.args
+        llrs = np.ascontiguousarray(llrs, dtype=np.int8)
+        tb = np.zeros(tb_bytes, dtype=np.uint8)
+        mm = (C.c_int * 2)()
+        ok = oracle().orc_pusch_decode(bg, rv, mod, C.c_uint(Nref), C.c_uint(nl), C.c_uint(nsym), C.c_uint(tb_bytes),
+                                       int(new_data), _p(llrs), C.c_uint(max_iter), int(early_stop), _p(self.softbuf),
+                                       _p(self.cb_crc), _p(self.cb_msgs), _p(tb), mm)
+        assert ok >= 0
+        return bool(ok), tb, (mm[0], mm[1])
+
+
+# ---------------------------------------------------------------------------------------------- reference wrappers
+IMPL = {"generic": 0, "avx2": 1, "avx512": 2, "auto": 3}
+
+
+def r_crc_bits(poly, bits, lut=False):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    return int(ref().ref_crc_bits(poly, _p(bits), C.c_uint(bits.size), int(lut)))
+
+
+def r_ldpc_encode(bg, Z, msg, out_len, impl="avx2"):
+    msg = np.ascontiguousarray(msg, dtype=np.uint8)
+    out = np.zeros(out_len, dtype=np.uint8)
+    rc = ref().ref_ldpc_encode(bg, Z, _p(msg), C.c_uint(msg.size), _p(out), C.c_uint(out_len), IMPL[impl])
+    assert rc == 0
+    return out
+
+
+class RefLdpcDecoder:
+    def __init__(self, impl="avx2"):
+        self.h = vp(ref().ref_ldpc_decoder_create(IMPL[impl]))
+        assert self.h.value, "reference decoder '%s' unavailable on this CPU" % impl
+
+    def decode(self, bg, Z, llr, nof_filler=0, crc_poly=-1, max_iter=6):
+        llr = np.ascontiguousarray(llr, dtype=np.int8)
+        K = BG_K[bg] * Z
+        out = np.zeros((K + 7) // 8, dtype=np.uint8)
+        it = ref().ref_ldpc_decode(self.h, bg, Z, _p(llr), C.c_uint(llr.size), C.c_uint(nof_filler), C.c_uint(24), crc_poly,
+                                   C.c_uint(max_iter), _p(out))
+        return it, out
+
+    def time_batch(self, bg, Z, llrs, in_len, n_cb, nof_filler, crc_poly, max_iter, reps):
+        llrs = np.ascontiguousarray(llrs, dtype=np.int8)
+        K = BG_K[bg] * Z
+        out = np.zeros(n_cb * ((K + 7) // 8), dtype=np.uint8)
+        t = ref().ref_ldpc_decode_time(self.h, bg, Z, _p(llrs), C.c_uint(in_len), C.c_uint(n_cb), C.c_uint(nof_filler), crc_poly,
+                                       C.c_uint(max_iter), C.c_uint(reps), _p(out))
+        return t, out
+
+    def __del__(self):
+        try:
+            ref().ref_ldpc_decoder_destroy(self.h)
+        except Exception:
+            pass
+
+
+def r_rate_match(bg, Z, rv, mod, Nref, nof_filler, cb, E):
+    cb = np.ascontiguousarray(cb, dtype=np.uint8)
+    out = np.zeros(E, dtype=np.uint8)
+    ref().ref_ldpc_rate_match(bg, Z, rv, mod, C.c_uint(Nref), C.c_uint(nof_filler), _p(cb), C.c_uint(cb.size), _p(out), C.c_uint(E))
+    return out
+
+
+def r_rate_dematch(bg, Z, rv, mod, Nref, nof_filler, new_data, llr, softbuf, impl="avx2"):
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    out = np.ascontiguousarray(softbuf, dtype=np.int8).copy()
+    rc = ref().ref_ldpc_rate_dematch(bg, Z, rv, mod, C.c_uint(Nref), C.c_uint(nof_filler), int(new_data), _p(llr),
+                                     C.c_uint(llr.size), _p(out), C.c_uint(out.size), IMPL[impl])
+    assert rc == 0
+    return out
+
+
+def r_pdsch_encode(bg, rv, mod, Nref, nof_layers, nof_ch_symbols, tb, impl="avx2"):
+    tb = np.ascontiguousarray(tb, dtype=np.uint8)
+    cw = np.zeros(nof_ch_symbols * mod, dtype=np.uint8)
+    rc = ref().ref_pdsch_encode(bg, rv, mod, C.c_uint(Nref), C.c_uint(nof_layers), C.c_uint(nof_ch_symbols), _p(tb),
+                                C.c_uint(tb.size), _p(cw), C.c_uint(cw.size), IMPL[impl])
+    assert rc == 0
+    return cw
+
+
+class RefPuschDecoder:
+    def __init__(self, impl="avx2"):
+        self.h = vp(ref().ref_pusch_decoder_create(IMPL[impl]))
+        assert self.h.value
+
+    def decode_sequence(self, bg, mod, Nref, nof_layers, nof_ch_symbols, tb_bytes, rvs, llrs, max_iter=6, early_stop=True):
+        """llrs: [nof_tx, cw_len]."""
+        llrs = np.ascontiguousarray(llrs, dtype=np.int8)
+        nof_tx, cw_len = llrs.shape
+        rv_arr = (C.c_int * nof_tx)(*rvs)
+        tb = np.zeros((nof_tx, tb_bytes), dtype=np.uint8)
+        ok = (C.c_int * nof_tx)()
+        mm = (C.c_int * (2 * nof_tx))()
+        n = ref().ref_pusch_decode(self.h, bg, mod, C.c_uint(Nref), C.c_uint(nof_layers), C.c_uint(nof_ch_symbols),
+                                   C.c_uint(tb_bytes), C.c_uint(nof_tx), rv_arr, _p(llrs), C.c_uint(cw_len), C.c_uint(max_iter),
+                                   int(early_stop), _p(tb), ok, mm)
+        assert n > 0, n
+        return [bool(x) for x in ok], tb, [(mm[2 * i], mm[2 * i + 1]) for i in range(nof_tx)]
+
+    def __del__(self):
+        try:
+            ref().ref_pusch_decoder_destroy(self.h)
+        except Exception:
+            pass
