@@ -1,0 +1,364 @@
+// LDPC decoder -- layered normalised min-sum on int8 LLRs, one workgroup per codeblock.
+//
+// Behaviour contract: srsran::ldpc_decoder_impl::decode (lib/phy/upper/channel_coding/ldpc/ldpc_decoder_impl.cpp:60-146)
+// with the arithmetic of the AVX2 hooks (ldpc_decoder_avx2.cpp:66-243, avx2_support.h:65-106).
+//
+// MI355X mapping (not a translation of the CPU data flow):
+//   * thread i of the workgroup owns lifted check row i of every layer; a cyclic shift is an LDS address rotation,
+//     so no data is ever moved to "rotate" a node;
+//   * the soft bits of the whole codeblock (<= 68*384 B) live in LDS for the lifetime of the decode;
+//   * check-to-variable messages are NOT stored: a check row's messages are fully determined by
+//     (scaled min1, scaled min2, argmin, per-edge sign), which is packed in one 32-bit word per (layer,row)
+//     (two words for the four degree-19 rows of BG1) -- exact, not an approximation;
+//   * the v2c values of a row stay in registers between the min search and the soft-bit update (the per-degree
+//     template makes every index static);
+//   * hard decision + CRC run in-kernel: each lane reduces one 32-bit word of the message to a partial remainder,
+//     multiplies it by x^(32k) mod P and the partial remainders are XOR-reduced with wavefront shuffles.
+#include "miphy_internal.h"
+
+namespace {
+
+constexpr int LLR_MAX = 120;
+constexpr int LLR_INF = 127;
+
+// State word layout: [6:0] scaled min1, [13:7] scaled min2, [18:14] argmin edge, [31:19] c2v sign of edges 0..12.
+// Second word (degree > 13 only): c2v sign of edges 13...
+template <int D, bool FIRST>
+__device__ __forceinline__ void
+update_row(int8_t* __restrict__ soft, uint32_t& w0, uint32_t& w1, const uint32_t* __restrict__ edges, int i, int Z)
+{
+  int      v2c[D];
+  int      addr[D];
+  int      min1 = LLR_MAX, min2 = LLR_MAX, arg = 0;
+  uint32_t sgn     = 0;
+  const int old_m1  = w0 & 127;
+  const int old_m2  = (w0 >> 7) & 127;
+  const int old_arg = (w0 >> 14) & 31;
+  const uint32_t old_sgn = (w0 >> 19) | (D > 13 ? (w1 << 13) : 0u);
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const uint32_t e   = edges[j];
+    int            pos = i + (int)(e >> 16);
+    pos                = (pos >= Z) ? pos - Z : pos;
+    const int a        = (int)(e & 0xffffu) + pos;
+    addr[j]            = a;
+    const int s        = soft[a];
+    int       v;
+    if (FIRST) {
+      v = s; // first visit of the layer: plain copy (ldpc_decoder_impl.cpp:181-185)
+    } else {
+      const int mag = (old_arg == j) ? old_m2 : old_m1;
+      const int c   = ((old_sgn >> j) & 1u) ? -mag : mag;
+      v             = s - c; // ldpc_decoder_avx2.cpp:85-105
+      v             = min(max(v, -LLR_MAX), LLR_MAX);
+      v             = (s >= LLR_INF) ? LLR_INF : v;
+      v             = (s <= -LLR_INF) ? -LLR_INF : v;
+    }
+    v2c[j] = v;
+    sgn |= (uint32_t)(v < 0) << j;
+    const int  av   = abs(v);
+    const bool m    = min1 > av; // strict: first occurrence keeps argmin (ldpc_decoder_avx2.cpp:141-156)
+    const int  help = m ? min1 : av;
+    arg             = m ? j : arg;
+    min1            = m ? av : min1;
+    min2            = (min2 > av) ? help : min2;
+  }
+  // Scaling by 0.8: floor(x * 52428 / 65536) (avx2_support.h:65-106).
+  const int      s1 = (min1 * 52428) >> 16;
+  const int      s2 = (min2 * 52428) >> 16;
+  const uint32_t sp = __popc(sgn) & 1u;
+  const uint32_t cs = (sp ? ~sgn : sgn) & ((1u << D) - 1u); // sign of each outgoing c2v message
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const int mag = (arg == j) ? s2 : s1;
+    const int c   = ((cs >> j) & 1u) ? -mag : mag;
+    const int v   = v2c[j];
+    int       r   = c + v; // ldpc_decoder_avx2.cpp:205-243 (c2v is never infinite)
+    r             = (r > LLR_MAX || v > LLR_MAX) ? LLR_INF : r;
+    r             = (r < -LLR_MAX || v < -LLR_MAX) ? -LLR_INF : r;
+    soft[addr[j]] = (int8_t)r;
+  }
+  w0 = (uint32_t)s1 | ((uint32_t)s2 << 7) | ((uint32_t)arg << 14) | (cs << 19);
+  if (D > 13)
+    w1 = cs >> 13;
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void update_row_any(int            d,
+                                               int8_t*        soft,
+                                               uint32_t&      w0,
+                                               uint32_t&      w1,
+                                               const uint32_t* edges,
+                                               int            i,
+                                               int            Z)
+{
+  switch (d) {
+    case 19:
+      update_row<19, FIRST>(soft, w0, w1, edges, i, Z);
+      break;
+    case 10:
+      update_row<10, FIRST>(soft, w0, w1, edges, i, Z);
+      break;
+    case 9:
+      update_row<9, FIRST>(soft, w0, w1, edges, i, Z);
+      break;
+    case 8:
+      update_row<8, FIRST>(soft, w0, w1, edges, i, Z);
+      break;
+    case 7:
+      update_row<7, FIRST>(soft, w0, w1, edges, i, Z);
+      break;
+    case 6:
+      update_row<6, FIRST>(soft, w0, w1, edges, i, Z);
+      break;
+    case 5:
+      update_row<5, FIRST>(soft, w0, w1, edges, i, Z);
+      break;
+    case 4:
+      update_row<4, FIRST>(soft, w0, w1, edges, i, Z);
+      break;
+    default:
+      update_row<3, FIRST>(soft, w0, w1, edges, i, Z);
+      break;
+  }
+}
+
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b, uint32_t poly, uint32_t order)
+{
+  uint32_t       r   = 0;
+  const uint32_t top = 1u << order;
+  for (int k = (int)order - 1; k >= 0; --k) {
+    r <<= 1;
+    r ^= (r & top) ? poly : 0u;
+    r ^= ((b >> k) & 1u) ? a : 0u;
+  }
+  return r;
+}
+
+// Hard decision of 32 consecutive soft bits starting at soft[32*t]; returns the big-endian numeric value (first bit in
+// bit 31). Positions >= K are masked to 0. bit = (llr <= 0), log_likelihood_ratio.h:86.
+__device__ __forceinline__ uint32_t hard_word(const int8_t* soft, int t, int K)
+{
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(soft) + 8 * t;
+  uint32_t        w = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const uint32_t x = p[q];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int v = (int8_t)(x >> (8 * b));
+      w |= (uint32_t)(v <= 0) << (31 - (4 * q + b));
+    }
+  }
+  const int rem = K - 32 * t;
+  if (rem < 32)
+    w &= (rem <= 0) ? 0u : (0xffffffffu << (32 - rem));
+  return w;
+}
+
+__global__ void __launch_bounds__(MIPHY_MAX_Z)
+ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
+                   const miphy_graph_tables* __restrict__ tab,
+                   const int8_t* __restrict__ llr_base,
+                   uint8_t* __restrict__ out_base,
+                   int32_t* __restrict__ iters_out)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const miphy_ldpc_dec_desc dsc = descs[blockIdx.x];
+  const int                 tid = threadIdx.x;
+  const int                 nt  = blockDim.x;
+  const int                 Z   = dsc.Z;
+  const int                 bgi = (dsc.bg == 1) ? 0 : 1;
+  const int                 bgK = bgi ? 10 : 22;
+  const int                 bgM = bgi ? 42 : 46;
+  const int                 NF  = bgK + bgM;
+  const int                 K   = bgK * Z;
+  const int                 NZ  = NF * Z;
+  const int                 zp  = tab->z_pos[Z];
+
+  int8_t*   soft = reinterpret_cast<int8_t*>(smem);
+  const int soft_bytes = (NZ + 15) & ~15;
+  uint32_t* st0  = reinterpret_cast<uint32_t*>(smem + soft_bytes);
+  uint32_t* st1  = st0 + bgM * Z;
+  uint32_t* red  = st1 + 4 * Z; // 16 words of scratch
+
+  const int8_t* llr = llr_base + dsc.llr_offset;
+  uint8_t*      out = out_base + dsc.out_offset;
+  const int     in_len = (int)dsc.in_len;
+
+  if (tid < 16)
+    red[tid] = 0;
+  // Stage LLRs into LDS (variable nodes 0,1 are punctured -> 0) and find the last non-zero input.
+  for (int k = tid; k < 2 * Z; k += nt)
+    soft[k] = 0;
+  for (int k = 2 * Z + in_len + tid; k < soft_bytes; k += nt)
+    soft[k] = 0;
+  __syncthreads();
+  int last = 0;
+  for (int k = tid; k < in_len; k += nt) {
+    const int8_t v  = llr[k];
+    soft[2 * Z + k] = v;
+    last            = (v != 0) ? k + 1 : last;
+  }
+  atomicMax(reinterpret_cast<int*>(&red[0]), last);
+  __syncthreads();
+  last = (int)red[0];
+
+  const bool use_crc = dsc.crc_poly != MIPHY_CRC_NONE;
+  const int  kwords  = (K + 31) >> 5;
+
+  if (last == 0) { // ldpc_decoder_impl.cpp:88-94
+    if (!use_crc) {
+      for (int b = tid; b < (K + 7) / 8; b += nt) {
+        const int rem = K - 8 * b;
+        out[b]        = (rem >= 8) ? 0xff : (uint8_t)(0xff << (8 - rem));
+      }
+    }
+    if (tid == 0)
+      iters_out[blockIdx.x] = 0;
+    return;
+  }
+
+  // ldpc_decoder_impl.cpp:101-114
+  int cb_len = max(last + 2 * Z, K + 4 * Z);
+  cb_len     = ((cb_len + Z - 1) / Z) * Z;
+  const int nof_layers = cb_len / Z - bgK;
+
+  const uint32_t* edges_g   = tab->edge[bgi][zp];
+  const uint16_t* row_start = tab->row_start[bgi];
+
+  // CRC constants.
+  uint32_t poly = 0, order = 0;
+  int      L = 0, nfull = 0, rbits = 0;
+  if (use_crc) {
+    poly  = tab->crc_poly[dsc.crc_poly];
+    order = tab->crc_order[dsc.crc_poly];
+    L     = K - dsc.nof_filler_bits; // ldpc_decoder_impl.cpp:55
+    nfull = L >> 5;
+    rbits = L & 31;
+  }
+
+  int result_iters = 0;
+  const int max_iter = dsc.max_iter;
+  for (int it = 0; it < max_iter; ++it) {
+    for (int m = 0; m < nof_layers; ++m) {
+      const int       e0    = row_start[m];
+      const int       d     = row_start[m + 1] - e0;
+      const uint32_t* edges = edges_g + e0;
+      if (tid < Z) {
+        uint32_t w0 = 0, w1 = 0;
+        if (it == 0) {
+          update_row_any<true>(d, soft, w0, w1, edges, tid, Z);
+        } else {
+          w0 = st0[m * Z + tid];
+          if (d > 13)
+            w1 = st1[m * Z + tid];
+          update_row_any<false>(d, soft, w0, w1, edges, tid, Z);
+        }
+        st0[m * Z + tid] = w0;
+        if (d > 13)
+          st1[m * Z + tid] = w1;
+      }
+      __syncthreads();
+    }
+    if (use_crc) { // ldpc_decoder_impl.cpp:126-133
+      uint32_t part = 0;
+      if (tid < kwords && 32 * tid < L) {
+        uint32_t  w   = hard_word(soft, tid, K);
+        const int len = min(32, L - 32 * tid);
+        const uint32_t top = 1u << order;
+        uint32_t  reg = 0;
+        for (int b = 0; b < len; ++b) {
+          reg = (reg << 1) ^ (((w >> (31 - b)) & 1u) << order);
+          reg ^= (reg & top) ? poly : 0u;
+        }
+        reg &= top - 1u;
+        if (tid < nfull) { // weight x^(32*(nfull-1-tid) + rbits)
+          reg = gf2_mulmod(reg, tab->crc_pow32[dsc.crc_poly][nfull - 1 - tid], poly, order);
+          for (int b = 0; b < rbits; ++b) {
+            reg <<= 1;
+            reg ^= (reg & top) ? poly : 0u;
+          }
+        }
+        part = reg;
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+        part ^= __shfl_xor(part, off);
+      if ((tid & 63) == 0)
+        red[2 + (tid >> 6)] = part;
+      __syncthreads();
+      uint32_t crc = 0;
+      for (int w = 0; w < (nt >> 6); ++w)
+        crc ^= red[2 + w];
+      __syncthreads();
+      if (crc == 0) {
+        result_iters = it + 1;
+        break;
+      }
+    }
+  }
+
+  // Final hard bits (identical to what the reference leaves in `output`: the bits of the last iteration run).
+  if (tid < kwords) {
+    const uint32_t w = hard_word(soft, tid, K);
+    const int      nbytes = min(4, (K - 32 * tid + 7) / 8);
+    for (int q = 0; q < nbytes; ++q)
+      out[4 * tid + q] = (uint8_t)(w >> (24 - 8 * q));
+  }
+  if (tid == 0)
+    iters_out[blockIdx.x] = result_iters;
+}
+
+} // namespace
+
+extern "C" int miphy_ldpc_decode_batch(miphy_ctx*                 ctx,
+                                       const miphy_ldpc_dec_desc* descs,
+                                       int                        descs_on_device,
+                                       uint32_t                   n,
+                                       const int8_t*              llr,
+                                       uint8_t*                   out_bits,
+                                       int32_t*                   iters,
+                                       void*                      stream)
+{
+  MIPHY_REQUIRE(ctx && descs && llr && out_bits && iters, "miphy_ldpc_decode_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  hipStream_t s = (hipStream_t)stream;
+  // Launch geometry comes from the largest Z / base graph in the batch. With device descriptors the caller vouches
+  // for validity; with host descriptors everything is checked here (the reference asserts the same conditions,
+  // ldpc_decoder_impl.cpp:66-84).
+  int max_threads = MIPHY_MAX_Z;
+  size_t max_lds  = 0;
+  if (!descs_on_device) {
+    max_threads = 64;
+    for (uint32_t i = 0; i < n; ++i) {
+      const miphy_ldpc_dec_desc& d = descs[i];
+      MIPHY_REQUIRE(d.bg == 1 || d.bg == 2, "ldpc_decode: desc %u: invalid base graph %u", i, d.bg);
+      MIPHY_REQUIRE(d.Z <= MIPHY_MAX_Z && ctx->h_tables->z_pos[d.Z] != 0xffff, "ldpc_decode: desc %u: invalid lifting size %u", i, d.Z);
+      const unsigned bgK = (d.bg == 1) ? 22 : 10, nshort = (d.bg == 1) ? 66 : 50, nfull = nshort + 2, bgM = nfull - bgK;
+      MIPHY_REQUIRE(d.in_len >= (bgK + 2) * d.Z && d.in_len <= nshort * d.Z, "ldpc_decode: desc %u: input length %u out of range", i, d.in_len);
+      MIPHY_REQUIRE(d.max_iter > 0, "ldpc_decode: desc %u: max_iter must be > 0", i);
+      MIPHY_REQUIRE(d.crc_poly == MIPHY_CRC_NONE || d.crc_poly <= MIPHY_CRC11, "ldpc_decode: desc %u: invalid CRC", i);
+      MIPHY_REQUIRE(d.nof_filler_bits < bgK * d.Z, "ldpc_decode: desc %u: invalid number of filler bits", i);
+      const int    threads = ((d.Z + 63) / 64) * 64;
+      const size_t lds     = ((nfull * d.Z + 15) & ~15u) + (size_t)(bgM + 4) * d.Z * 4 + 64;
+      max_threads          = threads > max_threads ? threads : max_threads;
+      max_lds              = lds > max_lds ? lds : max_lds;
+    }
+  } else {
+    max_lds = ((68 * MIPHY_MAX_Z + 15) & ~15u) + (size_t)(46 + 4) * MIPHY_MAX_Z * 4 + 64;
+  }
+  const void* d_descs = nullptr;
+  int         rc      = miphy_stage_descs(ctx, descs, descs_on_device, sizeof(miphy_ldpc_dec_desc) * (size_t)n, s, &d_descs);
+  if (rc)
+    return rc;
+  static thread_local size_t lds_set = 0;
+  if (max_lds > lds_set) {
+    MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
+    lds_set = max_lds;
+  }
+  hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n), dim3(max_threads), max_lds, s, (const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, llr, out_bits, iters);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}

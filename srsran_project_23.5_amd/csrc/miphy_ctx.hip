@@ -1,0 +1,145 @@
+// Context: device tables (TS 38.212 graphs, CRC constants), descriptor staging, error reporting.
+#include "miphy_internal.h"
+#include "tables/nr_ldpc_tables.h"
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+void miphy_set_error(const char* fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* miphy_last_error(void)
+{
+  return g_err;
+}
+
+extern "C" int miphy_version(void)
+{
+  return MIPHY_VERSION;
+}
+
+static int lifting_set(int Z)
+{
+  static const int A[8] = {2, 3, 5, 7, 9, 11, 13, 15};
+  for (int i = 7; i >= 0; --i) {
+    if (Z % A[i])
+      continue;
+    int q = Z / A[i];
+    if ((q & (q - 1)) == 0)
+      return i;
+  }
+  return -1;
+}
+
+static uint32_t gf2_mulmod(uint32_t a, uint32_t b, uint32_t poly, unsigned order)
+{
+  // a*b mod poly over GF(2), operands < 2^order.
+  uint32_t r = 0, top = 1u << order;
+  for (int i = (int)order - 1; i >= 0; --i) {
+    r <<= 1;
+    if (r & top)
+      r ^= poly;
+    if ((b >> i) & 1u)
+      r ^= a;
+  }
+  return r;
+}
+
+static void build_tables(miphy_graph_tables* t)
+{
+  memset(t, 0, sizeof(*t));
+  for (int z = 0; z <= MIPHY_MAX_Z; ++z) {
+    t->z_pos[z] = 0xffff;
+    t->i_ls[z]  = 0xff;
+  }
+  for (int p = 0; p < MIPHY_NOF_Z; ++p) {
+    int Z        = NR_LDPC_LIFTING_SIZES[p];
+    t->z_pos[Z]  = (uint16_t)p;
+    int ils      = lifting_set(Z);
+    t->i_ls[Z]   = (uint8_t)ils;
+    for (int e = 0; e < NR_LDPC_BG1_NOF_EDGES; ++e)
+      t->edge[0][p][e] = (uint32_t)(NR_LDPC_BG1_COL[e] * Z) | ((uint32_t)(NR_LDPC_BG1_SHIFT[ils][e] % Z) << 16);
+    for (int e = 0; e < NR_LDPC_BG2_NOF_EDGES; ++e)
+      t->edge[1][p][e] = (uint32_t)(NR_LDPC_BG2_COL[e] * Z) | ((uint32_t)(NR_LDPC_BG2_SHIFT[ils][e] % Z) << 16);
+  }
+  for (int m = 0; m <= NR_LDPC_BG1_M; ++m)
+    t->row_start[0][m] = NR_LDPC_BG1_ROW_START[m];
+  for (int m = 0; m <= NR_LDPC_BG2_M; ++m)
+    t->row_start[1][m] = NR_LDPC_BG2_ROW_START[m];
+  static const uint32_t POLY[5]  = {0x1864CFB, 0x1800063, 0x1B2B117, 0x11021, 0xE21};
+  static const uint32_t ORDER[5] = {24, 24, 24, 16, 11};
+  for (int p = 0; p < 5; ++p) {
+    t->crc_poly[p]  = POLY[p];
+    t->crc_order[p] = ORDER[p];
+    // x^32 mod poly
+    uint32_t x32 = 1, top = 1u << ORDER[p];
+    for (int i = 0; i < 32; ++i) {
+      x32 <<= 1;
+      if (x32 & top)
+        x32 ^= POLY[p];
+    }
+    uint32_t v = 1;
+    for (int k = 0; k < 320; ++k) {
+      t->crc_pow32[p][k] = v;
+      v                  = gf2_mulmod(v, x32, POLY[p], ORDER[p]);
+    }
+  }
+}
+
+extern "C" int miphy_create(int device, miphy_ctx** out)
+{
+  if (!out) {
+    miphy_set_error("miphy_create: null out pointer");
+    return MIPHY_EINVAL;
+  }
+  *out = nullptr;
+  MIPHY_HIP_CHECK(hipSetDevice(device));
+  miphy_ctx* c = new (std::nothrow) miphy_ctx();
+  if (!c)
+    return MIPHY_ENOMEM;
+  c->device   = device;
+  c->h_tables = (miphy_graph_tables*)malloc(sizeof(miphy_graph_tables));
+  build_tables(c->h_tables);
+  MIPHY_HIP_CHECK(hipMalloc((void**)&c->d_tables, sizeof(miphy_graph_tables)));
+  MIPHY_HIP_CHECK(hipMemcpy(c->d_tables, c->h_tables, sizeof(miphy_graph_tables), hipMemcpyHostToDevice));
+  c->desc_staging_bytes = 4u << 20;
+  MIPHY_HIP_CHECK(hipMalloc(&c->d_desc_staging, c->desc_staging_bytes));
+  MIPHY_HIP_CHECK(hipHostMalloc(&c->h_desc_staging, c->desc_staging_bytes, hipHostMallocDefault));
+  *out = c;
+  return MIPHY_OK;
+}
+
+extern "C" void miphy_destroy(miphy_ctx* c)
+{
+  if (!c)
+    return;
+  (void)hipSetDevice(c->device);
+  (void)hipFree(c->d_tables);
+  (void)hipFree(c->d_desc_staging);
+  (void)hipHostFree(c->h_desc_staging);
+  free(c->h_tables);
+  delete c;
+}
+
+int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t bytes, hipStream_t s, const void** out)
+{
+  if (on_device) {
+    *out = descs;
+    return MIPHY_OK;
+  }
+  MIPHY_REQUIRE(bytes <= ctx->desc_staging_bytes, "descriptor batch too large (%zu bytes > %zu)", bytes, ctx->desc_staging_bytes);
+  // The staging buffers are reused by the next call on this context: wait for the stream before overwriting.
+  MIPHY_HIP_CHECK(hipStreamSynchronize(s));
+  memcpy(ctx->h_desc_staging, descs, bytes);
+  MIPHY_HIP_CHECK(hipMemcpyAsync(ctx->d_desc_staging, ctx->h_desc_staging, bytes, hipMemcpyHostToDevice, s));
+  *out = ctx->d_desc_staging;
+  return MIPHY_OK;
+}

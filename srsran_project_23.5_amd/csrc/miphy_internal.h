@@ -1,0 +1,56 @@
+// Internal definitions shared by the HIP translation units of libmiphy.so (gfx950 only).
+#pragma once
+#include "../../include/miphy.h"
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+
+#define MIPHY_MAX_Z 384
+#define MIPHY_NOF_Z 51
+#define MIPHY_BG1_EDGES 316
+#define MIPHY_BG2_EDGES 197
+#define MIPHY_MAX_EDGES 316
+
+// Per-(base graph, lifting size) edge table entry: low 16 bits = column*Z (LDS byte offset of the variable node),
+// high 16 bits = cyclic shift (already reduced modulo Z).
+struct miphy_graph_tables {
+  uint32_t edge[2][MIPHY_NOF_Z][MIPHY_MAX_EDGES];
+  uint16_t row_start[2][48];
+  uint16_t z_pos[MIPHY_MAX_Z + 1]; // position of Z in the list of lifting sizes, 0xffff if invalid
+  uint8_t  i_ls[MIPHY_MAX_Z + 1];  // lifting-size set index
+  // CRC: pow32[p][k] = x^(32k) mod poly_p for k in [0, 320); poly/order per id.
+  uint32_t crc_pow32[5][320];
+  uint32_t crc_poly[5];
+  uint32_t crc_order[5];
+};
+
+struct miphy_ctx {
+  int                  device;
+  miphy_graph_tables*  d_tables; // device copy
+  miphy_graph_tables*  h_tables; // host copy
+  void*                d_desc_staging;
+  size_t               desc_staging_bytes;
+  void*                h_desc_staging; // pinned
+};
+
+void miphy_set_error(const char* fmt, ...);
+
+#define MIPHY_HIP_CHECK(expr)                                                                 \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      miphy_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));   \
+      return MIPHY_EHIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+#define MIPHY_REQUIRE(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      miphy_set_error(__VA_ARGS__);       \
+      return MIPHY_EINVAL;                \
+    }                                     \
+  } while (0)
+
+// Ensures the descriptor array is on the device; returns the device pointer through *out.
+int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t bytes, hipStream_t s, const void** out);

@@ -1,0 +1,12 @@
+"""miphy -- Python host-side binding of the MI355X-native 5G NR upper-PHY hot path (libmiphy.so, C ABI in include/miphy.h).
+
+PyTorch is used only as plumbing (device memory, streams, torch.distributed); all compute is in the hand-written HIP
+kernels behind the C ABI.  There is NO CPU fallback: importing this package without the built library, or calling it
+without a GPU, raises.
+"""
+from .binding import (Context, LdpcDecDesc, lib, lib_path, LibraryNotBuilt, CRC24A, CRC24B, CRC24C, CRC16, CRC11,
+                      CRC_NONE)
+from . import ldpc
+
+__all__ = ["Context", "LdpcDecDesc", "lib", "lib_path", "LibraryNotBuilt", "ldpc", "CRC24A", "CRC24B", "CRC24C", "CRC16",
+           "CRC11", "CRC_NONE"]

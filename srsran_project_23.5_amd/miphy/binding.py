@@ -1,0 +1,104 @@
+"""ctypes binding of include/miphy.h.  No torch types cross the C ABI: tensors are passed as raw device pointers."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(os.path.dirname(_HERE), "libmiphy.so")
+
+CRC24A, CRC24B, CRC24C, CRC16, CRC11 = range(5)
+CRC_NONE = 255
+
+
+class LibraryNotBuilt(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libmiphy.so (torch must already be imported so that its HIP runtime is the one in the process)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(lib_path):
+            raise LibraryNotBuilt("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C "
+                                  "srsran_project_23.5_amd`. There is no CPU fallback." % lib_path)
+        import torch  # noqa: F401  (loads libamdhip64 first; the C ABI itself has no torch dependency)
+        l = C.CDLL(lib_path)
+        l.miphy_last_error.restype = C.c_char_p
+        l.miphy_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        l.miphy_destroy.argtypes = [C.c_void_p]
+        l.miphy_ldpc_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]
+        _lib = l
+    return _lib
+
+
+# Mirrors miphy_ldpc_dec_desc.
+LdpcDecDesc = np.dtype([("bg", np.uint8), ("crc_poly", np.uint8), ("Z", np.uint16), ("max_iter", np.uint16),
+                        ("nof_filler_bits", np.uint16), ("in_len", np.uint32), ("reserved", np.uint32),
+                        ("llr_offset", np.uint64), ("out_offset", np.uint64)], align=True)
+assert LdpcDecDesc.itemsize == 32
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("miphy error %d: %s" % (rc, lib().miphy_last_error().decode()))
+
+
+def _stream_ptr(stream):
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def _dptr(t):
+    """Device pointer of a torch tensor (must be a contiguous CUDA/HIP tensor)."""
+    if not t.is_cuda:
+        raise ValueError("miphy expects device (HBM-resident) tensors; there is no CPU path")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One per host thread / GPU (miphy_create)."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("miphy needs a HIP device (MI355X); no CPU fallback exists")
+        self.device = device
+        torch.cuda.set_device(device)
+        h = C.c_void_p()
+        check(lib().miphy_create(device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().miphy_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ LDPC decoder
+    def ldpc_decode_batch(self, descs, llr, out_bits, iters, stream=None):
+        """descs: numpy LdpcDecDesc array (host) or torch uint8 device tensor holding the same bytes."""
+        import torch
+        if isinstance(descs, np.ndarray):
+            assert descs.dtype == LdpcDecDesc
+            descs = np.ascontiguousarray(descs)
+            n, ptr, on_dev = descs.size, C.c_void_p(descs.ctypes.data), 0
+        else:
+            assert descs.dtype == torch.uint8 and descs.numel() % LdpcDecDesc.itemsize == 0
+            n, ptr, on_dev = descs.numel() // LdpcDecDesc.itemsize, _dptr(descs), 1
+        assert iters.dtype == torch.int32 and iters.numel() >= n
+        check(lib().miphy_ldpc_decode_batch(self.h, ptr, on_dev, n, _dptr(llr), _dptr(out_bits), _dptr(iters),
+                                            _stream_ptr(stream)))
