@@ -79,6 +79,91 @@ int miphy_ldpc_decode_batch(miphy_ctx*                 ctx,
                             int32_t*                   iters,    /* device, n entries */
                             void*                      stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * LDPC rate dematcher  --  replaces srsran::ldpc_rate_dematcher::rate_dematch
+ *   include/srsran/phy/upper/channel_coding/ldpc/ldpc_rate_dematcher.h:52-55
+ *   lib/phy/upper/channel_coding/ldpc/ldpc_rate_dematcher_impl.cpp:43-254, AVX2 combine rule
+ *   (ldpc_rate_dematcher_avx2_impl.cpp:45-58: saturating add clamped to +-120).
+ * One descriptor per codeblock. The output is the HARQ soft buffer view of the FULL codeblock (N = 66Z / 50Z LLRs),
+ * read-modify-written exactly like the reference does: with new_data the same positions are cleared / set to +inf
+ * (fillers) / left untouched, otherwise the new LLRs are combined into the existing ones. */
+typedef struct {
+  uint8_t  bg;              /* 1 or 2 */
+  uint8_t  rv;              /* redundancy version 0..3 */
+  uint8_t  mod;             /* bits per symbol: 1, 2, 4, 6, 8 */
+  uint8_t  new_data;        /* 1: first transmission (copy mode), 0: combine with the soft buffer */
+  uint16_t Z;
+  uint16_t nof_filler_bits;
+  uint32_t Nref;            /* limited-buffer length, 0 = unlimited */
+  uint32_t E;               /* rate-matched length of this codeblock (multiple of mod) */
+  uint64_t in_offset;       /* element offset of the E input LLRs inside `llr_in` */
+  uint64_t out_offset;      /* element offset of the N-LLR soft buffer inside `softbuf` */
+} miphy_ldpc_rdm_desc;
+
+int miphy_ldpc_rate_dematch_batch(miphy_ctx*                 ctx,
+                                  const miphy_ldpc_rdm_desc* descs,
+                                  int                        descs_on_device,
+                                  uint32_t                   n,
+                                  const int8_t*              llr_in,  /* device */
+                                  int8_t*                    softbuf, /* device, in/out */
+                                  void*                      stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * LDPC rate matcher  --  replaces srsran::ldpc_rate_matcher::rate_match
+ *   include/srsran/phy/upper/channel_coding/ldpc/ldpc_rate_matcher.h:46
+ *   lib/phy/upper/channel_coding/ldpc/ldpc_rate_matcher_impl.cpp:42-182.
+ * in: full codeblock, N = 66Z / 50Z bytes, one bit per byte (fillers = 254 are skipped positionally);
+ * out: E bytes, one bit per byte. Uses the same descriptor as the dematcher (new_data ignored;
+ * in_offset -> codeblock inside `cb_in`, out_offset -> E output bytes inside `out`). */
+int miphy_ldpc_rate_match_batch(miphy_ctx*                 ctx,
+                                const miphy_ldpc_rdm_desc* descs,
+                                int                        descs_on_device,
+                                uint32_t                   n,
+                                const uint8_t*             cb_in, /* device */
+                                uint8_t*                   out,   /* device */
+                                void*                      stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * LDPC encoder  --  replaces srsran::ldpc_encoder::encode
+ *   include/srsran/phy/upper/channel_coding/ldpc/ldpc_encoder.h:46-47
+ *   lib/phy/upper/channel_coding/ldpc/ldpc_encoder_impl.cpp:44-81, ldpc_encoder_generic.cpp:30-223.
+ * in: bg_K*Z bytes, one bit per byte (filler bits = 254, copied through to the output);
+ * out: out_len <= N_short*Z bytes (codeblock without the first 2Z punctured bits). */
+typedef struct {
+  uint8_t  bg;
+  uint8_t  reserved0;
+  uint16_t Z;
+  uint32_t out_len;
+  uint64_t in_offset;  /* byte offset of the message inside `msg_in` */
+  uint64_t out_offset; /* byte offset of the codeblock inside `cb_out` */
+} miphy_ldpc_enc_desc;
+
+int miphy_ldpc_encode_batch(miphy_ctx*                 ctx,
+                            const miphy_ldpc_enc_desc* descs,
+                            int                        descs_on_device,
+                            uint32_t                   n,
+                            const uint8_t*             msg_in, /* device */
+                            uint8_t*                   cb_out, /* device */
+                            void*                      stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * CRC calculator  --  replaces srsran::crc_calculator::calculate / calculate_bit / calculate_byte
+ *   include/srsran/phy/upper/channel_coding/crc_calculator.h:45-67, lib/phy/upper/channel_coding/crc_calculator_lut_impl.cpp.
+ * One descriptor per message; messages are MSB-first packed (bit_offset may be unaligned). */
+typedef struct {
+  uint64_t bit_offset; /* first bit of the message inside `data` */
+  uint32_t nbits;
+  uint32_t poly;       /* MIPHY_CRC* */
+} miphy_crc_desc;
+
+int miphy_crc_batch(miphy_ctx*            ctx,
+                    const miphy_crc_desc* descs,
+                    int                   descs_on_device,
+                    uint32_t              n,
+                    const uint8_t*        data,      /* device, packed */
+                    uint32_t*             checksums, /* device, n entries */
+                    void*                 stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,11 @@ static void build_tables(miphy_graph_tables* t)
       t->crc_pow32[p][k] = v;
       v                  = gf2_mulmod(v, x32, POLY[p], ORDER[p]);
     }
+    v = x32;
+    for (int b = 0; b < 24; ++b) {
+      t->crc_pow2[p][b] = v;
+      v                 = gf2_mulmod(v, v, POLY[p], ORDER[p]);
+    }
   }
 }
 

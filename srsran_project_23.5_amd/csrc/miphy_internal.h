@@ -20,6 +20,7 @@ struct miphy_graph_tables {
   uint8_t  i_ls[MIPHY_MAX_Z + 1];  // lifting-size set index
   // CRC: pow32[p][k] = x^(32k) mod poly_p for k in [0, 320); poly/order per id.
   uint32_t crc_pow32[5][320];
+  uint32_t crc_pow2[5][24]; // x^(32 * 2^b) mod poly
   uint32_t crc_poly[5];
   uint32_t crc_order[5];
 };

@@ -32,6 +32,9 @@ def lib():
         l.miphy_destroy.argtypes = [C.c_void_p]
         l.miphy_ldpc_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p]
+        for name in ("miphy_ldpc_rate_dematch_batch", "miphy_ldpc_rate_match_batch", "miphy_ldpc_encode_batch"):
+            getattr(l, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_crc_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
 
@@ -41,6 +44,18 @@ LdpcDecDesc = np.dtype([("bg", np.uint8), ("crc_poly", np.uint8), ("Z", np.uint1
                         ("nof_filler_bits", np.uint16), ("in_len", np.uint32), ("reserved", np.uint32),
                         ("llr_offset", np.uint64), ("out_offset", np.uint64)], align=True)
 assert LdpcDecDesc.itemsize == 32
+# Mirrors miphy_ldpc_rdm_desc.
+LdpcRdmDesc = np.dtype([("bg", np.uint8), ("rv", np.uint8), ("mod", np.uint8), ("new_data", np.uint8), ("Z", np.uint16),
+                        ("nof_filler_bits", np.uint16), ("Nref", np.uint32), ("E", np.uint32), ("in_offset", np.uint64),
+                        ("out_offset", np.uint64)], align=True)
+assert LdpcRdmDesc.itemsize == 32
+# Mirrors miphy_ldpc_enc_desc.
+LdpcEncDesc = np.dtype([("bg", np.uint8), ("reserved0", np.uint8), ("Z", np.uint16), ("out_len", np.uint32),
+                        ("in_offset", np.uint64), ("out_offset", np.uint64)], align=True)
+assert LdpcEncDesc.itemsize == 24
+# Mirrors miphy_crc_desc.
+CrcDesc = np.dtype([("bit_offset", np.uint64), ("nbits", np.uint32), ("poly", np.uint32)], align=True)
+assert CrcDesc.itemsize == 16
 
 
 def check(rc):
@@ -88,17 +103,38 @@ class Context:
         except Exception:
             pass
 
-    # ------------------------------------------------------------------ LDPC decoder
-    def ldpc_decode_batch(self, descs, llr, out_bits, iters, stream=None):
-        """descs: numpy LdpcDecDesc array (host) or torch uint8 device tensor holding the same bytes."""
+    @staticmethod
+    def _descs(descs, dtype):
+        """descs: numpy structured array (host) or torch uint8 device tensor holding the same bytes."""
         import torch
         if isinstance(descs, np.ndarray):
-            assert descs.dtype == LdpcDecDesc
+            assert descs.dtype == dtype, (descs.dtype, dtype)
             descs = np.ascontiguousarray(descs)
-            n, ptr, on_dev = descs.size, C.c_void_p(descs.ctypes.data), 0
-        else:
-            assert descs.dtype == torch.uint8 and descs.numel() % LdpcDecDesc.itemsize == 0
-            n, ptr, on_dev = descs.numel() // LdpcDecDesc.itemsize, _dptr(descs), 1
+            return descs, descs.size, C.c_void_p(descs.ctypes.data), 0
+        assert descs.dtype == torch.uint8 and descs.numel() % dtype.itemsize == 0
+        return descs, descs.numel() // dtype.itemsize, _dptr(descs), 1
+
+    # ------------------------------------------------------------------ LDPC decoder
+    def ldpc_decode_batch(self, descs, llr, out_bits, iters, stream=None):
+        import torch
+        descs, n, ptr, on_dev = self._descs(descs, LdpcDecDesc)
         assert iters.dtype == torch.int32 and iters.numel() >= n
         check(lib().miphy_ldpc_decode_batch(self.h, ptr, on_dev, n, _dptr(llr), _dptr(out_bits), _dptr(iters),
                                             _stream_ptr(stream)))
+
+    # ------------------------------------------------------------------ LDPC rate (de)matching, encoder, CRC
+    def ldpc_rate_dematch_batch(self, descs, llr_in, softbuf, stream=None):
+        descs, n, ptr, on_dev = self._descs(descs, LdpcRdmDesc)
+        check(lib().miphy_ldpc_rate_dematch_batch(self.h, ptr, on_dev, n, _dptr(llr_in), _dptr(softbuf), _stream_ptr(stream)))
+
+    def ldpc_rate_match_batch(self, descs, cb_in, out, stream=None):
+        descs, n, ptr, on_dev = self._descs(descs, LdpcRdmDesc)
+        check(lib().miphy_ldpc_rate_match_batch(self.h, ptr, on_dev, n, _dptr(cb_in), _dptr(out), _stream_ptr(stream)))
+
+    def ldpc_encode_batch(self, descs, msg_in, cb_out, stream=None):
+        descs, n, ptr, on_dev = self._descs(descs, LdpcEncDesc)
+        check(lib().miphy_ldpc_encode_batch(self.h, ptr, on_dev, n, _dptr(msg_in), _dptr(cb_out), _stream_ptr(stream)))
+
+    def crc_batch(self, descs, data, checksums, stream=None):
+        descs, n, ptr, on_dev = self._descs(descs, CrcDesc)
+        check(lib().miphy_crc_batch(self.h, ptr, on_dev, n, _dptr(data), _dptr(checksums), _stream_ptr(stream)))
