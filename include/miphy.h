@@ -70,6 +70,13 @@ typedef struct {
   uint64_t out_offset;      /* byte offset of this codeblock's packed message inside `out_bits` */
 } miphy_ldpc_dec_desc;
 
+/* Optional launch bounds for device-resident descriptors (which the host cannot inspect): the largest lifting size
+ * and input length in the batch. NULL = worst case (Z = 384, full-length codeblocks: one workgroup per CU). */
+typedef struct {
+  uint32_t max_Z;
+  uint32_t max_in_len;
+} miphy_ldpc_dec_limits;
+
 int miphy_ldpc_decode_batch(miphy_ctx*                 ctx,
                             const miphy_ldpc_dec_desc* descs, /* n descriptors; host memory unless descs_on_device */
                             int                        descs_on_device,
@@ -77,6 +84,7 @@ int miphy_ldpc_decode_batch(miphy_ctx*                 ctx,
                             const int8_t*              llr,      /* device */
                             uint8_t*                   out_bits, /* device */
                             int32_t*                   iters,    /* device, n entries */
+                            const miphy_ldpc_dec_limits* limits, /* may be NULL */
                             void*                      stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -23,59 +23,67 @@ constexpr int LLR_INF = 127;
 
 // State word layout: [6:0] scaled min1, [13:7] scaled min2, [18:14] argmin edge, [31:19] c2v sign of edges 0..12.
 // Second word (degree > 13 only): c2v sign of edges 13...
+//
+// Inside a row update an infinite LLR (|x| > 120, i.e. +-127 in memory) is carried as +-INF_INT so that the
+// promotion rules of the reference (ldpc_decoder_avx2.cpp:85-105,205-243: "infinity is sticky", "|sum| > 120 becomes
+// infinity") collapse into one clamp: c2v magnitudes are <= 95, so INF_INT + c2v always stays beyond +-120.
+constexpr int INF_INT = 255;
+
 template <int D, bool FIRST>
 __device__ __forceinline__ void
 update_row(int8_t* __restrict__ soft, uint32_t& w0, uint32_t& w1, const uint32_t* __restrict__ edges, int i, int Z)
 {
-  int      v2c[D];
-  int      addr[D];
-  int      min1 = LLR_MAX, min2 = LLR_MAX, arg = 0;
-  uint32_t sgn     = 0;
-  const int old_m1  = w0 & 127;
-  const int old_m2  = (w0 >> 7) & 127;
-  const int old_arg = (w0 >> 14) & 31;
+  int v2c[D];
+  int addr[D];
+  int mag1 = LLR_MAX, mag2 = LLR_MAX; // running min / second min of |v2c|
+  int spx  = 0;                       // XOR of all v2c values: bit 31 = sign product
+  const int      old_m1  = w0 & 127;
+  const int      old_m2  = (w0 >> 7) & 127;
+  const int      old_arg = (w0 >> 14) & 31;
   const uint32_t old_sgn = (w0 >> 19) | (D > 13 ? (w1 << 13) : 0u);
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     const uint32_t e   = edges[j];
-    int            pos = i + (int)(e >> 16);
-    pos                = (pos >= Z) ? pos - Z : pos;
-    const int a        = (int)(e & 0xffffu) + pos;
+    uint32_t       pos = (uint32_t)i + (e >> 16);
+    pos                = min(pos, pos - (uint32_t)Z); // (i + shift) mod Z
+    const int a        = (int)((e & 0xffffu) + pos);
     addr[j]            = a;
     const int s        = soft[a];
     int       v;
     if (FIRST) {
       v = s; // first visit of the layer: plain copy (ldpc_decoder_impl.cpp:181-185)
     } else {
-      const int mag = (old_arg == j) ? old_m2 : old_m1;
-      const int c   = ((old_sgn >> j) & 1u) ? -mag : mag;
-      v             = s - c; // ldpc_decoder_avx2.cpp:85-105
-      v             = min(max(v, -LLR_MAX), LLR_MAX);
-      v             = (s >= LLR_INF) ? LLR_INF : v;
-      v             = (s <= -LLR_INF) ? -LLR_INF : v;
+      const int mag   = (old_arg == j) ? old_m2 : old_m1;
+      const int smask = (int)__builtin_amdgcn_sbfe((int)old_sgn, j, 1); // 0 or -1
+      const int c     = (mag ^ smask) - smask;
+      v               = min(max(s - c, -LLR_MAX), LLR_MAX); // ldpc_decoder_avx2.cpp:85-92
     }
-    v2c[j] = v;
-    sgn |= (uint32_t)(v < 0) << j;
-    const int  av   = abs(v);
-    const bool m    = min1 > av; // strict: first occurrence keeps argmin (ldpc_decoder_avx2.cpp:141-156)
-    const int  help = m ? min1 : av;
-    arg             = m ? j : arg;
-    min1            = m ? av : min1;
-    min2            = (min2 > av) ? help : min2;
+    // |s| > 120 <=> infinite soft bit: the message is infinite with the same sign (avx2.cpp:94-104).
+    const bool inf = (uint32_t)(s + LLR_MAX) > (uint32_t)(2 * LLR_MAX);
+    v              = inf ? ((s >> 31) ^ INF_INT) : v;
+    v2c[j]         = v;
+    spx ^= v;
+    const int av   = max(v, -v);
+    const int help = max(mag1, av); // strict "<" tie rule is value-equivalent: ties make min1 == min2
+    mag1           = min(mag1, av);
+    mag2           = min(mag2, help);
   }
   // Scaling by 0.8: floor(x * 52428 / 65536) (avx2_support.h:65-106).
-  const int      s1 = (min1 * 52428) >> 16;
-  const int      s2 = (min2 * 52428) >> 16;
-  const uint32_t sp = __popc(sgn) & 1u;
-  const uint32_t cs = (sp ? ~sgn : sgn) & ((1u << D) - 1u); // sign of each outgoing c2v message
+  const int s1    = (mag1 * 52428) >> 16;
+  const int s2    = (mag2 * 52428) >> 16;
+  const int spm   = spx & (int)0x80000000;
+  int       arg   = 0;
+  uint32_t  cs    = 0;
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const int mag = (arg == j) ? s2 : s1;
-    const int c   = ((cs >> j) & 1u) ? -mag : mag;
-    const int v   = v2c[j];
-    int       r   = c + v; // ldpc_decoder_avx2.cpp:205-243 (c2v is never infinite)
-    r             = (r > LLR_MAX || v > LLR_MAX) ? LLR_INF : r;
-    r             = (r < -LLR_MAX || v < -LLR_MAX) ? -LLR_INF : r;
+  for (int j = D - 1; j >= 0; --j) {
+    const int  v     = v2c[j];
+    const bool ismin = max(v, -v) == mag1;
+    const int  mag   = ismin ? s2 : s1;
+    arg              = ismin ? j : arg;
+    const int smask  = (v ^ spm) >> 31; // sign of the product of all other messages
+    const int c      = (mag ^ smask) - smask;
+    cs |= (uint32_t)(smask & 1) << j;
+    const int r   = min(max(c + v, -LLR_INF), LLR_INF); // avx2.cpp:205-243 in the +-INF_INT encoding
     soft[addr[j]] = (int8_t)r;
   }
   w0 = (uint32_t)s1 | ((uint32_t)s2 << 7) | ((uint32_t)arg << 14) | (cs << 19);
@@ -161,7 +169,8 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                    const miphy_graph_tables* __restrict__ tab,
                    const int8_t* __restrict__ llr_base,
                    uint8_t* __restrict__ out_base,
-                   int32_t* __restrict__ iters_out)
+                   int32_t* __restrict__ iters_out,
+                   int max_layers)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const miphy_ldpc_dec_desc dsc = descs[blockIdx.x];
@@ -173,13 +182,14 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   const int                 bgM = bgi ? 42 : 46;
   const int                 NF  = bgK + bgM;
   const int                 K   = bgK * Z;
-  const int                 NZ  = NF * Z;
   const int                 zp  = tab->z_pos[Z];
 
   int8_t*   soft = reinterpret_cast<int8_t*>(smem);
-  const int soft_bytes = (NZ + 15) & ~15;
+  const int soft_bytes = ((bgK + min(bgM, max_layers)) * Z + 15) & ~15;
+  // Check-row state is only allocated for the layers this launch can reach (host-side bound from in_len).
+  const int lay_alloc = min(bgM, max_layers);
   uint32_t* st0  = reinterpret_cast<uint32_t*>(smem + soft_bytes);
-  uint32_t* st1  = st0 + bgM * Z;
+  uint32_t* st1  = st0 + lay_alloc * Z;
   uint32_t* red  = st1 + 4 * Z; // 16 words of scratch
 
   const int8_t* llr = llr_base + dsc.llr_offset;
@@ -195,10 +205,32 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     soft[k] = 0;
   __syncthreads();
   int last = 0;
-  for (int k = tid; k < in_len; k += nt) {
-    const int8_t v  = llr[k];
-    soft[2 * Z + k] = v;
-    last            = (v != 0) ? k + 1 : last;
+  if ((((uintptr_t)llr | (uintptr_t)(2 * Z)) & 15) == 0) {
+    // 16-byte coalesced path (the common case: Z multiple of 8, 16-byte aligned codeblock buffers).
+    const uint4* src = reinterpret_cast<const uint4*>(llr);
+    uint4*       dst = reinterpret_cast<uint4*>(soft + 2 * Z);
+    const int    nq  = in_len >> 4;
+    for (int q = tid; q < nq; q += nt) {
+      const uint4 v = src[q];
+      dst[q]        = v;
+      int hi = -1;
+      hi     = v.x ? 3 - (__clz((int)v.x) >> 3) : hi;
+      hi     = v.y ? 7 - (__clz((int)v.y) >> 3) : hi;
+      hi     = v.z ? 11 - (__clz((int)v.z) >> 3) : hi;
+      hi     = v.w ? 15 - (__clz((int)v.w) >> 3) : hi;
+      last   = (hi >= 0) ? 16 * q + hi + 1 : last;
+    }
+    for (int k = (nq << 4) + tid; k < in_len; k += nt) {
+      const int8_t v  = llr[k];
+      soft[2 * Z + k] = v;
+      last            = (v != 0) ? k + 1 : last;
+    }
+  } else {
+    for (int k = tid; k < in_len; k += nt) {
+      const int8_t v  = llr[k];
+      soft[2 * Z + k] = v;
+      last            = (v != 0) ? k + 1 : last;
+    }
   }
   atomicMax(reinterpret_cast<int*>(&red[0]), last);
   __syncthreads();
@@ -319,35 +351,51 @@ extern "C" int miphy_ldpc_decode_batch(miphy_ctx*                 ctx,
                                        const int8_t*              llr,
                                        uint8_t*                   out_bits,
                                        int32_t*                   iters,
+                                       const miphy_ldpc_dec_limits* limits,
                                        void*                      stream)
 {
   MIPHY_REQUIRE(ctx && descs && llr && out_bits && iters, "miphy_ldpc_decode_batch: null argument");
   if (n == 0)
     return MIPHY_OK;
   hipStream_t s = (hipStream_t)stream;
-  // Launch geometry comes from the largest Z / base graph in the batch. With device descriptors the caller vouches
-  // for validity; with host descriptors everything is checked here (the reference asserts the same conditions,
-  // ldpc_decoder_impl.cpp:66-84).
-  int max_threads = MIPHY_MAX_Z;
-  size_t max_lds  = 0;
+  // Launch geometry: threads from the largest Z, LDS from the largest number of layers any codeblock can reach
+  // (nof_layers <= ceil((in_len + 2Z)/Z) - bg_K, ldpc_decoder_impl.cpp:101-114). Host descriptors are validated here
+  // (the reference asserts the same conditions, ldpc_decoder_impl.cpp:66-84); for device descriptors the caller
+  // vouches for validity and may pass `limits` (worst case assumed otherwise).
+  int    max_threads = 64;
+  int    max_layers  = 4;
+  size_t max_lds     = 0;
+  auto   account     = [&](unsigned bg, unsigned Z, unsigned in_len) {
+    const unsigned bgK = (bg == 1) ? 22 : 10, bgM = (bg == 1) ? 46 : 42;
+    unsigned       lay = (in_len + 2 * Z + Z - 1) / Z;
+    lay                = (lay > bgK + 4) ? lay - bgK : 4;
+    lay                = lay > bgM ? bgM : lay;
+    const int    threads = ((Z + 63) / 64) * 64;
+    max_threads          = threads > max_threads ? threads : max_threads;
+    max_layers           = (int)lay > max_layers ? (int)lay : max_layers;
+  };
   if (!descs_on_device) {
-    max_threads = 64;
     for (uint32_t i = 0; i < n; ++i) {
       const miphy_ldpc_dec_desc& d = descs[i];
       MIPHY_REQUIRE(d.bg == 1 || d.bg == 2, "ldpc_decode: desc %u: invalid base graph %u", i, d.bg);
       MIPHY_REQUIRE(d.Z <= MIPHY_MAX_Z && ctx->h_tables->z_pos[d.Z] != 0xffff, "ldpc_decode: desc %u: invalid lifting size %u", i, d.Z);
-      const unsigned bgK = (d.bg == 1) ? 22 : 10, nshort = (d.bg == 1) ? 66 : 50, nfull = nshort + 2, bgM = nfull - bgK;
+      const unsigned bgK = (d.bg == 1) ? 22 : 10, nshort = (d.bg == 1) ? 66 : 50;
       MIPHY_REQUIRE(d.in_len >= (bgK + 2) * d.Z && d.in_len <= nshort * d.Z, "ldpc_decode: desc %u: input length %u out of range", i, d.in_len);
       MIPHY_REQUIRE(d.max_iter > 0, "ldpc_decode: desc %u: max_iter must be > 0", i);
       MIPHY_REQUIRE(d.crc_poly == MIPHY_CRC_NONE || d.crc_poly <= MIPHY_CRC11, "ldpc_decode: desc %u: invalid CRC", i);
       MIPHY_REQUIRE(d.nof_filler_bits < bgK * d.Z, "ldpc_decode: desc %u: invalid number of filler bits", i);
-      const int    threads = ((d.Z + 63) / 64) * 64;
-      const size_t lds     = ((nfull * d.Z + 15) & ~15u) + (size_t)(bgM + 4) * d.Z * 4 + 64;
-      max_threads          = threads > max_threads ? threads : max_threads;
-      max_lds              = lds > max_lds ? lds : max_lds;
+      account(d.bg, d.Z, d.in_len);
     }
+  } else if (limits) {
+    MIPHY_REQUIRE(limits->max_Z >= 2 && limits->max_Z <= MIPHY_MAX_Z, "ldpc_decode: limits: invalid max_Z");
+    account(1, limits->max_Z, limits->max_in_len);
   } else {
-    max_lds = ((68 * MIPHY_MAX_Z + 15) & ~15u) + (size_t)(46 + 4) * MIPHY_MAX_Z * 4 + 64;
+    account(1, MIPHY_MAX_Z, 66 * MIPHY_MAX_Z);
+  }
+  {
+    // Worst case over base graphs for the chosen layer bound (BG1 has the larger K).
+    const unsigned Zt = (unsigned)max_threads; // >= max Z
+    max_lds           = (((22 + max_layers) * Zt + 15) & ~15u) + (size_t)(max_layers + 4) * Zt * 4 + 64;
   }
   const void* d_descs = nullptr;
   int         rc      = miphy_stage_descs(ctx, descs, descs_on_device, sizeof(miphy_ldpc_dec_desc) * (size_t)n, s, &d_descs);
@@ -358,7 +406,7 @@ extern "C" int miphy_ldpc_decode_batch(miphy_ctx*                 ctx,
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
     lds_set = max_lds;
   }
-  hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n), dim3(max_threads), max_lds, s, (const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, llr, out_bits, iters);
+  hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n), dim3(max_threads), max_lds, s, (const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, llr, out_bits, iters, max_layers);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

@@ -31,7 +31,7 @@ def lib():
         l.miphy_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         l.miphy_destroy.argtypes = [C.c_void_p]
         l.miphy_ldpc_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p,
-                                              C.c_void_p, C.c_void_p]
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
         for name in ("miphy_ldpc_rate_dematch_batch", "miphy_ldpc_rate_match_batch", "miphy_ldpc_encode_batch"):
             getattr(l, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_crc_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -115,12 +115,16 @@ class Context:
         return descs, descs.numel() // dtype.itemsize, _dptr(descs), 1
 
     # ------------------------------------------------------------------ LDPC decoder
-    def ldpc_decode_batch(self, descs, llr, out_bits, iters, stream=None):
+    def ldpc_decode_batch(self, descs, llr, out_bits, iters, stream=None, limits=None):
+        """limits: optional (max_Z, max_in_len) for device-resident descriptors."""
         import torch
         descs, n, ptr, on_dev = self._descs(descs, LdpcDecDesc)
         assert iters.dtype == torch.int32 and iters.numel() >= n
+        lim = None
+        if limits is not None:
+            lim = (C.c_uint32 * 2)(int(limits[0]), int(limits[1]))
         check(lib().miphy_ldpc_decode_batch(self.h, ptr, on_dev, n, _dptr(llr), _dptr(out_bits), _dptr(iters),
-                                            _stream_ptr(stream)))
+                                            lim, _stream_ptr(stream)))
 
     # ------------------------------------------------------------------ LDPC rate (de)matching, encoder, CRC
     def ldpc_rate_dematch_batch(self, descs, llr_in, softbuf, stream=None):
