@@ -172,6 +172,45 @@ int miphy_crc_batch(miphy_ctx*            ctx,
                     uint32_t*             checksums, /* device, n entries */
                     void*                 stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * DFT processor  --  replaces srsran::dft_processor (get_input/run), batched
+ *   include/srsran/phy/generic_functions/dft_processor.h:34-73, lib/phy/generic_functions/dft_processor_generic_impl.cpp.
+ * Unnormalised; DIRECT uses exp(-j...), INVERSE exp(+j...). `n` transforms stored back to back (size cf_t each).
+ * Supported sizes this round: 2^a * 3^b <= 4096 (128 ... 4096 of the reference's 18 sizes); larger -> MIPHY_EUNSUPP. */
+int miphy_dft_batch(miphy_ctx* ctx, uint32_t size, int inverse, uint32_t n, const float* in /* device cf_t */,
+                    float* out /* device cf_t */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * OFDM slot (de)modulator  --  replaces srsran::ofdm_slot_demodulator::demodulate / ofdm_slot_modulator::modulate
+ *   include/srsran/phy/lower/modulation/ofdm_demodulator.h:33-102, lib/phy/lower/modulation/ofdm_demodulator_impl.cpp:34-170
+ *   include/srsran/phy/lower/modulation/ofdm_modulator.h,          lib/phy/lower/modulation/ofdm_modulator_impl.cpp:55-138
+ *   phase compensation: include/srsran/phy/lower/modulation/phase_compensation_lut.h:49-96 (TS 38.211 5.4).
+ * The configuration struct has the fields of srsran::ofdm_demodulator_configuration / ofdm_modulator_configuration
+ * (normal cyclic prefix). One job = one (slot, port): 14 symbols. */
+typedef struct {
+  uint32_t numerology;                /* mu: SCS = 15 kHz * 2^mu (0..2) */
+  uint32_t bw_rb;                     /* resource grid width in PRB */
+  uint32_t dft_size;
+  uint32_t nof_samples_window_offset; /* demodulator only; 0 for the modulator */
+  float    scale;
+  float    reserved;
+  double   center_freq_hz;
+} miphy_ofdm_config;
+
+typedef struct {
+  uint64_t samples_offset; /* cf_t element offset of the first sample of the slot inside the time-domain buffer */
+  uint64_t grid_offset;    /* cf_t element offset of this port's [14][bw_rb*12] grid inside the grid buffer */
+  uint32_t slot_index;     /* slot index within the subframe */
+  uint32_t grid_empty;     /* modulator: non-zero reproduces the empty-grid shortcut (output zeros) */
+} miphy_ofdm_job;
+
+int miphy_ofdm_demodulate_slots(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm_job* jobs, int jobs_on_device,
+                                uint32_t n, const float* samples /* device cf_t */, float* grid /* device cf_t */, void* stream);
+int miphy_ofdm_modulate_slots(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm_job* jobs, int jobs_on_device,
+                              uint32_t n, const float* grid /* device cf_t */, float* samples /* device cf_t */, void* stream);
+/* Number of samples of slot `slot_index` (ofdm_slot_demodulator::get_slot_size). Returns 0 on invalid configuration. */
+uint32_t miphy_ofdm_slot_size(const miphy_ofdm_config* cfg, uint32_t slot_index);
+
 #ifdef __cplusplus
 }
 #endif

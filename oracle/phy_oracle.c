@@ -628,3 +628,157 @@ int orc_pusch_decode(int bg, int rv, int mod, unsigned Nref, unsigned nof_layers
   free(tmp_tb);
   return ok;
 }
+
+/* ------------------------------------------------------------------------------------------------ DFT / OFDM
+ * dft_processor contract: include/srsran/phy/generic_functions/dft_processor.h:34-73 (unnormalised, DIRECT = exp(-j..)). */
+#include <complex.h>
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+static void dft_double(unsigned N, int inverse, const double complex* in, double complex* out)
+{
+  double complex* w = (double complex*)malloc(sizeof(double complex) * N);
+  for (unsigned j = 0; j < N; ++j) {
+    double a = (inverse ? 2.0 : -2.0) * M_PI * (double)j / (double)N;
+    w[j]     = cos(a) + I * sin(a);
+  }
+  for (unsigned k = 0; k < N; ++k) {
+    double complex acc = 0;
+    unsigned       idx = 0;
+    for (unsigned n = 0; n < N; ++n) {
+      acc += in[n] * w[idx];
+      idx += k;
+      if (idx >= N)
+        idx -= N;
+    }
+    out[k] = acc;
+  }
+  free(w);
+}
+
+int orc_dft(unsigned N, int inverse, const float* in, float* out)
+{
+  double complex* a = (double complex*)malloc(sizeof(double complex) * N);
+  double complex* b = (double complex*)malloc(sizeof(double complex) * N);
+  for (unsigned i = 0; i < N; ++i)
+    a[i] = (double)in[2 * i] + I * (double)in[2 * i + 1];
+  dft_double(N, inverse, a, b);
+  for (unsigned i = 0; i < N; ++i) {
+    out[2 * i]     = (float)creal(b[i]);
+    out[2 * i + 1] = (float)cimag(b[i]);
+  }
+  free(a);
+  free(b);
+  return 0;
+}
+
+/* include/srsran/ran/cyclic_prefix.h:96-107 + phy_time_unit.h:98-108 (normal CP). */
+static unsigned cp_samples(unsigned mu, unsigned sym_sf, unsigned dft_size)
+{
+  unsigned units = 144u >> mu;
+  if (sym_sf == 0 || sym_sf == 7u * (1u << mu))
+    units += 16;
+  return (unsigned)((unsigned long long)units * (1u << mu) * dft_size / 2048u);
+}
+
+unsigned orc_ofdm_slot_size(const orc_ofdm_cfg* c, unsigned slot_index)
+{
+  unsigned n = 0;
+  for (unsigned l = 0; l < 14; ++l)
+    n += cp_samples(c->numerology, slot_index * 14 + l, c->dft_size) + c->dft_size;
+  return n;
+}
+
+/* phase_compensation_lut.h:55-82 */
+static float complex phase_coef(const orc_ofdm_cfg* c, unsigned sym_sf, int is_tx)
+{
+  double   srate = 15000.0 * (double)(1u << c->numerology) * (double)c->dft_size;
+  unsigned off   = 0;
+  for (unsigned s = 0; s <= sym_sf; ++s) {
+    off += cp_samples(c->numerology, s, c->dft_size);
+    if (s == sym_sf)
+      break;
+    off += c->dft_size;
+  }
+  double t     = (double)off / srate;
+  double phase = (is_tx ? -1.0 : 1.0) * 2.0 * M_PI * c->center_freq_hz * t;
+  double complex e = cexp(I * phase);
+  return (float)creal(e) + I * (float)cimag(e);
+}
+
+static float complex cmulf_(float complex a, float complex b)
+{ /* plain complex product, as the reference's srsvec::prod / sc_prod do (no inf/nan fix-ups) */
+  float ar = crealf(a), ai = cimagf(a), br = crealf(b), bi = cimagf(b);
+  return (ar * br - ai * bi) + I * (ar * bi + ai * br);
+}
+
+/* ofdm_demodulator_impl.cpp:93-138 */
+int orc_ofdm_demod_slot(const orc_ofdm_cfg* c, unsigned slot_index, const float* in, float* grid_out)
+{
+  unsigned        N = c->dft_size, rg = c->bw_rb * 12;
+  double complex* a = (double complex*)malloc(sizeof(double complex) * N);
+  double complex* b = (double complex*)malloc(sizeof(double complex) * N);
+  unsigned        pos = 0;
+  for (unsigned l = 0; l < 14; ++l) {
+    unsigned sym = slot_index * 14 + l;
+    unsigned cp  = cp_samples(c->numerology, sym, N);
+    const float* src = in + 2 * (size_t)(pos + cp - c->window_offset);
+    for (unsigned i = 0; i < N; ++i)
+      a[i] = (double)src[2 * i] + I * (double)src[2 * i + 1];
+    dft_double(N, 0, a, b);
+    float complex coef = phase_coef(c, sym, 0);
+    coef = (crealf(coef) * c->scale) + I * (cimagf(coef) * c->scale);
+    float complex omega = 0;
+    if (c->window_offset) /* :70-72, single precision like the reference */
+      omega = I * ((float)c->window_offset * (float)(2.0 * M_PI) / (float)N);
+    for (unsigned k = 0; k < rg; ++k) {
+      unsigned      bin = (k < rg / 2) ? N - rg / 2 + k : k - rg / 2;
+      float complex x   = (float)creal(b[bin]) + I * (float)cimag(b[bin]);
+      float complex v   = cmulf_(x, coef);
+      if (c->window_offset)
+        v = cmulf_(v, cexpf(omega * (float)bin));
+      grid_out[2 * ((size_t)l * rg + k)]     = crealf(v);
+      grid_out[2 * ((size_t)l * rg + k) + 1] = cimagf(v);
+    }
+    pos += cp + N;
+  }
+  free(a);
+  free(b);
+  return 0;
+}
+
+/* ofdm_modulator_impl.cpp:55-99 */
+int orc_ofdm_mod_slot(const orc_ofdm_cfg* c, unsigned slot_index, const float* grid_in, float* out)
+{
+  unsigned        N = c->dft_size, rg = c->bw_rb * 12;
+  double complex* a = (double complex*)malloc(sizeof(double complex) * N);
+  double complex* b = (double complex*)malloc(sizeof(double complex) * N);
+  unsigned        pos = 0;
+  for (unsigned l = 0; l < 14; ++l) {
+    unsigned sym = slot_index * 14 + l;
+    unsigned cp  = cp_samples(c->numerology, sym, N);
+    for (unsigned i = 0; i < N; ++i)
+      a[i] = 0;
+    const float* g = grid_in + 2 * (size_t)l * rg;
+    for (unsigned k = 0; k < rg / 2; ++k) {
+      a[N - rg / 2 + k] = (double)g[2 * k] + I * (double)g[2 * k + 1];
+      a[k]              = (double)g[2 * (rg / 2 + k)] + I * (double)g[2 * (rg / 2 + k) + 1];
+    }
+    dft_double(N, 1, a, b);
+    float complex coef = phase_coef(c, sym, 1);
+    coef = (crealf(coef) * c->scale) + I * (cimagf(coef) * c->scale);
+    float* dst = out + 2 * (size_t)pos;
+    for (unsigned i = 0; i < N + cp; ++i) {
+      unsigned      j = (i < cp) ? N - cp + i : i - cp;
+      float complex x = (float)creal(b[j]) + I * (float)cimag(b[j]);
+      float complex v = cmulf_(x, coef);
+      dst[2 * i]      = crealf(v);
+      dst[2 * i + 1]  = cimagf(v);
+    }
+    pos += cp + N;
+  }
+  free(a);
+  free(b);
+  return 0;
+}

@@ -74,6 +74,22 @@ int orc_pusch_decode(int bg, int rv, int mod, unsigned Nref, unsigned nof_layers
                      unsigned tb_bytes, int new_data, const int8_t* llrs, unsigned max_iter, int early_stop,
                      int8_t* softbuf, uint8_t* cb_crc, uint8_t* cb_msgs, uint8_t* tb_out, int* iters_minmax);
 
+
+/* ------------------------------------------------------------------------------------------------ DFT / OFDM
+ * Exact-arithmetic checkers: the transform itself is evaluated in double precision (the reference's generic radix-2 DFT
+ * and FFTW are only specified up to rounding: tests/unittests/phy/generic_functions/dft_processor_test.cpp:40-42),
+ * everything around it follows the reference's single-precision operation order. cf_t = interleaved float re,im. */
+int orc_dft(unsigned N, int inverse, const float* in, float* out);
+typedef struct {
+  unsigned numerology, bw_rb, dft_size, window_offset;
+  float    scale;
+  double   center_freq_hz;
+} orc_ofdm_cfg;
+unsigned orc_ofdm_slot_size(const orc_ofdm_cfg* c, unsigned slot_index);
+/* in: slot samples; grid_out: [14][bw_rb*12] cf_t */
+int orc_ofdm_demod_slot(const orc_ofdm_cfg* c, unsigned slot_index, const float* in, float* grid_out);
+int orc_ofdm_mod_slot(const orc_ofdm_cfg* c, unsigned slot_index, const float* grid_in, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,12 @@
 #include "srsran/phy/upper/rx_softbuffer_pool.h"
 #include "srsran/phy/upper/unique_rx_softbuffer.h"
 #include "srsran/srsvec/bit.h"
+#include "srsran/phy/lower/modulation/modulation_factories.h"
+#include "srsran/phy/support/support_factories.h"
+#include "srsran/phy/upper/channel_estimation.h"
+#include "srsran/phy/upper/sequence_generators/sequence_generator_factories.h"
+#include "srsran/phy/upper/signal_processors/signal_processor_factories.h"
+#include "lib/phy/generic_functions/dft_processor_generic_impl.h"
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -71,6 +77,22 @@ codeblock_metadata make_meta(int bg, int Z, int rv, int mod, unsigned Nref, unsi
   m.cb_specific.nof_crc_bits    = nof_crc_bits;
   return m;
 }
+
+// A dft_processor_factory (public abstract interface, include/srsran/phy/generic_functions/generic_functions_factories.h)
+// that hands out the reference's own generic radix-2 DFT implementation. (The reference's factory translation unit
+// unconditionally needs <fftw3.h>, which this image lacks, so that file is not compiled.)
+class generic_dft_factory : public dft_processor_factory
+{
+public:
+  std::unique_ptr<dft_processor> create(const dft_processor::configuration& config) override
+  {
+    auto p = std::make_unique<dft_processor_generic_impl>(config);
+    if (!p->is_valid()) {
+      return nullptr;
+    }
+    return p;
+  }
+};
 
 double now_s()
 {
@@ -391,6 +413,268 @@ int ref_pusch_decode(void*          hv,
   // Release the buffer for the next call.
   h->pool->run_slot(slot + 200000);
   return (int)nof_cbs;
+}
+
+// ---------------------------------------------------------------- DFT (generic radix-2 implementation of the reference)
+int ref_dft(unsigned size, int inverse, const float* in, float* out)
+{
+  generic_dft_factory          f;
+  dft_processor::configuration c;
+  c.size = size;
+  c.dir  = inverse ? dft_processor::direction::INVERSE : dft_processor::direction::DIRECT;
+  auto d = f.create(c);
+  if (!d) {
+    return -1;
+  }
+  std::memcpy(d->get_input().data(), in, sizeof(cf_t) * size);
+  span<const cf_t> o = d->run();
+  std::memcpy(out, o.data(), sizeof(cf_t) * size);
+  return 0;
+}
+
+// ---------------------------------------------------------------- OFDM slot demodulator / modulator
+// in: slot samples (get_slot_size) ; grid_out: [14][bw_rb*12] cf_t for one port.
+int ref_ofdm_demod_slot(unsigned     numerology,
+                        unsigned     bw_rb,
+                        unsigned     dft_size,
+                        unsigned     window_offset,
+                        float        scale,
+                        double       center_freq_hz,
+                        unsigned     slot_index,
+                        const float* in,
+                        unsigned     nof_in_samples,
+                        float*       grid_out)
+{
+  ofdm_factory_generic_configuration fc;
+  fc.dft_factory = std::make_shared<generic_dft_factory>();
+  auto                           f = create_ofdm_demodulator_factory_generic(fc);
+  ofdm_demodulator_configuration c;
+  c.numerology                = numerology;
+  c.bw_rb                     = bw_rb;
+  c.dft_size                  = dft_size;
+  c.cp                        = cyclic_prefix::NORMAL;
+  c.nof_samples_window_offset = window_offset;
+  c.scale                     = scale;
+  c.center_freq_hz            = center_freq_hz;
+  auto d                      = f->create_ofdm_slot_demodulator(c);
+  if (d->get_slot_size(slot_index) != nof_in_samples) {
+    return -(int)d->get_slot_size(slot_index);
+  }
+  auto grid = create_resource_grid(1, 14, bw_rb * 12);
+  d->demodulate(*grid, span<const cf_t>(reinterpret_cast<const cf_t*>(in), nof_in_samples), 0, slot_index);
+  for (unsigned l = 0; l != 14; ++l) {
+    grid->get(span<cf_t>(reinterpret_cast<cf_t*>(grid_out) + size_t(l) * bw_rb * 12, bw_rb * 12), 0, l, 0);
+  }
+  return 0;
+}
+
+int ref_ofdm_mod_slot(unsigned     numerology,
+                      unsigned     bw_rb,
+                      unsigned     dft_size,
+                      float        scale,
+                      double       center_freq_hz,
+                      unsigned     slot_index,
+                      const float* grid_in,
+                      float*       out,
+                      unsigned     nof_out_samples)
+{
+  ofdm_factory_generic_configuration fc;
+  fc.dft_factory = std::make_shared<generic_dft_factory>();
+  auto                         f = create_ofdm_modulator_factory_generic(fc);
+  ofdm_modulator_configuration c;
+  c.numerology     = numerology;
+  c.bw_rb          = bw_rb;
+  c.dft_size       = dft_size;
+  c.cp             = cyclic_prefix::NORMAL;
+  c.scale          = scale;
+  c.center_freq_hz = center_freq_hz;
+  auto m           = f->create_ofdm_slot_modulator(c);
+  if (m->get_slot_size(slot_index) != nof_out_samples) {
+    return -(int)m->get_slot_size(slot_index);
+  }
+  auto grid = create_resource_grid(1, 14, bw_rb * 12);
+  for (unsigned l = 0; l != 14; ++l) {
+    grid->put(0, l, 0, span<const cf_t>(reinterpret_cast<const cf_t*>(grid_in) + size_t(l) * bw_rb * 12, bw_rb * 12));
+  }
+  m->modulate(span<cf_t>(reinterpret_cast<cf_t*>(out), nof_out_samples), *grid, 0, slot_index);
+  return 0;
+}
+
+// Times `reps` slot demodulations (single thread); returns seconds.
+double ref_ofdm_demod_time(unsigned numerology, unsigned bw_rb, unsigned dft_size, unsigned window_offset, double center_freq_hz,
+                           const float* in, unsigned nof_in_samples, unsigned reps)
+{
+  ofdm_factory_generic_configuration fc;
+  fc.dft_factory = std::make_shared<generic_dft_factory>();
+  auto                           f = create_ofdm_demodulator_factory_generic(fc);
+  ofdm_demodulator_configuration c;
+  c.numerology                = numerology;
+  c.bw_rb                     = bw_rb;
+  c.dft_size                  = dft_size;
+  c.cp                        = cyclic_prefix::NORMAL;
+  c.nof_samples_window_offset = window_offset;
+  c.scale                     = 1.0F;
+  c.center_freq_hz            = center_freq_hz;
+  auto   d                    = f->create_ofdm_slot_demodulator(c);
+  auto   grid                 = create_resource_grid(1, 14, bw_rb * 12);
+  double t0                   = now_s();
+  for (unsigned r = 0; r != reps; ++r) {
+    d->demodulate(*grid, span<const cf_t>(reinterpret_cast<const cf_t*>(in), nof_in_samples), 0, 0);
+  }
+  return now_s() - t0;
+}
+
+// ---------------------------------------------------------------- DM-RS PUSCH channel estimator
+// grid_in: [nof_rx_ports][14][nof_prb_grid*12] cf_t. rb_mask: nof_prb_grid bytes (0/1). symbols_mask: 14 bytes.
+// ce_out: [nof_layers][nof_rx_ports][first+nof][nof_prb_grid*12] cf_t (path-major like channel_estimate).
+// scalars_out: per (port, layer): rsrp, epre, noise_var, snr, time_alignment_s  (5 floats).
+int ref_dmrs_pusch_estimate(unsigned       numerology,
+                            unsigned       slot_index,
+                            int            dmrs_type2,
+                            unsigned       scrambling_id,
+                            int            n_scid,
+                            float          scaling,
+                            const uint8_t* symbols_mask,
+                            const uint8_t* rb_mask,
+                            unsigned       nof_prb_grid,
+                            unsigned       first_symbol,
+                            unsigned       nof_symbols,
+                            unsigned       nof_tx_layers,
+                            unsigned       nof_rx_ports,
+                            const float*   grid_in,
+                            float*         ce_out,
+                            float*         scalars_out)
+{
+  auto prg_f  = create_pseudo_random_generator_sw_factory();
+  auto port_f = create_port_channel_estimator_factory_sw(std::make_shared<generic_dft_factory>());
+  auto est    = create_dmrs_pusch_estimator_factory_sw(prg_f, port_f)->create();
+  auto grid   = create_resource_grid(nof_rx_ports, 14, nof_prb_grid * 12);
+  for (unsigned p = 0; p != nof_rx_ports; ++p) {
+    for (unsigned l = 0; l != 14; ++l) {
+      grid->put(p, l, 0, span<const cf_t>(reinterpret_cast<const cf_t*>(grid_in) + (size_t(p) * 14 + l) * nof_prb_grid * 12, nof_prb_grid * 12));
+    }
+  }
+  dmrs_pusch_estimator::configuration cfg;
+  cfg.slot          = slot_point(numerology, slot_index);
+  cfg.type          = dmrs_type2 ? dmrs_type::TYPE2 : dmrs_type::TYPE1;
+  cfg.scrambling_id = scrambling_id;
+  cfg.n_scid        = n_scid != 0;
+  cfg.scaling       = scaling;
+  cfg.c_prefix      = cyclic_prefix::NORMAL;
+  cfg.symbols_mask  = bounded_bitset<MAX_NSYMB_PER_SLOT>(14);
+  for (unsigned l = 0; l != 14; ++l) {
+    if (symbols_mask[l]) {
+      cfg.symbols_mask.set(l);
+    }
+  }
+  cfg.rb_mask = bounded_bitset<MAX_RB>(nof_prb_grid);
+  for (unsigned r = 0; r != nof_prb_grid; ++r) {
+    if (rb_mask[r]) {
+      cfg.rb_mask.set(r);
+    }
+  }
+  cfg.first_symbol  = first_symbol;
+  cfg.nof_symbols   = nof_symbols;
+  cfg.nof_tx_layers = nof_tx_layers;
+  for (unsigned p = 0; p != nof_rx_ports; ++p) {
+    cfg.rx_ports.push_back(p);
+  }
+  channel_estimate ce;
+  est->estimate(ce, *grid, cfg);
+  unsigned nsymb = first_symbol + nof_symbols;
+  unsigned nsc   = nof_prb_grid * 12;
+  for (unsigned ly = 0; ly != nof_tx_layers; ++ly) {
+    for (unsigned p = 0; p != nof_rx_ports; ++p) {
+      for (unsigned l = 0; l != nsymb; ++l) {
+        span<const cf_t> v = static_cast<const channel_estimate&>(ce).get_symbol_ch_estimate(l, p, ly);
+        std::memcpy(ce_out + 2 * (((size_t(ly) * nof_rx_ports + p) * nsymb + l) * nsc), v.data(), sizeof(cf_t) * nsc);
+      }
+      float* sc = scalars_out + 5 * (size_t(p) * nof_tx_layers + ly);
+      sc[0]     = ce.get_rsrp(p, ly);
+      sc[1]     = ce.get_epre(p, ly);
+      sc[2]     = ce.get_noise_variance(p, ly);
+      sc[3]     = ce.get_snr(p, ly);
+      sc[4]     = (float)ce.get_time_alignment(p, ly).to_seconds();
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- polar
+// Code construction: fills N, nPC, K_set (N bytes), PC_set (up to 3), F_set (N bytes), blk_interleaver (N uint16).
+int ref_polar_code(unsigned K, unsigned E, unsigned nMax, int ibil, unsigned* n_out, unsigned* npc_out, uint8_t* k_set, uint16_t* pc_set,
+                   uint16_t* blk_interleaver)
+{
+  auto f    = create_polar_factory_sw();
+  auto code = f->create_code();
+  code->set(K, E, nMax, ibil ? polar_code_ibil::present : polar_code_ibil::not_present);
+  *n_out   = code->get_n();
+  *npc_out = code->get_nPC();
+  unsigned N = code->get_N();
+  for (unsigned i = 0; i != N; ++i) {
+    k_set[i] = code->get_K_set().test(i) ? 1 : 0;
+  }
+  span<const uint16_t> pc = code->get_PC_set();
+  for (unsigned i = 0; i != pc.size(); ++i) {
+    pc_set[i] = pc[i];
+  }
+  span<const uint16_t> bi = code->get_blk_interleaver();
+  for (unsigned i = 0; i != N; ++i) {
+    blk_interleaver[i] = bi[i];
+  }
+  return (int)pc.size();
+}
+
+// Mother-code reliability sequence for size 2^n (polar_code_impl.cpp get_mother_code).
+// Tx chain of polar_chain_test.cpp:176-190: allocate -> encode -> rate match. msg: K bytes (1 bit/byte) -> out: E bytes.
+int ref_polar_encode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, const uint8_t* msg, uint8_t* out, uint8_t* allocated_out,
+                           uint8_t* encoded_out)
+{
+  auto f    = create_polar_factory_sw();
+  auto code = f->create_code();
+  code->set(K, E, nMax, ibil ? polar_code_ibil::present : polar_code_ibil::not_present);
+  unsigned             N = code->get_N();
+  std::vector<uint8_t> alloc(N), enc(N);
+  f->create_allocator()->allocate(alloc, span<const uint8_t>(msg, K), *code);
+  f->create_encoder()->encode(enc, alloc, code->get_n());
+  f->create_rate_matcher()->rate_match(span<uint8_t>(out, E), enc, *code);
+  if (allocated_out) {
+    std::memcpy(allocated_out, alloc.data(), N);
+  }
+  if (encoded_out) {
+    std::memcpy(encoded_out, enc.data(), N);
+  }
+  return (int)N;
+}
+
+// Rx chain of polar_chain_test.cpp:197-206: rate dematch -> SSC decode -> deallocate. llr: E int8 -> msg: K bytes.
+int ref_polar_decode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, const int8_t* llr, uint8_t* msg, int8_t* dematched_out,
+                           uint8_t* decoded_u_out)
+{
+  auto f    = create_polar_factory_sw();
+  auto code = f->create_code();
+  code->set(K, E, nMax, ibil ? polar_code_ibil::present : polar_code_ibil::not_present);
+  unsigned                          N = code->get_N();
+  std::vector<log_likelihood_ratio> dem(N);
+  std::vector<uint8_t>              u(N);
+  f->create_rate_dematcher()->rate_dematch(dem, span<const log_likelihood_ratio>(reinterpret_cast<const log_likelihood_ratio*>(llr), E), *code);
+  f->create_decoder(nMax)->decode(u, dem, *code);
+  f->create_deallocator()->deallocate(span<uint8_t>(msg, K), u, *code);
+  if (dematched_out) {
+    std::memcpy(dematched_out, dem.data(), N);
+  }
+  if (decoded_u_out) {
+    std::memcpy(decoded_u_out, u.data(), N);
+  }
+  return (int)N;
+}
+
+// CRC interleaver (polar_interleaver, TS 38.212 5.3.1.1). dir: 0 = tx, 1 = rx.
+int ref_polar_interleave(const uint8_t* in, uint8_t* out, unsigned K, int dir)
+{
+  auto f = create_polar_factory_sw();
+  f->create_interleaver()->interleave(span<uint8_t>(out, K), span<const uint8_t>(in, K), dir ? polar_interleaver_direction::rx : polar_interleaver_direction::tx);
+  return 0;
 }
 
 } // extern "C"

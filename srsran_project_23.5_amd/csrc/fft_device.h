@@ -1,0 +1,170 @@
+// In-LDS Stockham FFT (autosort, decimation in frequency) for N = 2^a * 3^b <= 4096, one workgroup per transform.
+// Unnormalised, sign -1 for DIRECT and +1 for INVERSE like srsran::dft_processor
+// (include/srsran/phy/generic_functions/dft_processor.h:34-73, lib/phy/generic_functions/dft_processor_generic_impl.cpp:191).
+//
+// One LDS buffer of N float2: every pass loads its radix-R inputs into registers, barriers, then scatters the outputs
+// (two barriers per pass, half the LDS of a ping-pong scheme -> more transforms resident per CU).
+#pragma once
+#include "miphy_internal.h"
+
+struct cplx {
+  float x, y;
+};
+__device__ __forceinline__ cplx cmul(cplx a, cplx b)
+{
+  return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+__device__ __forceinline__ cplx cadd(cplx a, cplx b)
+{
+  return {a.x + b.x, a.y + b.y};
+}
+__device__ __forceinline__ cplx csub(cplx a, cplx b)
+{
+  return {a.x - b.x, a.y - b.y};
+}
+// multiply by -i (DIRECT) or +i (INVERSE)
+template <bool INV>
+__device__ __forceinline__ cplx cmul_mi(cplx a)
+{
+  return INV ? cplx{-a.y, a.x} : cplx{a.y, -a.x};
+}
+template <bool INV>
+__device__ __forceinline__ cplx cconj_if(cplx a)
+{
+  return INV ? cplx{a.x, -a.y} : a;
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft2(cplx& a, cplx& b)
+{
+  cplx t = csub(a, b);
+  a      = cadd(a, b);
+  b      = t;
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft4(cplx& a0, cplx& a1, cplx& a2, cplx& a3)
+{
+  cplx s02 = cadd(a0, a2), d02 = csub(a0, a2);
+  cplx s13 = cadd(a1, a3), d13 = cmul_mi<INV>(csub(a1, a3));
+  a0 = cadd(s02, s13);
+  a2 = csub(s02, s13);
+  a1 = cadd(d02, d13);
+  a3 = csub(d02, d13);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft3(cplx& a0, cplx& a1, cplx& a2)
+{
+  // w = exp(-+ 2 pi i / 3) = -1/2 -+ i sqrt(3)/2
+  const float hs = 0.86602540378443864676f;
+  cplx        s  = cadd(a1, a2);
+  cplx        d  = csub(a1, a2);
+  cplx        m  = {a0.x - 0.5f * s.x, a0.y - 0.5f * s.y};
+  cplx        r  = cmul_mi<INV>(cplx{hs * d.x, hs * d.y}); // -+ i * hs * (a1 - a2)
+  a0             = cadd(a0, s);
+  a1             = cadd(m, r);
+  a2             = csub(m, r);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft8(cplx* a)
+{
+  // Two radix-4 on even/odd + twiddles exp(-+ 2 pi i k / 8).
+  dft4<INV>(a[0], a[2], a[4], a[6]);
+  dft4<INV>(a[1], a[3], a[5], a[7]);
+  const float r = 0.70710678118654752440f;
+  cplx        t1 = INV ? cplx{r * (a[3].x - a[3].y), r * (a[3].x + a[3].y)} : cplx{r * (a[3].x + a[3].y), r * (a[3].y - a[3].x)};
+  cplx        t2 = cmul_mi<INV>(a[5]);
+  cplx        t3 = INV ? cplx{-r * (a[7].x + a[7].y), r * (a[7].x - a[7].y)} : cplx{r * (a[7].y - a[7].x), -r * (a[7].x + a[7].y)};
+  // outputs: X[k] = E[k] + w^k O[k], X[k+4] = E[k] - w^k O[k], with E = (a0,a2,a4,a6), O = (a1,a3,a5,a7)
+  cplx e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6], o0 = a[1];
+  a[0] = cadd(e0, o0);
+  a[4] = csub(e0, o0);
+  a[1] = cadd(e1, t1);
+  a[5] = csub(e1, t1);
+  a[2] = cadd(e2, t2);
+  a[6] = csub(e2, t2);
+  a[3] = cadd(e3, t3);
+  a[7] = csub(e3, t3);
+}
+
+// One Stockham pass of radix R over the N-point buffer `x` (LDS). n = current sub-transform length, s = stride (product of
+// the radices already applied). tw = exp(-2 pi i j / N) table in global memory. All threads of the block must call.
+template <int R, bool INV>
+__device__ __forceinline__ void fft_pass(cplx* x, int N, int n, int s, const cplx* __restrict__ tw, int tid, int nt)
+{
+  const int m  = n / R;
+  const int nb = N / R; // butterflies
+  // Butterflies per thread: the launcher guarantees N <= 16 * blockDim, i.e. nb <= MAXB * nt.
+  constexpr int MAXB = (R == 8) ? 2 : (R == 4) ? 4 : (R == 2) ? 8 : 6;
+  cplx          a[MAXB][R];
+#pragma unroll
+  for (int c = 0; c < MAXB; ++c) {
+    const int t = tid + c * nt;
+    if (t < nb) {
+      const int p = t / s, q = t - p * s;
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        a[c][k] = x[q + s * (p + m * k)];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < MAXB; ++c) {
+    const int t = tid + c * nt;
+    if (t < nb) {
+      const int p = t / s, q = t - p * s;
+      cplx*     v = a[c];
+      if (R == 2)
+        dft2<INV>(v[0], v[1]);
+      else if (R == 3)
+        dft3<INV>(v[0], v[1], v[2]);
+      else if (R == 4)
+        dft4<INV>(v[0], v[1], v[2], v[3]);
+      else
+        dft8<INV>(v);
+      if (m > 1) { // twiddle exp(-+ 2 pi i p k / n) = W_N^(p k s)
+        const cplx w1 = cconj_if<INV>(tw[p * s]);
+        cplx       w  = w1;
+#pragma unroll
+        for (int k = 1; k < R; ++k) {
+          v[k] = cmul(v[k], w);
+          if (k + 1 < R)
+            w = cmul(w, w1);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        x[q + s * (R * p + k)] = v[k];
+    }
+  }
+  __syncthreads();
+}
+
+// Full transform of the N points in LDS buffer x (natural order in, natural order out).
+template <bool INV>
+__device__ __forceinline__ void fft_lds(cplx* x, int N, const cplx* __restrict__ tw, int tid, int nt)
+{
+  int n = N, s = 1;
+  while (n % 8 == 0) {
+    fft_pass<8, INV>(x, N, n, s, tw, tid, nt);
+    n /= 8;
+    s *= 8;
+  }
+  while (n % 4 == 0) {
+    fft_pass<4, INV>(x, N, n, s, tw, tid, nt);
+    n /= 4;
+    s *= 4;
+  }
+  while (n % 2 == 0) {
+    fft_pass<2, INV>(x, N, n, s, tw, tid, nt);
+    n /= 2;
+    s *= 2;
+  }
+  while (n % 3 == 0) {
+    fft_pass<3, INV>(x, N, n, s, tw, tid, nt);
+    n /= 3;
+    s *= 3;
+  }
+}

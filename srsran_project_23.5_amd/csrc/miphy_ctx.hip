@@ -1,5 +1,6 @@
 // Context: device tables (TS 38.212 graphs, CRC constants), descriptor staging, error reporting.
 #include "miphy_internal.h"
+#include "miphy_ext.h"
 #include "tables/nr_ldpc_tables.h"
 #include <cstdarg>
 #include <cstdlib>
@@ -111,6 +112,7 @@ extern "C" int miphy_create(int device, miphy_ctx** out)
   if (!c)
     return MIPHY_ENOMEM;
   c->device   = device;
+  c->ext      = new miphy_ctx_ext();
   c->h_tables = (miphy_graph_tables*)malloc(sizeof(miphy_graph_tables));
   build_tables(c->h_tables);
   MIPHY_HIP_CHECK(hipMalloc((void**)&c->d_tables, sizeof(miphy_graph_tables)));
@@ -128,6 +130,9 @@ extern "C" void miphy_destroy(miphy_ctx* c)
     return;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_tables);
+  for (void* p : c->ext->to_free)
+    (void)hipFree(p);
+  delete c->ext;
   (void)hipFree(c->d_desc_staging);
   (void)hipHostFree(c->h_desc_staging);
   free(c->h_tables);

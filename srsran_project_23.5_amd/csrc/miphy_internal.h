@@ -25,8 +25,11 @@ struct miphy_graph_tables {
   uint32_t crc_order[5];
 };
 
+struct miphy_ctx_ext; // C++ side caches (twiddle tables, OFDM plans), see miphy_ext.h
+
 struct miphy_ctx {
   int                  device;
+  miphy_ctx_ext*       ext;
   miphy_graph_tables*  d_tables; // device copy
   miphy_graph_tables*  h_tables; // host copy
   void*                d_desc_staging;

@@ -1,0 +1,340 @@
+// Batched DFT and OFDM slot (de)modulation: one workgroup per OFDM symbol, FFT in LDS, CP / window-offset handling fused
+// into the load and the TS 38.211 5.4 phase compensation, window ramp and fftshift mapping fused into the store.
+//
+// Behaviour contract: lib/phy/lower/modulation/ofdm_demodulator_impl.cpp:93-138, ofdm_modulator_impl.cpp:55-99,
+// include/srsran/phy/lower/modulation/phase_compensation_lut.h:49-96, include/srsran/ran/cyclic_prefix.h:96-107.
+#include "fft_device.h"
+#include "miphy_ext.h"
+#include <cmath>
+#include <complex>
+
+namespace {
+
+template <bool INV>
+__global__ void __launch_bounds__(256) dft_kernel(const float2* __restrict__ in, float2* __restrict__ out, const cplx* __restrict__ tw, int N)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cplx*         x   = reinterpret_cast<cplx*>(smem);
+  const float2* src = in + (size_t)blockIdx.x * N;
+  float2*       dst = out + (size_t)blockIdx.x * N;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    float2 v = src[i];
+    x[i]     = {v.x, v.y};
+  }
+  __syncthreads();
+  fft_lds<INV>(x, N, tw, threadIdx.x, blockDim.x);
+  for (int i = threadIdx.x; i < N; i += blockDim.x)
+    dst[i] = make_float2(x[i].x, x[i].y);
+}
+
+__global__ void __launch_bounds__(256) ofdm_demod_kernel(const miphy_ofdm_job* __restrict__ jobs,
+                                                         const ofdm_plan_dev* __restrict__ plan,
+                                                         const cplx* __restrict__ tw,
+                                                         const cplx* __restrict__ ramp,
+                                                         const float2* __restrict__ samples,
+                                                         float2* __restrict__ grid)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cplx*                x   = reinterpret_cast<cplx*>(smem);
+  const miphy_ofdm_job job = jobs[blockIdx.y];
+  const int            l   = blockIdx.x;
+  const int            N = plan->N, rg = plan->rg;
+  const int            sym = (int)job.slot_index * 14 + l;
+  // FFT window: starts `window_offset` samples before the end of the cyclic prefix (demodulator_impl.cpp:115).
+  const float2* src = samples + job.samples_offset + plan->sym_off[sym] + plan->cp_len[sym] - plan->window_offset;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    float2 v = src[i];
+    x[i]     = {v.x, v.y};
+  }
+  __syncthreads();
+  fft_lds<false>(x, N, tw, threadIdx.x, blockDim.x);
+  const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
+  float2*    dst  = grid + job.grid_offset + (size_t)l * rg;
+  const int  half = rg / 2;
+  for (int k = threadIdx.x; k < rg; k += blockDim.x) {
+    const int bin = (k < half) ? N - half + k : k - half; // demodulator_impl.cpp:131-137
+    cplx      v   = cmul(x[bin], coef);                    // sc_prod(dft_output, phase * scale)
+    if (ramp)
+      v = cmul(v, ramp[bin]);                              // window-offset phase ramp (:60-76,127-129)
+    dst[k] = make_float2(v.x, v.y);
+  }
+}
+
+__global__ void __launch_bounds__(256) ofdm_mod_kernel(const miphy_ofdm_job* __restrict__ jobs,
+                                                       const ofdm_plan_dev* __restrict__ plan,
+                                                       const cplx* __restrict__ tw,
+                                                       const float2* __restrict__ grid,
+                                                       float2* __restrict__ samples)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cplx*                x   = reinterpret_cast<cplx*>(smem);
+  const miphy_ofdm_job job = jobs[blockIdx.y];
+  const int            l   = blockIdx.x;
+  const int            N = plan->N, rg = plan->rg;
+  const int            sym = (int)job.slot_index * 14 + l;
+  const int            cp  = plan->cp_len[sym];
+  float2*              dst = samples + job.samples_offset + plan->sym_off[sym];
+  if (job.grid_empty) { // modulator_impl.cpp:77-80
+    for (int i = threadIdx.x; i < N + cp; i += blockDim.x)
+      dst[i] = make_float2(0.f, 0.f);
+    return;
+  }
+  const float2* src  = grid + job.grid_offset + (size_t)l * rg;
+  const int     half = rg / 2;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    // bins [0, rg/2) <- upper half of the grid, bins [N - rg/2, N) <- lower half, the rest stays zero (:82-86)
+    cplx v = {0.f, 0.f};
+    if (i < half) {
+      float2 g = src[half + i];
+      v        = {g.x, g.y};
+    } else if (i >= N - half) {
+      float2 g = src[i - (N - half)];
+      v        = {g.x, g.y};
+    }
+    x[i] = v;
+  }
+  __syncthreads();
+  fft_lds<true>(x, N, tw, threadIdx.x, blockDim.x);
+  const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
+  for (int i = threadIdx.x; i < N + cp; i += blockDim.x) {
+    const int j = (i < cp) ? N - cp + i : i - cp; // cyclic prefix = copy of the tail (:98)
+    cplx      v = cmul(x[j], coef);
+    dst[i]      = make_float2(v.x, v.y);
+  }
+}
+
+bool size_supported(uint32_t N)
+{
+  if (N < 8 || N > 4096)
+    return false;
+  uint32_t n = N;
+  while (n % 2 == 0)
+    n /= 2;
+  while (n % 3 == 0)
+    n /= 3;
+  return n == 1;
+}
+
+int threads_for(uint32_t N)
+{
+  int nt = (int)(N / 16);
+  nt     = ((nt + 63) / 64) * 64;
+  return nt < 64 ? 64 : (nt > 256 ? 256 : nt);
+}
+
+// cyclic_prefix::get_length (normal CP) in samples: (144 >> mu) (+16 for symbol 0 and 7*2^mu) kappa units.
+int cp_samples(uint32_t mu, uint32_t sym_sf, uint32_t dft_size)
+{
+  uint32_t units = 144u >> mu;
+  if (sym_sf == 0 || sym_sf == 7u * (1u << mu))
+    units += 16;
+  // to_samples: units * srate / (15000 * 2048) with srate = 15000 * 2^mu * dft_size
+  return (int)((uint64_t)units * (1u << mu) * dft_size / 2048u);
+}
+
+int get_plan(miphy_ctx* ctx, const miphy_ofdm_config* c, int is_tx, ofdm_plan_dev** out)
+{
+  auto key = std::make_tuple(c->numerology, c->bw_rb, c->dft_size, c->nof_samples_window_offset, c->scale, c->center_freq_hz, is_tx);
+  auto it  = ctx->ext->plans.find(key);
+  if (it != ctx->ext->plans.end()) {
+    *out = it->second;
+    return MIPHY_OK;
+  }
+  ofdm_plan_dev h;
+  h.N             = (int)c->dft_size;
+  h.rg            = (int)c->bw_rb * 12;
+  h.window_offset = (int)c->nof_samples_window_offset;
+  const int nslots = 1 << c->numerology;
+  h.nsymb_sf       = 14 * nslots;
+  const double srate = 15000.0 * (double)(1u << c->numerology) * (double)c->dft_size;
+  // phase_compensation_lut.h:55-82: cumulative start time of each symbol in the subframe, in double precision.
+  unsigned symbol_offset = 0;
+  for (int sym = 0; sym < h.nsymb_sf; ++sym) {
+    if (sym % 14 == 0) {
+      // start of a slot: offsets inside the slot restart
+    }
+    const int cp   = cp_samples(c->numerology, (uint32_t)sym, c->dft_size);
+    h.cp_len[sym]  = cp;
+    symbol_offset += (unsigned)cp;
+    const double start_time_s = (double)symbol_offset / srate;
+    const double phase        = (is_tx ? -1.0 : 1.0) * 2.0 * M_PI * c->center_freq_hz * start_time_s;
+    std::complex<float> pc    = static_cast<std::complex<float>>(std::exp(std::complex<double>(0.0, 1.0) * phase));
+    std::complex<float> coef  = pc * c->scale; // "phase_compensation * scale" in float (demodulator_impl.cpp:124)
+    h.coef_re[sym]            = coef.real();
+    h.coef_im[sym]            = coef.imag();
+    symbol_offset += c->dft_size;
+  }
+  for (int slot = 0; slot < nslots; ++slot) {
+    int off = 0;
+    for (int l = 0; l < 14; ++l) {
+      h.sym_off[slot * 14 + l] = off;
+      off += h.cp_len[slot * 14 + l] + h.N;
+    }
+  }
+  ofdm_plan_dev* d = nullptr;
+  MIPHY_HIP_CHECK(hipMalloc((void**)&d, sizeof(h)));
+  MIPHY_HIP_CHECK(hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice));
+  ctx->ext->plans[key] = d;
+  ctx->ext->to_free.push_back(d);
+  *out = d;
+  return MIPHY_OK;
+}
+
+int get_ramp(miphy_ctx* ctx, uint32_t N, uint32_t offset, const float** out)
+{
+  auto key = std::make_pair(N, offset);
+  auto it  = ctx->ext->ramps.find(key);
+  if (it != ctx->ext->ramps.end()) {
+    *out = it->second;
+    return MIPHY_OK;
+  }
+  // demodulator_impl.cpp:70-75, in single precision like the reference.
+  std::vector<std::complex<float>> r(N);
+  const std::complex<float> omega = std::complex<float>(0.f, 1.f) * static_cast<float>(offset) * static_cast<float>(2.0 * M_PI) / static_cast<float>(N);
+  for (uint32_t i = 0; i < N; ++i)
+    r[i] = std::exp(omega * static_cast<float>(i));
+  float* d = nullptr;
+  MIPHY_HIP_CHECK(hipMalloc((void**)&d, sizeof(float) * 2 * N));
+  MIPHY_HIP_CHECK(hipMemcpy(d, r.data(), sizeof(float) * 2 * N, hipMemcpyHostToDevice));
+  ctx->ext->ramps[key] = d;
+  ctx->ext->to_free.push_back(d);
+  *out = d;
+  return MIPHY_OK;
+}
+
+int check_cfg(const miphy_ofdm_config* c, const char* who)
+{
+  MIPHY_REQUIRE(c->numerology <= 2, "%s: numerology %u not supported (0..2)", who, c->numerology);
+  MIPHY_REQUIRE(size_supported(c->dft_size), "%s: DFT size %u not supported (2^a*3^b <= 4096)", who, c->dft_size);
+  MIPHY_REQUIRE(c->dft_size > c->bw_rb * 12, "%s: the DFT size (%u) must be greater than the resource grid size (%u)", who, c->dft_size, c->bw_rb * 12);
+  MIPHY_REQUIRE(std::isnormal(c->scale), "%s: invalid scaling factor", who);
+  MIPHY_REQUIRE(c->dft_size % 128 == 0, "%s: DFT size %u gives a non-integer cyclic prefix", who, c->dft_size);
+  MIPHY_REQUIRE(c->nof_samples_window_offset < (144 * c->dft_size) / 2048, "%s: the DFT window offset (%u) must be lower than %u", who,
+                c->nof_samples_window_offset, (144 * c->dft_size) / 2048);
+  return MIPHY_OK;
+}
+
+} // namespace
+
+int miphy_get_twiddles(miphy_ctx* ctx, uint32_t N, const float** out)
+{
+  auto it = ctx->ext->twiddles.find(N);
+  if (it != ctx->ext->twiddles.end()) {
+    *out = it->second;
+    return MIPHY_OK;
+  }
+  std::vector<float> w(2 * (size_t)N);
+  for (uint32_t j = 0; j < N; ++j) {
+    const double a = -2.0 * M_PI * (double)j / (double)N;
+    w[2 * j]       = (float)std::cos(a);
+    w[2 * j + 1]   = (float)std::sin(a);
+  }
+  float* d = nullptr;
+  MIPHY_HIP_CHECK(hipMalloc((void**)&d, sizeof(float) * 2 * N));
+  MIPHY_HIP_CHECK(hipMemcpy(d, w.data(), sizeof(float) * 2 * N, hipMemcpyHostToDevice));
+  ctx->ext->twiddles[N] = d;
+  ctx->ext->to_free.push_back(d);
+  *out = d;
+  return MIPHY_OK;
+}
+
+extern "C" uint32_t miphy_ofdm_slot_size(const miphy_ofdm_config* c, uint32_t slot_index)
+{
+  if (!c || c->numerology > 2 || slot_index >= (1u << c->numerology) || c->dft_size % 128)
+    return 0;
+  uint32_t n = 0;
+  for (uint32_t l = 0; l < 14; ++l)
+    n += (uint32_t)cp_samples(c->numerology, slot_index * 14 + l, c->dft_size) + c->dft_size;
+  return n;
+}
+
+extern "C" int miphy_dft_batch(miphy_ctx* ctx, uint32_t size, int inverse, uint32_t n, const float* in, float* out, void* stream)
+{
+  MIPHY_REQUIRE(ctx && in && out, "miphy_dft_batch: null argument");
+  if (!size_supported(size)) {
+    miphy_set_error("miphy_dft_batch: size %u not supported this round (2^a*3^b <= 4096)", size);
+    return MIPHY_EUNSUPP;
+  }
+  if (n == 0)
+    return MIPHY_OK;
+  const float* tw = nullptr;
+  int          rc = miphy_get_twiddles(ctx, size, &tw);
+  if (rc)
+    return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (inverse)
+    hipLaunchKernelGGL(dft_kernel<true>, dim3(n), dim3(threads_for(size)), size * 8, s, (const float2*)in, (float2*)out, (const cplx*)tw, (int)size);
+  else
+    hipLaunchKernelGGL(dft_kernel<false>, dim3(n), dim3(threads_for(size)), size * 8, s, (const float2*)in, (float2*)out, (const cplx*)tw, (int)size);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_ofdm_demodulate_slots(miphy_ctx*               ctx,
+                                           const miphy_ofdm_config* cfg,
+                                           const miphy_ofdm_job*    jobs,
+                                           int                      jobs_on_device,
+                                           uint32_t                 n,
+                                           const float*             samples,
+                                           float*                   grid,
+                                           void*                    stream)
+{
+  MIPHY_REQUIRE(ctx && cfg && jobs && samples && grid, "miphy_ofdm_demodulate_slots: null argument");
+  int rc = check_cfg(cfg, "ofdm_demodulate");
+  if (rc)
+    return rc;
+  if (n == 0)
+    return MIPHY_OK;
+  MIPHY_REQUIRE(n <= 65535, "ofdm_demodulate: at most 65535 jobs per call");
+  if (!jobs_on_device)
+    for (uint32_t i = 0; i < n; ++i)
+      MIPHY_REQUIRE(jobs[i].slot_index < (1u << cfg->numerology), "ofdm_demodulate: job %u: slot index %u out of range", i, jobs[i].slot_index);
+  ofdm_plan_dev* plan = nullptr;
+  const float *  tw = nullptr, *ramp = nullptr;
+  if ((rc = get_plan(ctx, cfg, 0, &plan)) || (rc = miphy_get_twiddles(ctx, cfg->dft_size, &tw)))
+    return rc;
+  if (cfg->nof_samples_window_offset && (rc = get_ramp(ctx, cfg->dft_size, cfg->nof_samples_window_offset, &ramp)))
+    return rc;
+  hipStream_t s      = (hipStream_t)stream;
+  const void* d_jobs = nullptr;
+  if ((rc = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_ofdm_job) * (size_t)n, s, &d_jobs)))
+    return rc;
+  hipLaunchKernelGGL(ofdm_demod_kernel, dim3(14, n), dim3(threads_for(cfg->dft_size)), cfg->dft_size * 8, s, (const miphy_ofdm_job*)d_jobs, plan,
+                     (const cplx*)tw, (const cplx*)ramp, (const float2*)samples, (float2*)grid);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_ofdm_modulate_slots(miphy_ctx*               ctx,
+                                         const miphy_ofdm_config* cfg,
+                                         const miphy_ofdm_job*    jobs,
+                                         int                      jobs_on_device,
+                                         uint32_t                 n,
+                                         const float*             grid,
+                                         float*                   samples,
+                                         void*                    stream)
+{
+  MIPHY_REQUIRE(ctx && cfg && jobs && samples && grid, "miphy_ofdm_modulate_slots: null argument");
+  int rc = check_cfg(cfg, "ofdm_modulate");
+  if (rc)
+    return rc;
+  MIPHY_REQUIRE(cfg->nof_samples_window_offset == 0, "ofdm_modulate: window offset applies to the demodulator only");
+  if (n == 0)
+    return MIPHY_OK;
+  MIPHY_REQUIRE(n <= 65535, "ofdm_modulate: at most 65535 jobs per call");
+  if (!jobs_on_device)
+    for (uint32_t i = 0; i < n; ++i)
+      MIPHY_REQUIRE(jobs[i].slot_index < (1u << cfg->numerology), "ofdm_modulate: job %u: slot index %u out of range", i, jobs[i].slot_index);
+  ofdm_plan_dev* plan = nullptr;
+  const float*   tw   = nullptr;
+  if ((rc = get_plan(ctx, cfg, 1, &plan)) || (rc = miphy_get_twiddles(ctx, cfg->dft_size, &tw)))
+    return rc;
+  hipStream_t s      = (hipStream_t)stream;
+  const void* d_jobs = nullptr;
+  if ((rc = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_ofdm_job) * (size_t)n, s, &d_jobs)))
+    return rc;
+  hipLaunchKernelGGL(ofdm_mod_kernel, dim3(14, n), dim3(threads_for(cfg->dft_size)), cfg->dft_size * 8, s, (const miphy_ofdm_job*)d_jobs, plan,
+                     (const cplx*)tw, (const float2*)grid, (float2*)samples);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}

@@ -34,6 +34,11 @@ def lib():
                                               C.c_void_p, C.c_void_p, C.c_void_p]
         for name in ("miphy_ldpc_rate_dematch_batch", "miphy_ldpc_rate_match_batch", "miphy_ldpc_encode_batch"):
             getattr(l, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_dft_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        for name in ("miphy_ofdm_demodulate_slots", "miphy_ofdm_modulate_slots"):
+            getattr(l, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_ofdm_slot_size.argtypes = [C.c_void_p, C.c_uint32]
+        l.miphy_ofdm_slot_size.restype = C.c_uint32
         l.miphy_crc_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
@@ -53,6 +58,22 @@ assert LdpcRdmDesc.itemsize == 32
 LdpcEncDesc = np.dtype([("bg", np.uint8), ("reserved0", np.uint8), ("Z", np.uint16), ("out_len", np.uint32),
                         ("in_offset", np.uint64), ("out_offset", np.uint64)], align=True)
 assert LdpcEncDesc.itemsize == 24
+# Mirrors miphy_ofdm_job.
+OfdmJob = np.dtype([("samples_offset", np.uint64), ("grid_offset", np.uint64), ("slot_index", np.uint32), ("grid_empty", np.uint32)],
+                   align=True)
+assert OfdmJob.itemsize == 24
+
+
+class OfdmConfig(C.Structure):
+    """Mirrors miphy_ofdm_config (= srsran::ofdm_demodulator_configuration / ofdm_modulator_configuration)."""
+    _fields_ = [("numerology", C.c_uint32), ("bw_rb", C.c_uint32), ("dft_size", C.c_uint32),
+                ("nof_samples_window_offset", C.c_uint32), ("scale", C.c_float), ("reserved", C.c_float),
+                ("center_freq_hz", C.c_double)]
+
+    def slot_size(self, slot_index):
+        return int(lib().miphy_ofdm_slot_size(C.byref(self), slot_index))
+
+
 # Mirrors miphy_crc_desc.
 CrcDesc = np.dtype([("bit_offset", np.uint64), ("nbits", np.uint32), ("poly", np.uint32)], align=True)
 assert CrcDesc.itemsize == 16
@@ -142,3 +163,15 @@ class Context:
     def crc_batch(self, descs, data, checksums, stream=None):
         descs, n, ptr, on_dev = self._descs(descs, CrcDesc)
         check(lib().miphy_crc_batch(self.h, ptr, on_dev, n, _dptr(data), _dptr(checksums), _stream_ptr(stream)))
+
+    # ------------------------------------------------------------------ DFT / OFDM
+    def dft_batch(self, size, inverse, n, x, out, stream=None):
+        check(lib().miphy_dft_batch(self.h, size, int(inverse), n, _dptr(x), _dptr(out), _stream_ptr(stream)))
+
+    def ofdm_demodulate_slots(self, cfg, jobs, samples, grid, stream=None):
+        jobs, n, ptr, on_dev = self._descs(jobs, OfdmJob)
+        check(lib().miphy_ofdm_demodulate_slots(self.h, C.byref(cfg), ptr, on_dev, n, _dptr(samples), _dptr(grid), _stream_ptr(stream)))
+
+    def ofdm_modulate_slots(self, cfg, jobs, grid, samples, stream=None):
+        jobs, n, ptr, on_dev = self._descs(jobs, OfdmJob)
+        check(lib().miphy_ofdm_modulate_slots(self.h, C.byref(cfg), ptr, on_dev, n, _dptr(grid), _dptr(samples), _stream_ptr(stream)))

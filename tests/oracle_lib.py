@@ -155,6 +155,38 @@ class OraclePuschDecoder:
         return bool(ok), tb, (mm[0], mm[1])
 
 
+class OfdmCfg(C.Structure):
+    _fields_ = [("numerology", C.c_uint), ("bw_rb", C.c_uint), ("dft_size", C.c_uint), ("window_offset", C.c_uint),
+                ("scale", C.c_float), ("center_freq_hz", C.c_double)]
+
+
+def o_dft(x, inverse=False):
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    out = np.zeros_like(x)
+    oracle().orc_dft(C.c_uint(x.size), int(inverse), _p(x), _p(out))
+    return out
+
+
+def o_ofdm_slot_size(cfg, slot_index):
+    oracle().orc_ofdm_slot_size.restype = C.c_uint
+    return int(oracle().orc_ofdm_slot_size(C.byref(cfg), C.c_uint(slot_index)))
+
+
+def o_ofdm_demod_slot(cfg, slot_index, samples):
+    samples = np.ascontiguousarray(samples, dtype=np.complex64)
+    assert samples.size == o_ofdm_slot_size(cfg, slot_index)
+    grid = np.zeros((14, cfg.bw_rb * 12), dtype=np.complex64)
+    oracle().orc_ofdm_demod_slot(C.byref(cfg), C.c_uint(slot_index), _p(samples), _p(grid))
+    return grid
+
+
+def o_ofdm_mod_slot(cfg, slot_index, grid):
+    grid = np.ascontiguousarray(grid, dtype=np.complex64)
+    out = np.zeros(o_ofdm_slot_size(cfg, slot_index), dtype=np.complex64)
+    oracle().orc_ofdm_mod_slot(C.byref(cfg), C.c_uint(slot_index), _p(grid), _p(out))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- reference wrappers
 IMPL = {"generic": 0, "avx2": 1, "avx512": 2, "auto": 3}
 
@@ -249,3 +281,30 @@ class RefPuschDecoder:
             ref().ref_pusch_decoder_destroy(self.h)
         except Exception:
             pass
+
+
+def r_dft(x, inverse=False):
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    out = np.zeros_like(x)
+    rc = ref().ref_dft(C.c_uint(x.size), int(inverse), _p(x), _p(out))
+    assert rc == 0
+    return out
+
+
+def r_ofdm_demod_slot(cfg, slot_index, samples):
+    samples = np.ascontiguousarray(samples, dtype=np.complex64)
+    grid = np.zeros((14, cfg.bw_rb * 12), dtype=np.complex64)
+    rc = ref().ref_ofdm_demod_slot(C.c_uint(cfg.numerology), C.c_uint(cfg.bw_rb), C.c_uint(cfg.dft_size), C.c_uint(cfg.window_offset),
+                                   C.c_float(cfg.scale), C.c_double(cfg.center_freq_hz), C.c_uint(slot_index), _p(samples),
+                                   C.c_uint(samples.size), _p(grid))
+    assert rc == 0, rc
+    return grid
+
+
+def r_ofdm_mod_slot(cfg, slot_index, grid, nsamples):
+    grid = np.ascontiguousarray(grid, dtype=np.complex64)
+    out = np.zeros(nsamples, dtype=np.complex64)
+    rc = ref().ref_ofdm_mod_slot(C.c_uint(cfg.numerology), C.c_uint(cfg.bw_rb), C.c_uint(cfg.dft_size), C.c_float(cfg.scale),
+                                 C.c_double(cfg.center_freq_hz), C.c_uint(slot_index), _p(grid), _p(out), C.c_uint(nsamples))
+    assert rc == 0, rc
+    return out
