@@ -211,6 +211,42 @@ int miphy_ofdm_modulate_slots(miphy_ctx* ctx, const miphy_ofdm_config* cfg, cons
 /* Number of samples of slot `slot_index` (ofdm_slot_demodulator::get_slot_size). Returns 0 on invalid configuration. */
 uint32_t miphy_ofdm_slot_size(const miphy_ofdm_config* cfg, uint32_t slot_index);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * DM-RS based PUSCH channel estimator  --  replaces srsran::dmrs_pusch_estimator::estimate (which drives
+ * srsran::port_channel_estimator::compute for every receive port)
+ *   include/srsran/phy/upper/signal_processors/dmrs_pusch_estimator.h:39-85
+ *   lib/phy/upper/signal_processors/dmrs_pusch_estimator_impl.cpp:71-212      (Gold-sequence pilots, layer weights)
+ *   include/srsran/phy/upper/signal_processors/port_channel_estimator.h:45-107
+ *   lib/phy/upper/signal_processors/port_channel_estimator_average_impl.cpp:97-347 (LS, averaging, RSRP/EPRE/noise/SNR,
+ *   time alignment through a 4096-point IDFT, linear interpolation, broadcast to all symbols).
+ * One job = one PUSCH allocation in one slot; the kernel runs one workgroup per (job, rx port, layer).
+ * DM-RS type 1 only (the reference's estimator asserts out of bounds for type 2); no intra-slot frequency hopping
+ * (dmrs_pusch_estimator_impl.cpp never configures it). */
+typedef struct {
+  uint32_t numerology;     /* slot.numerology() */
+  uint32_t slot_in_frame;  /* slot.slot_index(): slot number within the radio frame */
+  uint32_t scrambling_id;
+  float    scaling;        /* beta_DMRS amplitude scaling */
+  uint8_t  n_scid;
+  uint8_t  nof_tx_layers;  /* 1..4 */
+  uint8_t  nof_rx_ports;   /* 1..4, port p is grid port rx_ports[p] */
+  uint8_t  first_symbol;
+  uint8_t  nof_symbols;
+  uint8_t  rx_ports[4];
+  uint8_t  reserved[3];
+  uint16_t symbols_mask;   /* bit l = OFDM symbol l carries DM-RS */
+  uint16_t grid_nof_prb;   /* width of the resource grid / rb_mask.size() */
+  uint64_t rb_mask[5];     /* bit i = PRB i belongs to the allocation */
+  uint64_t grid_offset;    /* cf_t offset of grid port 0: [port][14][grid_nof_prb*12] */
+  uint64_t ce_offset;      /* cf_t offset of the estimate: [layer][rx port][first_symbol+nof_symbols][grid_nof_prb*12];
+                              only the allocated PRBs of symbols [first_symbol, first_symbol+nof_symbols) are written */
+  uint64_t scalars_offset; /* float offset: per (rx port, layer) {rsrp, epre, noise_var, snr, time_alignment_s} */
+} miphy_pusch_chest_job;
+
+int miphy_dmrs_pusch_estimate_batch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int jobs_on_device, uint32_t n,
+                                    const float* grid /* device cf_t */, float* ce /* device cf_t */, float* scalars /* device */,
+                                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -782,3 +782,242 @@ int orc_ofdm_mod_slot(const orc_ofdm_cfg* c, unsigned slot_index, const float* g
   free(b);
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------ Gold sequence
+ * TS 38.211 5.2.1: c(n) = x1(n + 1600) ^ x2(n + 1600), x1(n+31) = x1(n+3)^x1(n), x2(n+31) = x2(n+3)^x2(n+2)^x2(n+1)^x2(n),
+ * x1(0)=1, x2 = c_init (lib/phy/upper/sequence_generators/pseudo_random_generator_impl.cpp:43-83). */
+void orc_gold_sequence(unsigned c_init, unsigned offset, unsigned nbits, uint8_t* out)
+{
+  unsigned total = 1600 + offset + nbits + 31;
+  uint8_t* x1    = (uint8_t*)calloc(total + 31, 1);
+  uint8_t* x2    = (uint8_t*)calloc(total + 31, 1);
+  x1[0]          = 1;
+  for (int i = 0; i < 31; ++i)
+    x2[i] = (c_init >> i) & 1u;
+  for (unsigned n = 0; n + 31 < total + 31; ++n) {
+    x1[n + 31] = x1[n + 3] ^ x1[n];
+    x2[n + 31] = x2[n + 3] ^ x2[n + 2] ^ x2[n + 1] ^ x2[n];
+  }
+  for (unsigned n = 0; n < nbits; ++n)
+    out[n] = x1[n + offset + 1600] ^ x2[n + offset + 1600];
+  free(x1);
+  free(x2);
+}
+
+/* re_pattern / w_f / w_t of dmrs_pusch_estimator_impl.cpp:31-69 */
+static void dmrs_port_params(int type2, unsigned layer, unsigned* re_idx /* pilots positions inside a PRB */, unsigned* nre, float* wf1, float* wt1)
+{
+  if (!type2) {
+    unsigned delta = (layer / 2) % 2; /* ports 0,1,4,5 -> even; 2,3,6,7 -> odd */
+    *nre           = 6;
+    for (unsigned i = 0; i < 6; ++i)
+      re_idx[i] = 2 * i + delta;
+    *wf1 = (layer % 2) ? -1.f : 1.f;
+    *wt1 = (layer >= 4) ? -1.f : 1.f;
+  } else {
+    unsigned delta = 2 * ((layer / 2) % 3);
+    *nre           = 4;
+    re_idx[0] = delta, re_idx[1] = delta + 1, re_idx[2] = delta + 6, re_idx[3] = delta + 7;
+    *wf1 = (layer % 2) ? -1.f : 1.f;
+    *wt1 = (layer >= 6) ? -1.f : 1.f;
+  }
+}
+
+int orc_dmrs_pusch_estimate(unsigned numerology, unsigned slot_in_frame, int dmrs_type2, unsigned scrambling_id, int n_scid,
+                            float scaling, const uint8_t* symbols_mask, const uint8_t* rb_mask, unsigned nof_prb_grid,
+                            unsigned first_symbol, unsigned nof_symbols, unsigned nof_tx_layers, unsigned nof_rx_ports,
+                            const float* grid_in, float* ce_out, float* scalars_out)
+{
+  const unsigned DFT_SIZE = 4096, HALF_CP = ((144 / 2) * DFT_SIZE) / 2048;
+  unsigned       nsc = nof_prb_grid * 12, nsymb_out = first_symbol + nof_symbols;
+  unsigned       per_rb = dmrs_type2 ? 4 : 6;
+  unsigned       nprb = 0;
+  for (unsigned r = 0; r < nof_prb_grid; ++r)
+    nprb += rb_mask[r] ? 1 : 0;
+  unsigned dmrs_syms[14], nds = 0;
+  for (unsigned l = first_symbol; l < first_symbol + nof_symbols; ++l)
+    if (symbols_mask[l])
+      dmrs_syms[nds++] = l;
+  if (!nprb || !nds)
+    return -1;
+  unsigned np = nprb * per_rb; /* pilots per symbol */
+  /* Layer-0 pilots (dmrs_pusch_estimator_impl.cpp:112-172, dmrs_helper.h:45-96): QPSK from c(2i), c(2i+1), counted from PRB 0. */
+  float complex* pil0 = (float complex*)malloc(sizeof(float complex) * np * nds);
+  uint8_t*       c    = (uint8_t*)malloc(2 * per_rb * nof_prb_grid + 8);
+  const float    amp  = (float)M_SQRT1_2;
+  for (unsigned d = 0; d < nds; ++d) {
+    unsigned long long t = ((unsigned long long)(14 * slot_in_frame + dmrs_syms[d] + 1) * (2ull * scrambling_id + 1)) % (1ull << 31);
+    unsigned c_init = (unsigned)((t * (1ull << 17) + (2ull * scrambling_id + (n_scid ? 1 : 0))) % (1ull << 31));
+    orc_gold_sequence(c_init, 0, 2 * per_rb * nof_prb_grid, c);
+    unsigned i = 0;
+    for (unsigned r = 0; r < nof_prb_grid; ++r) {
+      if (!rb_mask[r])
+        continue;
+      for (unsigned q = 0; q < per_rb; ++q, ++i) {
+        unsigned g = r * per_rb + q;
+        pil0[d * np + i] = amp * (1.f - 2.f * c[2 * g]) + I * (amp * (1.f - 2.f * c[2 * g + 1]));
+      }
+    }
+  }
+  free(c);
+  (void)numerology;
+  float complex* pil  = (float complex*)malloc(sizeof(float complex) * np * nds);
+  float complex* rx   = (float complex*)malloc(sizeof(float complex) * np * nds);
+  float complex* lse  = (float complex*)malloc(sizeof(float complex) * np);
+  float complex* ce   = (float complex*)malloc(sizeof(float complex) * nprb * 12);
+  double complex* fa  = (double complex*)malloc(sizeof(double complex) * DFT_SIZE);
+  double complex* fb  = (double complex*)malloc(sizeof(double complex) * DFT_SIZE);
+  for (unsigned ly = 0; ly < nof_tx_layers; ++ly) {
+    unsigned re_idx[6], nre;
+    float    wf1, wt1;
+    dmrs_port_params(dmrs_type2, ly, re_idx, &nre, &wf1, &wt1);
+    /* layer weights (dmrs_pusch_estimator_impl.cpp:175-206) */
+    for (unsigned d = 0; d < nds; ++d)
+      for (unsigned i = 0; i < np; ++i) {
+        float complex v = pil0[d * np + i];
+        if (ly != 0) {
+          if (wt1 != 1.f && (d % 2 == 1))
+            v = v * wt1;
+          if (wf1 != 1.f && (i % 2 == 1))
+            v = v * wf1;
+        }
+        pil[d * np + i] = v;
+      }
+    for (unsigned p = 0; p < nof_rx_ports; ++p) {
+      const float* g = grid_in + 2 * (size_t)p * 14 * nsc;
+      /* extract pilots REs (port_channel_estimator_average_impl.cpp:227-269) */
+      for (unsigned d = 0; d < nds; ++d) {
+        unsigned i = 0;
+        for (unsigned r = 0; r < nof_prb_grid; ++r) {
+          if (!rb_mask[r])
+            continue;
+          for (unsigned q = 0; q < nre; ++q, ++i) {
+            size_t k       = (size_t)dmrs_syms[d] * nsc + r * 12 + re_idx[q];
+            rx[d * np + i] = g[2 * k] + I * g[2 * k + 1];
+          }
+        }
+      }
+      float epre = 0, rsrp = 0;
+      for (unsigned i = 0; i < np; ++i)
+        lse[i] = 0;
+      for (unsigned d = 0; d < nds; ++d) {
+        float e = 0;
+        for (unsigned i = 0; i < np; ++i) {
+          lse[i] += cmulf_(rx[d * np + i], conjf(pil[d * np + i]));
+          e += crealf(rx[d * np + i]) * crealf(rx[d * np + i]) + cimagf(rx[d * np + i]) * cimagf(rx[d * np + i]);
+        }
+        epre += e;
+      }
+      {
+        float e = 0;
+        for (unsigned i = 0; i < np; ++i)
+          e += crealf(lse[i]) * crealf(lse[i]) + cimagf(lse[i]) * cimagf(lse[i]);
+        rsrp += e / (float)nds;
+      }
+      float total_scaling = 1.0f / ((float)nds * scaling);
+      for (unsigned i = 0; i < np; ++i)
+        lse[i] = lse[i] * total_scaling;
+      /* noise (:271-310) */
+      float noise = 0;
+      {
+        unsigned win = nre;
+        for (unsigned d = 0; d < nds; ++d) {
+          float pw = 0;
+          for (unsigned b = 0; b < np; b += win) {
+            float complex avg = 0;
+            for (unsigned i = 0; i < win; ++i)
+              avg += lse[b + i];
+            avg = avg / (float)win;
+            avg = cmulf_(avg, -scaling + 0.0f * I);
+            for (unsigned i = 0; i < win; ++i) {
+              float complex pr = cmulf_(avg, pil[d * np + b + i]) + rx[d * np + b + i];
+              pw += crealf(pr) * crealf(pr) + cimagf(pr) * cimagf(pr);
+            }
+          }
+          noise += pw / (float)np * (float)win;
+        }
+      }
+      /* time alignment (:312-347) */
+      float ta;
+      {
+        for (unsigned i = 0; i < DFT_SIZE; ++i)
+          fa[i] = 0;
+        unsigned i = 0;
+        for (unsigned r = 0; r < nof_prb_grid; ++r) {
+          if (!rb_mask[r])
+            continue;
+          for (unsigned q = 0; q < nre; ++q, ++i)
+            fa[r * 12 + re_idx[q]] = (double)crealf(lse[i]) + I * (double)cimagf(lse[i]);
+        }
+        dft_double(DFT_SIZE, 1, fa, fb);
+        unsigned id = 0, ia = 0;
+        float    md = -1, ma = -1;
+        for (unsigned k = 0; k < HALF_CP; ++k) {
+          float vd = (float)(creal(fb[k]) * creal(fb[k]) + cimag(fb[k]) * cimag(fb[k]));
+          if (vd > md)
+            md = vd, id = k;
+          unsigned kk = DFT_SIZE - HALF_CP + k;
+          float    va = (float)(creal(fb[kk]) * creal(fb[kk]) + cimag(fb[kk]) * cimag(fb[kk]));
+          if (va > ma)
+            ma = va, ia = k;
+        }
+        ta = (md >= ma) ? (float)id : -(float)(HALF_CP - ia);
+      }
+      /* interpolation (interpolator_linear_impl.cpp:32-79): offset = first pilot RE, stride = distance to the second */
+      {
+        unsigned nout = nprb * 12, offset = re_idx[0], stride = re_idx[1] - re_idx[0];
+        if (nout == np) {
+          memcpy(ce, lse, sizeof(float complex) * np);
+        } else if (np == 1) {
+          for (unsigned k = 0; k < nout; ++k)
+            ce[k] = lse[0];
+        } else {
+          unsigned io = offset, ii = 0;
+          for (unsigned k = 0; k <= io; ++k)
+            ce[k] = lse[0];
+          for (unsigned next = io + stride; next < nout; next += stride) {
+            float complex jump = (lse[ii + 1] - lse[ii]) / (float)stride;
+            float complex val  = ce[io];
+            for (unsigned k = 0; k < stride; ++k) {
+              val += jump;
+              ce[io + 1 + k] = val;
+            }
+            io = next;
+            ++ii;
+          }
+          for (unsigned k = io + 1; k < nout; ++k)
+            ce[k] = lse[ii];
+        }
+      }
+      /* broadcast to every symbol of the allocation (:216-224) */
+      for (unsigned l = first_symbol; l < first_symbol + nof_symbols; ++l) {
+        float*   dst = ce_out + 2 * ((((size_t)ly * nof_rx_ports + p) * nsymb_out + l) * nsc);
+        unsigned j   = 0;
+        for (unsigned r = 0; r < nof_prb_grid; ++r) {
+          if (!rb_mask[r])
+            continue;
+          for (unsigned k = 0; k < 12; ++k) {
+            dst[2 * (r * 12 + k)]     = crealf(ce[j * 12 + k]);
+            dst[2 * (r * 12 + k) + 1] = cimagf(ce[j * 12 + k]);
+          }
+          ++j;
+        }
+      }
+      /* scalars (:118-144) */
+      float ndp = (float)(np * nds);
+      rsrp /= ndp;
+      epre /= ndp;
+      float scs_khz   = 15.0f * (float)(1u << numerology);
+      float ta_s      = ta / ((float)DFT_SIZE * scs_khz * 1000.0F);
+      float noise_var = noise / (float)(nre * nds - 1);
+      if (nds < 3)
+        noise_var = powf(10.0F, -30.0F / 10.0F) * epre;
+      float datarp = rsrp / scaling / scaling;
+      float snr    = (noise_var != 0) ? datarp / noise_var : 1000.f;
+      float* sc    = scalars_out + 5 * ((size_t)p * nof_tx_layers + ly);
+      sc[0] = rsrp, sc[1] = epre, sc[2] = noise_var, sc[3] = snr, sc[4] = ta_s;
+    }
+  }
+  free(pil0), free(pil), free(rx), free(lse), free(ce), free(fa), free(fb);
+  return 0;
+}

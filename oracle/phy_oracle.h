@@ -90,6 +90,18 @@ unsigned orc_ofdm_slot_size(const orc_ofdm_cfg* c, unsigned slot_index);
 int orc_ofdm_demod_slot(const orc_ofdm_cfg* c, unsigned slot_index, const float* in, float* grid_out);
 int orc_ofdm_mod_slot(const orc_ofdm_cfg* c, unsigned slot_index, const float* grid_in, float* out);
 
+
+/* ------------------------------------------------------------------------------------------------ DM-RS PUSCH estimator
+ * dmrs_pusch_estimator_impl.cpp:71-212 + port_channel_estimator_average_impl.cpp:97-347 (no frequency hopping: the
+ * PUSCH estimator of 23.5 never configures it). Gold sequence: TS 38.211 5.2.1 (pseudo_random_generator_impl.cpp).
+ * grid_in: [nof_rx_ports][14][nof_prb_grid*12] cf_t; ce_out: [layer][port][first+nof][nof_prb_grid*12] cf_t (only the
+ * allocated PRBs are written); scalars_out: per (port, layer) {rsrp, epre, noise_var, snr, time_alignment_s}. */
+void orc_gold_sequence(unsigned c_init, unsigned offset, unsigned nbits, uint8_t* out);
+int  orc_dmrs_pusch_estimate(unsigned numerology, unsigned slot_in_frame, int dmrs_type2, unsigned scrambling_id, int n_scid,
+                             float scaling, const uint8_t* symbols_mask, const uint8_t* rb_mask, unsigned nof_prb_grid,
+                             unsigned first_symbol, unsigned nof_symbols, unsigned nof_tx_layers, unsigned nof_rx_ports,
+                             const float* grid_in, float* ce_out, float* scalars_out);
+
 #ifdef __cplusplus
 }
 #endif

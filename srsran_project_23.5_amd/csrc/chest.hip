@@ -1,0 +1,324 @@
+// DM-RS based PUSCH channel estimator: one workgroup per (allocation, rx port, layer).
+//
+// Behaviour contract: lib/phy/upper/signal_processors/dmrs_pusch_estimator_impl.cpp:71-212 and
+// port_channel_estimator_average_impl.cpp:97-347 (LS at the pilots, average over DM-RS symbols, RSRP / EPRE / noise /
+// SNR, time alignment from the peak of a zero-padded 4096-point IDFT, linear interpolation, copy to all symbols).
+// Everything stays on chip: Gold-sequence pilots are generated into LDS (28 bits per LFSR step), the LS estimates and the
+// IDFT buffer live in LDS, HBM sees the DM-RS resource elements once and the estimate once.
+#include "fft_device.h"
+#include "miphy_ext.h"
+#include <cmath>
+
+namespace {
+
+constexpr int CE_DFT = 4096;                       // port_channel_estimator_average_impl::DFT_SIZE
+constexpr int HALF_CP = ((144 / 2) * CE_DFT) / 2048; // 144
+constexpr int MAX_PILOTS = 275 * 6;
+
+// Gold sequence of TS 38.211 5.2.1 produced 28 bits per step: x(n+31+k) only depends on x(n+k), x(n+3+k) (x1) or
+// x(n+k..n+3+k) (x2) for k <= 27, so a 31-bit window yields the next 28 bits with shifts and XORs.
+__device__ __forceinline__ uint32_t x1_step28(uint32_t s)
+{ // s: bits n..n+30 ; returns bits n+31..n+58 in [27:0]
+  return ((s >> 3) ^ s) & 0x0fffffffu;
+}
+__device__ __forceinline__ uint32_t x2_step28(uint32_t s)
+{
+  return ((s >> 3) ^ (s >> 2) ^ (s >> 1) ^ s) & 0x0fffffffu;
+}
+
+// Writes c(0..nbits-1) bit-packed LSB-first into `out` (32-bit words). Single thread.
+__device__ void gold_bits(uint32_t c_init, int nbits, uint32_t* out)
+{
+  uint32_t s1 = 1u, s2 = c_init & 0x7fffffffu;
+  // advance both registers by Nc = 1600 = 57 * 28 + 4
+  for (int i = 0; i < 57; ++i) {
+    const uint32_t n1 = x1_step28(s1), n2 = x2_step28(s2);
+    s1 = ((s1 >> 28) | (n1 << 3)) & 0x7fffffffu;
+    s2 = ((s2 >> 28) | (n2 << 3)) & 0x7fffffffu;
+  }
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t b1 = ((s1 >> 3) ^ s1) & 1u, b2 = ((s2 >> 3) ^ (s2 >> 2) ^ (s2 >> 1) ^ s2) & 1u;
+    s1 = (s1 >> 1) | (b1 << 30);
+    s2 = (s2 >> 1) | (b2 << 30);
+  }
+  // now s1, s2 hold x(1600..1630); emit 28 bits per step
+  int      pos = 0;
+  uint64_t acc = 0;
+  int      have = 0, w = 0;
+  while (pos < nbits) {
+    const uint32_t c28 = (s1 ^ s2) & 0x0fffffffu; // c(pos..pos+27)
+    acc |= (uint64_t)c28 << have;
+    have += 28;
+    pos += 28;
+    while (have >= 32) {
+      out[w++] = (uint32_t)acc;
+      acc >>= 32;
+      have -= 32;
+    }
+    const uint32_t n1 = x1_step28(s1), n2 = x2_step28(s2);
+    s1 = ((s1 >> 28) | (n1 << 3)) & 0x7fffffffu;
+    s2 = ((s2 >> 28) | (n2 << 3)) & 0x7fffffffu;
+  }
+  if (have > 0)
+    out[w++] = (uint32_t)acc;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red, int tid)
+{
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+    v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((tid & 63) == 0)
+    red[tid >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job* __restrict__ jobs,
+                                                    const cplx* __restrict__ tw,
+                                                    const float2* __restrict__ grid,
+                                                    float2* __restrict__ ce_out,
+                                                    float* __restrict__ scalars)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cplx*     fbuf   = reinterpret_cast<cplx*>(smem);                  // 4096 cplx: IDFT buffer, later interpolated response
+  cplx*     lse    = fbuf + CE_DFT;                                   // MAX_PILOTS
+  uint32_t* cbits  = reinterpret_cast<uint32_t*>(lse + MAX_PILOTS);   // 4 symbols x 104 words
+  uint16_t* prb_of = reinterpret_cast<uint16_t*>(cbits + 4 * 104);    // allocated PRB list (<= 275)
+  float*    red    = reinterpret_cast<float*>(prb_of + 276);          // reductions
+  int*      ired   = reinterpret_cast<int*>(red + 8);
+
+  const miphy_pusch_chest_job job = jobs[blockIdx.x];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int port = blockIdx.y, layer = blockIdx.z;
+  if (port >= job.nof_rx_ports || layer >= job.nof_tx_layers)
+    return;
+  const int nprb_grid = job.grid_nof_prb, nsc = nprb_grid * 12;
+  const int first = job.first_symbol, nsymb_out = first + job.nof_symbols;
+
+  // DM-RS symbol list inside the allocation.
+  int dsym[4], nds = 0;
+  for (int l = first; l < nsymb_out; ++l)
+    if ((job.symbols_mask >> l) & 1) {
+      if (nds < 4)
+        dsym[nds] = l;
+      ++nds;
+    }
+  // Allocated PRB list (compact), built by thread 0 of each wave-uniform pass.
+  if (tid == 0) {
+    int c = 0;
+    for (int r = 0; r < nprb_grid; ++r)
+      if ((job.rb_mask[r >> 6] >> (r & 63)) & 1ull)
+        prb_of[c++] = (uint16_t)r;
+    ired[0] = c;
+  }
+  // Gold sequences, one thread per DM-RS symbol (dmrs_pusch_estimator_impl.cpp:158-162).
+  if (tid < nds && tid < 4) {
+    const uint64_t t      = ((uint64_t)(14u * job.slot_in_frame + (uint32_t)dsym[tid] + 1u) * (2ull * job.scrambling_id + 1ull)) % (1ull << 31);
+    const uint32_t c_init = (uint32_t)((t * (1ull << 17) + (2ull * job.scrambling_id + (job.n_scid ? 1u : 0u))) % (1ull << 31));
+    gold_bits(c_init, 12 * nprb_grid, cbits + tid * 104);
+  }
+  __syncthreads();
+  const int nprb = ired[0];
+  const int np   = nprb * 6;
+  const int delta = (layer >> 1) & 1;             // RE pattern: even subcarriers for ports 0,1 ; odd for 2,3
+  const float wf1 = (layer & 1) ? -1.f : 1.f;     // frequency weight on odd pilots (layers > 0)
+  const float amp = 0.70710678118654752440f;
+  const float2* g = grid + job.grid_offset + (size_t)job.rx_ports[port] * 14 * nsc;
+  const float   beta = job.scaling;
+
+  // ---- LS estimate, EPRE (port_channel_estimator_average_impl.cpp:180-201)
+  float epre_acc = 0.f, rsrp_acc = 0.f;
+  for (int i = tid; i < np; i += nt) {
+    const int r = prb_of[i / 6], q = i % 6;
+    const int gp = r * 6 + q;                      // pilot index counted from PRB 0 (dmrs_helper.h:45-96)
+    cplx      acc = {0.f, 0.f};
+    for (int d = 0; d < nds && d < 4; ++d) {
+      const uint32_t* cb = cbits + d * 104;
+      const int       b0 = 2 * gp;
+      const float     pr = amp * (1.f - 2.f * (float)((cb[b0 >> 5] >> (b0 & 31)) & 1u));
+      const float     pi = amp * (1.f - 2.f * (float)((cb[(b0 + 1) >> 5] >> ((b0 + 1) & 31)) & 1u));
+      const float     w  = (layer != 0 && (i & 1)) ? wf1 : 1.f;
+      const cplx      p  = {pr * w, pi * w};
+      const float2    x  = g[(size_t)dsym[d] * nsc + r * 12 + 2 * q + delta];
+      acc.x += x.x * p.x + x.y * p.y; // rx * conj(pilot)
+      acc.y += x.y * p.x - x.x * p.y;
+      epre_acc += x.x * x.x + x.y * x.y;
+    }
+    rsrp_acc += acc.x * acc.x + acc.y * acc.y;
+    const float ts = 1.0f / ((float)nds * beta);
+    lse[i]         = {acc.x * ts, acc.y * ts};
+  }
+  const float epre_sum = block_sum(epre_acc, red, tid);
+  const float rsrp_sum = block_sum(rsrp_acc, red, tid) / (float)nds;
+  __syncthreads();
+
+  // ---- noise (:271-310): per-PRB mean of the estimates, predicted observation, residual power
+  float noise_acc = 0.f;
+  for (int i = tid; i < np; i += nt) {
+    const int b = (i / 6) * 6;
+    cplx      avg = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      avg = cadd(avg, lse[b + k]);
+    avg = {avg.x / 6.f * -beta, avg.y / 6.f * -beta};
+    const int r = prb_of[i / 6], q = i % 6, gp = r * 6 + q;
+    for (int d = 0; d < nds && d < 4; ++d) {
+      const uint32_t* cb = cbits + d * 104;
+      const int       b0 = 2 * gp;
+      const float     pr = amp * (1.f - 2.f * (float)((cb[b0 >> 5] >> (b0 & 31)) & 1u));
+      const float     pi = amp * (1.f - 2.f * (float)((cb[(b0 + 1) >> 5] >> ((b0 + 1) & 31)) & 1u));
+      const float     w  = (layer != 0 && (i & 1)) ? wf1 : 1.f;
+      const cplx      pred = cmul(avg, cplx{pr * w, pi * w});
+      const float2    x    = g[(size_t)dsym[d] * nsc + r * 12 + 2 * q + delta];
+      const float     er = pred.x + x.x, ei = pred.y + x.y;
+      noise_acc += er * er + ei * ei;
+    }
+  }
+  const float noise_sum = block_sum(noise_acc, red, tid); // = sum over symbols of |pred|^2 ; x window / np applied below
+
+  // ---- time alignment (:312-347): zero-padded IDFT of the LS estimates at their RE positions
+  for (int i = tid; i < CE_DFT; i += nt)
+    fbuf[i] = {0.f, 0.f};
+  __syncthreads();
+  for (int i = tid; i < np; i += nt)
+    fbuf[prb_of[i / 6] * 12 + 2 * (i % 6) + delta] = lse[i];
+  __syncthreads();
+  fft_lds<true>(fbuf, CE_DFT, tw, tid, nt);
+  // arg-max of |.|^2 over the first / last HALF_CP taps (first occurrence wins, like std::max_element)
+  float best = -1.f;
+  int   bidx = 0x7fffffff;
+  if (tid < HALF_CP) {
+    const cplx v = fbuf[tid];
+    best = v.x * v.x + v.y * v.y;
+    bidx = tid;
+  } else if (tid < 2 * HALF_CP - 0 && tid >= HALF_CP && tid < 256) {
+    const int  k = tid - HALF_CP; // 0..111 ; the remaining taps are handled below
+    const cplx v = fbuf[CE_DFT - HALF_CP + k];
+    best = v.x * v.x + v.y * v.y;
+    bidx = HALF_CP + k;
+  }
+  // taps HALF_CP-? : 2*HALF_CP = 288 > 256 threads -> second round for the rest of the "advance" window
+  float best2 = -1.f;
+  int   bidx2 = 0x7fffffff;
+  if (tid + 256 < 2 * HALF_CP) {
+    const int  k = tid + 256 - HALF_CP;
+    const cplx v = fbuf[CE_DFT - HALF_CP + k];
+    best2 = v.x * v.x + v.y * v.y;
+    bidx2 = HALF_CP + k;
+  }
+  // Reduce separately for delay (idx < HALF_CP) and advance (idx >= HALF_CP) windows using LDS atomics on a 64-bit key:
+  // key = (value bits << 32) | (0xffffffff - idx) so that the max picks the largest value, then the smallest index.
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(red);
+  __syncthreads();
+  if (tid < 2)
+    keys[tid] = 0ull;
+  __syncthreads();
+  if (bidx != 0x7fffffff)
+    atomicMax(&keys[bidx >= HALF_CP ? 1 : 0], ((unsigned long long)__float_as_uint(best) << 32) | (0xffffffffu - (unsigned)bidx));
+  if (bidx2 != 0x7fffffff)
+    atomicMax(&keys[1], ((unsigned long long)__float_as_uint(best2) << 32) | (0xffffffffu - (unsigned)bidx2));
+  __syncthreads();
+  const float md = __uint_as_float((unsigned)(keys[0] >> 32)), ma = __uint_as_float((unsigned)(keys[1] >> 32));
+  const int   id = (int)(0xffffffffu - (unsigned)(keys[0] & 0xffffffffu));
+  const int   ia = (int)(0xffffffffu - (unsigned)(keys[1] & 0xffffffffu)) - HALF_CP;
+  const float ta_samples = (md >= ma) ? (float)id : -(float)(HALF_CP - ia);
+  __syncthreads();
+
+  // ---- linear interpolation over the concatenated allocated PRBs (interpolator_linear_impl.cpp:58-78; offset = delta,
+  // stride 2, edges held) written straight to every OFDM symbol of the allocation (:216-224).
+  const int nout = nprb * 12;
+  float2*   dst0 = ce_out + job.ce_offset + ((size_t)(layer * job.nof_rx_ports + port) * nsymb_out) * nsc;
+  for (int k = tid; k < nout; k += nt) {
+    cplx v;
+    const int kk = k - delta;
+    if (kk <= 0) {
+      v = lse[0];
+    } else {
+      const int i = kk >> 1;
+      if (i >= np - 1) {
+        v = lse[np - 1];
+      } else if (kk & 1) {
+        v = {lse[i].x + (lse[i + 1].x - lse[i].x) * 0.5f, lse[i].y + (lse[i + 1].y - lse[i].y) * 0.5f};
+      } else {
+        v = lse[i];
+      }
+    }
+    const int    r   = prb_of[k / 12];
+    const size_t col = (size_t)r * 12 + (k % 12);
+    for (int l = first; l < nsymb_out; ++l)
+      dst0[(size_t)l * nsc + col] = make_float2(v.x, v.y);
+  }
+
+  // ---- side-band scalars (:118-144)
+  if (tid == 0) {
+    const float ndp  = (float)(np * nds);
+    const float rsrp = rsrp_sum / ndp;
+    const float epre = epre_sum / ndp;
+    // noise_energy = sum_sym (sum|pred|^2 / np) * window ; noise_var = noise_energy / (window * nds - 1)
+    float noise_var = (noise_sum / (float)np * 6.f) / (float)(6 * nds - 1);
+    if (nds < 3)
+      noise_var = 0.001f * epre; // convert_dB_to_power(-30) * epre
+    const float datarp = rsrp / beta / beta;
+    const float snr    = (noise_var != 0.f) ? datarp / noise_var : 1000.f;
+    const float scs_khz = 15.f * (float)(1u << job.numerology);
+    float*      sc      = scalars + job.scalars_offset + 5 * ((size_t)port * job.nof_tx_layers + layer);
+    sc[0] = rsrp;
+    sc[1] = epre;
+    sc[2] = noise_var;
+    sc[3] = snr;
+    sc[4] = ta_samples / ((float)CE_DFT * scs_khz * 1000.0f);
+  }
+}
+
+} // namespace
+
+extern "C" int miphy_dmrs_pusch_estimate_batch(miphy_ctx*                   ctx,
+                                               const miphy_pusch_chest_job* jobs,
+                                               int                          jobs_on_device,
+                                               uint32_t                     n,
+                                               const float*                 grid,
+                                               float*                       ce,
+                                               float*                       scalars,
+                                               void*                        stream)
+{
+  MIPHY_REQUIRE(ctx && jobs && grid && ce && scalars, "miphy_dmrs_pusch_estimate_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  unsigned max_ports = 4, max_layers = 4;
+  if (!jobs_on_device) {
+    max_ports = max_layers = 1;
+    for (uint32_t i = 0; i < n; ++i) {
+      const miphy_pusch_chest_job& j = jobs[i];
+      MIPHY_REQUIRE(j.numerology <= 4, "pusch_chest: job %u: invalid numerology", i);
+      MIPHY_REQUIRE(j.nof_tx_layers >= 1 && j.nof_tx_layers <= 4, "pusch_chest: job %u: invalid number of layers %u", i, j.nof_tx_layers);
+      MIPHY_REQUIRE(j.nof_rx_ports >= 1 && j.nof_rx_ports <= 4, "pusch_chest: job %u: invalid number of rx ports %u", i, j.nof_rx_ports);
+      MIPHY_REQUIRE(j.grid_nof_prb >= 1 && j.grid_nof_prb <= 275, "pusch_chest: job %u: invalid grid width", i);
+      MIPHY_REQUIRE(j.first_symbol + j.nof_symbols <= 14 && j.nof_symbols > 0, "pusch_chest: job %u: invalid symbol range", i);
+      MIPHY_REQUIRE(j.scaling > 0, "pusch_chest: job %u: the DM-RS to data scaling factor should be a positive number", i);
+      unsigned nds = 0, nprb = 0;
+      for (unsigned l = j.first_symbol; l < (unsigned)j.first_symbol + j.nof_symbols; ++l)
+        nds += (j.symbols_mask >> l) & 1;
+      for (unsigned r = 0; r < j.grid_nof_prb; ++r)
+        nprb += (unsigned)((j.rb_mask[r >> 6] >> (r & 63)) & 1ull);
+      MIPHY_REQUIRE(nds >= 1 && nds <= 4, "pusch_chest: job %u: %u DM-RS symbols (1..4 supported)", i, nds);
+      MIPHY_REQUIRE(nprb >= 1, "pusch_chest: job %u: empty allocation", i);
+      max_ports  = j.nof_rx_ports > max_ports ? j.nof_rx_ports : max_ports;
+      max_layers = j.nof_tx_layers > max_layers ? j.nof_tx_layers : max_layers;
+    }
+  }
+  const float* tw = nullptr;
+  int          rc = miphy_get_twiddles(ctx, CE_DFT, &tw);
+  if (rc)
+    return rc;
+  hipStream_t s      = (hipStream_t)stream;
+  const void* d_jobs = nullptr;
+  if ((rc = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_pusch_chest_job) * (size_t)n, s, &d_jobs)))
+    return rc;
+  const size_t lds = (size_t)CE_DFT * 8 + (size_t)MAX_PILOTS * 8 + 4 * 104 * 4 + 276 * 2 + 64 + 64;
+  hipLaunchKernelGGL(chest_kernel, dim3(n, max_ports, max_layers), dim3(256), lds, s, (const miphy_pusch_chest_job*)d_jobs, (const cplx*)tw,
+                     (const float2*)grid, (float2*)ce, scalars);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}

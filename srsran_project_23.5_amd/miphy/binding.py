@@ -39,6 +39,8 @@ def lib():
             getattr(l, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_ofdm_slot_size.argtypes = [C.c_void_p, C.c_uint32]
         l.miphy_ofdm_slot_size.restype = C.c_uint32
+        l.miphy_dmrs_pusch_estimate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p]
         l.miphy_crc_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
@@ -72,6 +74,16 @@ class OfdmConfig(C.Structure):
 
     def slot_size(self, slot_index):
         return int(lib().miphy_ofdm_slot_size(C.byref(self), slot_index))
+
+
+# Mirrors miphy_pusch_chest_job.
+PuschChestJob = np.dtype([("numerology", np.uint32), ("slot_in_frame", np.uint32), ("scrambling_id", np.uint32), ("scaling", np.float32),
+                          ("n_scid", np.uint8), ("nof_tx_layers", np.uint8), ("nof_rx_ports", np.uint8), ("first_symbol", np.uint8),
+                          ("nof_symbols", np.uint8), ("rx_ports", np.uint8, 4), ("reserved", np.uint8, 3), ("symbols_mask", np.uint16),
+                          ("grid_nof_prb", np.uint16), ("rb_mask", np.uint64, 5), ("grid_offset", np.uint64), ("ce_offset", np.uint64),
+                          ("scalars_offset", np.uint64)], align=True)
+assert PuschChestJob.itemsize == 96, PuschChestJob.itemsize
+assert PuschChestJob.fields["rb_mask"][1] == 32 and PuschChestJob.fields["symbols_mask"][1] == 28
 
 
 # Mirrors miphy_crc_desc.
@@ -175,3 +187,8 @@ class Context:
     def ofdm_modulate_slots(self, cfg, jobs, grid, samples, stream=None):
         jobs, n, ptr, on_dev = self._descs(jobs, OfdmJob)
         check(lib().miphy_ofdm_modulate_slots(self.h, C.byref(cfg), ptr, on_dev, n, _dptr(grid), _dptr(samples), _stream_ptr(stream)))
+
+    # ------------------------------------------------------------------ DM-RS PUSCH channel estimator
+    def dmrs_pusch_estimate_batch(self, jobs, grid, ce, scalars, stream=None):
+        jobs, n, ptr, on_dev = self._descs(jobs, PuschChestJob)
+        check(lib().miphy_dmrs_pusch_estimate_batch(self.h, ptr, on_dev, n, _dptr(grid), _dptr(ce), _dptr(scalars), _stream_ptr(stream)))

@@ -187,6 +187,32 @@ def o_ofdm_mod_slot(cfg, slot_index, grid):
     return out
 
 
+def _chest_args(numerology, slot, type2, scr_id, n_scid, scaling, symbols_mask, rb_mask, first, nof, nl, grid):
+    symbols_mask = np.ascontiguousarray(symbols_mask, dtype=np.uint8)
+    rb_mask = np.ascontiguousarray(rb_mask, dtype=np.uint8)
+    grid = np.ascontiguousarray(grid, dtype=np.complex64)
+    nports, nsym, nsc = grid.shape
+    assert nsym == 14 and nsc == rb_mask.size * 12 and symbols_mask.size == 14
+    ce = np.ones((nl, nports, first + nof, nsc), dtype=np.complex64)
+    sc = np.zeros((nports, nl, 5), dtype=np.float32)
+    args = (C.c_uint(numerology), C.c_uint(slot), int(type2), C.c_uint(scr_id), int(n_scid), C.c_float(scaling), _p(symbols_mask),
+            _p(rb_mask), C.c_uint(rb_mask.size), C.c_uint(first), C.c_uint(nof), C.c_uint(nl), C.c_uint(nports), _p(grid), _p(ce), _p(sc))
+    return args, ce, sc, (symbols_mask, rb_mask, grid)
+
+
+def o_dmrs_pusch_estimate(*a):
+    args, ce, sc, keep = _chest_args(*a)
+    rc = oracle().orc_dmrs_pusch_estimate(*args)
+    assert rc == 0, rc
+    return ce, sc
+
+
+def o_gold(c_init, offset, nbits):
+    out = np.zeros(nbits, dtype=np.uint8)
+    oracle().orc_gold_sequence(C.c_uint(c_init), C.c_uint(offset), C.c_uint(nbits), _p(out))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- reference wrappers
 IMPL = {"generic": 0, "avx2": 1, "avx512": 2, "auto": 3}
 
@@ -308,3 +334,10 @@ def r_ofdm_mod_slot(cfg, slot_index, grid, nsamples):
                                  C.c_double(cfg.center_freq_hz), C.c_uint(slot_index), _p(grid), _p(out), C.c_uint(nsamples))
     assert rc == 0, rc
     return out
+
+
+def r_dmrs_pusch_estimate(*a):
+    args, ce, sc, keep = _chest_args(*a)
+    rc = ref().ref_dmrs_pusch_estimate(*args)
+    assert rc == 0, rc
+    return ce, sc

@@ -1,0 +1,116 @@
+"""GPU parity for the DM-RS PUSCH channel estimator vs the CPU oracle.
+
+Tolerances (floating point; the reference's own vector test uses 5e-4 on every output, port_channel_estimator_test.cpp:114-169):
+channel coefficients 1e-4 * max|h| (the reference interpolates by repeated float accumulation, the kernel in closed form),
+RSRP / EPRE / noise / SNR 1e-4 relative, time alignment exact to one IDFT tap (1/(4096*scs))."""
+import numpy as np
+import pytest
+
+from oracle_lib import o_dmrs_pusch_estimate, o_gold
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(rng, nprb_grid, alloc, nports, nl, dm_syms, numerology=1, slot=3, scr=77, nscid=0, scaling=1.0, delay=0.0, snr_db=25.0):
+    """Builds a grid that really contains the DM-RS of a flat/2-tap channel with a delay (valid pilots), plus noise."""
+    rb = np.zeros(nprb_grid, np.uint8)
+    rb[alloc] = 1
+    sm = np.zeros(14, np.uint8)
+    sm[dm_syms] = 1
+    nsc = nprb_grid * 12
+    g = ((rng.standard_normal((nports, 14, nsc)) + 1j * rng.standard_normal((nports, 14, nsc))) * 0.05).astype(np.complex64)
+    k = np.arange(nsc)
+    for p in range(nports):
+        h = (0.8 + 0.3j) * np.exp(-2j * np.pi * k * delay / 4096) * np.exp(1j * p) + 0.2 * np.exp(-2j * np.pi * k * (delay + 9) / 4096)
+        for l in dm_syms:
+            c_init = (((14 * slot + l + 1) * (2 * scr + 1)) % (1 << 31) * (1 << 17) + 2 * scr + nscid) % (1 << 31)
+            c = o_gold(c_init, 0, 12 * nprb_grid)
+            pil = ((1 - 2.0 * c[0::2]) + 1j * (1 - 2.0 * c[1::2])) / np.sqrt(2)  # one per (prb, q) counted from PRB 0
+            for ly in range(nl):
+                delta = (ly // 2) % 2
+                w = np.ones(6 * nprb_grid)
+                if ly % 2:
+                    w[1::2] = -1  # applied on the *allocated* pilot index parity below
+                idx = 0
+                for r in range(nprb_grid):
+                    if not rb[r]:
+                        continue
+                    for q in range(6):
+                        wf = -1.0 if (ly % 2 and idx % 2) else 1.0
+                        kk = r * 12 + 2 * q + delta
+                        g[p, l, kk] += np.complex64(scaling * h[kk] * pil[r * 6 + q] * wf)
+                        idx += 1
+    return (numerology, slot, False, scr, nscid, scaling, sm, rb, 0, 14, nl, g)
+
+
+def run(ctx, cases):
+    import torch
+    import miphy
+    jobs = np.zeros(len(cases), dtype=miphy.PuschChestJob)
+    grids, g_off, ce_off, sc_off = [], 0, 0, 0
+    for i, (mu, slot, t2, scr, nscid, scaling, sm, rb, first, nof, nl, g) in enumerate(cases):
+        nports, _, nsc = g.shape
+        j = jobs[i]
+        j["numerology"], j["slot_in_frame"], j["scrambling_id"], j["scaling"] = mu, slot, scr, scaling
+        j["n_scid"], j["nof_tx_layers"], j["nof_rx_ports"], j["first_symbol"], j["nof_symbols"] = nscid, nl, nports, first, nof
+        j["rx_ports"] = [0, 1, 2, 3]
+        j["symbols_mask"] = sum(int(b) << l for l, b in enumerate(sm))
+        j["grid_nof_prb"] = rb.size
+        m = [0] * 5
+        for r, b in enumerate(rb):
+            if b:
+                m[r >> 6] |= 1 << (r & 63)
+        j["rb_mask"] = m
+        j["grid_offset"], j["ce_offset"], j["scalars_offset"] = g_off, ce_off, sc_off
+        grids.append(g.reshape(-1))
+        g_off += g.size
+        ce_off += nl * nports * (first + nof) * nsc
+        sc_off += nports * nl * 5
+    g_d = torch.from_numpy(np.concatenate(grids)).cuda()
+    ce_d = torch.ones(ce_off, dtype=torch.complex64, device="cuda")
+    sc_d = torch.zeros(sc_off, dtype=torch.float32, device="cuda")
+    ctx.dmrs_pusch_estimate_batch(jobs, g_d, ce_d, sc_d)
+    torch.cuda.synchronize()
+    ce, sc = ce_d.cpu().numpy(), sc_d.cpu().numpy()
+    for i, a in enumerate(cases):
+        mu, slot, t2, scr, nscid, scaling, sm, rb, first, nof, nl, g = a
+        nports, _, nsc = g.shape
+        exp_ce, exp_sc = o_dmrs_pusch_estimate(*a)
+        got_ce = ce[int(jobs[i]["ce_offset"]):][:exp_ce.size].reshape(exp_ce.shape)
+        got_sc = sc[int(jobs[i]["scalars_offset"]):][:exp_sc.size].reshape(exp_sc.shape)
+        mask = np.repeat(rb.astype(bool), 12)
+        err = np.abs(got_ce[..., mask] - exp_ce[..., mask]).max() / np.abs(exp_ce[..., mask]).max()
+        assert err < 1e-4, (i, err)
+        # unallocated PRBs are left untouched (they keep the caller's initial value)
+        assert np.all(got_ce[..., ~mask] == 1.0)
+        for k in range(4):
+            rel = np.abs(got_sc[..., k] - exp_sc[..., k]) / (np.abs(exp_sc[..., k]) + 1e-30)
+            assert rel.max() < 1e-4, (i, k, got_sc[..., k], exp_sc[..., k])
+        tap = 1.0 / (4096 * 15000.0 * (1 << mu))
+        assert np.abs(got_sc[..., 4] - exp_sc[..., 4]).max() <= 1.01 * tap, (i, got_sc[..., 4], exp_sc[..., 4])
+
+
+def test_chest_configs(ctx):
+    rng = np.random.default_rng(31)
+    cases = [
+        make_case(rng, 273, slice(0, 273), 1, 1, [2], delay=5.0),
+        make_case(rng, 273, slice(0, 273), 2, 1, [2, 7, 11], delay=-7.0),
+        make_case(rng, 106, slice(10, 60), 2, 2, [2, 11], scaling=0.7071, delay=20.0),
+        make_case(rng, 52, [0, 1, 2, 10, 11, 30, 31, 32, 33], 1, 1, [3], slot=17, scr=1000, nscid=1, delay=3.0),
+        make_case(rng, 25, slice(0, 25), 4, 4, [2, 3, 10, 11], numerology=0, slot=9, delay=-30.0),
+        make_case(rng, 273, slice(100, 101), 1, 1, [2], delay=0.0),
+    ]
+    run(ctx, cases)
+
+
+def test_chest_random_grid_like_benchmark(ctx):
+    """pusch_processor_benchmark.cpp:536-555 fills the grid with N(0, 1/2) noise: no valid pilots, still deterministic."""
+    rng = np.random.default_rng(32)
+    cases = []
+    for nports, nl, syms in ((1, 1, [2]), (2, 1, [2, 7, 11]), (4, 2, [2, 11])):
+        rb = np.ones(273, np.uint8)
+        sm = np.zeros(14, np.uint8)
+        sm[syms] = 1
+        g = ((rng.standard_normal((nports, 14, 273 * 12)) + 1j * rng.standard_normal((nports, 14, 273 * 12))) * np.sqrt(0.5)).astype(np.complex64)
+        cases.append((1, 0, False, 0, 0, 1.0, sm, rb, 0, 14, nl, g))
+    run(ctx, cases)
