@@ -247,6 +247,40 @@ int miphy_dmrs_pusch_estimate_batch(miphy_ctx* ctx, const miphy_pusch_chest_job*
                                     const float* grid /* device cf_t */, float* ce /* device cf_t */, float* scalars /* device */,
                                     void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Polar code chains  --  replace the chain of srsran::polar_code::set + polar_allocator::allocate + polar_encoder::encode
+ * + polar_rate_matcher::rate_match (transmit) and polar_rate_dematcher::rate_dematch + polar_decoder::decode +
+ * polar_deallocator::deallocate (receive), as wired in tests/unittests/phy/upper/channel_coding/polar/polar_chain_test.cpp:156-210
+ *   include/srsran/phy/upper/channel_coding/polar/polar_{code,allocator,encoder,rate_matcher,rate_dematcher,decoder,deallocator}.h
+ *   lib/phy/upper/channel_coding/polar/polar_code_impl.cpp:325-490 and the *_impl.cpp files next to it.
+ * The decoder is the reference's simplified successive cancellation (list size 1) with rate-0 / rate-1 node pruning.
+ * All codewords of one call share the code (K, E, nMax, ibil), like one polar_code object does.
+ * msg: n x K bytes (one bit per byte); rm: n x E bytes / LLRs. Optional taps (may be NULL) expose the intermediate
+ * results with the layouts of the single reference blocks: `allocated` / `encoded` / `decoded_u`: n x N bytes,
+ * `dematched`: n x N LLRs. */
+typedef struct {
+  uint32_t K;    /* message length incl. CRC */
+  uint32_t E;    /* rate-matched length */
+  uint32_t nMax; /* 9 (downlink) or 10 (uplink) */
+  uint32_t ibil; /* channel interleaver present (uplink) */
+} miphy_polar_code;
+
+/* Host-side query of the derived code parameters (polar_code::get_n / get_N / get_nPC). Returns 0 or MIPHY_EINVAL. */
+int miphy_polar_code_info(const miphy_polar_code* code, uint32_t* n, uint32_t* N, uint32_t* nPC);
+
+int miphy_polar_encode_batch(miphy_ctx* ctx, const miphy_polar_code* code, uint32_t n, const uint8_t* msg /* device */,
+                             uint8_t* rm_out /* device */, uint8_t* allocated_tap, uint8_t* encoded_tap, void* stream);
+int miphy_polar_decode_batch(miphy_ctx* ctx, const miphy_polar_code* code, uint32_t n, const int8_t* llr /* device */,
+                             uint8_t* msg_out /* device */, int8_t* dematched_tap, uint8_t* decoded_u_tap, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * PDCCH encoder  --  replaces srsran::pdcch_encoder::encode
+ *   include/srsran/phy/upper/channel_processors/pdcch_encoder.h:36-53, lib/phy/upper/channel_processors/pdcch_encoder_impl.cpp:33-98
+ * (CRC24C over 24 leading ones + payload, RNTI scrambling of the last 16 CRC bits, CRC interleaver, polar chain with
+ * nMax = 9). payload: n x A bytes (one bit per byte); rnti: n entries; out: n x E bytes. */
+int miphy_pdcch_encode_batch(miphy_ctx* ctx, uint32_t A, uint32_t E, uint32_t n, const uint8_t* payload /* device */,
+                             const uint16_t* rnti /* device */, uint8_t* out /* device */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

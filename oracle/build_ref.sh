@@ -43,4 +43,6 @@ rm -f $OUT/libsrsran_ref.a
 ar rcs $OUT/libsrsran_ref.a $OBJ/*.o
 # Harness: C API over the reference classes (my code, reference headers).
 $CXX $BASE -shared -o $OUT/libref_capi.so $HERE/ref_capi.cpp -Wl,--whole-archive -Wl,--no-whole-archive $OUT/libsrsran_ref.a -lpthread
+# One-off table generator (3GPP polar tables -> srsran_project_23.5_amd/csrc/tables/nr_polar_tables.h); built here, run by hand.
+$CXX $BASE -O1 $HERE/gen_polar_tables.cpp $OUT/libsrsran_ref.a -lpthread -o $OUT/gen_polar_tables
 echo "build_ref: OK -> $OUT/libref_capi.so"

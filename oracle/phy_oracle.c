@@ -1021,3 +1021,341 @@ int orc_dmrs_pusch_estimate(unsigned numerology, unsigned slot_in_frame, int dmr
   free(pil0), free(pil), free(rx), free(lse), free(ce), free(fa), free(fb);
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------ polar */
+#include "../srsran_project_23.5_amd/csrc/tables/nr_polar_tables.h"
+
+/* polar_code_impl.cpp:325-490 */
+int orc_polar_code_set(orc_polar_code_t* c, unsigned K, unsigned E, unsigned nMax, int ibil)
+{
+  memset(c, 0, sizeof(*c));
+  c->K = K, c->E = E, c->nMax = nMax, c->ibil = (unsigned)ibil;
+  if (E > 8192)
+    return -1;
+  if (nMax == 9) {
+    if (K < 36 || K > 164)
+      return -1;
+  } else if (nMax == 10) {
+    if (K < 18 || (K > 25 && K < 31) || K > 1023)
+      return -1;
+  } else
+    return -1;
+  unsigned nPC = 0, nWmPC = 0;
+  if (K <= 25) {
+    nPC = 3;
+    if (E > K + 189)
+      nWmPC = 1;
+  }
+  if (!(K + nPC < E))
+    return -1;
+  unsigned e = 1;
+  for (; e <= 13; ++e)
+    if ((1u << e) >= E)
+      break;
+  unsigned n1 = ((8 * E <= 9 * (1u << (e - 1))) && (16 * K < 9 * E)) ? e - 1 : e;
+  unsigned k  = 0;
+  for (; k <= 10; ++k)
+    if ((1u << k) >= K)
+      break;
+  unsigned n2 = k + 3;
+  unsigned n  = n1 < n2 ? n1 : n2;
+  if (nMax < n)
+    n = nMax;
+  if (n < 5)
+    n = 5;
+  unsigned N = 1u << n;
+  if (!(K < N))
+    return -1;
+  c->n = n, c->N = N, c->nPC = nPC, c->nWmPC = nWmPC;
+  /* tables for this n */
+  uint16_t mother[1024];
+  unsigned m = 0;
+  for (unsigned i = 0; i < 1024; ++i)
+    if (NR_POLAR_Q1024[i] < N)
+      mother[m++] = NR_POLAR_Q1024[i];
+  for (unsigned j = 0; j < N; ++j)
+    c->blk_interleaver[j] = (uint16_t)(NR_POLAR_SUBBLOCK_P[32 * j / N] * (N / 32) + j % (N / 32));
+  uint16_t        tmpK[1024];
+  const uint16_t* Kset = mother + (N - (K + nPC));
+  if (N > E) {
+    unsigned T = 0, nF = N - E, N_th = 3 * N / 4;
+    uint16_t F[1024];
+    if (16 * K <= 7 * E) { /* puncturing */
+      T = (E >= N_th) ? N_th - (E >> 1) - 1 : 9 * N / 16 - (E >> 2);
+      for (unsigned i = 0; i < nF; ++i)
+        F[i] = c->blk_interleaver[i];
+    } else { /* shortening */
+      for (unsigned i = 0; i < nF; ++i)
+        F[i] = c->blk_interleaver[E + i];
+    }
+    unsigned o = 0; /* setdiff_stable (:294-323): drops x <= T and members of F */
+    for (unsigned i = 0; i < N; ++i) {
+      int flag = mother[i] <= T;
+      for (unsigned j = 0; j < nF && !flag; ++j)
+        flag = (mother[i] == F[j]);
+      if (!flag)
+        tmpK[o++] = mother[i];
+    }
+    Kset = tmpK + (o - K - nPC);
+  }
+  unsigned npc_lo = (nPC > nWmPC) ? nPC - nWmPC : 0;
+  for (unsigned i = 0; i < npc_lo; ++i)
+    c->PC_set[i] = Kset[i];
+  if (nWmPC == 1)
+    c->PC_set[nPC - 1] = (K <= 21) ? 252 : 248;
+  for (unsigned i = 0; i < K + nPC; ++i)
+    c->K_set[Kset[i]] = 1;
+  for (unsigned i = 0; i + 1 < nPC; ++i) /* sort */
+    for (unsigned j = i + 1; j < nPC; ++j)
+      if (c->PC_set[j] < c->PC_set[i]) {
+        uint16_t t = c->PC_set[i];
+        c->PC_set[i] = c->PC_set[j], c->PC_set[j] = t;
+      }
+  c->PC_set[nPC] = 1024;
+  return 0;
+}
+
+static void polar_transform(uint8_t* x, unsigned n)
+{ /* polar_encoder_impl.cpp:32-52: out[i] ^= out[i + half] at every level (natural order, no bit reversal) */
+  unsigned N = 1u << n;
+  for (unsigned half = 1; half < N; half <<= 1)
+    for (unsigned b = 0; b < N; b += 2 * half)
+      for (unsigned i = 0; i < half; ++i)
+        x[b + i] ^= x[b + i + half];
+}
+
+int orc_polar_encode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, const uint8_t* msg, uint8_t* out, uint8_t* allocated_out,
+                           uint8_t* encoded_out)
+{
+  orc_polar_code_t c;
+  if (orc_polar_code_set(&c, K, E, nMax, ibil))
+    return -1;
+  unsigned N = c.N;
+  uint8_t  u[1024];
+  memset(u, 0, N);
+  if (c.nPC == 0) { /* polar_allocator_impl.cpp:37-41 */
+    unsigned i = 0;
+    for (unsigned p = 0; p < N; ++p)
+      if (c.K_set[p])
+        u[p] = msg[i++];
+  } else { /* :42-68 */
+    unsigned y0 = 0, y1 = 0, y2 = 0, y3 = 0, y4 = 0, iPC = 0, iK = 0;
+    for (unsigned p = 0; p < N; ++p) {
+      unsigned t = y0;
+      y0 = y1, y1 = y2, y2 = y3, y3 = y4, y4 = t;
+      if (c.K_set[p]) {
+        if (p == c.PC_set[iPC]) {
+          ++iPC;
+          u[p] = (uint8_t)y0;
+        } else {
+          u[p] = msg[iK];
+          y0 ^= msg[iK];
+          ++iK;
+        }
+      }
+    }
+  }
+  if (allocated_out)
+    memcpy(allocated_out, u, N);
+  uint8_t d[1024];
+  memcpy(d, u, N);
+  polar_transform(d, c.n);
+  if (encoded_out)
+    memcpy(encoded_out, d, N);
+  /* rate matching (polar_rate_matcher_impl.cpp:31-106) */
+  uint8_t* y = (uint8_t*)malloc(8192 + 1024);
+  for (unsigned j = 0; j < N; ++j)
+    y[j] = d[c.blk_interleaver[j]];
+  uint8_t* e = y;
+  if (E >= N) {
+    for (unsigned k2 = N; k2 < E; ++k2)
+      y[k2] = y[k2 % N];
+  } else if (16 * K <= 7 * E) {
+    e = y + (N - E);
+  }
+  if (!ibil) {
+    memcpy(out, e, E);
+  } else {
+    unsigned S = 1, T = 1;
+    while (S < E) {
+      ++T;
+      S += T;
+    }
+    unsigned io = 0;
+    for (unsigned r = 0; r < T; ++r) {
+      unsigned ii = r;
+      for (unsigned cc = 0; cc < T - r; ++cc) {
+        if (ii < E) {
+          out[io++] = e[ii];
+          ii += T - cc;
+        } else
+          break;
+      }
+    }
+  }
+  free(y);
+  return (int)N;
+}
+
+/* LLR algebra (log_likelihood_ratio.cpp:38-85, .h:208-216) */
+static int8_t llr_add(int8_t a, int8_t b)
+{ /* a + b: the reference evaluates `rhs += *this`, i.e. the special cases look at the right operand first */
+  if (b == -a)
+    return 0;
+  if (b > LLR_MAX || b < -LLR_MAX)
+    return b;
+  if (a > LLR_MAX || a < -LLR_MAX)
+    return a;
+  int t = a + b;
+  if (abs(t) > LLR_MAX)
+    return (int8_t)(t > 0 ? LLR_MAX : -LLR_MAX);
+  return (int8_t)t;
+}
+static int8_t llr_promotion_sum(int8_t a, int8_t b)
+{
+  if (a == -b)
+    return 0;
+  if (a > LLR_MAX || a < -LLR_MAX)
+    return a;
+  if (b > LLR_MAX || b < -LLR_MAX)
+    return b;
+  int t = a + b;
+  if (abs(t) > LLR_MAX)
+    return (int8_t)(t > 0 ? LLR_INF : -LLR_INF);
+  return (int8_t)t;
+}
+static int8_t llr_soft_xor(int8_t x, int8_t y)
+{
+  int ax = abs(x), ay = abs(y), m = ax < ay ? ax : ay;
+  return (int8_t)(((int)x * (int)y < 0) ? -m : m);
+}
+
+/* SSC decoder, recursive form of polar_decoder_impl.cpp:209-333. llr: 2^s values, u/est: outputs at offset pos. */
+static void ssc_node(const uint8_t* frozen, const int8_t* llr, unsigned s, unsigned pos, uint8_t* u, uint8_t* est)
+{
+  unsigned size = 1u << s;
+  int      any = 0, all = 1;
+  for (unsigned i = 0; i < size; ++i) {
+    any |= !frozen[pos + i];
+    all &= !frozen[pos + i];
+  }
+  if (!any) /* rate 0 */
+    return;
+  if (all) { /* rate 1 (:227-257): hard decision, then re-encode the subtree to obtain the u-domain bits */
+    for (unsigned i = 0; i < size; ++i)
+      est[pos + i] = (uint8_t)(llr[i] <= 0);
+    memcpy(u + pos, est + pos, size);
+    if (s > 0)
+      polar_transform(u + pos, s);
+    return;
+  }
+  unsigned half = size / 2;
+  int8_t   l0[512];
+  for (unsigned i = 0; i < half; ++i)
+    l0[i] = llr_soft_xor(llr[i], llr[i + half]);
+  ssc_node(frozen, l0, s - 1, pos, u, est);
+  for (unsigned i = 0; i < half; ++i) { /* g: y + x or y - x with the saturating operator (:32-61) */
+    int8_t x = llr[i], y = llr[i + half];
+    l0[i]    = est[pos + i] ? llr_add(y, (int8_t)-x) : llr_add(y, x);
+  }
+  ssc_node(frozen, l0, s - 1, pos + half, u, est);
+  for (unsigned i = 0; i < half; ++i)
+    est[pos + i] ^= est[pos + half + i];
+}
+
+int orc_polar_decode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, const int8_t* llr, uint8_t* msg, int8_t* dematched_out,
+                           uint8_t* decoded_u_out)
+{
+  orc_polar_code_t c;
+  if (orc_polar_code_set(&c, K, E, nMax, ibil))
+    return -1;
+  unsigned N = c.N;
+  /* rate dematching (polar_rate_dematcher_impl.cpp:29-118) */
+  int8_t* buf = (int8_t*)calloc(8192 + 2048, 1);
+  int8_t* e   = buf + 1024;
+  if (!ibil) {
+    memcpy(e, llr, E);
+  } else {
+    unsigned S = 1, T = 1;
+    while (S < E)
+      S += ++T;
+    unsigned io = 0;
+    for (unsigned r = 0; r < T; ++r) {
+      unsigned ii = r;
+      for (unsigned cc = 0; cc < T - r; ++cc) {
+        if (ii < E) {
+          e[ii] = llr[io++];
+          ii += T - cc;
+        } else
+          break;
+      }
+    }
+  }
+  int8_t* y = e;
+  if (E >= N) {
+    for (unsigned k2 = N; k2 < E; ++k2)
+      y[k2 % N] = llr_promotion_sum(y[k2 % N], e[k2]);
+  } else if (16 * K <= 7 * E) {
+    y = e - (N - E);
+    for (unsigned k2 = 0; k2 < N - E; ++k2)
+      y[k2] = 0;
+  } else {
+    for (unsigned k2 = E; k2 < N; ++k2)
+      y[k2] = LLR_INF;
+  }
+  int8_t d[1024];
+  for (unsigned j = 0; j < N; ++j)
+    d[c.blk_interleaver[j]] = y[j];
+  free(buf);
+  if (dematched_out)
+    memcpy(dematched_out, d, N);
+  uint8_t frozen[1024], u[1024], est[1024];
+  for (unsigned i = 0; i < N; ++i)
+    frozen[i] = !c.K_set[i];
+  memset(u, 0, N);
+  memset(est, 0, N);
+  ssc_node(frozen, d, c.n, 0, u, est);
+  if (decoded_u_out)
+    memcpy(decoded_u_out, u, N);
+  /* deallocation (polar_deallocator_impl.cpp:27-42) */
+  unsigned iPC = 0, iK = 0;
+  for (unsigned p = 0; p < N; ++p) {
+    if (!c.K_set[p])
+      continue;
+    if (p == c.PC_set[iPC])
+      ++iPC;
+    else
+      msg[iK++] = u[p];
+  }
+  return (int)N;
+}
+
+void orc_polar_interleave(const uint8_t* in, uint8_t* out, unsigned K, int rx)
+{ /* polar_interleaver_impl.cpp:37-56 */
+  unsigned k = 0;
+  for (unsigned m = 0; m < NR_POLAR_K_MAX_IL; ++m) {
+    if (NR_POLAR_PI_IL_MAX[m] >= NR_POLAR_K_MAX_IL - K) {
+      unsigned pi_k = NR_POLAR_PI_IL_MAX[m] - (NR_POLAR_K_MAX_IL - K);
+      if (!rx)
+        out[k] = in[pi_k];
+      else
+        out[pi_k] = in[k];
+      ++k;
+    }
+  }
+}
+
+int orc_pdcch_encode(const uint8_t* payload, unsigned A, unsigned rnti, unsigned E, uint8_t* out)
+{ /* pdcch_encoder_impl.cpp:33-98 */
+  unsigned K = A + 24;
+  uint8_t  c[24 + 164 + 24], cp[164];
+  memset(c, 1, 24);
+  memcpy(c + 24, payload, A);
+  uint32_t crc = orc_crc_bits(ORC_CRC24C, c, 24 + A);
+  for (unsigned i = 0; i < 24; ++i)
+    c[24 + A + i] = (uint8_t)((crc >> (23 - i)) & 1u);
+  for (unsigned i = 0; i < 16; ++i)
+    c[24 + A + 8 + i] ^= (uint8_t)((rnti >> (15 - i)) & 1u);
+  orc_polar_interleave(c + 24, cp, K, 0);
+  return orc_polar_encode_chain(K, E, 9, 0, cp, out, 0, 0) > 0 ? 0 : -1;
+}

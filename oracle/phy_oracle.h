@@ -102,6 +102,27 @@ int  orc_dmrs_pusch_estimate(unsigned numerology, unsigned slot_in_frame, int dm
                              unsigned first_symbol, unsigned nof_symbols, unsigned nof_tx_layers, unsigned nof_rx_ports,
                              const float* grid_in, float* ce_out, float* scalars_out);
 
+
+/* ------------------------------------------------------------------------------------------------ polar
+ * polar_code_impl.cpp:325-490 (code construction), polar_allocator_impl.cpp:28-70, polar_encoder_impl.cpp:32-86,
+ * polar_rate_matcher_impl.cpp:31-106, polar_interleaver_impl.cpp:27-56, polar_rate_dematcher_impl.cpp:29-118,
+ * polar_decoder_impl.cpp:32-350 (SSC), polar_deallocator_impl.cpp:27-42, pdcch_encoder_impl.cpp:33-98. */
+typedef struct {
+  unsigned K, E, nMax, ibil;
+  unsigned n, N, nPC, nWmPC;
+  uint8_t  K_set[1024];  /* 1 = information (or parity-check) position */
+  uint16_t PC_set[4];    /* nPC sorted positions, terminated by 1024 */
+  uint16_t blk_interleaver[1024];
+} orc_polar_code_t;
+int orc_polar_code_set(orc_polar_code_t* c, unsigned K, unsigned E, unsigned nMax, int ibil);
+int orc_polar_encode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, const uint8_t* msg, uint8_t* out, uint8_t* allocated_out,
+                           uint8_t* encoded_out);
+int orc_polar_decode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, const int8_t* llr, uint8_t* msg, int8_t* dematched_out,
+                           uint8_t* decoded_u_out);
+void orc_polar_interleave(const uint8_t* in, uint8_t* out, unsigned K, int rx);
+/* PDCCH: payload A bits (1 bit/byte) + rnti -> E rate-matched bits. */
+int orc_pdcch_encode(const uint8_t* payload, unsigned A, unsigned rnti, unsigned E, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

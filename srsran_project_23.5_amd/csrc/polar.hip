@@ -1,0 +1,504 @@
+// Polar coding chains (PDCCH / PBCH / UCI): code construction on the host, one wavefront per codeword on the device.
+//
+// Behaviour contract (all under lib/phy/upper/channel_coding/polar/): polar_code_impl.cpp:325-490 (sets, n, nPC),
+// polar_allocator_impl.cpp:28-70, polar_encoder_impl.cpp:32-86, polar_rate_matcher_impl.cpp:31-106,
+// polar_rate_dematcher_impl.cpp:29-118, polar_decoder_impl.cpp:32-350 (simplified successive cancellation),
+// polar_deallocator_impl.cpp:27-42, polar_interleaver_impl.cpp:27-56; PDCCH: channel_processors/pdcch_encoder_impl.cpp:33-98.
+//
+// MI355X mapping: the decoding tree only depends on the frozen set, so the host flattens the recursion into a pruned
+// schedule (f / g / rate-1 / combine ops); a 64-lane wavefront executes it with all LLR stages, partial sums and
+// decisions resident in LDS (2N + 2N bytes per codeword). Rate matching and its inverse are single gathers through
+// host-composed index tables (sub-block interleaver o bit selection o channel interleaver).
+#include "crc_device.h"
+#include "miphy_ext.h"
+#include "tables/nr_polar_tables.h"
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+enum { OP_F = 1, OP_G = 2, OP_R1 = 3, OP_COMB = 4 };
+
+struct host_code {
+  uint32_t              K, E, n, N, nPC, nWmPC;
+  std::vector<uint8_t>  k_set;
+  std::vector<uint16_t> pc_set;
+  std::vector<uint16_t> blk;
+};
+
+// polar_code_impl.cpp:325-490
+int build_code(const miphy_polar_code* c, host_code& h)
+{
+  const uint32_t K = c->K, E = c->E, nMax = c->nMax;
+  MIPHY_REQUIRE(E <= 8192, "polar: E = %u exceeds EMAX", E);
+  if (nMax == 9) {
+    MIPHY_REQUIRE(!(K < 36 || K > 164), "polar: codeblock length (K=%u) not supported for downlink transmission, choose 165 > K > 35", K);
+  } else if (nMax == 10) {
+    MIPHY_REQUIRE(!(K < 18 || (K > 25 && K < 31) || K > 1023), "polar: codeblock length (K=%u) not supported for uplink transmission", K);
+  } else {
+    MIPHY_REQUIRE(false, "polar: nMax not supported, choose 9 for downlink and 10 for uplink transmissions");
+  }
+  uint32_t nPC = 0, nWmPC = 0;
+  if (K <= 25) {
+    nPC = 3;
+    if (E > K + 189)
+      nWmPC = 1;
+  }
+  MIPHY_REQUIRE(K + nPC < E, "polar: rate-matched codeword length (E=%u) not supported, choose E > K + nPC", E);
+  uint32_t e = 1;
+  while (e <= 13 && (1u << e) < E)
+    ++e;
+  const uint32_t n1 = ((8 * E <= 9 * (1u << (e - 1))) && (16 * K < 9 * E)) ? e - 1 : e;
+  uint32_t       k  = 0;
+  while (k <= 10 && (1u << k) < K)
+    ++k;
+  uint32_t n = std::min(std::min(n1, k + 3), nMax);
+  n          = std::max(n, 5u);
+  const uint32_t N = 1u << n;
+  MIPHY_REQUIRE(K < N, "polar: codeblock length (K=%u) not supported, choose K < N", K);
+  h.K = K, h.E = E, h.n = n, h.N = N, h.nPC = nPC, h.nWmPC = nWmPC;
+  std::vector<uint16_t> mother;
+  for (uint32_t i = 0; i < 1024; ++i)
+    if (NR_POLAR_Q1024[i] < N)
+      mother.push_back(NR_POLAR_Q1024[i]);
+  h.blk.resize(N);
+  for (uint32_t j = 0; j < N; ++j)
+    h.blk[j] = (uint16_t)(NR_POLAR_SUBBLOCK_P[32 * j / N] * (N / 32) + j % (N / 32));
+  std::vector<uint16_t> cand(mother);
+  if (N > E) {
+    std::vector<uint8_t> drop(N, 0);
+    uint32_t             T = 0;
+    if (16 * K <= 7 * E) { // puncturing
+      const uint32_t N_th = 3 * N / 4;
+      T                   = (E >= N_th) ? N_th - (E >> 1) - 1 : 9 * N / 16 - (E >> 2);
+      for (uint32_t i = 0; i < N - E; ++i)
+        drop[h.blk[i]] = 1;
+    } else { // shortening
+      for (uint32_t i = E; i < N; ++i)
+        drop[h.blk[i]] = 1;
+    }
+    cand.clear();
+    for (uint16_t q : mother)
+      if (!(q <= T) && !drop[q]) // setdiff_stable: also drops every index <= T (T = 0 when shortening)
+        cand.push_back(q);
+  }
+  MIPHY_REQUIRE(cand.size() >= K + nPC, "polar: not enough reliable positions");
+  const uint16_t* Kset = cand.data() + (cand.size() - K - nPC);
+  h.pc_set.clear();
+  for (uint32_t i = 0; i < ((nPC > nWmPC) ? nPC - nWmPC : 0); ++i)
+    h.pc_set.push_back(Kset[i]);
+  if (nWmPC == 1)
+    h.pc_set.push_back((K <= 21) ? 252 : 248);
+  std::sort(h.pc_set.begin(), h.pc_set.end());
+  h.k_set.assign(N, 0);
+  for (uint32_t i = 0; i < K + nPC; ++i)
+    h.k_set[Kset[i]] = 1;
+  return MIPHY_OK;
+}
+
+void emit(std::vector<uint32_t>& s, uint32_t op, uint32_t stage, uint32_t pos)
+{
+  s.push_back(op | (stage << 4) | (pos << 8));
+}
+
+// Flattens polar_decoder_impl.cpp:209-333 (rate_0_node / rate_1_node / rate_r_node) into a list of vector operations.
+void build_schedule(const std::vector<uint8_t>& k_set, uint32_t s, uint32_t pos, std::vector<uint32_t>& out)
+{
+  const uint32_t size = 1u << s;
+  bool           any = false, all = true;
+  for (uint32_t i = 0; i < size; ++i) {
+    any |= k_set[pos + i] != 0;
+    all &= k_set[pos + i] != 0;
+  }
+  if (!any)
+    return;
+  if (all) {
+    emit(out, OP_R1, s, pos);
+    return;
+  }
+  emit(out, OP_F, s, pos);
+  build_schedule(k_set, s - 1, pos, out);
+  emit(out, OP_G, s, pos);
+  build_schedule(k_set, s - 1, pos + size / 2, out);
+  emit(out, OP_COMB, s, pos);
+}
+
+template <typename T>
+int upload(miphy_ctx* ctx, const std::vector<T>& v, T** d)
+{
+  const size_t bytes = std::max<size_t>(sizeof(T), v.size() * sizeof(T));
+  MIPHY_HIP_CHECK(hipMalloc((void**)d, bytes));
+  if (!v.empty())
+    MIPHY_HIP_CHECK(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  ctx->ext->to_free.push_back(*d);
+  return MIPHY_OK;
+}
+
+int get_plan(miphy_ctx* ctx, const miphy_polar_code* c, const polar_plan** out)
+{
+  auto key = std::make_tuple(c->K, c->E, c->nMax, c->ibil ? 1u : 0u);
+  auto it  = ctx->ext->polar_plans.find(key);
+  if (it != ctx->ext->polar_plans.end()) {
+    *out = &it->second;
+    return MIPHY_OK;
+  }
+  host_code h;
+  int       rc = build_code(c, h);
+  if (rc)
+    return rc;
+  const uint32_t N = h.N, E = h.E, K = h.K;
+  polar_plan     p = {};
+  p.K = K, p.E = E, p.n = h.n, p.N = N, p.nPC = h.nPC;
+  std::vector<uint16_t> info_pos;
+  std::vector<uint8_t>  is_pc;
+  for (uint32_t q = 0; q < N; ++q)
+    if (h.k_set[q]) {
+      info_pos.push_back((uint16_t)q);
+      is_pc.push_back(std::find(h.pc_set.begin(), h.pc_set.end(), (uint16_t)q) != h.pc_set.end());
+    }
+  // Channel interleaver (polar_rate_matcher_impl.cpp:62-88): f[io] = e[ii].
+  std::vector<uint16_t> perm(E);
+  if (c->ibil) {
+    uint32_t S = 1, T = 1;
+    while (S < E) {
+      ++T;
+      S += T;
+    }
+    uint32_t io = 0;
+    for (uint32_t r = 0; r < T; ++r) {
+      uint32_t ii = r;
+      for (uint32_t cc = 0; cc < T - r; ++cc) {
+        if (ii < E) {
+          perm[io++] = (uint16_t)ii;
+          ii += T - cc;
+        } else
+          break;
+      }
+    }
+  } else {
+    for (uint32_t i = 0; i < E; ++i)
+      perm[i] = (uint16_t)i;
+  }
+  // Bit selection (polar_rate_matcher_impl.cpp:43-60): e[k] = y[sel(k)], y[j] = d[blk[j]].
+  const bool punct = (E < N) && (16 * K <= 7 * E);
+  auto       sel   = [&](uint32_t k) { return (E >= N) ? k % N : (punct ? k + (N - E) : k); };
+  std::vector<uint16_t> tx_src(E), rx_fidx(E);
+  for (uint32_t o = 0; o < E; ++o) {
+    tx_src[o]        = h.blk[sel(perm[o])];
+    rx_fidx[perm[o]] = (uint16_t)o;
+  }
+  // Inverse (polar_rate_dematcher_impl.cpp:43-68): for codeword position q = blk[j], y[j] comes from e[j'] (+ repetitions).
+  std::vector<int32_t> rx_first(N);
+  for (uint32_t j = 0; j < N; ++j) {
+    int32_t first;
+    if (E >= N)
+      first = (int32_t)j;
+    else if (punct)
+      first = (j < N - E) ? -1 : (int32_t)(j - (N - E));
+    else
+      first = (j < E) ? (int32_t)j : -2;
+    rx_first[h.blk[j]] = first;
+  }
+  std::vector<uint32_t> sched;
+  build_schedule(h.k_set, h.n, 0, sched);
+  std::vector<uint8_t> pi_il;
+  for (uint32_t m = 0; m < NR_POLAR_K_MAX_IL; ++m)
+    if (K <= NR_POLAR_K_MAX_IL && NR_POLAR_PI_IL_MAX[m] >= NR_POLAR_K_MAX_IL - K)
+      pi_il.push_back((uint8_t)(NR_POLAR_PI_IL_MAX[m] - (NR_POLAR_K_MAX_IL - K)));
+  p.sched_len = (uint32_t)sched.size();
+  if ((rc = upload(ctx, info_pos, &p.d_info_pos)) || (rc = upload(ctx, is_pc, &p.d_is_pc)) || (rc = upload(ctx, tx_src, &p.d_tx_src)) ||
+      (rc = upload(ctx, rx_first, &p.d_rx_first)) || (rc = upload(ctx, rx_fidx, &p.d_rx_fidx)) || (rc = upload(ctx, sched, &p.d_sched)) ||
+      (rc = upload(ctx, pi_il, &p.d_pi_il)))
+    return rc;
+  auto ins = ctx->ext->polar_plans.emplace(key, p);
+  *out     = &ins.first->second;
+  return MIPHY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- device side
+__device__ __forceinline__ void polar_transform_lds(uint8_t* x, int n, int lane)
+{ // polar_encoder_impl.cpp:32-52: x[i] ^= x[i + half] for every level, natural order.
+  const int N = 1 << n;
+  for (int half = 1; half < N; half <<= 1) {
+    for (int t = lane; t < N / 2; t += 64) {
+      const int b = ((t / half) * 2 * half) + (t % half);
+      x[b] ^= x[b + half];
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void polar_tx_chain(const polar_plan& p, uint8_t* u, const uint8_t* msg_lds, uint8_t* __restrict__ out,
+                                               uint8_t* __restrict__ alloc_tap, uint8_t* __restrict__ enc_tap, int lane)
+{
+  const int N = (int)p.N, KP = (int)(p.K + p.nPC);
+  for (int i = lane; i < N; i += 64)
+    u[i] = 0;
+  __syncthreads();
+  if (p.nPC == 0) { // polar_allocator_impl.cpp:37-41
+    for (int i = lane; i < KP; i += 64)
+      u[p.d_info_pos[i]] = msg_lds[i];
+  } else if (lane == 0) { // :42-68, five-stage cyclic shift register, inherently serial and only used for K <= 25
+    unsigned y[5] = {0, 0, 0, 0, 0};
+    int      iK = 0, ip = 0;
+    for (int q = 0; q < N; ++q) {
+      const unsigned t = y[0];
+      y[0] = y[1], y[1] = y[2], y[2] = y[3], y[3] = y[4], y[4] = t;
+      if (ip < KP && p.d_info_pos[ip] == q) {
+        if (p.d_is_pc[ip]) {
+          u[q] = (uint8_t)y[0];
+        } else {
+          u[q] = msg_lds[iK];
+          y[0] ^= msg_lds[iK];
+          ++iK;
+        }
+        ++ip;
+      }
+    }
+  }
+  __syncthreads();
+  if (alloc_tap)
+    for (int i = lane; i < N; i += 64)
+      alloc_tap[i] = u[i];
+  polar_transform_lds(u, (int)p.n, lane);
+  if (enc_tap)
+    for (int i = lane; i < N; i += 64)
+      enc_tap[i] = u[i];
+  for (int o = lane; o < (int)p.E; o += 64) // sub-block interleaver, bit selection, channel interleaver: one gather
+    out[o] = u[p.d_tx_src[o]];
+}
+
+__global__ void __launch_bounds__(64) polar_encode_kernel(polar_plan p, const uint8_t* __restrict__ msg, uint8_t* __restrict__ out,
+                                                          uint8_t* __restrict__ alloc_tap, uint8_t* __restrict__ enc_tap)
+{
+  __shared__ uint8_t u[1024];
+  __shared__ uint8_t m[1024];
+  const int          lane = threadIdx.x;
+  const size_t       cw   = blockIdx.x;
+  for (int i = lane; i < (int)p.K; i += 64)
+    m[i] = msg[cw * p.K + i];
+  __syncthreads();
+  polar_tx_chain(p, u, m, out + cw * p.E, alloc_tap ? alloc_tap + cw * p.N : nullptr, enc_tap ? enc_tap + cw * p.N : nullptr, lane);
+}
+
+__global__ void __launch_bounds__(64) pdcch_encode_kernel(polar_plan p, uint32_t A, const uint8_t* __restrict__ payload,
+                                                          const uint16_t* __restrict__ rnti, uint8_t* __restrict__ out)
+{
+  __shared__ uint8_t u[1024];
+  __shared__ uint8_t c[24 + 164];
+  __shared__ uint8_t cp[164];
+  const int          lane = threadIdx.x;
+  const size_t       cw   = blockIdx.x;
+  const int          K    = (int)p.K;
+  // pdcch_encoder_impl.cpp:33-59: 24 leading ones, payload, CRC24C, RNTI mask on the last 16 parity bits.
+  for (int i = lane; i < 24 + (int)A; i += 64)
+    c[i] = (i < 24) ? 1 : payload[cw * A + (i - 24)];
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t reg = 0;
+    for (int i = 0; i < 24 + (int)A; ++i) {
+      reg = (reg << 1) ^ ((uint32_t)(c[i] & 1u) << 24);
+      reg ^= (reg & 0x1000000u) ? 0x1B2B117u : 0u;
+    }
+    const uint32_t r = rnti[cw];
+    for (int i = 0; i < 24; ++i) {
+      uint32_t b = (reg >> (23 - i)) & 1u;
+      if (i >= 8)
+        b ^= (r >> (15 - (i - 8))) & 1u;
+      c[24 + A + i] = (uint8_t)b;
+    }
+  }
+  __syncthreads();
+  for (int k = lane; k < K; k += 64) // CRC interleaver (polar_interleaver_impl.cpp:37-56), tx direction
+    cp[k] = c[24 + p.d_pi_il[k]];
+  __syncthreads();
+  polar_tx_chain(p, u, cp, out + cw * p.E, nullptr, nullptr, lane);
+}
+
+// LLR algebra of log_likelihood_ratio.cpp:38-85 / .h:208-216.
+__device__ __forceinline__ int llr_add(int a, int b)
+{ // a + b (special cases inspect the right operand first, like `rhs += *this`)
+  if (b == -a)
+    return 0;
+  if (b > 120 || b < -120)
+    return b;
+  if (a > 120 || a < -120)
+    return a;
+  return min(max(a + b, -120), 120);
+}
+__device__ __forceinline__ int llr_promotion_sum(int a, int b)
+{
+  if (a == -b)
+    return 0;
+  if (a > 120 || a < -120)
+    return a;
+  if (b > 120 || b < -120)
+    return b;
+  const int t = a + b;
+  return (t > 120) ? 127 : ((t < -120) ? -127 : t);
+}
+__device__ __forceinline__ int llr_soft_xor(int x, int y)
+{
+  const int m = min(abs(x), abs(y));
+  return (x * y < 0) ? -m : m;
+}
+
+__global__ void __launch_bounds__(64) polar_decode_kernel(polar_plan p, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ msg_out,
+                                                          int8_t* __restrict__ dem_tap, uint8_t* __restrict__ u_tap)
+{
+  __shared__ int8_t  L[2048]; // stage s buffer at offset 2^s (size 2^s)
+  __shared__ uint8_t est[1024];
+  __shared__ uint8_t u[1024];
+  const int          lane = threadIdx.x;
+  const size_t       cw   = blockIdx.x;
+  const int          N = (int)p.N, n = (int)p.n, E = (int)p.E;
+  const int8_t*      f = llr_in + cw * p.E;
+  // Rate dematching (polar_rate_dematcher_impl.cpp:29-118) as a gather: repetitions are accumulated in order.
+  for (int q = lane; q < N; q += 64) {
+    const int first = p.d_rx_first[q];
+    int       v;
+    if (first == -1) {
+      v = 0;
+    } else if (first == -2) {
+      v = 127;
+    } else {
+      v = f[p.d_rx_fidx[first]];
+      for (int k = first + N; k < E; k += N)
+        v = llr_promotion_sum(v, f[p.d_rx_fidx[k]]);
+    }
+    L[N + q] = (int8_t)v;
+    est[q]   = 0;
+    u[q]     = 0;
+    if (dem_tap)
+      dem_tap[cw * N + q] = (int8_t)v;
+  }
+  __syncthreads();
+  for (uint32_t k = 0; k < p.sched_len; ++k) {
+    const uint32_t op    = p.d_sched[k];
+    const int      type  = op & 15, s = (op >> 4) & 15, pos = (int)(op >> 8);
+    const int      size  = 1 << s, half = size >> 1;
+    int8_t*        ls    = L + size;
+    int8_t*        lc    = L + half;
+    if (type == OP_F) {
+      for (int i = lane; i < half; i += 64)
+        lc[i] = (int8_t)llr_soft_xor(ls[i], ls[i + half]);
+    } else if (type == OP_G) {
+      for (int i = lane; i < half; i += 64) {
+        const int x = ls[i], y = ls[i + half];
+        lc[i]       = (int8_t)(est[pos + i] ? llr_add(y, -x) : llr_add(y, x));
+      }
+    } else if (type == OP_R1) {
+      for (int i = lane; i < size; i += 64) {
+        const uint8_t b = ls[i] <= 0;
+        est[pos + i]    = b;
+        u[pos + i]      = b;
+      }
+      __syncthreads();
+      for (int h = 1; h < size; h <<= 1) { // re-encode the subtree (polar_decoder_impl.cpp:243-248)
+        for (int t = lane; t < half; t += 64) {
+          const int b = ((t / h) * 2 * h) + (t % h);
+          u[pos + b] ^= u[pos + b + h];
+        }
+        __syncthreads();
+      }
+    } else { // OP_COMB
+      for (int i = lane; i < half; i += 64)
+        est[pos + i] ^= est[pos + half + i];
+    }
+    __syncthreads();
+  }
+  if (u_tap)
+    for (int i = lane; i < N; i += 64)
+      u_tap[cw * N + i] = u[i];
+  // Deallocation (polar_deallocator_impl.cpp:27-42): K-set positions that are not parity checks, ascending.
+  if (p.nPC == 0) {
+    for (int i = lane; i < (int)p.K; i += 64)
+      msg_out[cw * p.K + i] = u[p.d_info_pos[i]];
+  } else if (lane == 0) {
+    int iK = 0;
+    for (int i = 0; i < (int)(p.K + p.nPC); ++i)
+      if (!p.d_is_pc[i])
+        msg_out[cw * p.K + iK++] = u[p.d_info_pos[i]];
+  }
+  (void)n;
+}
+
+} // namespace
+
+extern "C" int miphy_polar_code_info(const miphy_polar_code* code, uint32_t* n, uint32_t* N, uint32_t* nPC)
+{
+  if (!code) {
+    miphy_set_error("miphy_polar_code_info: null argument");
+    return MIPHY_EINVAL;
+  }
+  host_code h;
+  int       rc = build_code(code, h);
+  if (rc)
+    return rc;
+  if (n)
+    *n = h.n;
+  if (N)
+    *N = h.N;
+  if (nPC)
+    *nPC = h.nPC;
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_polar_encode_batch(miphy_ctx*              ctx,
+                                        const miphy_polar_code* code,
+                                        uint32_t                n,
+                                        const uint8_t*          msg,
+                                        uint8_t*                rm_out,
+                                        uint8_t*                allocated_tap,
+                                        uint8_t*                encoded_tap,
+                                        void*                   stream)
+{
+  MIPHY_REQUIRE(ctx && code && msg && rm_out, "miphy_polar_encode_batch: null argument");
+  const polar_plan* p  = nullptr;
+  int               rc = get_plan(ctx, code, &p);
+  if (rc || n == 0)
+    return rc;
+  hipLaunchKernelGGL(polar_encode_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, *p, msg, rm_out, allocated_tap, encoded_tap);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_polar_decode_batch(miphy_ctx*              ctx,
+                                        const miphy_polar_code* code,
+                                        uint32_t                n,
+                                        const int8_t*           llr,
+                                        uint8_t*                msg_out,
+                                        int8_t*                 dematched_tap,
+                                        uint8_t*                decoded_u_tap,
+                                        void*                   stream)
+{
+  MIPHY_REQUIRE(ctx && code && llr && msg_out, "miphy_polar_decode_batch: null argument");
+  const polar_plan* p  = nullptr;
+  int               rc = get_plan(ctx, code, &p);
+  if (rc || n == 0)
+    return rc;
+  hipLaunchKernelGGL(polar_decode_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, *p, llr, msg_out, dematched_tap, decoded_u_tap);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_pdcch_encode_batch(miphy_ctx*      ctx,
+                                        uint32_t        A,
+                                        uint32_t        E,
+                                        uint32_t        n,
+                                        const uint8_t*  payload,
+                                        const uint16_t* rnti,
+                                        uint8_t*        out,
+                                        void*           stream)
+{
+  MIPHY_REQUIRE(ctx && payload && rnti && out, "miphy_pdcch_encode_batch: null argument");
+  MIPHY_REQUIRE(A >= 12 && A <= 140, "pdcch_encode: payload size %u out of range (12..140)", A);
+  miphy_polar_code  code = {A + 24, E, 9, 0};
+  const polar_plan* p    = nullptr;
+  int               rc   = get_plan(ctx, &code, &p);
+  if (rc || n == 0)
+    return rc;
+  hipLaunchKernelGGL(pdcch_encode_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, *p, A, payload, rnti, out);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}

@@ -41,6 +41,10 @@ def lib():
         l.miphy_ofdm_slot_size.restype = C.c_uint32
         l.miphy_dmrs_pusch_estimate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p]
+        l.miphy_polar_code_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_polar_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_polar_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_pdcch_encode_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_crc_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
@@ -84,6 +88,16 @@ PuschChestJob = np.dtype([("numerology", np.uint32), ("slot_in_frame", np.uint32
                           ("scalars_offset", np.uint64)], align=True)
 assert PuschChestJob.itemsize == 96, PuschChestJob.itemsize
 assert PuschChestJob.fields["rb_mask"][1] == 32 and PuschChestJob.fields["symbols_mask"][1] == 28
+
+
+class PolarCode(C.Structure):
+    """Mirrors miphy_polar_code (the arguments of srsran::polar_code::set)."""
+    _fields_ = [("K", C.c_uint32), ("E", C.c_uint32), ("nMax", C.c_uint32), ("ibil", C.c_uint32)]
+
+    def info(self):
+        n, N, npc = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().miphy_polar_code_info(C.byref(self), C.byref(n), C.byref(N), C.byref(npc)))
+        return n.value, N.value, npc.value
 
 
 # Mirrors miphy_crc_desc.
@@ -192,3 +206,17 @@ class Context:
     def dmrs_pusch_estimate_batch(self, jobs, grid, ce, scalars, stream=None):
         jobs, n, ptr, on_dev = self._descs(jobs, PuschChestJob)
         check(lib().miphy_dmrs_pusch_estimate_batch(self.h, ptr, on_dev, n, _dptr(grid), _dptr(ce), _dptr(scalars), _stream_ptr(stream)))
+
+    # ------------------------------------------------------------------ polar chains / PDCCH encoder
+    def polar_encode_batch(self, code, n, msg, rm_out, allocated_tap=None, encoded_tap=None, stream=None):
+        check(lib().miphy_polar_encode_batch(self.h, C.byref(code), n, _dptr(msg), _dptr(rm_out),
+                                             _dptr(allocated_tap) if allocated_tap is not None else None,
+                                             _dptr(encoded_tap) if encoded_tap is not None else None, _stream_ptr(stream)))
+
+    def polar_decode_batch(self, code, n, llr, msg_out, dematched_tap=None, decoded_u_tap=None, stream=None):
+        check(lib().miphy_polar_decode_batch(self.h, C.byref(code), n, _dptr(llr), _dptr(msg_out),
+                                             _dptr(dematched_tap) if dematched_tap is not None else None,
+                                             _dptr(decoded_u_tap) if decoded_u_tap is not None else None, _stream_ptr(stream)))
+
+    def pdcch_encode_batch(self, A, E, n, payload, rnti, out, stream=None):
+        check(lib().miphy_pdcch_encode_batch(self.h, A, E, n, _dptr(payload), _dptr(rnti), _dptr(out), _stream_ptr(stream)))

@@ -213,6 +213,30 @@ def o_gold(c_init, offset, nbits):
     return out
 
 
+def o_polar_encode_chain(K, E, nMax, ibil, msg):
+    msg = np.ascontiguousarray(msg, dtype=np.uint8)
+    out, alloc, enc = np.zeros(E, np.uint8), np.zeros(1024, np.uint8), np.zeros(1024, np.uint8)
+    N = oracle().orc_polar_encode_chain(C.c_uint(K), C.c_uint(E), C.c_uint(nMax), int(ibil), _p(msg), _p(out), _p(alloc), _p(enc))
+    assert N > 0, N
+    return out, alloc[:N], enc[:N]
+
+
+def o_polar_decode_chain(K, E, nMax, ibil, llr):
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    msg, dem, u = np.zeros(K, np.uint8), np.zeros(1024, np.int8), np.zeros(1024, np.uint8)
+    N = oracle().orc_polar_decode_chain(C.c_uint(K), C.c_uint(E), C.c_uint(nMax), int(ibil), _p(llr), _p(msg), _p(dem), _p(u))
+    assert N > 0, N
+    return msg, dem[:N], u[:N]
+
+
+def o_pdcch_encode(payload, rnti, E):
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    out = np.zeros(E, np.uint8)
+    rc = oracle().orc_pdcch_encode(_p(payload), C.c_uint(payload.size), C.c_uint(rnti), C.c_uint(E), _p(out))
+    assert rc == 0
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- reference wrappers
 IMPL = {"generic": 0, "avx2": 1, "avx512": 2, "auto": 3}
 
@@ -341,3 +365,17 @@ def r_dmrs_pusch_estimate(*a):
     rc = ref().ref_dmrs_pusch_estimate(*args)
     assert rc == 0, rc
     return ce, sc
+
+
+def r_polar_encode_chain(K, E, nMax, ibil, msg):
+    msg = np.ascontiguousarray(msg, dtype=np.uint8)
+    out, alloc, enc = np.zeros(E, np.uint8), np.zeros(1024, np.uint8), np.zeros(1024, np.uint8)
+    N = ref().ref_polar_encode_chain(C.c_uint(K), C.c_uint(E), C.c_uint(nMax), int(ibil), _p(msg), _p(out), _p(alloc), _p(enc))
+    return out, alloc[:N], enc[:N]
+
+
+def r_polar_decode_chain(K, E, nMax, ibil, llr):
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    msg, dem, u = np.zeros(K, np.uint8), np.zeros(1024, np.int8), np.zeros(1024, np.uint8)
+    N = ref().ref_polar_decode_chain(C.c_uint(K), C.c_uint(E), C.c_uint(nMax), int(ibil), _p(llr), _p(msg), _p(dem), _p(u))
+    return msg, dem[:N], u[:N]

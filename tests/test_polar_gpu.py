@@ -1,0 +1,96 @@
+"""GPU parity for the polar chains (encode: allocate+encode+rate-match; decode: dematch+SSC+deallocate) and the PDCCH
+encoder vs the CPU oracle -- bit-exact, including every intermediate tap."""
+import numpy as np
+import pytest
+
+from oracle_lib import o_pdcch_encode, o_polar_decode_chain, o_polar_encode_chain
+
+pytestmark = pytest.mark.gpu
+
+
+def polar_cases():
+    cases = []
+    for A in (12, 40, 70, 140):  # PDCCH: K = A + 24, E = 108 * AL (BASELINE config C4)
+        for AL in (1, 2, 4, 8, 16):
+            if A + 24 < 108 * AL:
+                cases.append((A + 24, 108 * AL, 9, 0))
+    cases.append((56, 864, 9, 0))  # PBCH
+    for K, E in ((18, 60), (20, 100), (25, 300), (31, 64), (40, 100), (100, 200), (200, 1000), (500, 1500), (1023, 2000),
+                 (64, 8192), (300, 400), (22, 500), (19, 29)):  # uplink (UCI) incl. parity-check bits and all RM modes
+        for ibil in (0, 1):
+            cases.append((K, E, 10, ibil))
+    return cases
+
+
+@pytest.mark.parametrize("K,E,nMax,ibil", polar_cases())
+def test_polar_chains(ctx, K, E, nMax, ibil):
+    import torch
+    import miphy
+    rng = np.random.default_rng(K * 7 + E)
+    code = miphy.PolarCode(K, E, nMax, ibil)
+    n_log, N, nPC = code.info()
+    nb = 6
+    msgs = rng.integers(0, 2, (nb, K), dtype=np.uint8)
+    m_d = torch.from_numpy(msgs.reshape(-1)).cuda()
+    out_d = torch.zeros(nb * E, dtype=torch.uint8, device="cuda")
+    al_d = torch.zeros(nb * N, dtype=torch.uint8, device="cuda")
+    en_d = torch.zeros(nb * N, dtype=torch.uint8, device="cuda")
+    ctx.polar_encode_batch(code, nb, m_d, out_d, al_d, en_d)
+    torch.cuda.synchronize()
+    out, al, en = out_d.cpu().numpy().reshape(nb, E), al_d.cpu().numpy().reshape(nb, N), en_d.cpu().numpy().reshape(nb, N)
+    exp = [o_polar_encode_chain(K, E, nMax, ibil, msgs[i]) for i in range(nb)]
+    for i in range(nb):
+        assert exp[i][1].size == N
+        assert np.array_equal(al[i], exp[i][1]) and np.array_equal(en[i], exp[i][2]) and np.array_equal(out[i], exp[i][0]), (K, E, i)
+    # decode: noiseless +-1 (polar_chain_test.cpp:192-210), AWGN, and arbitrary LLRs incl. infinities
+    llrs = np.zeros((nb, E), dtype=np.int8)
+    for i in range(nb):
+        if i < 2:
+            llrs[i] = 1 - 2 * exp[i][0].astype(np.int16)
+        elif i < 4:
+            y = (1.0 - 2.0 * exp[i][0]) + [0.7, 1.0][i - 2] * rng.standard_normal(E)
+            llrs[i] = np.round(np.clip(4 * y, -20, 20) / 20 * 120)
+        else:
+            v = rng.integers(-120, 121, E)
+            v[rng.random(E) < 0.1] = 0
+            v[rng.random(E) < 0.05] = 127
+            v[rng.random(E) < 0.05] = -127
+            llrs[i] = v
+    l_d = torch.from_numpy(llrs.reshape(-1)).cuda()
+    msg_d = torch.zeros(nb * K, dtype=torch.uint8, device="cuda")
+    dem_d = torch.zeros(nb * N, dtype=torch.int8, device="cuda")
+    u_d = torch.zeros(nb * N, dtype=torch.uint8, device="cuda")
+    ctx.polar_decode_batch(code, nb, l_d, msg_d, dem_d, u_d)
+    torch.cuda.synchronize()
+    got_m, got_d, got_u = msg_d.cpu().numpy().reshape(nb, K), dem_d.cpu().numpy().reshape(nb, N), u_d.cpu().numpy().reshape(nb, N)
+    for i in range(nb):
+        em, ed, eu = o_polar_decode_chain(K, E, nMax, ibil, llrs[i])
+        assert np.array_equal(got_d[i], ed), (K, E, i, "dematch")
+        assert np.array_equal(got_u[i], eu), (K, E, i, "decode")
+        assert np.array_equal(got_m[i], em), (K, E, i, "deallocate")
+        if i < 2:
+            assert np.array_equal(got_m[i], msgs[i])
+
+
+def test_pdcch_encoder_batch(ctx):
+    import torch
+    rng = np.random.default_rng(41)
+    for A, AL in ((12, 1), (40, 2), (39, 4), (70, 8), (140, 16), (41, 16)):
+        E = 108 * AL
+        n = 50
+        pay = rng.integers(0, 2, (n, A), dtype=np.uint8)
+        rnti = rng.integers(0, 65536, n).astype(np.uint16)
+        out_d = torch.zeros(n * E, dtype=torch.uint8, device="cuda")
+        ctx.pdcch_encode_batch(A, E, n, torch.from_numpy(pay.reshape(-1)).cuda(), torch.from_numpy(rnti.view(np.int16)).cuda(), out_d)
+        torch.cuda.synchronize()
+        out = out_d.cpu().numpy().reshape(n, E)
+        for i in range(n):
+            assert np.array_equal(out[i], o_pdcch_encode(pay[i], int(rnti[i]), E)), (A, AL, i)
+
+
+def test_polar_invalid_code(ctx):
+    import miphy
+    with pytest.raises(RuntimeError):
+        miphy.PolarCode(30, 100, 9, 0).info()  # downlink needs 36 <= K <= 164 (polar_code_impl.cpp:335-341)
+    with pytest.raises(RuntimeError):
+        miphy.PolarCode(50, 40, 10, 0).info()  # E must exceed K
