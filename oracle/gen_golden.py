@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: generates the golden fixtures under tests/golden/ by running THE REFERENCE ITSELF
+(srsRAN_Project 23.5 compiled in place into oracle/_ref/libref_capi.so by oracle/build_ref.sh).
+
+Each .npz holds seeded inputs and the outputs the reference produced for them (AVX2 implementations where the reference
+has several).  The fixtures are data only; they let the GPU box -- which has neither /root/reference nor oracle/_ref
+sources -- check the CPU oracle (tests/test_oracle_golden.py) and the HIP kernels against reference-produced vectors.
+Run:  bash oracle/build_ref.sh && python oracle/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+rng = np.random.default_rng(20231005)
+
+
+def noisy(cw, sigma):
+    y = (1.0 - 2.0 * (cw & 1)) + sigma * rng.standard_normal(cw.size)
+    return np.round(np.clip(4 * y, -20, 20) / 20 * 120).astype(np.int8)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %7.1f KiB" % (name, os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------ CRC
+d = {}
+for i, (poly, n) in enumerate([(p, n) for p in range(5) for n in (1, 24, 100, 1001, 8424)]):
+    bits = rng.integers(0, 2, n, dtype=np.uint8)
+    d["bits_%d" % i] = bits
+    d["meta_%d" % i] = np.array([poly, O.r_crc_bits(poly, bits)], dtype=np.int64)
+save("crc", **d)
+
+# ------------------------------------------------------------------ LDPC encoder / decoder (subset of the 102 graphs)
+d = {}
+dec = O.RefLdpcDecoder("avx2")
+i = 0
+for bg in (1, 2):
+    for Z in (2, 7, 24, 52, 104, 208, 352, 384):
+        K, NS = O.BG_K[bg] * Z, O.BG_NS[bg] * Z
+        nf = int(rng.integers(0, max(1, Z // 2)))
+        poly, nb = (O.CRC24B, 24) if K - nf > 60 else (O.CRC16, 16)
+        if K - nf <= nb + 2:
+            nf = 0
+        msg = rng.integers(0, 2, K, dtype=np.uint8)
+        c = O.r_crc_bits(poly, msg[:K - nf - nb])
+        msg[K - nf - nb:K - nf] = [(c >> (nb - 1 - j)) & 1 for j in range(nb)]
+        if nf:
+            msg[K - nf:] = 254
+        cw = O.r_ldpc_encode(bg, Z, msg, NS, "avx2")
+        L = [NS, K + 2 * Z, (K + 2 * Z + NS) // 2 // Z * Z][i % 3]
+        llr = noisy(cw[:L], [0.55, 0.3, 0.8][i % 3])
+        if nf:
+            llr[K - 2 * Z - nf:K - 2 * Z] = 127
+        rows = []
+        for crc, mi in ((poly, 6), (-1, 2), (poly, 1)):
+            it, bits = dec.decode(bg, Z, llr, nf, crc, mi)
+            rows.append(np.concatenate([[crc, mi, it], bits]).astype(np.int64))
+        d["msg_%d" % i], d["cw_%d" % i], d["llr_%d" % i] = msg, cw, llr
+        d["meta_%d" % i] = np.array([bg, Z, nf, L], dtype=np.int64)
+        d["dec_%d" % i] = np.stack(rows)
+        i += 1
+save("ldpc_enc_dec", **d)
+
+# ------------------------------------------------------------------ rate matcher / dematcher
+d = {}
+i = 0
+for bg, Z in ((1, 384), (2, 208), (1, 16), (2, 7)):
+    N, K = O.BG_NS[bg] * Z, O.BG_K[bg] * Z
+    for rv in range(4):
+        for mod, Nref in ((1, 0), (2, N - 3 * Z), (4, 0), (6, (2 * N) // 3), (8, 0)):
+            if Z > 100 and (rv, mod) not in ((0, 8), (2, 2), (3, 6)):
+                continue  # keep the fixture small: three large-Z cases per graph
+            nf = int(rng.integers(0, Z))
+            cb = rng.integers(0, 2, N, dtype=np.uint8)
+            if nf:
+                cb[K - 2 * Z - nf:K - 2 * Z] = 254
+            E = mod * int(rng.integers(K // (2 * mod), (2 * N) // mod))
+            rm = O.r_rate_match(bg, Z, rv, mod, Nref, nf, cb, E)
+            llr = rng.integers(-120, 121, E).astype(np.int8)
+            sb = rng.integers(-120, 121, N).astype(np.int8)
+            d["cb_%d" % i], d["rm_%d" % i], d["llr_%d" % i], d["sb_%d" % i] = cb, rm, llr, sb
+            d["rdm_new_%d" % i] = O.r_rate_dematch(bg, Z, rv, mod, Nref, nf, 1, llr, sb, "avx2")
+            d["rdm_comb_%d" % i] = O.r_rate_dematch(bg, Z, rv, mod, Nref, nf, 0, llr, sb, "avx2")
+            d["meta_%d" % i] = np.array([bg, Z, rv, mod, Nref, nf, E], dtype=np.int64)
+            i += 1
+save("ldpc_rate_match", **d)
+
+# ------------------------------------------------------------------ PDSCH encoder / PUSCH decoder with HARQ
+d = {}
+for i, (bg, mod, nl, nprb, tbs, sigma) in enumerate([(2, 2, 1, 20, 1032, 1.1), (1, 4, 1, 40, 15880, 0.62), (1, 6, 2, 25, 40976, 0.45),
+                                                     (2, 2, 1, 2, 24, 0.9)]):
+    nsym = nprb * 156 * nl
+    tb = rng.integers(0, 256, tbs // 8, dtype=np.uint8)
+    rvs = [0, 2, 3, 1]
+    cws = np.stack([O.r_pdsch_encode(bg, rv, mod, 0, nl, nsym, tb, "avx2") for rv in rvs])
+    llrs = np.stack([noisy(c, sigma) for c in cws])
+    pd = O.RefPuschDecoder("avx2")
+    ok, tbo, mm = pd.decode_sequence(bg, mod, 0, nl, nsym, tbs // 8, rvs, llrs, 6, True)
+    d["tb_%d" % i], d["cw_%d" % i], d["llr_%d" % i] = tb, cws, llrs
+    d["meta_%d" % i] = np.array([bg, mod, nl, nsym, tbs], dtype=np.int64)
+    d["res_%d" % i] = np.array([[int(o), a, b] for o, (a, b) in zip(ok, mm)], dtype=np.int64)
+    d["tbo_%d" % i] = tbo
+save("sch_chain", **d)
+
+# ------------------------------------------------------------------ DFT / OFDM
+d = {}
+for i, N in enumerate((128, 384, 512, 1536)):
+    x = (rng.uniform(-1, 1, N) + 1j * rng.uniform(-1, 1, N)).astype(np.complex64)
+    d["x_%d" % i], d["fwd_%d" % i], d["inv_%d" % i] = x, O.r_dft(x, False), O.r_dft(x, True)
+save("dft", **d)
+d = {}
+for i, (mu, rb, N, wo, fc, slot) in enumerate([(0, 25, 512, 18, 2.6e9, 0), (1, 51, 1024, 36, 3.5e9, 1)]):
+    cfg = O.OfdmCfg(mu, rb, N, wo, 0.5, fc)
+    ns = O.o_ofdm_slot_size(cfg, slot)
+    x = ((rng.standard_normal(ns) + 1j * rng.standard_normal(ns)) * 0.7).astype(np.complex64)
+    g = (rng.standard_normal((14, rb * 12)) + 1j * rng.standard_normal((14, rb * 12))).astype(np.complex64)
+    d["x_%d" % i], d["grid_%d" % i] = x, O.r_ofdm_demod_slot(cfg, slot, x)
+    d["g_%d" % i], d["y_%d" % i] = g, O.r_ofdm_mod_slot(O.OfdmCfg(mu, rb, N, 0, 0.01, fc), slot, g, ns)
+    d["meta_%d" % i] = np.array([mu, rb, N, wo, fc, slot], dtype=np.float64)
+save("ofdm", **d)
+
+# ------------------------------------------------------------------ DM-RS PUSCH estimator
+d = {}
+for i, (nprb, alloc, nports, nl, syms, mu, slot, scr, nscid, scaling) in enumerate([
+        (25, slice(0, 25), 2, 1, [2], 1, 3, 77, 0, 1.0), (52, slice(10, 40), 1, 2, [2, 11], 1, 17, 1000, 1, 0.7071),
+        (30, [0, 1, 2, 10, 11, 20], 2, 1, [2, 7, 11], 0, 9, 5, 0, 1.0)]):
+    rb = np.zeros(nprb, np.uint8)
+    rb[alloc] = 1
+    sm = np.zeros(14, np.uint8)
+    sm[syms] = 1
+    g = ((rng.standard_normal((nports, 14, nprb * 12)) + 1j * rng.standard_normal((nports, 14, nprb * 12))) * 0.7).astype(np.complex64)
+    ce, sc = O.r_dmrs_pusch_estimate(mu, slot, False, scr, nscid, scaling, sm, rb, 0, 14, nl, g)
+    mask = np.repeat(rb.astype(bool), 12)
+    d["grid_%d" % i], d["ce_%d" % i], d["sc_%d" % i] = g, ce[..., mask], sc
+    d["rb_%d" % i], d["sm_%d" % i] = rb, sm
+    d["meta_%d" % i] = np.array([mu, slot, scr, nscid, scaling, nl], dtype=np.float64)
+save("dmrs_pusch_estimator", **d)
+
+# ------------------------------------------------------------------ polar chains / PDCCH
+d = {}
+for i, (K, E, nMax, ibil) in enumerate([(36, 108, 9, 0), (64, 216, 9, 0), (94, 432, 9, 0), (152, 1728, 9, 0), (56, 864, 9, 0),
+                                        (20, 100, 10, 1), (25, 300, 10, 0), (100, 200, 10, 1), (500, 1500, 10, 0), (300, 400, 10, 1)]):
+    msg = rng.integers(0, 2, K, dtype=np.uint8)
+    rm, al, en = O.r_polar_encode_chain(K, E, nMax, ibil, msg)
+    llr = noisy(rm, 0.8)
+    m2, dem, u = O.r_polar_decode_chain(K, E, nMax, ibil, llr)
+    d["msg_%d" % i], d["rm_%d" % i], d["alloc_%d" % i], d["enc_%d" % i] = msg, rm, al, en
+    d["llr_%d" % i], d["dec_msg_%d" % i], d["dem_%d" % i], d["u_%d" % i] = llr, m2, dem, u
+    d["meta_%d" % i] = np.array([K, E, nMax, ibil], dtype=np.int64)
+for i, (A, AL) in enumerate([(12, 1), (40, 2), (70, 8), (128, 16)]):
+    pay = rng.integers(0, 2, A, dtype=np.uint8)
+    rnti = int(rng.integers(0, 65536))
+    d["pdcch_pay_%d" % i], d["pdcch_out_%d" % i] = pay, O.r_pdcch_encode(pay, rnti, 108 * AL)
+    d["pdcch_meta_%d" % i] = np.array([A, 108 * AL, rnti], dtype=np.int64)
+save("polar", **d)

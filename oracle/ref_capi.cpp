@@ -677,4 +677,15 @@ int ref_polar_interleave(const uint8_t* in, uint8_t* out, unsigned K, int dir)
   return 0;
 }
 
+// ---------------------------------------------------------------- PDCCH encoder
+int ref_pdcch_encode(const uint8_t* payload, unsigned A, unsigned rnti, unsigned E, uint8_t* out)
+{
+  auto                     enc = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
+  pdcch_encoder::config_t cfg;
+  cfg.E    = E;
+  cfg.rnti = rnti;
+  enc->encode(span<uint8_t>(out, E), span<const uint8_t>(payload, A), cfg);
+  return 0;
+}
+
 } // extern "C"

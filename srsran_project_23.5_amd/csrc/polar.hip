@@ -492,7 +492,7 @@ extern "C" int miphy_pdcch_encode_batch(miphy_ctx*      ctx,
                                         void*           stream)
 {
   MIPHY_REQUIRE(ctx && payload && rnti && out, "miphy_pdcch_encode_batch: null argument");
-  MIPHY_REQUIRE(A >= 12 && A <= 140, "pdcch_encode: payload size %u out of range (12..140)", A);
+  MIPHY_REQUIRE(A >= 12 && A <= 128, "pdcch_encode: payload size %u out of range (12..MAX_DCI_PAYLOAD_SIZE = 128)", A);
   miphy_polar_code  code = {A + 24, E, 9, 0};
   const polar_plan* p    = nullptr;
   int               rc   = get_plan(ctx, &code, &p);

@@ -379,3 +379,10 @@ def r_polar_decode_chain(K, E, nMax, ibil, llr):
     msg, dem, u = np.zeros(K, np.uint8), np.zeros(1024, np.int8), np.zeros(1024, np.uint8)
     N = ref().ref_polar_decode_chain(C.c_uint(K), C.c_uint(E), C.c_uint(nMax), int(ibil), _p(llr), _p(msg), _p(dem), _p(u))
     return msg, dem[:N], u[:N]
+
+
+def r_pdcch_encode(payload, rnti, E):
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    out = np.zeros(E, np.uint8)
+    ref().ref_pdcch_encode(_p(payload), C.c_uint(payload.size), C.c_uint(rnti), C.c_uint(E), _p(out))
+    return out

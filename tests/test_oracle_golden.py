@@ -1,0 +1,138 @@
+"""CPU: the oracle (oracle/phy_oracle.c) against the golden fixtures that oracle/gen_golden.py produced BY RUNNING THE
+REFERENCE (srsRAN_Project 23.5, AVX2 paths). Integer work bit-exact; floating point within the stated tolerances.
+This is what pins the oracle on machines where /root/reference does not exist (the GPU box)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def count(d, prefix):
+    return len([k for k in d.files if k.startswith(prefix)])
+
+
+def test_crc():
+    d = load("crc")
+    for i in range(count(d, "bits_")):
+        poly, exp = d["meta_%d" % i]
+        assert O.o_crc_bits(int(poly), d["bits_%d" % i]) == int(exp)
+
+
+def test_ldpc_encoder_decoder():
+    d = load("ldpc_enc_dec")
+    for i in range(count(d, "msg_")):
+        bg, Z, nf, L = (int(x) for x in d["meta_%d" % i])
+        cw = O.o_ldpc_encode(bg, Z, d["msg_%d" % i], O.BG_NS[bg] * Z)
+        assert np.array_equal(cw, d["cw_%d" % i]), (bg, Z)
+        for row in d["dec_%d" % i]:
+            crc, mi, it = (int(x) for x in row[:3])
+            ito, bits = O.o_ldpc_decode(bg, Z, d["llr_%d" % i], nf, crc, mi)
+            assert ito == it and np.array_equal(bits, row[3:].astype(np.uint8)), (bg, Z, crc, mi)
+
+
+def test_rate_matcher_dematcher():
+    d = load("ldpc_rate_match")
+    for i in range(count(d, "cb_")):
+        bg, Z, rv, mod, Nref, nf, E = (int(x) for x in d["meta_%d" % i])
+        assert np.array_equal(O.o_rate_match(rv, mod, Nref, nf, d["cb_%d" % i], E), d["rm_%d" % i])
+        assert np.array_equal(O.o_rate_dematch(rv, mod, Nref, nf, 1, d["llr_%d" % i], d["sb_%d" % i]), d["rdm_new_%d" % i])
+        assert np.array_equal(O.o_rate_dematch(rv, mod, Nref, nf, 0, d["llr_%d" % i], d["sb_%d" % i]), d["rdm_comb_%d" % i])
+
+
+def test_sch_chain_with_harq():
+    d = load("sch_chain")
+    for i in range(count(d, "tb_")):
+        bg, mod, nl, nsym, tbs = (int(x) for x in d["meta_%d" % i])
+        tb = d["tb_%d" % i]
+        rvs = [0, 2, 3, 1]
+        for t, rv in enumerate(rvs):
+            assert np.array_equal(O.o_pdsch_encode(bg, rv, mod, 0, nl, nsym, tb), d["cw_%d" % i][t])
+        od = O.OraclePuschDecoder(bg, mod, 0, nl, nsym, tbs // 8)
+        for t, rv in enumerate(rvs):
+            ok, tbo, mm = od.decode(d["llr_%d" % i][t], rv, t == 0, 6, True)
+            eo, ea, eb = (int(x) for x in d["res_%d" % i][t])
+            assert (int(ok), mm[0], mm[1]) == (eo, ea, eb), (i, t)
+            if ok:
+                assert np.array_equal(tbo, d["tbo_%d" % i][t])
+
+
+def test_dft():
+    """Reference = float radix-2 generic DFT; oracle = exact transform. Tolerance 3e-6 * rms (the reference's own test allows
+    MSE < 1e-6, dft_processor_test.cpp:40-42)."""
+    d = load("dft")
+    for i in range(count(d, "x_")):
+        for key, inv in (("fwd", False), ("inv", True)):
+            ref = d["%s_%d" % (key, i)]
+            got = O.o_dft(d["x_%d" % i], inv)
+            assert np.abs(got - ref).max() < 3e-6 * np.sqrt(np.mean(np.abs(ref) ** 2))
+
+
+def test_ofdm():
+    d = load("ofdm")
+    for i in range(count(d, "x_")):
+        mu, rb, N, wo, fc, slot = d["meta_%d" % i]
+        cfg = O.OfdmCfg(int(mu), int(rb), int(N), int(wo), 0.5, float(fc))
+        g = O.o_ofdm_demod_slot(cfg, int(slot), d["x_%d" % i])
+        ref = d["grid_%d" % i]
+        assert np.abs(g - ref).max() < 3e-6 * np.sqrt(np.mean(np.abs(ref) ** 2))
+        y = O.o_ofdm_mod_slot(O.OfdmCfg(int(mu), int(rb), int(N), 0, 0.01, float(fc)), int(slot), d["g_%d" % i])
+        ref = d["y_%d" % i]
+        assert np.abs(y - ref).max() < 3e-6 * np.sqrt(np.mean(np.abs(ref) ** 2))
+
+
+def test_dmrs_pusch_estimator():
+    """Tolerances: coefficients 1e-5 * max|h|, scalars 1e-5 relative, time alignment exact (reference test: 5e-4)."""
+    d = load("dmrs_pusch_estimator")
+    for i in range(count(d, "grid_")):
+        mu, slot, scr, nscid, scaling, nl = d["meta_%d" % i]
+        rb, sm = d["rb_%d" % i], d["sm_%d" % i]
+        ce, sc = O.o_dmrs_pusch_estimate(int(mu), int(slot), False, int(scr), int(nscid), float(scaling), sm, rb, 0, 14, int(nl), d["grid_%d" % i])
+        mask = np.repeat(rb.astype(bool), 12)
+        ref = d["ce_%d" % i]
+        assert np.abs(ce[..., mask] - ref).max() < 1e-5 * np.abs(ref).max()
+        rsc = d["sc_%d" % i]
+        assert np.all(np.abs(sc[..., :4] - rsc[..., :4]) <= 1e-5 * np.abs(rsc[..., :4]))
+        assert np.array_equal(sc[..., 4], rsc[..., 4])
+
+
+def test_polar_and_pdcch():
+    d = load("polar")
+    for i in range(count(d, "msg_")):
+        K, E, nMax, ibil = (int(x) for x in d["meta_%d" % i])
+        rm, al, en = O.o_polar_encode_chain(K, E, nMax, ibil, d["msg_%d" % i])
+        assert np.array_equal(rm, d["rm_%d" % i]) and np.array_equal(al, d["alloc_%d" % i]) and np.array_equal(en, d["enc_%d" % i])
+        m, dem, u = O.o_polar_decode_chain(K, E, nMax, ibil, d["llr_%d" % i])
+        assert np.array_equal(m, d["dec_msg_%d" % i]) and np.array_equal(dem, d["dem_%d" % i]) and np.array_equal(u, d["u_%d" % i])
+    for i in range(count(d, "pdcch_pay_")):
+        A, E, rnti = (int(x) for x in d["pdcch_meta_%d" % i])
+        assert np.array_equal(O.o_pdcch_encode(d["pdcch_pay_%d" % i], rnti, E), d["pdcch_out_%d" % i])
+
+
+def test_llr_algebra_kats():
+    """Known answers of tests/unittests/phy/upper/log_likelihood_ratio_test.cpp:37-86 as they surface through the oracle's
+    rate-dematcher combine (clamp to +-120) and the polar repetition combine (promotion to +-127)."""
+    # saturating combine: 100 + 50 -> 120, -100 + -50 -> -120, 5 + -5 -> 0
+    N = 66 * 2
+    sb = np.zeros(N, np.int8)
+    sb[:3] = [100, -100, 5]
+    llr = np.array([50, -50, -5, 0], np.int8)
+    out = O.o_rate_dematch(0, 1, 0, 0, 0, llr, sb)
+    assert list(out[:3]) == [120, -120, 0]
+    # promotion sum through polar repetition (E >= N): 100 + 50 -> +inf (127)
+    K, E = 36, 1728  # PDCCH AL16: N = 512 < E, every codeword position receives 3 or 4 repetitions
+    llr = np.zeros(E, np.int8)
+    llr[0], llr[512] = 100, 50
+    llr[1], llr[513] = -100, -50
+    llr[2], llr[514] = 127, -127
+    _, dem, _ = O.o_polar_decode_chain(K, E, 9, 0, llr)
+    assert dem.size == 512
+    # the sub-block interleaver maps positions 0, 1, 2 to themselves (P(0) = 0)
+    assert dem[0] == 127 and dem[1] == -127 and dem[2] == 0

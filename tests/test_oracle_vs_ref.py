@@ -1,0 +1,160 @@
+"""CPU: the oracle against the reference itself (oracle/_ref/libref_capi.so, built from /root/reference by
+oracle/build_ref.sh). Skipped where the reference build is not present. Seeded, sized to run in well under a minute."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (no /root/reference here)")
+
+
+def noisy(cw, sigma, rng):
+    y = (1.0 - 2.0 * (cw & 1)) + sigma * rng.standard_normal(cw.size)
+    return np.round(np.clip(4 * y, -20, 20) / 20 * 120).astype(np.int8)
+
+
+def test_crc_all_polynomials():
+    rng = np.random.default_rng(0)
+    for poly in range(5):  # CRC6 is not on the hot path (UCI only) and not restated
+        for n in (1, 7, 8, 9, 24, 100, 1001, 8424, 8423):
+            b = rng.integers(0, 2, n, dtype=np.uint8)
+            assert O.o_crc_bits(poly, b) == O.r_crc_bits(poly, b) == O.r_crc_bits(poly, b, True)
+
+
+def test_ldpc_encoder_all_102_graphs():
+    rng = np.random.default_rng(1)
+    for bg in (1, 2):
+        for Z in O.ALL_Z:
+            K = O.BG_K[bg] * Z
+            msg = rng.integers(0, 2, K, dtype=np.uint8)
+            nf = int(rng.integers(0, Z))
+            if nf:
+                msg[-nf:] = 254
+            for ol in (O.BG_NS[bg] * Z, K + 2 * Z):
+                o = O.o_ldpc_encode(bg, Z, msg, ol)
+                assert np.array_equal(o, O.r_ldpc_encode(bg, Z, msg, ol, "avx2"))
+                assert np.array_equal(o, O.r_ldpc_encode(bg, Z, msg, ol, "generic"))
+
+
+def test_ldpc_decoder_all_102_graphs_avx2():
+    rng = np.random.default_rng(2)
+    dec = O.RefLdpcDecoder("avx2")
+    for bg in (1, 2):
+        for Z in O.ALL_Z:
+            K, NS = O.BG_K[bg] * Z, O.BG_NS[bg] * Z
+            msg = rng.integers(0, 2, K, dtype=np.uint8)
+            poly, nb = (O.CRC24B, 24) if K > 60 else (O.CRC16, 16)
+            c = O.o_crc_bits(poly, msg[:K - nb])
+            msg[K - nb:] = [(c >> (nb - 1 - i)) & 1 for i in range(nb)]
+            cw = O.o_ldpc_encode(bg, Z, msg, NS)
+            for L, sigma in ((NS, 0.6), (K + 2 * Z, 0.3)):
+                llr = noisy(cw[:L], sigma, rng)
+                for crc, mi in ((poly, 6), (-1, 3)):
+                    a = O.o_ldpc_decode(bg, Z, llr, 0, crc, mi)
+                    b = dec.decode(bg, Z, llr, 0, crc, mi)
+                    assert a[0] == b[0] and np.array_equal(a[1], b[1]), (bg, Z, L, crc, mi)
+    # full-range inputs incl. infinities and zero tails
+    for bg, Z in ((1, 384), (2, 8), (1, 3), (2, 208)):
+        r = rng.integers(-127, 128, O.BG_NS[bg] * Z).astype(np.int8)
+        r[-(Z + Z // 2):] = 0
+        a, b = O.o_ldpc_decode(bg, Z, r, 0, -1, 4), dec.decode(bg, Z, r, 0, -1, 4)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1])
+        z = np.zeros_like(r)
+        a, b = O.o_ldpc_decode(bg, Z, z, 0, -1, 4), dec.decode(bg, Z, z, 0, -1, 4)
+        assert a[0] == b[0] == 0 and np.array_equal(a[1], b[1])
+
+
+def test_rate_match_dematch():
+    rng = np.random.default_rng(3)
+    for bg in (1, 2):
+        for Z in (2, 7, 52, 384):
+            N, K = O.BG_NS[bg] * Z, O.BG_K[bg] * Z
+            for rv in range(4):
+                for mod in (1, 2, 4, 6, 8):
+                    for Nref in (0, N - 3 * Z):
+                        nf = int(rng.integers(0, Z))
+                        cb = rng.integers(0, 2, N, dtype=np.uint8)
+                        if nf:
+                            cb[K - 2 * Z - nf:K - 2 * Z] = 254
+                        E = mod * int(rng.integers(1, 3 * N // mod))
+                        assert np.array_equal(O.o_rate_match(rv, mod, Nref, nf, cb, E), O.r_rate_match(bg, Z, rv, mod, Nref, nf, cb, E))
+                        llr = rng.integers(-120, 121, E).astype(np.int8)
+                        sb = rng.integers(-120, 121, N).astype(np.int8)
+                        for nd in (1, 0):
+                            o = O.o_rate_dematch(rv, mod, Nref, nf, nd, llr, sb)
+                            assert np.array_equal(o, O.r_rate_dematch(bg, Z, rv, mod, Nref, nf, nd, llr, sb, "avx2"))
+                            assert np.array_equal(o, O.r_rate_dematch(bg, Z, rv, mod, Nref, nf, nd, llr, sb, "generic"))
+
+
+def test_sch_chain_harq():
+    rng = np.random.default_rng(4)
+    for bg, mod, nl, nprb, tbs, sigma in ((2, 2, 1, 106, 3848, 1.3), (1, 4, 1, 106, 42016, 0.62), (1, 8, 1, 273, 319784, 0.45)):
+        nsym = nprb * 156 * nl
+        tb = rng.integers(0, 256, tbs // 8, dtype=np.uint8)
+        rvs = [0, 2, 3, 1]
+        cws = [O.o_pdsch_encode(bg, rv, mod, 0, nl, nsym, tb) for rv in rvs]
+        for rv, cw in zip(rvs, cws):
+            assert np.array_equal(cw, O.r_pdsch_encode(bg, rv, mod, 0, nl, nsym, tb, "avx2"))
+        llrs = np.stack([noisy(c, sigma, rng) for c in cws])
+        ok_r, tb_r, mm_r = O.RefPuschDecoder("avx2").decode_sequence(bg, mod, 0, nl, nsym, tbs // 8, rvs, llrs, 6, True)
+        od = O.OraclePuschDecoder(bg, mod, 0, nl, nsym, tbs // 8)
+        for t, rv in enumerate(rvs):
+            ok, tbo, mm = od.decode(llrs[t], rv, t == 0, 6, True)
+            assert ok == ok_r[t] and mm == mm_r[t]
+            if ok:
+                assert np.array_equal(tbo, tb_r[t]) and np.array_equal(tbo, tb)
+
+
+def test_dft_ofdm_tolerance():
+    rng = np.random.default_rng(5)
+    for N in (128, 384, 1024, 3072, 4096):
+        x = (rng.uniform(-1, 1, N) + 1j * rng.uniform(-1, 1, N)).astype(np.complex64)
+        for inv in (False, True):
+            o, r = O.o_dft(x, inv), O.r_dft(x, inv)
+            assert np.abs(o - r).max() < 3e-6 * np.sqrt(np.mean(np.abs(r) ** 2))
+    for mu, rb, N, wo, fc, slot in ((1, 273, 4096, 144, 3.5e9, 0), (1, 106, 2048, 72, 3.5e9, 1)):
+        cfg = O.OfdmCfg(mu, rb, N, wo, 0.5, fc)
+        ns = O.o_ofdm_slot_size(cfg, slot)
+        x = ((rng.standard_normal(ns) + 1j * rng.standard_normal(ns)) * 0.7).astype(np.complex64)
+        o, r = O.o_ofdm_demod_slot(cfg, slot, x), O.r_ofdm_demod_slot(cfg, slot, x)
+        assert np.abs(o - r).max() < 3e-6 * np.sqrt(np.mean(np.abs(r) ** 2))
+
+
+def test_dmrs_pusch_estimator():
+    rng = np.random.default_rng(6)
+    for nprb, alloc, nports, nl, syms in ((273, slice(0, 273), 1, 1, [2]), (106, slice(10, 60), 2, 2, [2, 11]),
+                                          (52, [0, 1, 2, 10, 11, 30], 1, 1, [3]), (25, slice(0, 25), 4, 4, [2, 3, 10, 11])):
+        rb = np.zeros(nprb, np.uint8)
+        rb[alloc] = 1
+        sm = np.zeros(14, np.uint8)
+        sm[syms] = 1
+        g = ((rng.standard_normal((nports, 14, nprb * 12)) + 1j * rng.standard_normal((nports, 14, nprb * 12))) * 0.7).astype(np.complex64)
+        a = (1, 3, False, 77, 0, 1.0, sm, rb, 0, 14, nl, g)
+        (co, so), (cr, sr) = O.o_dmrs_pusch_estimate(*a), O.r_dmrs_pusch_estimate(*a)
+        mask = np.repeat(rb.astype(bool), 12)
+        assert np.abs(co[..., mask] - cr[..., mask]).max() < 1e-5 * np.abs(cr[..., mask]).max()
+        assert np.all(np.abs(so[..., :4] - sr[..., :4]) <= 1e-5 * np.abs(sr[..., :4]))
+        assert np.array_equal(so[..., 4], sr[..., 4])
+
+
+def test_polar_chains_and_pdcch():
+    rng = np.random.default_rng(7)
+    cases = [(A + 24, 108 * AL, 9, 0) for A in (12, 40, 70, 128) for AL in (1, 2, 4, 8, 16) if A + 24 < 108 * AL] + [(56, 864, 9, 0)]
+    cases += [(K, E, 10, ib) for K, E in ((18, 60), (25, 300), (31, 64), (100, 200), (500, 1500), (1023, 2000), (64, 8192), (22, 500)) for ib in (0, 1)]
+    for K, E, nMax, ibil in cases:
+        msg = rng.integers(0, 2, K, dtype=np.uint8)
+        oo, rr = O.o_polar_encode_chain(K, E, nMax, ibil, msg), O.r_polar_encode_chain(K, E, nMax, ibil, msg)
+        assert all(np.array_equal(a, b) for a, b in zip(oo, rr)), (K, E)
+        for kind in range(3):
+            if kind == 0:
+                llr = (1 - 2 * oo[0].astype(np.int16)).astype(np.int8)
+            elif kind == 1:
+                llr = noisy(oo[0], 0.8, rng)
+            else:
+                llr = rng.integers(-120, 121, E).astype(np.int8)
+                llr[rng.random(E) < 0.05] = 127
+            od, rd = O.o_polar_decode_chain(K, E, nMax, ibil, llr), O.r_polar_decode_chain(K, E, nMax, ibil, llr)
+            assert all(np.array_equal(a, b) for a, b in zip(od, rd)), (K, E, kind)
+    for A, AL in ((12, 1), (40, 2), (70, 8), (128, 16)):
+        pay = rng.integers(0, 2, A, dtype=np.uint8)
+        assert np.array_equal(O.o_pdcch_encode(pay, 0x1234, 108 * AL), O.r_pdcch_encode(pay, 0x1234, 108 * AL))

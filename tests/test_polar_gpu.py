@@ -75,7 +75,7 @@ def test_polar_chains(ctx, K, E, nMax, ibil):
 def test_pdcch_encoder_batch(ctx):
     import torch
     rng = np.random.default_rng(41)
-    for A, AL in ((12, 1), (40, 2), (39, 4), (70, 8), (140, 16), (41, 16)):
+    for A, AL in ((12, 1), (40, 2), (39, 4), (70, 8), (128, 16), (41, 16)):
         E = 108 * AL
         n = 50
         pay = rng.integers(0, 2, (n, A), dtype=np.uint8)
