@@ -149,23 +149,55 @@ def main():
     dec_d = torch.from_numpy(dec.view(np.uint8)).to(dev)
     stream = torch.cuda.current_stream()
 
-    stages = ["rate_dematch", "ldpc_decode"]
+    # ---- front end of the slot: OFDM demodulation of the time-domain slot and DM-RS channel estimation (1 rx port,
+    # 1 layer, DM-RS in symbol 2 like pusch_processor_benchmark.cpp:104-105). The soft demapper between the estimator
+    # and the decoder is outside this path, so the codeword LLRs above are synthetic.
+    ocfg = miphy.OfdmConfig(1, w["nprb"], 4096, 144, 1.0, 0.0, 3.5e9)
+    slot_samples = ocfg.slot_size(0)
+    nsc = w["nprb"] * 12
+    g = torch.Generator(device=dev)
+    g.manual_seed(99 + rank)
+    samples_d = torch.view_as_complex(torch.randn(S * slot_samples, 2, device=dev, generator=g) * 0.7071)
+    grid_d = torch.zeros(S * 14 * nsc, dtype=torch.complex64, device=dev)
+    ce_d = torch.zeros(S * 14 * nsc, dtype=torch.complex64, device=dev)
+    sc_d = torch.zeros(S * 5, dtype=torch.float32, device=dev)
+    ojobs = np.zeros(S, dtype=miphy.OfdmJob)
+    cjobs = np.zeros(S, dtype=miphy.PuschChestJob)
+    for s in range(S):
+        ojobs[s] = (s * slot_samples, s * 14 * nsc, s % 2, 0)
+        j = cjobs[s]
+        j["numerology"], j["slot_in_frame"], j["scrambling_id"], j["scaling"] = 1, s % 20, 1, 1.0
+        j["nof_tx_layers"], j["nof_rx_ports"], j["first_symbol"], j["nof_symbols"] = 1, 1, 0, 14
+        j["rx_ports"] = [0, 1, 2, 3]
+        j["symbols_mask"], j["grid_nof_prb"] = 1 << 2, w["nprb"]
+        j["rb_mask"] = [0xFFFFFFFFFFFFFFFF] * 4 + [(1 << (w["nprb"] - 256)) - 1]
+        j["grid_offset"], j["ce_offset"], j["scalars_offset"] = s * 14 * nsc, s * 14 * nsc, s * 5
+    ojobs_d = torch.from_numpy(ojobs.view(np.uint8)).to(dev)
+    cjobs_d = torch.from_numpy(cjobs.view(np.uint8)).to(dev)
+
+    stages = ["ofdm_demod", "dmrs_chest", "rate_dematch", "ldpc_decode"]
     ev = {k: [] for k in stages}
 
     def step(timed):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] if timed else None
         if timed:
             e[0].record(stream)
+        ctx.ofdm_demodulate_slots(ocfg, ojobs_d, samples_d, grid_d, stream)
+        if timed:
+            e[1].record(stream)
+        ctx.dmrs_pusch_estimate_batch(cjobs_d, grid_d, ce_d, sc_d, stream)
+        if timed:
+            e[2].record(stream)
         # rate dematch in chunks of <= 65535 codeblocks
         n = S * C
         for a in range(0, n, 65535):
             b = min(n, a + 65535)
             ctx.ldpc_rate_dematch_batch(rdm_d[a * 32:b * 32], llr_d, softbuf_d, stream)
         if timed:
-            e[1].record(stream)
+            e[3].record(stream)
         ctx.ldpc_decode_batch(dec_d, softbuf_d, bits_d, iters_d, stream, limits=(Z, max(dec_in_len)))
         if timed:
-            e[2].record(stream)
+            e[4].record(stream)
             for i, k in enumerate(stages):
                 ev[k].append((e[i], e[i + 1]))
 
@@ -205,12 +237,16 @@ def main():
     value = info_bits / dt
     # Roofline of the dominant kernel (LDPC decode): algorithmic bytes per codeblock = N LLR bytes in + K/8 bytes out
     # + 4 bytes iteration count; units per launch = S*C codeblocks.
+    # Algorithmic bytes per launch: decode = LLRs in + K/8 out + 4 B iterations per codeblock;
+    # dematch = E in + N out per codeblock; OFDM demod = 61440*8 in + 14*3276*8 out per slot-port; estimator = DM-RS REs in
+    # (n_dmrs * 13104 B) + 14*3276*8 out per (slot, port, layer).
+    alg = {"ldpc_decode": S * sum(dec_in_len[c] + K // 8 + 4 for c in range(C)),
+           "rate_dematch": S * (G + C * N),
+           "ofdm_demod": S * (slot_samples * 8 + 14 * nsc * 8),
+           "dmrs_chest": S * (1 * (nsc // 2) * 8 + 14 * nsc * 8)}
+    gbs = {k: alg[k] / (kernel_ms[k] * 1e-3) / 1e9 for k in stages}
     dom = max(kernel_ms, key=kernel_ms.get)
-    if dom == "ldpc_decode":
-        alg_bytes = S * sum(dec_in_len[c] + K // 8 + 4 for c in range(C))
-    else:
-        alg_bytes = S * (G + C * N)
-    achieved = alg_bytes / (kernel_ms[dom] * 1e-3) / 1e9
+    achieved = gbs[dom]
     out = {
         "metric": "LDPC info-bits/sec + OFDM slots/sec, 100 MHz n78 273-PRB grid",
         "value": value,
@@ -225,11 +261,16 @@ def main():
         "dtype": "int8",
         "data": "synthetic",
         "config": {"workload": "273-PRB 30kHz PUSCH, 256QAM R=948/1024, 1 layer, 38 CB/slot BG1 Z=384, TBS 319784; "
-                               "rate-dematch + LDPC decode (%d it, early_stop=%d)" % (args.max_iter, args.early_stop),
+                               "per slot: OFDM demod (4096-pt, 1 port) + DM-RS channel estimate + rate-dematch + LDPC decode "
+                               "(%d it, early_stop=%d)" % (args.max_iter, args.early_stop),
                    "slots_per_gpu_per_step": S, "codeblocks_per_step": S * C * world, "sigma": args.sigma,
                    "parallelism": "slots sharded across GPUs, no data-path collective"},
         "slots_per_s": total_slots / dt,
         "kernel_ms": kernel_ms,
+        "kernel_algorithmic_GBps": gbs,
+        "ofdm_slots_per_s": S * world / (kernel_ms["ofdm_demod"] * 1e-3),
+        "roofline_ofdm": {"kernel": "ofdm_demod", "bound": "hbm", "achieved": gbs["ofdm_demod"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": gbs["ofdm_demod"] / HBM_PEAK_GBS, "traffic": None},
         "mean_ldpc_iterations": float(iters.mean()) if args.early_stop else float(args.max_iter),
         "parity_check": "%d/%d slots identical to oracle" % (ok_slots, checked),
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

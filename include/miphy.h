@@ -65,7 +65,7 @@ typedef struct {
   uint16_t max_iter;        /* algorithm_conf.max_iterations (default 6) */
   uint16_t nof_filler_bits; /* cb_specific.nof_filler_bits */
   uint32_t in_len;          /* number of input LLRs (first one belongs to variable node 2) */
-  uint32_t reserved;
+  uint32_t flags;           /* bit 0: check the CRC only after the last iteration (pusch_decoder_impl.cpp:105-118) */
   uint64_t llr_offset;      /* element offset of this codeblock's LLRs inside `llr` */
   uint64_t out_offset;      /* byte offset of this codeblock's packed message inside `out_bits` */
 } miphy_ldpc_dec_desc;
@@ -280,6 +280,80 @@ int miphy_polar_decode_batch(miphy_ctx* ctx, const miphy_polar_code* code, uint3
  * nMax = 9). payload: n x A bytes (one bit per byte); rnti: n entries; out: n x E bytes. */
 int miphy_pdcch_encode_batch(miphy_ctx* ctx, uint32_t A, uint32_t E, uint32_t n, const uint8_t* payload /* device */,
                              const uint16_t* rnti /* device */, uint8_t* out /* device */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * PUSCH decoder (whole transport blocks)  --  replaces srsran::pusch_decoder::decode
+ *   include/srsran/phy/upper/channel_processors/pusch_decoder.h:41-78
+ *   lib/phy/upper/channel_processors/pusch_decoder_impl.cpp:121-225 (segment_rx -> per codeblock rate-dematch + LDPC decode
+ *   with the per-codeblock CRC, skip of codeblocks already decoded in a previous transmission, TB assembly, TB CRC24A,
+ *   reset of the codeblock CRC flags when the TB CRC fails), ldpc_segmenter_impl.cpp:253-334 for the segmentation.
+ * The HARQ state the reference keeps in an rx_softbuffer (include/srsran/phy/upper/rx_softbuffer.h:42-72) lives in three
+ * caller-owned DEVICE arrays: soft bits [codeblock][N], decoded codeblock messages [codeblock][ceil(K/8)] and CRC flags
+ * [codeblock]; a transport block addresses its slice through `harq_cb_index` (index of its first codeblock).
+ * The transport block bytes are written only when every codeblock CRC passed (like the reference). */
+typedef struct {
+  uint8_t  bg;                  /* segmenter_cfg.base_graph: 1 or 2 */
+  uint8_t  rv;                  /* segmenter_cfg.rv */
+  uint8_t  mod;                 /* bits per symbol of segmenter_cfg.mod */
+  uint8_t  nof_layers;          /* segmenter_cfg.nof_layers */
+  uint8_t  new_data;            /* configuration::new_data */
+  uint8_t  use_early_stop;      /* configuration::use_early_stop */
+  uint16_t nof_ldpc_iterations; /* configuration::nof_ldpc_iterations */
+  uint32_t Nref;                /* segmenter_cfg.Nref */
+  uint32_t nof_ch_symbols;      /* segmenter_cfg.nof_ch_symbols */
+  uint32_t tb_bytes;            /* transport_block.size() */
+  uint32_t harq_cb_index;       /* first codeblock slot of this TB in the HARQ arrays */
+  uint64_t llr_offset;          /* element offset of the nof_ch_symbols*mod codeword LLRs inside `llrs` */
+  uint64_t tb_offset;           /* byte offset of the transport block inside `tb_out` */
+} miphy_pusch_tb_desc;
+
+typedef struct {              /* srsran::pusch_decoder_result */
+  int32_t  tb_crc_ok;
+  uint32_t nof_codeblocks_total;
+  uint32_t iters_min;           /* ldpc_decoder_stats over the codeblocks decoded in this call (0 when none) */
+  uint32_t iters_max;
+  float    iters_mean;
+  uint32_t nof_decoded;         /* number of observations */
+} miphy_pusch_result;
+
+/* Segmentation parameters of a transport block (ldpc::compute_nof_codeblocks / compute_lifting_size /
+ * compute_codeblock_size, include/srsran/phy/upper/channel_coding/ldpc/ldpc.h:128-207). Host only. */
+typedef struct {
+  uint32_t nof_cbs, Z, K, N, nof_filler_bits, nof_tb_crc_bits, nof_cb_crc_bits, cb_info_bits, zero_pad;
+} miphy_sch_segmentation;
+int miphy_sch_segmentation_info(uint32_t tb_bytes, uint32_t bg, miphy_sch_segmentation* out);
+
+int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
+                             const miphy_pusch_tb_desc* tbs, /* host */
+                             uint32_t                   n,
+                             const int8_t*              llrs,          /* device */
+                             int8_t*                    harq_softbits, /* device, in/out, stride 66*384 per codeblock slot */
+                             uint8_t*                   harq_msgs,     /* device, in/out, stride 1056 B per codeblock slot */
+                             uint8_t*                   harq_crc_ok,   /* device, in/out, 1 B per codeblock slot */
+                             uint8_t*                   tb_out,        /* device */
+                             miphy_pusch_result*        results,       /* device, n entries */
+                             void*                      stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * PDSCH encoder (whole transport blocks)  --  replaces srsran::pdsch_encoder::encode
+ *   include/srsran/phy/upper/channel_processors/pdsch_encoder.h, lib/phy/upper/channel_processors/pdsch_encoder_impl.cpp:28-65
+ *   (segment_tx: TB CRC16/24A, CB CRC24B, zero padding, fillers -> LDPC encode -> rate match into the codeword),
+ *   ldpc_segmenter_impl.cpp:89-234.
+ * tb_in: packed transport blocks; codeword_out: one bit per byte, nof_ch_symbols*mod bytes per TB. */
+typedef struct {
+  uint8_t  bg;
+  uint8_t  rv;
+  uint8_t  mod;
+  uint8_t  nof_layers;
+  uint32_t Nref;
+  uint32_t nof_ch_symbols;
+  uint32_t tb_bytes;
+  uint64_t tb_offset;       /* byte offset of the packed transport block inside `tb_in` */
+  uint64_t codeword_offset; /* byte offset of the codeword inside `codeword_out` */
+} miphy_pdsch_tb_desc;
+
+int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs /* host */, uint32_t n, const uint8_t* tb_in /* device */,
+                             uint8_t* codeword_out /* device */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -164,13 +164,55 @@ __device__ __forceinline__ uint32_t hard_word(const int8_t* soft, int t, int K)
   return w;
 }
 
+
+// CRC of the first L hard bits of the message held in `soft` (every thread of the block must call). One 32-bit word of the
+// message per lane: partial remainder, weight x^(32*(nfull-1-t)+rbits) mod P, XOR reduction over the block.
+__device__ __forceinline__ uint32_t block_crc(const int8_t* soft, const miphy_graph_tables* __restrict__ tab, int crc_id, uint32_t poly,
+                                              uint32_t order, int K, int L, uint32_t* red, int tid, int nt)
+{
+  const int kwords = (K + 31) >> 5, nfull = L >> 5, rbits = L & 31;
+  uint32_t  part   = 0;
+  if (tid < kwords && 32 * tid < L) {
+    const uint32_t w   = hard_word(soft, tid, K);
+    const int      len = min(32, L - 32 * tid);
+    const uint32_t top = 1u << order;
+    uint32_t       reg = 0;
+    for (int b = 0; b < len; ++b) {
+      reg = (reg << 1) ^ (((w >> (31 - b)) & 1u) << order);
+      reg ^= (reg & top) ? poly : 0u;
+    }
+    reg &= top - 1u;
+    if (tid < nfull) {
+      reg = gf2_mulmod(reg, tab->crc_pow32[crc_id][nfull - 1 - tid], poly, order);
+      for (int b = 0; b < rbits; ++b) {
+        reg <<= 1;
+        reg ^= (reg & top) ? poly : 0u;
+      }
+    }
+    part = reg;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+    part ^= __shfl_xor(part, off);
+  if ((tid & 63) == 0)
+    red[2 + (tid >> 6)] = part;
+  __syncthreads();
+  uint32_t crc = 0;
+  for (int w = 0; w < (nt >> 6); ++w)
+    crc ^= red[2 + w];
+  __syncthreads();
+  return crc;
+}
+
 __global__ void __launch_bounds__(MIPHY_MAX_Z)
 ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                    const miphy_graph_tables* __restrict__ tab,
                    const int8_t* __restrict__ llr_base,
                    uint8_t* __restrict__ out_base,
                    int32_t* __restrict__ iters_out,
-                   int max_layers)
+                   int max_layers,
+                   const uint32_t* __restrict__ harq_slot, // optional: per-descriptor codeblock slot in harq_crc_ok
+                   uint8_t* __restrict__ harq_crc_ok)       // optional: skip codeblocks already decoded, flag new successes
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const miphy_ldpc_dec_desc dsc = descs[blockIdx.x];
@@ -196,6 +238,11 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   uint8_t*      out = out_base + dsc.out_offset;
   const int     in_len = (int)dsc.in_len;
 
+  if (harq_crc_ok && harq_crc_ok[harq_slot[blockIdx.x]]) { // pusch_decoder_impl.cpp:184: CRC already OK, keep the message
+    if (tid == 0)
+      iters_out[blockIdx.x] = -1;
+    return;
+  }
   if (tid < 16)
     red[tid] = 0;
   // Stage LLRs into LDS (variable nodes 0,1 are punctured -> 0) and find the last non-zero input.
@@ -261,14 +308,13 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 
   // CRC constants.
   uint32_t poly = 0, order = 0;
-  int      L = 0, nfull = 0, rbits = 0;
+  int      L = 0;
   if (use_crc) {
     poly  = tab->crc_poly[dsc.crc_poly];
     order = tab->crc_order[dsc.crc_poly];
     L     = K - dsc.nof_filler_bits; // ldpc_decoder_impl.cpp:55
-    nfull = L >> 5;
-    rbits = L & 31;
   }
+  const bool final_only = use_crc && (dsc.flags & 1u);
 
   int result_iters = 0;
   const int max_iter = dsc.max_iter;
@@ -293,43 +339,15 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       }
       __syncthreads();
     }
-    if (use_crc) { // ldpc_decoder_impl.cpp:126-133
-      uint32_t part = 0;
-      if (tid < kwords && 32 * tid < L) {
-        uint32_t  w   = hard_word(soft, tid, K);
-        const int len = min(32, L - 32 * tid);
-        const uint32_t top = 1u << order;
-        uint32_t  reg = 0;
-        for (int b = 0; b < len; ++b) {
-          reg = (reg << 1) ^ (((w >> (31 - b)) & 1u) << order);
-          reg ^= (reg & top) ? poly : 0u;
-        }
-        reg &= top - 1u;
-        if (tid < nfull) { // weight x^(32*(nfull-1-tid) + rbits)
-          reg = gf2_mulmod(reg, tab->crc_pow32[dsc.crc_poly][nfull - 1 - tid], poly, order);
-          for (int b = 0; b < rbits; ++b) {
-            reg <<= 1;
-            reg ^= (reg & top) ? poly : 0u;
-          }
-        }
-        part = reg;
-      }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1)
-        part ^= __shfl_xor(part, off);
-      if ((tid & 63) == 0)
-        red[2 + (tid >> 6)] = part;
-      __syncthreads();
-      uint32_t crc = 0;
-      for (int w = 0; w < (nt >> 6); ++w)
-        crc ^= red[2 + w];
-      __syncthreads();
-      if (crc == 0) {
+    if (use_crc && !final_only) { // ldpc_decoder_impl.cpp:126-133
+      if (block_crc(soft, tab, dsc.crc_poly, poly, order, K, L, red, tid, nt) == 0) {
         result_iters = it + 1;
         break;
       }
     }
   }
+  if (final_only) // pusch_decoder_impl.cpp:105-118: decode without early stop, then check the CRC once
+    result_iters = (block_crc(soft, tab, dsc.crc_poly, poly, order, K, L, red, tid, nt) == 0) ? max_iter : 0;
 
   // Final hard bits (identical to what the reference leaves in `output`: the bits of the last iteration run).
   if (tid < kwords) {
@@ -338,23 +356,28 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     for (int q = 0; q < nbytes; ++q)
       out[4 * tid + q] = (uint8_t)(w >> (24 - 8 * q));
   }
-  if (tid == 0)
+  if (tid == 0) {
     iters_out[blockIdx.x] = result_iters;
+    if (harq_crc_ok && result_iters > 0)
+      harq_crc_ok[harq_slot[blockIdx.x]] = 1;
+  }
 }
 
 } // namespace
 
-extern "C" int miphy_ldpc_decode_batch(miphy_ctx*                 ctx,
-                                       const miphy_ldpc_dec_desc* descs,
-                                       int                        descs_on_device,
-                                       uint32_t                   n,
-                                       const int8_t*              llr,
-                                       uint8_t*                   out_bits,
-                                       int32_t*                   iters,
-                                       const miphy_ldpc_dec_limits* limits,
-                                       void*                      stream)
+int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
+                             const miphy_ldpc_dec_desc*   descs,
+                             int                          descs_on_device,
+                             uint32_t                     n,
+                             const int8_t*                llr,
+                             uint8_t*                     out_bits,
+                             int32_t*                     iters,
+                             const miphy_ldpc_dec_limits* limits,
+                             const uint32_t*              harq_slot,
+                             uint8_t*                     harq_crc_ok,
+                             void*                        stream)
 {
-  MIPHY_REQUIRE(ctx && descs && llr && out_bits && iters, "miphy_ldpc_decode_batch: null argument");
+  MIPHY_REQUIRE(ctx && descs && llr && out_bits && iters, "ldpc_decode: null argument");
   if (n == 0)
     return MIPHY_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -406,7 +429,20 @@ extern "C" int miphy_ldpc_decode_batch(miphy_ctx*                 ctx,
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
     lds_set = max_lds;
   }
-  hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n), dim3(max_threads), max_lds, s, (const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, llr, out_bits, iters, max_layers);
+  hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n), dim3(max_threads), max_lds, s, (const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, llr, out_bits, iters, max_layers, harq_slot, harq_crc_ok);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
+}
+
+extern "C" int miphy_ldpc_decode_batch(miphy_ctx*                   ctx,
+                                       const miphy_ldpc_dec_desc*   descs,
+                                       int                          descs_on_device,
+                                       uint32_t                     n,
+                                       const int8_t*                llr,
+                                       uint8_t*                     out_bits,
+                                       int32_t*                     iters,
+                                       const miphy_ldpc_dec_limits* limits,
+                                       void*                        stream)
+{
+  return miphy_ldpc_decode_launch(ctx, descs, descs_on_device, n, llr, out_bits, iters, limits, nullptr, nullptr, stream);
 }

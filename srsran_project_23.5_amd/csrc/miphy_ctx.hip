@@ -134,6 +134,7 @@ extern "C" void miphy_destroy(miphy_ctx* c)
     (void)hipFree(p);
   delete c->ext;
   (void)hipFree(c->d_desc_staging);
+  (void)hipFree(c->d_work);
   (void)hipHostFree(c->h_desc_staging);
   free(c->h_tables);
   delete c;
@@ -151,5 +152,21 @@ int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t b
   memcpy(ctx->h_desc_staging, descs, bytes);
   MIPHY_HIP_CHECK(hipMemcpyAsync(ctx->d_desc_staging, ctx->h_desc_staging, bytes, hipMemcpyHostToDevice, s));
   *out = ctx->d_desc_staging;
+  return MIPHY_OK;
+}
+
+int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out)
+{
+  if (bytes > ctx->work_bytes) {
+    MIPHY_HIP_CHECK(hipStreamSynchronize(s));
+    if (ctx->d_work)
+      MIPHY_HIP_CHECK(hipFree(ctx->d_work));
+    ctx->d_work     = nullptr;
+    ctx->work_bytes = 0;
+    size_t want     = bytes + bytes / 4 + (1u << 20);
+    MIPHY_HIP_CHECK(hipMalloc(&ctx->d_work, want));
+    ctx->work_bytes = want;
+  }
+  *out = ctx->d_work;
   return MIPHY_OK;
 }

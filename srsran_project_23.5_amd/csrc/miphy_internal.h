@@ -35,6 +35,8 @@ struct miphy_ctx {
   void*                d_desc_staging;
   size_t               desc_staging_bytes;
   void*                h_desc_staging; // pinned
+  void*                d_work;         // scratch workspace for the transport-block level entry points (grown on demand)
+  size_t               work_bytes;
 };
 
 void miphy_set_error(const char* fmt, ...);
@@ -58,3 +60,11 @@ void miphy_set_error(const char* fmt, ...);
 
 // Ensures the descriptor array is on the device; returns the device pointer through *out.
 int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t bytes, hipStream_t s, const void** out);
+
+// Decoder launch shared by miphy_ldpc_decode_batch and the transport-block level PUSCH decoder.
+int miphy_ldpc_decode_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* descs, int descs_on_device, uint32_t n, const int8_t* llr,
+                             uint8_t* out_bits, int32_t* iters, const miphy_ldpc_dec_limits* limits, const uint32_t* harq_slot,
+                             uint8_t* harq_crc_ok, void* stream);
+
+// Returns a device scratch buffer of at least `bytes` (reallocated, after a stream sync, when it has to grow).
+int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out);

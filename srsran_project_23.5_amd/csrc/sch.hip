@@ -1,0 +1,470 @@
+// Transport-block level shared-channel entry points: whole pusch_decoder::decode / pdsch_encoder::encode calls in one C call.
+//
+// Behaviour contract: lib/phy/upper/channel_processors/pusch_decoder_impl.cpp:121-225, pdsch_encoder_impl.cpp:28-65,
+// lib/phy/upper/channel_coding/ldpc/ldpc_segmenter_impl.cpp:57-334, include/srsran/phy/upper/channel_coding/ldpc/ldpc.h:128-207.
+// The segmentation arithmetic runs on the host (it is bookkeeping) and turns every transport block into
+// codeblock descriptors for the batched kernels; two small kernels do the bit plumbing around them (TB -> codeblock
+// messages with CRCs and fillers; codeblock messages -> TB with the TB CRC and the result record).
+#include "crc_device.h"
+#include "miphy_ext.h"
+#include "tables/nr_ldpc_tables.h"
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr uint32_t HARQ_CB_STRIDE  = 66 * 384; // soft bits per codeblock slot
+constexpr uint32_t HARQ_MSG_STRIDE = 1056;     // packed message bytes per codeblock slot
+
+struct seg_t {
+  uint32_t tbs, nof_tb_crc_bits, nof_cbs, Z, K, N, cb_info_bits, nof_cb_crc_bits, nof_filler_bits, zero_pad, crc_poly;
+};
+
+// ldpc.h:128-207 + ldpc_segmenter_impl.cpp:104-141
+int segmentation(uint32_t tb_bytes, uint32_t bg, seg_t& s)
+{
+  MIPHY_REQUIRE(bg == 1 || bg == 2, "sch: invalid base graph %u", bg);
+  MIPHY_REQUIRE(tb_bytes > 0 && (uint64_t)tb_bytes * 8 + 24 <= 1277992, "sch: transport block size %u bytes out of range", tb_bytes);
+  s.tbs             = tb_bytes * 8;
+  s.nof_tb_crc_bits = (s.tbs <= 3824) ? 16 : 24;
+  const uint32_t B   = s.tbs + s.nof_tb_crc_bits;
+  const uint32_t Kcb = (bg == 1) ? 8448 : 3840;
+  s.nof_cbs          = (B <= Kcb) ? 1 : (B + (Kcb - 24) - 1) / (Kcb - 24);
+  MIPHY_REQUIRE(s.nof_cbs <= 52, "sch: %u codeblocks exceed MAX_NOF_SEGMENTS", s.nof_cbs);
+  const uint32_t Bp = B + ((s.nof_cbs > 1) ? 24 * s.nof_cbs : 0);
+  uint32_t       Kb = 22;
+  if (bg == 2)
+    Kb = (B > 640) ? 10 : (B > 560) ? 9 : (B > 192) ? 8 : 6;
+  s.Z = 0;
+  for (int i = 0; i < NR_LDPC_NOF_LIFTING_SIZES; ++i)
+    if ((uint32_t)NR_LDPC_LIFTING_SIZES[i] * s.nof_cbs * Kb >= Bp) {
+      s.Z = NR_LDPC_LIFTING_SIZES[i];
+      break;
+    }
+  MIPHY_REQUIRE(s.Z != 0, "sch: no lifting size fits the transport block");
+  s.K               = ((bg == 1) ? 22 : 10) * s.Z;
+  s.N               = s.K * ((bg == 1) ? 3 : 5);
+  s.nof_cb_crc_bits = (s.nof_cbs > 1) ? 24 : 0;
+  s.cb_info_bits    = (Bp + s.nof_cbs - 1) / s.nof_cbs - s.nof_cb_crc_bits;
+  s.zero_pad        = (s.cb_info_bits + s.nof_cb_crc_bits) * s.nof_cbs - Bp;
+  s.nof_filler_bits = s.K - s.cb_info_bits - s.nof_cb_crc_bits;
+  // pusch_decoder_impl.cpp:44-55
+  s.crc_poly = (s.nof_cbs > 1) ? MIPHY_CRC24B : ((s.tbs > 3824) ? MIPHY_CRC24A : MIPHY_CRC16);
+  return MIPHY_OK;
+}
+
+// ldpc_segmenter_impl.cpp:57-67
+uint32_t rm_length(const seg_t& s, uint32_t i_seg, uint32_t mod, uint32_t nof_layers, uint32_t nof_ch_symbols)
+{
+  const uint32_t sym_layer = nof_ch_symbols / nof_layers;
+  const uint32_t nshort    = s.nof_cbs - (sym_layer % s.nof_cbs);
+  const uint32_t t         = (i_seg < nshort) ? sym_layer / s.nof_cbs : (sym_layer + s.nof_cbs - 1) / s.nof_cbs;
+  return t * nof_layers * mod;
+}
+
+struct tb_asm_desc { // per transport block, consumed by pusch_tb_assemble_kernel
+  uint32_t first_desc;  // first codeblock descriptor / iters entry of this TB
+  uint32_t nof_cbs;
+  uint32_t harq_cb_index;
+  uint32_t nof_data_bits; // data bits per codeblock (msg_length - crc - filler)
+  uint32_t tb_and_crc_bits;
+  uint32_t tb_bytes;
+  uint32_t max_iter;
+  uint32_t pad;
+  uint64_t tb_offset;
+};
+
+__global__ void harq_reset_kernel(const uint32_t* __restrict__ slots, uint32_t n, uint8_t* __restrict__ harq_crc_ok)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    harq_crc_ok[slots[i]] = 0; // pusch_decoder_impl.cpp:146-149
+}
+
+// One workgroup per transport block (pusch_decoder_impl.cpp:198-222): concatenates the codeblock data bits, checks the TB
+// CRC24A when there are several codeblocks, writes the TB and the result record, resets the CRC flags on a TB CRC failure.
+__global__ void __launch_bounds__(256) pusch_tb_assemble_kernel(const tb_asm_desc* __restrict__ descs,
+                                                                const miphy_graph_tables* __restrict__ tab,
+                                                                const int32_t* __restrict__ iters,
+                                                                const uint8_t* __restrict__ harq_msgs,
+                                                                uint8_t* __restrict__ harq_crc_ok,
+                                                                uint8_t* __restrict__ tmp_tb_base, // workspace: per TB, tb_and_crc bytes (+8 pad)
+                                                                const uint64_t* __restrict__ tmp_off,
+                                                                uint8_t* __restrict__ tb_out,
+                                                                miphy_pusch_result* __restrict__ results)
+{
+  __shared__ uint32_t red[8];
+  __shared__ int      all_ok;
+  const tb_asm_desc d   = descs[blockIdx.x];
+  const int         tid = threadIdx.x;
+  uint8_t*          tmp = tmp_tb_base + tmp_off[blockIdx.x];
+  if (tid == 0) {
+    int      ok = 1;
+    uint32_t mn = 0xffffffffu, mx = 0, cnt = 0, sum = 0;
+    for (uint32_t c = 0; c < d.nof_cbs; ++c) {
+      ok &= harq_crc_ok[d.harq_cb_index + c] != 0;
+      const int it = iters[d.first_desc + c];
+      if (it >= 0) { // decoded in this call: stats.update(iterations or max) (pusch_decoder_impl.cpp:188-194)
+        const uint32_t v = it > 0 ? (uint32_t)it : d.max_iter;
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+        sum += v;
+        ++cnt;
+      }
+    }
+    all_ok = ok;
+    miphy_pusch_result r;
+    r.tb_crc_ok            = 0;
+    r.nof_codeblocks_total = d.nof_cbs;
+    r.iters_min            = cnt ? mn : 0;
+    r.iters_max            = mx;
+    r.iters_mean           = cnt ? (float)sum / (float)cnt : 0.f;
+    r.nof_decoded          = cnt;
+    results[blockIdx.x]    = r;
+  }
+  __syncthreads();
+  if (!all_ok)
+    return; // nothing is copied, flags stay as they are (multiple codeblocks) / tb_crc_ok = false (single codeblock)
+  // tmp_tb_bits: nof_new_bits = min(free, nof_data_bits) from every codeblock message, bit-granular.
+  const uint32_t nbytes = (d.tb_and_crc_bits + 7) / 8;
+  for (uint32_t b = tid; b < nbytes + 8; b += blockDim.x) {
+    uint32_t v = 0;
+    if (b < nbytes) {
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t bit = 8 * b + k;
+        if (bit >= d.tb_and_crc_bits)
+          break;
+        const uint32_t c   = bit / d.nof_data_bits, o = bit - c * d.nof_data_bits;
+        const uint8_t* msg = harq_msgs + (size_t)(d.harq_cb_index + c) * HARQ_MSG_STRIDE;
+        v |= (uint32_t)((msg[o >> 3] >> (7 - (o & 7))) & 1u) << (7 - k);
+      }
+    }
+    tmp[b] = (uint8_t)v;
+  }
+  __syncthreads();
+  int tb_ok = 1;
+  if (d.nof_cbs > 1) {
+    uint32_t part = crc_partial(tab, MIPHY_CRC24A, tmp, 0, d.tb_and_crc_bits, tid, blockDim.x);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+      part ^= __shfl_xor(part, off);
+    if ((tid & 63) == 0)
+      red[tid >> 6] = part;
+    __syncthreads();
+    tb_ok = ((red[0] ^ red[1] ^ red[2] ^ red[3]) == 0);
+  }
+  for (uint32_t b = tid; b < d.tb_bytes; b += blockDim.x)
+    tb_out[d.tb_offset + b] = tmp[b];
+  if (tid == 0)
+    results[blockIdx.x].tb_crc_ok = tb_ok;
+  if (!tb_ok) // pusch_decoder_impl.cpp:218-220: at least one codeblock is a false negative, reset all of them
+    for (uint32_t c = tid; c < d.nof_cbs; c += blockDim.x)
+      harq_crc_ok[d.harq_cb_index + c] = 0;
+}
+
+struct cb_prep_desc { // per codeblock, consumed by pdsch_cb_prepare_kernel
+  uint64_t tb_offset;     // packed TB bytes
+  uint32_t tb_bit_offset; // first TB bit of this codeblock
+  uint32_t take_bits;     // TB bits copied
+  uint32_t tb_index;      // index into the TB CRC array
+  uint32_t nof_tb_crc_bits; // > 0 on the last codeblock: append the TB CRC ...
+  uint32_t zero_pad;        // ... and the zero padding
+  uint32_t nof_cb_crc_bits;
+  uint32_t K;
+  uint32_t pad;
+  uint64_t msg_offset;    // output: K bytes in the message workspace
+};
+
+// One workgroup per codeblock (ldpc_segmenter_impl.cpp:150-220, pdsch_encoder_impl.cpp:46-50): unpack the TB bits, append the
+// TB CRC and zero padding on the last codeblock, append CRC24B, mark the fillers.
+__global__ void __launch_bounds__(256) pdsch_cb_prepare_kernel(const cb_prep_desc* __restrict__ descs,
+                                                               const miphy_graph_tables* __restrict__ tab,
+                                                               const uint8_t* __restrict__ tb_in,
+                                                               const uint32_t* __restrict__ tb_crc,
+                                                               uint8_t* __restrict__ msg_ws)
+{
+  __shared__ uint32_t red[4];
+  const cb_prep_desc  d   = descs[blockIdx.x];
+  const int           tid = threadIdx.x;
+  uint8_t*            msg = msg_ws + d.msg_offset;
+  const uint8_t*      tb  = tb_in + d.tb_offset;
+  uint32_t            used = d.take_bits;
+  for (uint32_t i = tid; i < d.take_bits; i += blockDim.x) {
+    const uint32_t bit = d.tb_bit_offset + i;
+    msg[i]             = (tb[bit >> 3] >> (7 - (bit & 7))) & 1u;
+  }
+  if (d.nof_tb_crc_bits) {
+    const uint32_t crc = tb_crc[d.tb_index];
+    for (uint32_t i = tid; i < d.nof_tb_crc_bits + d.zero_pad; i += blockDim.x)
+      msg[used + i] = (i < d.nof_tb_crc_bits) ? (uint8_t)((crc >> (d.nof_tb_crc_bits - 1 - i)) & 1u) : 0;
+    used += d.nof_tb_crc_bits + d.zero_pad;
+  }
+  __syncthreads();
+  if (d.nof_cb_crc_bits) {
+    // CRC24B over the `used` unpacked bits: lane t reduces its run of bits, weights with x^(remaining).
+    const uint32_t poly = tab->crc_poly[MIPHY_CRC24B], order = 24, top = 1u << 24;
+    const uint32_t per  = (used + blockDim.x - 1) / blockDim.x;
+    const uint32_t b0   = tid * per;
+    uint32_t       reg  = 0;
+    if (b0 < used) {
+      const uint32_t b1 = min(b0 + per, used);
+      for (uint32_t i = b0; i < b1; ++i) {
+        reg = (reg << 1) ^ ((uint32_t)msg[i] << order);
+        reg ^= (reg & top) ? poly : 0u;
+      }
+      reg &= top - 1u;
+      const uint32_t after = used - b1;
+      if (after) {
+        reg = crc_gf2_mulmod(reg, crc_pow32(tab, MIPHY_CRC24B, after >> 5, poly, order), poly, order);
+        for (uint32_t b = 0; b < (after & 31u); ++b) {
+          reg <<= 1;
+          reg ^= (reg & top) ? poly : 0u;
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+      reg ^= __shfl_xor(reg, off);
+    if ((tid & 63) == 0)
+      red[tid >> 6] = reg;
+    __syncthreads();
+    const uint32_t crc = red[0] ^ red[1] ^ red[2] ^ red[3];
+    if (tid < 24)
+      msg[used + tid] = (uint8_t)((crc >> (23 - tid)) & 1u);
+    used += 24;
+  }
+  for (uint32_t i = used + tid; i < d.K; i += blockDim.x)
+    msg[i] = 254; // ldpc::FILLER_BIT
+}
+
+template <typename T>
+T* stage_vec(uint8_t*& h, uint8_t*& d, const std::vector<T>& v, size_t& off)
+{
+  off              = (off + 15) & ~(size_t)15;
+  T* dev           = reinterpret_cast<T*>(d + off);
+  if (!v.empty())
+    std::memcpy(h + off, v.data(), v.size() * sizeof(T));
+  off += v.size() * sizeof(T);
+  return dev;
+}
+
+} // namespace
+
+extern "C" int miphy_sch_segmentation_info(uint32_t tb_bytes, uint32_t bg, miphy_sch_segmentation* out)
+{
+  if (!out) {
+    miphy_set_error("miphy_sch_segmentation_info: null argument");
+    return MIPHY_EINVAL;
+  }
+  seg_t s;
+  int   rc = segmentation(tb_bytes, bg, s);
+  if (rc)
+    return rc;
+  out->nof_cbs = s.nof_cbs, out->Z = s.Z, out->K = s.K, out->N = s.N, out->nof_filler_bits = s.nof_filler_bits;
+  out->nof_tb_crc_bits = s.nof_tb_crc_bits, out->nof_cb_crc_bits = s.nof_cb_crc_bits, out->cb_info_bits = s.cb_info_bits;
+  out->zero_pad = s.zero_pad;
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
+                                        const miphy_pusch_tb_desc* tbs,
+                                        uint32_t                   n,
+                                        const int8_t*              llrs,
+                                        int8_t*                    harq_softbits,
+                                        uint8_t*                   harq_msgs,
+                                        uint8_t*                   harq_crc_ok,
+                                        uint8_t*                   tb_out,
+                                        miphy_pusch_result*        results,
+                                        void*                      stream)
+{
+  MIPHY_REQUIRE(ctx && tbs && llrs && harq_softbits && harq_msgs && harq_crc_ok && tb_out && results, "miphy_pusch_decode_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  hipStream_t                      s = (hipStream_t)stream;
+  std::vector<miphy_ldpc_rdm_desc> rdm;
+  std::vector<miphy_ldpc_dec_desc> dec;
+  std::vector<uint32_t>            slots, reset_slots;
+  std::vector<tb_asm_desc>         asmd(n);
+  std::vector<uint64_t>            tmp_off(n);
+  uint64_t                         tmp_bytes = 0;
+  uint32_t                         max_Z = 2, max_in_len = 0;
+  for (uint32_t t = 0; t < n; ++t) {
+    const miphy_pusch_tb_desc& d = tbs[t];
+    seg_t                      sg;
+    int                        rc = segmentation(d.tb_bytes, d.bg, sg);
+    if (rc)
+      return rc;
+    MIPHY_REQUIRE(d.rv <= 3, "pusch_decode: TB %u: invalid redundancy version", t);
+    MIPHY_REQUIRE(d.nof_layers >= 1 && d.nof_layers <= 4, "pusch_decode: TB %u: invalid number of layers", t);
+    MIPHY_REQUIRE(d.mod == 1 || d.mod == 2 || d.mod == 4 || d.mod == 6 || d.mod == 8, "pusch_decode: TB %u: invalid modulation", t);
+    MIPHY_REQUIRE(d.nof_ch_symbols % d.nof_layers == 0, "pusch_decode: TB %u: channel symbols not a multiple of the layers", t);
+    MIPHY_REQUIRE(d.nof_ldpc_iterations > 0, "pusch_decode: TB %u: nof_ldpc_iterations must be > 0", t);
+    MIPHY_REQUIRE((sg.cb_info_bits % 8) == 0 || sg.nof_cbs == 1,
+                  "pusch_decode: TB %u: TBS %u is not a TS 38.214 transport block size (codeblock payloads are not byte aligned)", t, sg.tbs);
+    const uint32_t bgK = (d.bg == 1) ? 22 : 10;
+    tb_asm_desc&   a   = asmd[t];
+    a.first_desc       = (uint32_t)dec.size();
+    a.nof_cbs          = sg.nof_cbs;
+    a.harq_cb_index    = d.harq_cb_index;
+    a.nof_data_bits    = sg.K - ((sg.nof_cbs == 1) ? sg.nof_tb_crc_bits : 24) - sg.nof_filler_bits; // get_cblk_bit_breakdown
+    a.tb_and_crc_bits  = sg.tbs + ((sg.nof_cbs > 1) ? 24 : 0);
+    a.tb_bytes         = d.tb_bytes;
+    a.max_iter         = d.nof_ldpc_iterations;
+    a.tb_offset        = d.tb_offset;
+    tmp_off[t]         = tmp_bytes;
+    tmp_bytes += ((a.tb_and_crc_bits + 7) / 8 + 8 + 15) & ~15ull;
+    uint32_t cw_off = 0;
+    for (uint32_t c = 0; c < sg.nof_cbs; ++c) {
+      const uint32_t      E    = rm_length(sg, c, d.mod, d.nof_layers, d.nof_ch_symbols);
+      const uint32_t      slot = d.harq_cb_index + c;
+      miphy_ldpc_rdm_desc r    = {};
+      r.bg = d.bg, r.rv = d.rv, r.mod = d.mod, r.new_data = d.new_data ? 1 : 0, r.Z = (uint16_t)sg.Z;
+      r.nof_filler_bits = (uint16_t)sg.nof_filler_bits, r.Nref = d.Nref, r.E = E;
+      r.in_offset = d.llr_offset + cw_off, r.out_offset = (uint64_t)slot * HARQ_CB_STRIDE;
+      MIPHY_REQUIRE(E > 0, "pusch_decode: TB %u: empty codeblock", t);
+      rdm.push_back(r);
+      miphy_ldpc_dec_desc q = {};
+      q.bg = d.bg, q.crc_poly = (uint8_t)sg.crc_poly, q.Z = (uint16_t)sg.Z, q.max_iter = d.nof_ldpc_iterations;
+      q.nof_filler_bits = (uint16_t)sg.nof_filler_bits;
+      q.in_len          = sg.N; // the reference hands the full-length soft buffer to the decoder (pusch_decoder_impl.cpp:177,186)
+      q.flags           = d.use_early_stop ? 0u : 1u;
+      q.llr_offset = (uint64_t)slot * HARQ_CB_STRIDE, q.out_offset = (uint64_t)slot * HARQ_MSG_STRIDE;
+      dec.push_back(q);
+      slots.push_back(slot);
+      if (d.new_data)
+        reset_slots.push_back(slot);
+      cw_off += E;
+      (void)bgK;
+    }
+    MIPHY_REQUIRE(cw_off == d.nof_ch_symbols * d.mod, "pusch_decode: TB %u: codeblock lengths (%u) do not add up to the codeword (%u)", t, cw_off,
+                  d.nof_ch_symbols * d.mod);
+    max_Z      = sg.Z > max_Z ? sg.Z : max_Z;
+    max_in_len = sg.N > max_in_len ? sg.N : max_in_len;
+  }
+  const uint32_t ncb = (uint32_t)dec.size();
+  MIPHY_REQUIRE(ncb <= 65535, "pusch_decode: %u codeblocks in one call (max 65535)", ncb);
+  // Workspace: descriptors + per-TB assembly buffers + iteration counts.
+  size_t bytes = 64 + rdm.size() * sizeof(rdm[0]) + dec.size() * sizeof(dec[0]) + (slots.size() + reset_slots.size()) * 4 + asmd.size() * sizeof(asmd[0]) +
+                 tmp_off.size() * 8 + ncb * 4 + tmp_bytes + 16 * 8;
+  std::vector<uint8_t> host(bytes);
+  void*                wsv = nullptr;
+  int                  rc  = miphy_get_workspace(ctx, bytes, s, &wsv);
+  if (rc)
+    return rc;
+  uint8_t *h = host.data(), *dv = (uint8_t*)wsv;
+  size_t   off = 0;
+  auto*    d_rdm   = stage_vec(h, dv, rdm, off);
+  auto*    d_dec   = stage_vec(h, dv, dec, off);
+  auto*    d_slots = stage_vec(h, dv, slots, off);
+  auto*    d_reset = stage_vec(h, dv, reset_slots, off);
+  auto*    d_asm   = stage_vec(h, dv, asmd, off);
+  auto*    d_tmpo  = stage_vec(h, dv, tmp_off, off);
+  const size_t staged = off;
+  off                 = (off + 15) & ~(size_t)15;
+  int32_t* d_iters    = reinterpret_cast<int32_t*>(dv + off);
+  off += (size_t)ncb * 4;
+  off          = (off + 15) & ~(size_t)15;
+  uint8_t* d_tmp = dv + off;
+  // The staging copy is synchronous with respect to the host vector (pageable memory): it completes before returning.
+  MIPHY_HIP_CHECK(hipMemcpyAsync(dv, h, staged, hipMemcpyHostToDevice, s));
+  MIPHY_HIP_CHECK(hipStreamSynchronize(s));
+  if (!reset_slots.empty())
+    hipLaunchKernelGGL(harq_reset_kernel, dim3((unsigned)(reset_slots.size() + 255) / 256), dim3(256), 0, s, d_reset, (uint32_t)reset_slots.size(), harq_crc_ok);
+  if ((rc = miphy_ldpc_rate_dematch_batch(ctx, d_rdm, 1, ncb, llrs, harq_softbits, s)))
+    return rc;
+  miphy_ldpc_dec_limits lim = {max_Z, max_in_len};
+  if ((rc = miphy_ldpc_decode_launch(ctx, d_dec, 1, ncb, harq_softbits, harq_msgs, d_iters, &lim, d_slots, harq_crc_ok, s)))
+    return rc;
+  hipLaunchKernelGGL(pusch_tb_assemble_kernel, dim3(n), dim3(256), 0, s, d_asm, ctx->d_tables, d_iters, harq_msgs, harq_crc_ok, d_tmp, d_tmpo, tb_out, results);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs, uint32_t n, const uint8_t* tb_in, uint8_t* codeword_out, void* stream)
+{
+  MIPHY_REQUIRE(ctx && tbs && tb_in && codeword_out, "miphy_pdsch_encode_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  hipStream_t                      s = (hipStream_t)stream;
+  std::vector<miphy_crc_desc>      crcd(n);
+  std::vector<cb_prep_desc>        prep;
+  std::vector<miphy_ldpc_enc_desc> enc;
+  std::vector<miphy_ldpc_rdm_desc> rm;
+  uint64_t                         msg_bytes = 0, cb_bytes = 0;
+  for (uint32_t t = 0; t < n; ++t) {
+    const miphy_pdsch_tb_desc& d = tbs[t];
+    seg_t                      sg;
+    int                        rc = segmentation(d.tb_bytes, d.bg, sg);
+    if (rc)
+      return rc;
+    MIPHY_REQUIRE(d.rv <= 3, "pdsch_encode: TB %u: invalid redundancy version", t);
+    MIPHY_REQUIRE(d.nof_layers >= 1 && d.nof_layers <= 4, "pdsch_encode: TB %u: invalid number of layers", t);
+    MIPHY_REQUIRE(d.mod == 1 || d.mod == 2 || d.mod == 4 || d.mod == 6 || d.mod == 8, "pdsch_encode: TB %u: invalid modulation", t);
+    MIPHY_REQUIRE(d.nof_ch_symbols % d.nof_layers == 0, "pdsch_encode: TB %u: channel symbols not a multiple of the layers", t);
+    crcd[t].bit_offset = d.tb_offset * 8;
+    crcd[t].nbits      = sg.tbs;
+    crcd[t].poly       = (sg.nof_tb_crc_bits == 16) ? MIPHY_CRC16 : MIPHY_CRC24A;
+    uint32_t tb_bit = 0, cw_off = 0;
+    for (uint32_t c = 0; c < sg.nof_cbs; ++c) {
+      const bool   last = (c == sg.nof_cbs - 1);
+      cb_prep_desc p    = {};
+      p.tb_offset = d.tb_offset, p.tb_bit_offset = tb_bit, p.tb_index = t;
+      p.take_bits       = sg.cb_info_bits - (last ? sg.nof_tb_crc_bits + sg.zero_pad : 0);
+      p.nof_tb_crc_bits = last ? sg.nof_tb_crc_bits : 0;
+      p.zero_pad        = last ? sg.zero_pad : 0;
+      p.nof_cb_crc_bits = sg.nof_cb_crc_bits;
+      p.K               = sg.K;
+      p.msg_offset      = msg_bytes;
+      prep.push_back(p);
+      tb_bit += p.take_bits;
+      miphy_ldpc_enc_desc e = {};
+      e.bg = d.bg, e.Z = (uint16_t)sg.Z, e.out_len = sg.N, e.in_offset = msg_bytes, e.out_offset = cb_bytes;
+      enc.push_back(e);
+      const uint32_t      E = rm_length(sg, c, d.mod, d.nof_layers, d.nof_ch_symbols);
+      miphy_ldpc_rdm_desc r = {};
+      r.bg = d.bg, r.rv = d.rv, r.mod = d.mod, r.new_data = 1, r.Z = (uint16_t)sg.Z, r.nof_filler_bits = (uint16_t)sg.nof_filler_bits;
+      r.Nref = d.Nref, r.E = E, r.in_offset = cb_bytes, r.out_offset = d.codeword_offset + cw_off;
+      MIPHY_REQUIRE(E > 0, "pdsch_encode: TB %u: empty codeblock", t);
+      rm.push_back(r);
+      cw_off += E;
+      msg_bytes += (sg.K + 15) & ~15u;
+      cb_bytes += (sg.N + 15) & ~15u;
+    }
+    MIPHY_REQUIRE(cw_off == d.nof_ch_symbols * d.mod, "pdsch_encode: TB %u: codeblock lengths (%u) do not add up to the codeword (%u)", t, cw_off,
+                  d.nof_ch_symbols * d.mod);
+  }
+  const uint32_t ncb = (uint32_t)enc.size();
+  MIPHY_REQUIRE(ncb <= 65535, "pdsch_encode: %u codeblocks in one call (max 65535)", ncb);
+  size_t bytes = 128 + crcd.size() * sizeof(crcd[0]) + prep.size() * sizeof(prep[0]) + enc.size() * sizeof(enc[0]) + rm.size() * sizeof(rm[0]) + n * 4 +
+                 msg_bytes + cb_bytes + 16 * 8;
+  void* wsv = nullptr;
+  int   rc  = miphy_get_workspace(ctx, bytes, s, &wsv);
+  if (rc)
+    return rc;
+  std::vector<uint8_t> host(bytes - msg_bytes - cb_bytes);
+  uint8_t *            h = host.data(), *dv = (uint8_t*)wsv;
+  size_t               off = 0;
+  auto*                d_crcd = stage_vec(h, dv, crcd, off);
+  auto*                d_prep = stage_vec(h, dv, prep, off);
+  auto*                d_enc  = stage_vec(h, dv, enc, off);
+  auto*                d_rm   = stage_vec(h, dv, rm, off);
+  const size_t         staged = off;
+  off                         = (off + 15) & ~(size_t)15;
+  uint32_t* d_tbcrc           = reinterpret_cast<uint32_t*>(dv + off);
+  off += (size_t)n * 4;
+  off            = (off + 15) & ~(size_t)15;
+  uint8_t* d_msg = dv + off;
+  off += msg_bytes;
+  uint8_t* d_cb = dv + off;
+  MIPHY_HIP_CHECK(hipMemcpyAsync(dv, h, staged, hipMemcpyHostToDevice, s));
+  MIPHY_HIP_CHECK(hipStreamSynchronize(s));
+  if ((rc = miphy_crc_batch(ctx, d_crcd, 1, n, tb_in, d_tbcrc, s)))
+    return rc;
+  hipLaunchKernelGGL(pdsch_cb_prepare_kernel, dim3(ncb), dim3(256), 0, s, d_prep, ctx->d_tables, tb_in, d_tbcrc, d_msg);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  if ((rc = miphy_ldpc_encode_batch(ctx, d_enc, 1, ncb, d_msg, d_cb, s)))
+    return rc;
+  if ((rc = miphy_ldpc_rate_match_batch(ctx, d_rm, 1, ncb, d_cb, codeword_out, s)))
+    return rc;
+  return MIPHY_OK;
+}

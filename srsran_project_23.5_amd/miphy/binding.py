@@ -45,6 +45,9 @@ def lib():
         l.miphy_polar_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_polar_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_pdcch_encode_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_pusch_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
+        l.miphy_pdsch_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_sch_segmentation_info.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         l.miphy_crc_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
@@ -52,7 +55,7 @@ def lib():
 
 # Mirrors miphy_ldpc_dec_desc.
 LdpcDecDesc = np.dtype([("bg", np.uint8), ("crc_poly", np.uint8), ("Z", np.uint16), ("max_iter", np.uint16),
-                        ("nof_filler_bits", np.uint16), ("in_len", np.uint32), ("reserved", np.uint32),
+                        ("nof_filler_bits", np.uint16), ("in_len", np.uint32), ("flags", np.uint32),
                         ("llr_offset", np.uint64), ("out_offset", np.uint64)], align=True)
 assert LdpcDecDesc.itemsize == 32
 # Mirrors miphy_ldpc_rdm_desc.
@@ -98,6 +101,35 @@ class PolarCode(C.Structure):
         n, N, npc = C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(lib().miphy_polar_code_info(C.byref(self), C.byref(n), C.byref(N), C.byref(npc)))
         return n.value, N.value, npc.value
+
+
+# Mirrors miphy_pusch_tb_desc / miphy_pusch_result / miphy_pdsch_tb_desc / miphy_sch_segmentation.
+PuschTbDesc = np.dtype([("bg", np.uint8), ("rv", np.uint8), ("mod", np.uint8), ("nof_layers", np.uint8), ("new_data", np.uint8),
+                        ("use_early_stop", np.uint8), ("nof_ldpc_iterations", np.uint16), ("Nref", np.uint32),
+                        ("nof_ch_symbols", np.uint32), ("tb_bytes", np.uint32), ("harq_cb_index", np.uint32),
+                        ("llr_offset", np.uint64), ("tb_offset", np.uint64)], align=True)
+assert PuschTbDesc.itemsize == 40
+PuschResult = np.dtype([("tb_crc_ok", np.int32), ("nof_codeblocks_total", np.uint32), ("iters_min", np.uint32),
+                        ("iters_max", np.uint32), ("iters_mean", np.float32), ("nof_decoded", np.uint32)], align=True)
+assert PuschResult.itemsize == 24
+PdschTbDesc = np.dtype([("bg", np.uint8), ("rv", np.uint8), ("mod", np.uint8), ("nof_layers", np.uint8), ("Nref", np.uint32),
+                        ("nof_ch_symbols", np.uint32), ("tb_bytes", np.uint32), ("tb_offset", np.uint64),
+                        ("codeword_offset", np.uint64)], align=True)
+assert PdschTbDesc.itemsize == 32
+HARQ_CB_STRIDE = 66 * 384
+HARQ_MSG_STRIDE = 1056
+
+
+class SchSegmentation(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("nof_cbs", "Z", "K", "N", "nof_filler_bits", "nof_tb_crc_bits", "nof_cb_crc_bits",
+                                          "cb_info_bits", "zero_pad")]
+
+
+def sch_segmentation(tb_bytes, bg):
+    """Host-side segmentation parameters (ldpc::compute_nof_codeblocks / compute_lifting_size / compute_codeblock_size)."""
+    s = SchSegmentation()
+    check(lib().miphy_sch_segmentation_info(tb_bytes, bg, C.byref(s)))
+    return s
 
 
 # Mirrors miphy_crc_desc.
@@ -220,3 +252,17 @@ class Context:
 
     def pdcch_encode_batch(self, A, E, n, payload, rnti, out, stream=None):
         check(lib().miphy_pdcch_encode_batch(self.h, A, E, n, _dptr(payload), _dptr(rnti), _dptr(out), _stream_ptr(stream)))
+
+    # ------------------------------------------------------------------ transport-block level shared channel
+    def pusch_decode_batch(self, tbs, llrs, harq_softbits, harq_msgs, harq_crc_ok, tb_out, results, stream=None):
+        """tbs: numpy PuschTbDesc array (host). results: torch uint8 tensor of n * PuschResult.itemsize bytes."""
+        assert isinstance(tbs, np.ndarray) and tbs.dtype == PuschTbDesc
+        tbs = np.ascontiguousarray(tbs)
+        check(lib().miphy_pusch_decode_batch(self.h, C.c_void_p(tbs.ctypes.data), tbs.size, _dptr(llrs), _dptr(harq_softbits),
+                                             _dptr(harq_msgs), _dptr(harq_crc_ok), _dptr(tb_out), _dptr(results), _stream_ptr(stream)))
+
+    def pdsch_encode_batch(self, tbs, tb_in, codeword_out, stream=None):
+        assert isinstance(tbs, np.ndarray) and tbs.dtype == PdschTbDesc
+        tbs = np.ascontiguousarray(tbs)
+        check(lib().miphy_pdsch_encode_batch(self.h, C.c_void_p(tbs.ctypes.data), tbs.size, _dptr(tb_in), _dptr(codeword_out),
+                                             _stream_ptr(stream)))

@@ -75,6 +75,7 @@ def test_binding_struct_sizes_match_header():
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(miphy_ldpc_dec_desc), sizeof(miphy_ldpc_rdm_desc), sizeof(miphy_ldpc_enc_desc),
          sizeof(miphy_crc_desc), sizeof(miphy_ofdm_job), sizeof(miphy_ofdm_config), sizeof(miphy_pusch_chest_job), sizeof(miphy_polar_code));
+  printf("%zu %zu %zu %zu\n", sizeof(miphy_pusch_tb_desc), sizeof(miphy_pusch_result), sizeof(miphy_pdsch_tb_desc), sizeof(miphy_sch_segmentation));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -84,8 +85,21 @@ int main(void) {
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe], text=True).split()]
     mine = [miphy.LdpcDecDesc.itemsize, miphy.LdpcRdmDesc.itemsize, miphy.LdpcEncDesc.itemsize, miphy.CrcDesc.itemsize,
-            miphy.OfdmJob.itemsize, ctypes.sizeof(miphy.OfdmConfig), miphy.PuschChestJob.itemsize, ctypes.sizeof(miphy.PolarCode)]
+            miphy.OfdmJob.itemsize, ctypes.sizeof(miphy.OfdmConfig), miphy.PuschChestJob.itemsize, ctypes.sizeof(miphy.PolarCode),
+            miphy.PuschTbDesc.itemsize, miphy.PuschResult.itemsize, miphy.PdschTbDesc.itemsize, ctypes.sizeof(miphy.binding.SchSegmentation)]
     assert sizes == mine, (sizes, mine)
+
+
+def test_host_segmentation_matches_oracle():
+    """Host-side a6 logic (ldpc.h:128-207, ldpc_segmenter_impl.cpp:104-141) against the oracle for TS 38.214-like TB sizes."""
+    import miphy
+    import oracle_lib as O
+    for bg, tbs_bits in ((2, 24), (2, 320), (2, 3848), (1, 3824), (1, 3848), (1, 8424), (1, 8448), (1, 42016), (1, 83976), (1, 319784),
+                         (2, 9984), (1, 1277992 - 24), (2, 3840 - 16), (2, 3840)):
+        s = miphy.sch_segmentation(tbs_bits // 8, bg)
+        o = O.o_segmentation(tbs_bits // 8 * 8, bg, 2, 1, 2 * 52 * 156)
+        for k in ("nof_cbs", "Z", "K", "N", "nof_filler_bits", "nof_tb_crc_bits", "nof_cb_crc_bits", "cb_info_bits", "zero_pad"):
+            assert getattr(s, k) == getattr(o, k), (bg, tbs_bits, k)
 
 
 def test_no_cpu_fallback():

@@ -1,0 +1,102 @@
+"""GPU parity for the transport-block level entry points (pusch_decoder::decode with HARQ, pdsch_encoder::encode) vs the
+CPU oracle: TB bytes, CRC verdicts and LDPC iteration statistics must be identical."""
+import numpy as np
+import pytest
+
+from oracle_lib import OraclePuschDecoder, o_pdsch_encode, o_segmentation
+
+pytestmark = pytest.mark.gpu
+
+
+def noisy(cw, sigma, rng):
+    y = (1.0 - 2.0 * (cw & 1)) + sigma * rng.standard_normal(cw.size)
+    return np.round(np.clip(4 * y, -20, 20) / 20 * 120).astype(np.int8)
+
+
+CASES = [  # bg, mod, nof_layers, nprb, tbs bits, sigmas
+    (2, 2, 1, 106, 3848, (0.75, 1.3)),
+    (1, 4, 1, 106, 42016, (0.45, 0.62)),
+    (1, 6, 1, 106, 83976, (0.3, 0.62)),
+    (1, 8, 1, 273, 319784, (0.3, 0.45)),
+    (2, 2, 1, 273, 9984, (0.75, 1.3)),
+    (1, 4, 2, 50, 40976, (0.45, 0.62)),
+    (2, 2, 1, 4, 320, (0.5, 1.0)),
+    (2, 2, 1, 2, 24, (0.5, 1.1)),
+]
+
+
+def test_pdsch_encode_batch(ctx):
+    import torch
+    import miphy
+    rng = np.random.default_rng(51)
+    tbs, descs, cw_off, tb_off, tb_list = [], [], 0, 0, []
+    for bg, mod, nl, nprb, tbs_bits, _ in CASES:
+        nsym = nprb * 156 * nl
+        for rv, Nref in ((0, 0), (2, 0), (3, 20000 if bg == 1 else 0)):
+            tb = rng.integers(0, 256, tbs_bits // 8, dtype=np.uint8)
+            descs.append((bg, rv, mod, nl, Nref, nsym, tb.size, tb_off, cw_off))
+            tb_list.append(tb)
+            tb_off += (tb.size + 15) // 16 * 16
+            cw_off += nsym * mod
+    d = np.zeros(len(descs), dtype=miphy.PdschTbDesc)
+    tb_all = np.zeros(tb_off + 16, dtype=np.uint8)
+    for i, x in enumerate(descs):
+        d[i] = x
+        tb_all[x[7]:x[7] + tb_list[i].size] = tb_list[i]
+    cw_d = torch.full((cw_off,), 9, dtype=torch.uint8, device="cuda")
+    ctx.pdsch_encode_batch(d, torch.from_numpy(tb_all).cuda(), cw_d)
+    torch.cuda.synchronize()
+    cw = cw_d.cpu().numpy()
+    for i, (bg, rv, mod, nl, Nref, nsym, nb, to, co) in enumerate(descs):
+        exp = o_pdsch_encode(bg, rv, mod, Nref, nl, nsym, tb_list[i])
+        assert np.array_equal(cw[co:co + nsym * mod], exp), descs[i]
+
+
+@pytest.mark.parametrize("early_stop,max_iter", [(1, 6), (0, 2), (1, 2)])
+def test_pusch_decode_batch_with_harq(ctx, early_stop, max_iter):
+    import torch
+    import miphy
+    rng = np.random.default_rng(52 + max_iter + early_stop)
+    rvs = [0, 2, 3, 1]
+    tbs = []
+    slot = 0
+    for bg, mod, nl, nprb, tbs_bits, sigmas in CASES:
+        for sigma in sigmas:
+            nsym = nprb * 156 * nl
+            tb = rng.integers(0, 256, tbs_bits // 8, dtype=np.uint8)
+            seg = o_segmentation(tbs_bits, bg, mod, nl, nsym)
+            llrs = [noisy(o_pdsch_encode(bg, rv, mod, 0, nl, nsym, tb), sigma, rng) for rv in rvs]
+            tbs.append(dict(bg=bg, mod=mod, nl=nl, nsym=nsym, tb=tb, llrs=llrs, slot=slot, ncb=seg.nof_cbs,
+                            od=OraclePuschDecoder(bg, mod, 0, nl, nsym, tbs_bits // 8)))
+            slot += seg.nof_cbs
+    n = len(tbs)
+    soft_d = torch.full((slot * miphy.HARQ_CB_STRIDE,), 33, dtype=torch.int8, device="cuda")  # stale garbage, new_data must cope
+    msgs_d = torch.zeros(slot * miphy.HARQ_MSG_STRIDE, dtype=torch.uint8, device="cuda")
+    crc_d = torch.ones(slot, dtype=torch.uint8, device="cuda")
+    res_d = torch.zeros(n * miphy.PuschResult.itemsize, dtype=torch.uint8, device="cuda")
+    for t, rv in enumerate(rvs):
+        d = np.zeros(n, dtype=miphy.PuschTbDesc)
+        llr_off, tb_off, chunks = 0, 0, []
+        for i, x in enumerate(tbs):
+            d[i] = (x["bg"], rv, x["mod"], x["nl"], 1 if t == 0 else 0, early_stop, max_iter, 0, x["nsym"], x["tb"].size, x["slot"], llr_off, tb_off)
+            chunks.append(x["llrs"][t])
+            llr_off += x["llrs"][t].size
+            tb_off += x["tb"].size
+        tb_d = torch.full((tb_off,), 0xEE, dtype=torch.uint8, device="cuda")
+        ctx.pusch_decode_batch(d, torch.from_numpy(np.concatenate(chunks)).cuda(), soft_d, msgs_d, crc_d, tb_d, res_d)
+        torch.cuda.synchronize()
+        res = res_d.cpu().numpy().view(miphy.PuschResult)
+        tb_out = tb_d.cpu().numpy()
+        for i, x in enumerate(tbs):
+            ok, tbo, mm = x["od"].decode(x["llrs"][t], rv, t == 0, max_iter, bool(early_stop))
+            r = res[i]
+            key = (i, t, x["bg"], x["mod"], x["tb"].size * 8)
+            assert bool(r["tb_crc_ok"]) == ok, key
+            assert r["nof_codeblocks_total"] == x["ncb"], key
+            assert (int(r["iters_min"]), int(r["iters_max"])) == mm, (key, r, mm)
+            o0 = int(d[i]["tb_offset"])
+            got = tb_out[o0:o0 + x["tb"].size]
+            if ok:
+                assert np.array_equal(got, tbo) and np.array_equal(got, x["tb"]), key
+            elif not np.all(x["od"].cb_crc):
+                assert np.all(got == 0xEE), key  # untouched unless every codeblock passed
