@@ -1,0 +1,353 @@
+// TEST INFRASTRUCTURE: drop-in test. Links the reference (libsrsran_ref.a, compiled in place by build_ref.sh), the
+// adapters (srsran_project_23.5_amd/adapters/miphy_srsran_adapters.h) and libmiphy.so, and runs the SAME stimuli through the
+// reference's "avx2"/sw objects and through the "hip" objects created by the adapter factories -- i.e. what adding "hip" to
+// the INSTANTIATE_TEST_SUITE_P lists of the reference's own tests would do (tests/unittests/phy/upper/channel_coding/ldpc/
+// ldpc_enc_dec_test.cpp:322-335, pusch_decoder_test.cpp, pdsch_encoder_test.cpp, ofdm_*_vectortest.cpp, ...).
+// Built here (needs /root/reference), executed on the GPU box by tests/test_dropin_gpu.py.
+#include "lib/phy/generic_functions/dft_processor_generic_impl.h"
+#include "miphy_srsran_adapters.h"
+#include "srsran/phy/support/support_factories.h"
+#include "srsran/phy/upper/rx_softbuffer_pool.h"
+#include "srsran/phy/upper/sequence_generators/sequence_generator_factories.h"
+#include "srsran/phy/upper/unique_rx_softbuffer.h"
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+using namespace srsran;
+
+static int failures = 0;
+#define CHECK(cond, ...)                      \
+  do {                                        \
+    if (!(cond)) {                            \
+      ++failures;                             \
+      if (failures < 20) {                    \
+        printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+        printf(__VA_ARGS__);                  \
+        printf("\n");                         \
+      }                                       \
+    }                                         \
+  } while (0)
+
+class generic_dft_factory : public dft_processor_factory
+{
+public:
+  std::unique_ptr<dft_processor> create(const dft_processor::configuration& config) override
+  {
+    return std::make_unique<dft_processor_generic_impl>(config);
+  }
+};
+
+static std::mt19937 rgen(0);
+
+static std::vector<log_likelihood_ratio> noisy(span<const uint8_t> cw, float sigma)
+{
+  std::normal_distribution<float> n(0.F, sigma);
+  std::vector<log_likelihood_ratio> out(cw.size());
+  for (size_t i = 0; i != cw.size(); ++i) {
+    out[i] = log_likelihood_ratio::quantize(4.F * ((1.F - 2.F * (cw[i] & 1)) + n(rgen)), 20.F);
+  }
+  return out;
+}
+
+static void test_ldpc(std::shared_ptr<miphy::context> c)
+{
+  auto enc_ref = create_ldpc_encoder_factory_sw("avx2")->create();
+  auto dec_ref = create_ldpc_decoder_factory_sw("avx2")->create();
+  auto enc_hip = miphy::create_ldpc_encoder_factory_hip(c)->create();
+  auto dec_hip = miphy::create_ldpc_decoder_factory_hip(c)->create();
+  auto crc     = create_crc_calculator_factory_sw("auto")->create(crc_generator_poly::CRC24B);
+  auto crc16   = create_crc_calculator_factory_sw("auto")->create(crc_generator_poly::CRC16);
+  std::uniform_int_distribution<int> bit(0, 1);
+  for (auto bg : {ldpc_base_graph_type::BG1, ldpc_base_graph_type::BG2}) {
+    for (auto ls : ldpc::all_lifting_sizes) {
+      unsigned bgK = (bg == ldpc_base_graph_type::BG1) ? 22 : 10, ns = (bg == ldpc_base_graph_type::BG1) ? 66 : 50;
+      unsigned K = bgK * ls, N = ns * ls;
+      crc_calculator*      cc = (K > 60) ? crc.get() : crc16.get();
+      unsigned             nb = (K > 60) ? 24 : 16;
+      std::vector<uint8_t> msg(K);
+      for (auto& b : msg) {
+        b = bit(rgen);
+      }
+      unsigned cs = cc->calculate_bit(span<const uint8_t>(msg).first(K - nb));
+      for (unsigned i = 0; i != nb; ++i) {
+        msg[K - nb + i] = (cs >> (nb - 1 - i)) & 1U;
+      }
+      codeblock_metadata meta;
+      meta.tb_common.base_graph   = bg;
+      meta.tb_common.lifting_size = ls;
+      std::vector<uint8_t> cw_ref(N), cw_hip(N);
+      enc_ref->encode(cw_ref, msg, meta.tb_common);
+      enc_hip->encode(cw_hip, msg, meta.tb_common);
+      CHECK(cw_ref == cw_hip, "LDPC encoder mismatch bg %d Z %d", (int)bg, (int)ls);
+      for (float sigma : {0.3F, 0.62F}) {
+        auto llr = noisy(cw_ref, sigma);
+        for (bool use_crc : {true, false}) {
+          ldpc_decoder::configuration cfg;
+          cfg.block_conf                    = meta;
+          cfg.block_conf.cb_specific.nof_crc_bits = nb;
+          cfg.algorithm_conf.max_iterations = 6;
+          dynamic_bit_buffer o_ref(K), o_hip(K);
+          auto r1 = dec_ref->decode(o_ref, llr, use_crc ? cc : nullptr, cfg);
+          auto r2 = dec_hip->decode(o_hip, llr, use_crc ? cc : nullptr, cfg);
+          CHECK(r1.has_value() == r2.has_value() && (!r1.has_value() || r1.value() == r2.value()), "LDPC decoder iterations mismatch bg %d Z %d", (int)bg, (int)ls);
+          CHECK(std::equal(o_ref.get_buffer().begin(), o_ref.get_buffer().begin() + (K + 7) / 8, o_hip.get_buffer().begin()),
+                "LDPC decoder bits mismatch bg %d Z %d", (int)bg, (int)ls);
+        }
+      }
+    }
+  }
+  printf("ldpc enc/dec: 102 graphs done, failures so far %d\n", failures);
+}
+
+static void test_rate_matching(std::shared_ptr<miphy::context> c)
+{
+  auto rm_ref  = create_ldpc_rate_matcher_factory_sw()->create();
+  auto rdm_ref = create_ldpc_rate_dematcher_factory_sw("avx2")->create();
+  auto rm_hip  = miphy::create_ldpc_rate_matcher_factory_hip(c)->create();
+  auto rdm_hip = miphy::create_ldpc_rate_dematcher_factory_hip(c)->create();
+  std::uniform_int_distribution<int> bit(0, 1), l(-120, 120);
+  for (unsigned bgi = 0; bgi != 2; ++bgi) {
+    for (unsigned Z : {7U, 104U, 384U}) {
+      unsigned N = (bgi ? 50 : 66) * Z, K = (bgi ? 10 : 22) * Z;
+      for (unsigned rv = 0; rv != 4; ++rv) {
+        for (auto mod : {modulation_scheme::QPSK, modulation_scheme::QAM64, modulation_scheme::QAM256}) {
+          for (unsigned Nref : {0U, N - 3 * Z}) {
+            codeblock_metadata m;
+            m.tb_common.base_graph       = bgi ? ldpc_base_graph_type::BG2 : ldpc_base_graph_type::BG1;
+            m.tb_common.lifting_size     = static_cast<ldpc::lifting_size_t>(Z);
+            m.tb_common.rv               = rv;
+            m.tb_common.mod              = mod;
+            m.tb_common.Nref             = Nref;
+            m.cb_specific.nof_filler_bits = Z / 3;
+            unsigned             E = get_bits_per_symbol(mod) * ((K + 5 * Z + 7 * rv) / get_bits_per_symbol(mod));
+            std::vector<uint8_t> cb(N), o1(E), o2(E);
+            for (auto& b : cb) {
+              b = bit(rgen);
+            }
+            for (unsigned i = 0; i != m.cb_specific.nof_filler_bits; ++i) {
+              cb[K - 2 * Z - 1 - i] = ldpc::FILLER_BIT;
+            }
+            rm_ref->rate_match(o1, cb, m);
+            rm_hip->rate_match(o2, cb, m);
+            CHECK(o1 == o2, "rate matcher mismatch");
+            std::vector<log_likelihood_ratio> in(E), s1(N), s2(N);
+            for (auto& v : in) {
+              v = l(rgen);
+            }
+            for (unsigned i = 0; i != N; ++i) {
+              s1[i] = s2[i] = l(rgen);
+            }
+            for (bool nd : {true, false}) {
+              rdm_ref->rate_dematch(s1, in, nd, m);
+              rdm_hip->rate_dematch(s2, in, nd, m);
+              CHECK(std::memcmp(s1.data(), s2.data(), N) == 0, "rate dematcher mismatch bg %u Z %u rv %u nd %d", bgi, Z, rv, (int)nd);
+            }
+          }
+        }
+      }
+    }
+  }
+  printf("rate (de)matching done, failures so far %d\n", failures);
+}
+
+static void test_sch(std::shared_ptr<miphy::context> c)
+{
+  auto                                   crcf = create_crc_calculator_factory_sw("auto");
+  pdsch_encoder_factory_sw_configuration ec;
+  ec.encoder_factory      = create_ldpc_encoder_factory_sw("avx2");
+  ec.rate_matcher_factory = create_ldpc_rate_matcher_factory_sw();
+  ec.segmenter_factory    = create_ldpc_segmenter_tx_factory_sw(crcf);
+  auto                                   enc_ref = create_pdsch_encoder_factory_sw(ec)->create();
+  auto                                   enc_hip = miphy::create_pdsch_encoder_factory_hip(c)->create();
+  pusch_decoder_factory_sw_configuration dc;
+  dc.crc_factory       = crcf;
+  dc.decoder_factory   = create_ldpc_decoder_factory_sw("avx2");
+  dc.dematcher_factory = create_ldpc_rate_dematcher_factory_sw("avx2");
+  dc.segmenter_factory = create_ldpc_segmenter_rx_factory_sw();
+  auto dec_ref         = create_pusch_decoder_factory_sw(dc)->create();
+  auto dec_hip         = miphy::create_pusch_decoder_factory_hip(c)->create();
+  struct tc {
+    ldpc_base_graph_type bg;
+    modulation_scheme    mod;
+    unsigned             nl, nprb, tbs;
+    float                sigma;
+  };
+  std::uniform_int_distribution<int> byte(0, 255);
+  for (const tc& t : {tc{ldpc_base_graph_type::BG2, modulation_scheme::QPSK, 1, 106, 3848, 1.2F},
+                      tc{ldpc_base_graph_type::BG1, modulation_scheme::QAM16, 1, 106, 42016, 0.62F},
+                      tc{ldpc_base_graph_type::BG1, modulation_scheme::QAM256, 1, 273, 319784, 0.42F},
+                      tc{ldpc_base_graph_type::BG2, modulation_scheme::QPSK, 1, 2, 24, 1.0F}}) {
+    unsigned             nsym = t.nprb * 156 * t.nl, G = nsym * get_bits_per_symbol(t.mod);
+    std::vector<uint8_t> tb(t.tbs / 8);
+    for (auto& b : tb) {
+      b = byte(rgen);
+    }
+    unsigned nof_cbs = ldpc::compute_nof_codeblocks(units::bits(t.tbs), t.bg);
+    rx_softbuffer_pool_config pc;
+    pc.max_codeblock_size = ldpc::MAX_CODEBLOCK_SIZE, pc.max_softbuffers = 2, pc.max_nof_codeblocks = 128, pc.expire_timeout_slots = 1000;
+    auto                     pool1 = create_rx_softbuffer_pool(pc), pool2 = create_rx_softbuffer_pool(pc);
+    rx_softbuffer_identifier id;
+    id.rnti = 1, id.harq_ack_id = 0;
+    unsigned rvs[4] = {0, 2, 3, 1};
+    for (unsigned tx = 0; tx != 4; ++tx) {
+      segmenter_config sc;
+      sc.base_graph = t.bg, sc.rv = rvs[tx], sc.mod = t.mod, sc.Nref = 0, sc.nof_layers = t.nl, sc.nof_ch_symbols = nsym;
+      std::vector<uint8_t> cw1(G), cw2(G);
+      enc_ref->encode(cw1, tb, sc);
+      enc_hip->encode(cw2, tb, sc);
+      CHECK(cw1 == cw2, "pdsch_encoder mismatch tbs %u rv %u", t.tbs, rvs[tx]);
+      auto                         llr = noisy(cw1, t.sigma);
+      pusch_decoder::configuration cfg;
+      cfg.segmenter_cfg = sc, cfg.nof_ldpc_iterations = 6, cfg.use_early_stop = true, cfg.new_data = (tx == 0);
+      auto                 sb1 = pool1->reserve_softbuffer(slot_point(1, 0), id, nof_cbs), sb2 = pool2->reserve_softbuffer(slot_point(1, 0), id, nof_cbs);
+      std::vector<uint8_t> o1(tb.size(), 0), o2(tb.size(), 0);
+      pusch_decoder_result r1, r2;
+      dec_ref->decode(o1, r1, &sb1.get(), llr, cfg);
+      dec_hip->decode(o2, r2, &sb2.get(), llr, cfg);
+      CHECK(r1.tb_crc_ok == r2.tb_crc_ok, "pusch_decoder tb_crc_ok mismatch tbs %u tx %u (%d vs %d)", t.tbs, tx, (int)r1.tb_crc_ok, (int)r2.tb_crc_ok);
+      CHECK(r1.nof_codeblocks_total == r2.nof_codeblocks_total, "nof_codeblocks_total mismatch");
+      CHECK(r1.ldpc_decoder_stats.get_nof_observations() == r2.ldpc_decoder_stats.get_nof_observations(), "stats observations mismatch tbs %u tx %u: %zu vs %zu",
+            t.tbs, tx, r1.ldpc_decoder_stats.get_nof_observations(), r2.ldpc_decoder_stats.get_nof_observations());
+      if (r1.ldpc_decoder_stats.get_nof_observations()) {
+        CHECK(r1.ldpc_decoder_stats.get_min() == r2.ldpc_decoder_stats.get_min() && r1.ldpc_decoder_stats.get_max() == r2.ldpc_decoder_stats.get_max(),
+              "stats min/max mismatch tbs %u tx %u: ref %u..%u hip %u..%u", t.tbs, tx, r1.ldpc_decoder_stats.get_min(), r1.ldpc_decoder_stats.get_max(),
+              r2.ldpc_decoder_stats.get_min(), r2.ldpc_decoder_stats.get_max());
+      }
+      if (r1.tb_crc_ok) {
+        CHECK(o1 == o2 && o1 == tb, "pusch_decoder TB mismatch tbs %u tx %u", t.tbs, tx);
+      }
+    }
+  }
+  printf("pdsch_encoder / pusch_decoder (HARQ) done, failures so far %d\n", failures);
+}
+
+static float rel_err(span<const cf_t> a, span<const cf_t> b)
+{
+  float m = 0, p = 0;
+  for (size_t i = 0; i != a.size(); ++i) {
+    m = std::max(m, std::abs(a[i] - b[i]));
+    p += std::norm(b[i]);
+  }
+  return m / std::sqrt(p / b.size());
+}
+
+static void test_ofdm_and_estimator(std::shared_ptr<miphy::context> c)
+{
+  ofdm_factory_generic_configuration fc;
+  fc.dft_factory = std::make_shared<generic_dft_factory>();
+  auto                           dem_f = create_ofdm_demodulator_factory_generic(fc);
+  auto                           mod_f = create_ofdm_modulator_factory_generic(fc);
+  miphy::ofdm_demodulator_factory_hip dem_h(c);
+  miphy::ofdm_modulator_factory_hip   mod_h(c);
+  std::normal_distribution<float>     n(0.F, 0.7071F);
+  for (unsigned rb : {106U, 273U}) {
+    unsigned                       N = (rb == 273) ? 4096 : 2048;
+    ofdm_demodulator_configuration dc;
+    dc.numerology = 1, dc.bw_rb = rb, dc.dft_size = N, dc.cp = cyclic_prefix::NORMAL, dc.nof_samples_window_offset = N * 72 / 2048;
+    dc.scale = 1.0F, dc.center_freq_hz = 3.5e9;
+    auto              d1 = dem_f->create_ofdm_slot_demodulator(dc), d2 = dem_h.create_ofdm_slot_demodulator(dc);
+    unsigned          ns = d1->get_slot_size(1);
+    CHECK(ns == d2->get_slot_size(1), "slot size mismatch");
+    std::vector<cf_t> x(ns);
+    for (auto& v : x) {
+      v = cf_t(n(rgen), n(rgen));
+    }
+    auto g1 = create_resource_grid(1, 14, rb * 12), g2 = create_resource_grid(1, 14, rb * 12);
+    d1->demodulate(*g1, x, 0, 1);
+    d2->demodulate(*g2, x, 0, 1);
+    std::vector<cf_t> a(14 * rb * 12), b(14 * rb * 12);
+    for (unsigned l = 0; l != 14; ++l) {
+      g1->get(span<cf_t>(a).subspan(l * rb * 12, rb * 12), 0, l, 0);
+      g2->get(span<cf_t>(b).subspan(l * rb * 12, rb * 12), 0, l, 0);
+    }
+    float e = rel_err(b, a);
+    CHECK(e < 5e-6F, "ofdm demodulator rel err %g (rb %u)", e, rb);
+    ofdm_modulator_configuration mc;
+    mc.numerology = 1, mc.bw_rb = rb, mc.dft_size = N, mc.cp = cyclic_prefix::NORMAL, mc.scale = 0.01F, mc.center_freq_hz = 3.5e9;
+    auto              m1 = mod_f->create_ofdm_slot_modulator(mc), m2 = mod_h.create_ofdm_slot_modulator(mc);
+    std::vector<cf_t> y1(ns), y2(ns);
+    m1->modulate(y1, *g1, 0, 1);
+    m2->modulate(y2, *g1, 0, 1);
+    e = rel_err(y2, y1);
+    CHECK(e < 5e-6F, "ofdm modulator rel err %g (rb %u)", e, rb);
+
+    // DM-RS estimator on the demodulated (random) grid, like pusch_processor_benchmark.cpp:536-555.
+    auto est_ref = create_dmrs_pusch_estimator_factory_sw(create_pseudo_random_generator_sw_factory(),
+                                                         create_port_channel_estimator_factory_sw(std::make_shared<generic_dft_factory>()))
+                       ->create();
+    auto est_hip = miphy::create_dmrs_pusch_estimator_factory_hip(c)->create();
+    dmrs_pusch_estimator::configuration ecfg;
+    ecfg.slot = slot_point(1, 7), ecfg.type = dmrs_type::TYPE1, ecfg.scrambling_id = 42, ecfg.n_scid = false, ecfg.scaling = 1.0F;
+    ecfg.symbols_mask = bounded_bitset<MAX_NSYMB_PER_SLOT>(14);
+    ecfg.symbols_mask.set(2);
+    if (rb == 106) {
+      ecfg.symbols_mask.set(7);
+      ecfg.symbols_mask.set(11);
+    }
+    ecfg.rb_mask = bounded_bitset<MAX_RB>(rb);
+    ecfg.rb_mask.fill(rb == 106 ? 10 : 0, rb, true);
+    ecfg.first_symbol = 0, ecfg.nof_symbols = 14, ecfg.nof_tx_layers = 1;
+    ecfg.rx_ports.push_back(0);
+    channel_estimate ce1, ce2;
+    est_ref->estimate(ce1, *g1, ecfg);
+    est_hip->estimate(ce2, *g1, ecfg);
+    float mx = 0, err = 0;
+    for (unsigned l = 0; l != 14; ++l) {
+      auto v1 = static_cast<const channel_estimate&>(ce1).get_symbol_ch_estimate(l, 0, 0);
+      auto v2 = static_cast<const channel_estimate&>(ce2).get_symbol_ch_estimate(l, 0, 0);
+      for (unsigned k = (rb == 106 ? 120 : 0); k != rb * 12; ++k) {
+        mx  = std::max(mx, std::abs(v1[k]));
+        err = std::max(err, std::abs(v1[k] - v2[k]));
+      }
+    }
+    CHECK(err < 1e-4F * mx, "channel estimate err %g (max %g)", err, mx);
+    CHECK(std::abs(ce1.get_rsrp(0, 0) - ce2.get_rsrp(0, 0)) < 1e-4F * ce1.get_rsrp(0, 0), "rsrp mismatch");
+    CHECK(std::abs(ce1.get_epre(0, 0) - ce2.get_epre(0, 0)) < 1e-4F * ce1.get_epre(0, 0), "epre mismatch");
+    CHECK(std::abs(ce1.get_noise_variance(0, 0) - ce2.get_noise_variance(0, 0)) < 1e-4F * ce1.get_noise_variance(0, 0), "noise mismatch");
+    CHECK(std::abs(ce1.get_snr(0, 0) - ce2.get_snr(0, 0)) < 1e-4F * ce1.get_snr(0, 0), "snr mismatch");
+    CHECK(std::abs(ce1.get_time_alignment(0, 0).to_seconds() - ce2.get_time_alignment(0, 0).to_seconds()) < 1.1 / (4096 * 30e3),
+          "time alignment mismatch %g vs %g", ce1.get_time_alignment(0, 0).to_seconds(), ce2.get_time_alignment(0, 0).to_seconds());
+  }
+  printf("ofdm (de)modulator + dmrs_pusch_estimator done, failures so far %d\n", failures);
+}
+
+static void test_pdcch(std::shared_ptr<miphy::context> c)
+{
+  auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
+  auto e2 = miphy::create_pdcch_encoder_factory_hip(c)->create();
+  std::uniform_int_distribution<int> bit(0, 1);
+  for (unsigned A : {12U, 40U, 70U, 128U}) {
+    for (unsigned AL : {1U, 2U, 4U, 8U, 16U}) {
+      if (A + 24 >= 108 * AL) {
+        continue;
+      }
+      std::vector<uint8_t> pay(A), o1(108 * AL), o2(108 * AL);
+      for (auto& b : pay) {
+        b = bit(rgen);
+      }
+      pdcch_encoder::config_t cfg;
+      cfg.E = 108 * AL, cfg.rnti = 0x4601 + A;
+      e1->encode(o1, pay, cfg);
+      e2->encode(o2, pay, cfg);
+      CHECK(o1 == o2, "pdcch_encoder mismatch A %u AL %u", A, AL);
+    }
+  }
+  printf("pdcch_encoder done, failures so far %d\n", failures);
+}
+
+int main()
+{
+  auto c = std::make_shared<miphy::context>(0);
+  test_ldpc(c);
+  test_rate_matching(c);
+  test_sch(c);
+  test_ofdm_and_estimator(c);
+  test_pdcch(c);
+  if (failures) {
+    printf("DROPIN TEST FAILED: %d failures\n", failures);
+    return 1;
+  }
+  printf("DROPIN TEST PASSED\n");
+  return 0;
+}

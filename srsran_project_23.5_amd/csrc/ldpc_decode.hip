@@ -210,7 +210,7 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                    const int8_t* __restrict__ llr_base,
                    uint8_t* __restrict__ out_base,
                    int32_t* __restrict__ iters_out,
-                   int max_layers,
+                   int max_nodes, // host bound on ceil((in_len + 2Z) / Z) over the batch
                    const uint32_t* __restrict__ harq_slot, // optional: per-descriptor codeblock slot in harq_crc_ok
                    uint8_t* __restrict__ harq_crc_ok)       // optional: skip codeblocks already decoded, flag new successes
 {
@@ -227,9 +227,9 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   const int                 zp  = tab->z_pos[Z];
 
   int8_t*   soft = reinterpret_cast<int8_t*>(smem);
-  const int soft_bytes = ((bgK + min(bgM, max_layers)) * Z + 15) & ~15;
+  const int lay_alloc  = min(bgM, max(4, max_nodes - bgK));
+  const int soft_bytes = ((bgK + lay_alloc) * Z + 15) & ~15;
   // Check-row state is only allocated for the layers this launch can reach (host-side bound from in_len).
-  const int lay_alloc = min(bgM, max_layers);
   uint32_t* st0  = reinterpret_cast<uint32_t*>(smem + soft_bytes);
   uint32_t* st1  = st0 + lay_alloc * Z;
   uint32_t* red  = st1 + 4 * Z; // 16 words of scratch
@@ -386,16 +386,12 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   // (the reference asserts the same conditions, ldpc_decoder_impl.cpp:66-84); for device descriptors the caller
   // vouches for validity and may pass `limits` (worst case assumed otherwise).
   int    max_threads = 64;
-  int    max_layers  = 4;
-  size_t max_lds     = 0;
-  auto   account     = [&](unsigned bg, unsigned Z, unsigned in_len) {
-    const unsigned bgK = (bg == 1) ? 22 : 10, bgM = (bg == 1) ? 46 : 42;
-    unsigned       lay = (in_len + 2 * Z + Z - 1) / Z;
-    lay                = (lay > bgK + 4) ? lay - bgK : 4;
-    lay                = lay > bgM ? bgM : lay;
-    const int    threads = ((Z + 63) / 64) * 64;
-    max_threads          = threads > max_threads ? threads : max_threads;
-    max_layers           = (int)lay > max_layers ? (int)lay : max_layers;
+  int    max_nodes[2] = {0, 0}; // per base graph: largest ceil((in_len + 2Z) / Z)
+  auto   account      = [&](unsigned bg, unsigned Z, unsigned in_len) {
+    const int nodes   = (int)((in_len + 2 * Z + Z - 1) / Z);
+    const int threads = ((Z + 63) / 64) * 64;
+    max_threads       = threads > max_threads ? threads : max_threads;
+    max_nodes[bg - 1] = nodes > max_nodes[bg - 1] ? nodes : max_nodes[bg - 1];
   };
   if (!descs_on_device) {
     for (uint32_t i = 0; i < n; ++i) {
@@ -411,14 +407,24 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
     }
   } else if (limits) {
     MIPHY_REQUIRE(limits->max_Z >= 2 && limits->max_Z <= MIPHY_MAX_Z, "ldpc_decode: limits: invalid max_Z");
-    account(1, limits->max_Z, limits->max_in_len);
+    account(1, limits->max_Z, limits->max_in_len); // the base graph of device descriptors is unknown: size for both
+    account(2, limits->max_Z, limits->max_in_len);
   } else {
     account(1, MIPHY_MAX_Z, 66 * MIPHY_MAX_Z);
+    account(2, MIPHY_MAX_Z, 50 * MIPHY_MAX_Z);
   }
-  {
-    // Worst case over base graphs for the chosen layer bound (BG1 has the larger K).
-    const unsigned Zt = (unsigned)max_threads; // >= max Z
-    max_lds           = (((22 + max_layers) * Zt + 15) & ~15u) + (size_t)(max_layers + 4) * Zt * 4 + 64;
+  const int nodes_all = max_nodes[0] > max_nodes[1] ? max_nodes[0] : max_nodes[1];
+  size_t    max_lds   = 0;
+  for (int b = 0; b < 2; ++b) {
+    if (!max_nodes[b])
+      continue;
+    // The kernel sizes its arrays from the batch-wide node bound (same formula as below).
+    const int    bgK = b ? 10 : 22, bgM = b ? 42 : 46;
+    int          lay = nodes_all - bgK;
+    lay              = lay < 4 ? 4 : (lay > bgM ? bgM : lay);
+    const size_t Zt  = (size_t)max_threads; // >= max Z
+    const size_t lds = (((bgK + lay) * Zt + 15) & ~(size_t)15) + (size_t)(lay + 4) * Zt * 4 + 64;
+    max_lds          = lds > max_lds ? lds : max_lds;
   }
   const void* d_descs = nullptr;
   int         rc      = miphy_stage_descs(ctx, descs, descs_on_device, sizeof(miphy_ldpc_dec_desc) * (size_t)n, s, &d_descs);
@@ -429,7 +435,7 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
     lds_set = max_lds;
   }
-  hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n), dim3(max_threads), max_lds, s, (const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, llr, out_bits, iters, max_layers, harq_slot, harq_crc_ok);
+  hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n), dim3(max_threads), max_lds, s, (const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot, harq_crc_ok);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

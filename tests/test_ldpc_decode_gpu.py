@@ -154,3 +154,31 @@ def test_large_uniform_batch_device_descs(ctx):
     for u in range(n_unique):
         assert exp[u][0] > 0
         assert np.array_equal(np.unpackbits(exp[u][1])[:K], msgs[u] & 1)
+
+
+@pytest.mark.parametrize("bg,Z,use_limits", [(2, 208, True), (2, 208, False), (1, 208, True), (2, 384, True), (2, 6, True)])
+def test_device_descriptors_any_base_graph(ctx, bg, Z, use_limits):
+    """Device-resident descriptors: the host cannot see the base graph, so LDS must be sized for either
+    (regression: BG2 full-length codeblocks reach 42 layers, more than BG1 at the same input length)."""
+    import torch
+    import miphy
+    from miphy.ldpc import make_dec_descs
+    rng = np.random.default_rng(15)
+    K, N = BG_K[bg] * Z, BG_NS[bg] * Z
+    poly = CRC24B if K > 60 else CRC16
+    n = 3
+    llrs, exp = [], []
+    for i in range(n):
+        msg, cw = make_codeword(bg, Z, rng, 0, poly)
+        llr = noisy_llr(cw, 0.7, rng)
+        llrs.append(llr)
+        exp.append(o_ldpc_decode(bg, Z, llr, 0, poly, 6))
+    descs = make_dec_descs(n, bg, Z, N, poly, 6, 0)
+    d_descs = torch.from_numpy(descs.view(np.uint8)).cuda()
+    out_d = torch.zeros(n * ((K + 7) // 8), dtype=torch.uint8, device="cuda")
+    it_d = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx.ldpc_decode_batch(d_descs, torch.from_numpy(np.concatenate(llrs)).cuda(), out_d, it_d, limits=(Z, N) if use_limits else None)
+    torch.cuda.synchronize()
+    out, its = out_d.cpu().numpy().reshape(n, -1), it_d.cpu().numpy()
+    for i in range(n):
+        assert its[i] == exp[i][0] and np.array_equal(out[i], exp[i][1]), (bg, Z, i)
