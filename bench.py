@@ -192,7 +192,7 @@ def main():
         n = S * C
         for a in range(0, n, 65535):
             b = min(n, a + 65535)
-            ctx.ldpc_rate_dematch_batch(rdm_d[a * 32:b * 32], llr_d, softbuf_d, stream)
+            ctx.ldpc_rate_dematch_batch(rdm_d[a * 32:b * 32], llr_d, softbuf_d, stream, max_E=max(seg.E[:C]))
         if timed:
             e[3].record(stream)
         ctx.ldpc_decode_batch(dec_d, softbuf_d, bits_d, iters_d, stream, limits=(Z, max(dec_in_len)))

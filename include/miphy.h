@@ -108,13 +108,20 @@ typedef struct {
   uint64_t out_offset;      /* element offset of the N-LLR soft buffer inside `softbuf` */
 } miphy_ldpc_rdm_desc;
 
-int miphy_ldpc_rate_dematch_batch(miphy_ctx*                 ctx,
-                                  const miphy_ldpc_rdm_desc* descs,
-                                  int                        descs_on_device,
-                                  uint32_t                   n,
-                                  const int8_t*              llr_in,  /* device */
-                                  int8_t*                    softbuf, /* device, in/out */
-                                  void*                      stream);
+/* Optional launch bound for device-resident descriptors: the largest E in the batch (sizes the LDS staging buffer;
+ * NULL = assume up to 60 KiB, which limits residency). */
+typedef struct {
+  uint32_t max_E;
+} miphy_ldpc_rdm_limits;
+
+int miphy_ldpc_rate_dematch_batch(miphy_ctx*                   ctx,
+                                  const miphy_ldpc_rdm_desc*   descs,
+                                  int                          descs_on_device,
+                                  uint32_t                     n,
+                                  const int8_t*                llr_in,  /* device */
+                                  int8_t*                      softbuf, /* device, in/out */
+                                  const miphy_ldpc_rdm_limits* limits,  /* may be NULL */
+                                  void*                        stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * LDPC rate matcher  --  replaces srsran::ldpc_rate_matcher::rate_match

@@ -228,7 +228,7 @@ public:
     auto* d_out = static_cast<int8_t*>(c->buf(1, output.size()));
     c->h2d(d_in, input.data(), input.size());
     c->h2d(d_out, output.data(), output.size()); // in/out: the soft buffer content is combined or partially kept
-    context::check(miphy_ldpc_rate_dematch_batch(c->ctx, &d, 0, 1, d_in, d_out, c->stream), "ldpc_rate_dematch");
+    context::check(miphy_ldpc_rate_dematch_batch(c->ctx, &d, 0, 1, d_in, d_out, nullptr, c->stream), "ldpc_rate_dematch");
     c->d2h(output.data(), d_out, output.size());
     c->sync();
   }

@@ -204,7 +204,10 @@ __device__ __forceinline__ uint32_t block_crc(const int8_t* soft, const miphy_gr
   return crc;
 }
 
-__global__ void __launch_bounds__(MIPHY_MAX_Z)
+#ifndef LDPC_MIN_WAVES
+#define LDPC_MIN_WAVES 1
+#endif
+__global__ void __launch_bounds__(MIPHY_MAX_Z, LDPC_MIN_WAVES)
 ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                    const miphy_graph_tables* __restrict__ tab,
                    const int8_t* __restrict__ llr_base,

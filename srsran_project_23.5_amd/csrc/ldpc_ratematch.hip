@@ -45,89 +45,200 @@ __device__ __forceinline__ int combine(int a, int b)
   return min(max(s, -120), 120);
 }
 
-__global__ void __launch_bounds__(256)
-rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t* __restrict__ in_base, int8_t* __restrict__ out_base)
-{
-  const miphy_ldpc_rdm_desc d = descs[blockIdx.y];
-  const rm_geom             g = make_geom(d);
-  const int8_t*             in  = in_base + d.in_offset;
-  int8_t*                   out = out_base + d.out_offset;
-  const bool                nd  = d.new_data != 0;
+// One workgroup per codeblock. The E input LLRs are staged once into LDS with coalesced 16-byte loads (when they fit), every
+// thread then produces 16 consecutive output positions and writes them with one 16-byte store; the (rare) positions the
+// reference leaves untouched fall back to byte stores.
+constexpr int RDM_LDS_BYTES = 60 * 1024;
 
+struct rdm_ctx {
+  rm_geom g;
+  bool    nd, wrapped, tail_on;
+  int     k0p, tail_start;
+};
+
+// Value of output position j. Returns false when the reference leaves the position untouched.
+template <typename IN>
+__device__ __forceinline__ bool rdm_value(const rdm_ctx& c, const IN& in, const int8_t* __restrict__ out, int j, int& result)
+{
+  const rm_geom& g      = c.g;
+  const bool     in_buf = j < g.Ncb;
+  const bool     filler = j >= g.f0 && j < g.f1;
+  int            acc    = 0;
+  bool           write  = false;
+  int            i_next = g.E;
+  if (c.nd) {
+    if (filler) {
+      result = 127;
+      return true;
+    }
+    bool has0 = false;
+    if (in_buf) {
+      const int r  = (j < g.f0) ? j : j - g.F;
+      const int i0 = r - g.r0;
+      if (i0 >= 0) {
+        has0 = i0 < g.E;
+        if (has0) {
+          const int q = i0 / g.Kq;
+          acc         = in[(i0 - q * g.Kq) * g.mod + q];
+          write       = true;
+          i_next      = i0 + g.L;
+        }
+      } else {
+        i_next = i0 + g.L;
+      }
+    }
+    if (!has0) {
+      const bool zeroed = (j < g.f0) && ((c.k0p < g.f0) ? (j < c.k0p) : true);
+      const bool tail   = c.tail_on && j >= c.tail_start;
+      if (zeroed || tail) {
+        acc   = 0;
+        write = true;
+      } else {
+        acc = out[j];
+      }
+    }
+  } else {
+    if (!in_buf || filler)
+      return false;
+    const int r  = (j < g.f0) ? j : j - g.F;
+    int       i0 = r - g.r0;
+    i0           = (i0 < 0) ? i0 + g.L : i0;
+    i_next       = i0;
+    if (i_next < g.E)
+      acc = out[j];
+  }
+  for (int i = i_next; i < g.E; i += g.L) {
+    const int q = i / g.Kq;
+    acc         = combine(acc, in[(i - q * g.Kq) * g.mod + q]);
+    write       = true;
+  }
+  result = acc;
+  return write;
+}
+
+__global__ void __launch_bounds__(256)
+rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t* __restrict__ in_base, int8_t* __restrict__ out_base, int lds_bytes)
+{
+  extern __shared__ __attribute__((aligned(16))) int8_t lds_in[];
+  const miphy_ldpc_rdm_desc d = descs[blockIdx.x];
+  rdm_ctx                   c;
+  c.g                         = make_geom(d);
+  const rm_geom& g            = c.g;
+  const int8_t*  in           = in_base + d.in_offset;
+  int8_t*        out          = out_base + d.out_offset;
+  c.nd                        = d.new_data != 0;
   // Pass-0 bookkeeping for the copy mode (rate_dematcher_impl.cpp:125-198, restated in closed form).
-  const int  cap0    = g.L - g.r0; // elements the first pass can take before wrapping
-  const bool wrapped = g.E > cap0;
-  int        idx_end;
-  const int  k0p = (g.k0 >= g.f0 && g.k0 < g.f1) ? g.f1 : g.k0;
-  if (k0p < g.f0) {
-    if (g.E <= g.f0 - k0p) {
+  const int cap0 = g.L - g.r0; // elements the first pass can take before wrapping
+  c.wrapped      = g.E > cap0;
+  int idx_end;
+  c.k0p = (g.k0 >= g.f0 && g.k0 < g.f1) ? g.f1 : g.k0;
+  if (c.k0p < g.f0) {
+    if (g.E <= g.f0 - c.k0p) {
       idx_end = g.f1 % g.Ncb;
     } else {
-      int rem = g.E - (g.f0 - k0p);
+      int rem = g.E - (g.f0 - c.k0p);
       int n   = min(g.Ncb - g.f1, rem);
       idx_end = (g.f1 + n) % g.Ncb;
     }
   } else {
-    int n   = min(g.Ncb - k0p, g.E);
-    idx_end = (k0p + n) % g.Ncb;
+    int n   = min(g.Ncb - c.k0p, g.E);
+    idx_end = (c.k0p + n) % g.Ncb;
   }
-  const bool tail_on    = nd && !wrapped && idx_end != 0;
-  const int  tail_start = g.N - (g.Ncb - idx_end);
+  c.tail_on    = c.nd && !c.wrapped && idx_end != 0;
+  c.tail_start = g.N - (g.Ncb - idx_end);
 
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < g.N; j += gridDim.x * blockDim.x) {
-    const bool in_buf = j < g.Ncb;
-    const bool filler = j >= g.f0 && j < g.f1;
-    int        acc    = 0;
-    bool       write  = false;
-    int        i_next = g.E; // first input index still to combine
-    if (nd) {
-      if (filler) {
-        out[j] = 127;
-        continue;
-      }
-      bool has0 = false;
-      if (in_buf) {
-        const int r = (j < g.f0) ? j : j - g.F;
-        int       i0 = r - g.r0;
-        if (i0 >= 0) {
-          has0 = i0 < g.E;
-          if (has0) {
-            const int q = i0 / g.Kq;
-            acc         = in[(i0 - q * g.Kq) * g.mod + q];
-            write       = true;
-            i_next      = i0 + g.L;
-          }
-        } else {
-          i_next = i0 + g.L;
-        }
-      }
-      if (!has0) {
-        const bool zeroed = (j < g.f0) && ((k0p < g.f0) ? (j < k0p) : true);
-        const bool tail   = tail_on && j >= tail_start;
-        if (zeroed || tail) {
-          acc   = 0;
-          write = true;
-        } else {
-          acc = out[j];
-        }
-      }
+  const int  tid     = threadIdx.x, nt = blockDim.x;
+  const bool use_lds = g.E <= lds_bytes;
+  if (use_lds) {
+    if ((((uintptr_t)in) & 15) == 0) {
+      const uint4* src = reinterpret_cast<const uint4*>(in);
+      uint4*       dst = reinterpret_cast<uint4*>(lds_in);
+      const int    nq  = g.E >> 4;
+      for (int q = tid; q < nq; q += nt)
+        dst[q] = src[q];
+      for (int k = (nq << 4) + tid; k < g.E; k += nt)
+        lds_in[k] = in[k];
     } else {
-      if (!in_buf || filler)
-        continue;
-      const int r  = (j < g.f0) ? j : j - g.F;
-      int       i0 = r - g.r0;
-      i0           = (i0 < 0) ? i0 + g.L : i0;
-      i_next       = i0;
-      if (i_next < g.E)
-        acc = out[j];
+      for (int k = tid; k < g.E; k += nt)
+        lds_in[k] = in[k];
     }
-    for (int i = i_next; i < g.E; i += g.L) {
-      const int q = i / g.Kq;
-      acc         = combine(acc, in[(i - q * g.Kq) * g.mod + q]);
-      write       = true;
+    __syncthreads();
+  }
+  const bool vec_out = (((uintptr_t)out) & 15) == 0;
+  const int  nvec    = (g.N + 15) >> 4;
+  // Single-pass geometry (E does not wrap around the circular buffer): the overwhelmingly common case. Rank interval
+  // [r0, r0 + E) holds the data; a 16-byte output vector that lies entirely inside it, or entirely outside every written /
+  // cleared / combined region, takes a fast path with one division per vector.
+  const bool single = g.E <= cap0;
+  const int  r_end  = g.r0 + g.E;
+  for (int v = tid; v < nvec; v += nt) {
+    const int j0 = v << 4;
+    if (single && vec_out && j0 + 16 <= g.N) {
+      const int  j1      = j0 + 15;
+      const bool no_fill = (j1 < g.f0) || (j0 >= g.f1);
+      if (no_fill && j1 < g.Ncb) {
+        const int ra = (j0 < g.f0) ? j0 : j0 - g.F, rb = ra + 15;
+        if (ra >= g.r0 && rb < r_end) { // all data
+          int      i = ra - g.r0;
+          int      q = i / g.Kq;
+          int      p = i - q * g.Kq;
+          uint32_t w[4] = {0, 0, 0, 0};
+          uint4    old  = make_uint4(0, 0, 0, 0);
+          if (!c.nd)
+            old = *reinterpret_cast<const uint4*>(out + j0);
+          const uint32_t ow[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+          for (int b = 0; b < 16; ++b) {
+            int x = use_lds ? (int)lds_in[p * g.mod + q] : (int)in[p * g.mod + q];
+            if (!c.nd)
+              x = combine((int)(int8_t)(ow[b >> 2] >> (8 * (b & 3))), x);
+            w[b >> 2] |= (uint32_t)(x & 0xff) << (8 * (b & 3));
+            ++p;
+            if (p == g.Kq) {
+              p = 0;
+              ++q;
+            }
+          }
+          *reinterpret_cast<uint4*>(out + j0) = make_uint4(w[0], w[1], w[2], w[3]);
+          continue;
+        }
+        if (rb < g.r0 || ra >= r_end) { // no input maps here
+          if (!c.nd)
+            continue; // untouched
+          const bool zeroed_all = (j1 < g.f0) && ((c.k0p < g.f0) ? (j1 < c.k0p) : true);
+          const bool tail_all   = c.tail_on && j0 >= c.tail_start;
+          if (zeroed_all || tail_all) {
+            *reinterpret_cast<uint4*>(out + j0) = make_uint4(0, 0, 0, 0);
+            continue;
+          }
+        }
+      } else if (j0 >= g.Ncb && (!c.nd || (c.tail_on && j0 >= c.tail_start) || !c.tail_on)) {
+        // beyond the circular buffer: only the tail clear can touch it
+        if (c.nd && c.tail_on && j0 >= c.tail_start)
+          *reinterpret_cast<uint4*>(out + j0) = make_uint4(0, 0, 0, 0);
+        if (!(c.nd && c.tail_on && j0 < c.tail_start))
+          continue;
+      }
     }
-    if (write)
-      out[j] = (int8_t)acc;
+    uint32_t w[4] = {0, 0, 0, 0};
+    uint32_t keep = 0;
+#pragma unroll 4
+    for (int b = 0; b < 16; ++b) {
+      const int j = j0 + b;
+      int       r = 0;
+      bool      wr = false;
+      if (j < g.N)
+        wr = use_lds ? rdm_value(c, lds_in, out, j, r) : rdm_value(c, in, out, j, r);
+      keep |= (wr ? 0u : 1u) << b;
+      w[b >> 2] |= (uint32_t)(r & 0xff) << (8 * (b & 3));
+    }
+    if (keep == 0 && vec_out && j0 + 16 <= g.N) {
+      *reinterpret_cast<uint4*>(out + j0) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+      for (int b = 0; b < 16; ++b)
+        if (!((keep >> b) & 1u) && j0 + b < g.N)
+          out[j0 + b] = (int8_t)(w[b >> 2] >> (8 * (b & 3)));
+    }
   }
 }
 
@@ -175,12 +286,12 @@ extern "C" int miphy_ldpc_rate_dematch_batch(miphy_ctx*                 ctx,
                                              uint32_t                   n,
                                              const int8_t*              llr_in,
                                              int8_t*                    softbuf,
+                                             const miphy_ldpc_rdm_limits* limits,
                                              void*                      stream)
 {
   MIPHY_REQUIRE(ctx && descs && llr_in && softbuf, "miphy_ldpc_rate_dematch_batch: null argument");
   if (n == 0)
     return MIPHY_OK;
-  MIPHY_REQUIRE(n <= 65535, "rate_dematch: batch too large (max 65535 codeblocks per call)");
   if (!descs_on_device) {
     int rc = check_descs(ctx, descs, n, "rate_dematch");
     if (rc)
@@ -191,7 +302,17 @@ extern "C" int miphy_ldpc_rate_dematch_batch(miphy_ctx*                 ctx,
   int         rc      = miphy_stage_descs(ctx, descs, descs_on_device, sizeof(miphy_ldpc_rdm_desc) * (size_t)n, s, &d_descs);
   if (rc)
     return rc;
-  hipLaunchKernelGGL(rate_dematch_kernel, dim3(25, n), dim3(256), 0, s, (const miphy_ldpc_rdm_desc*)d_descs, llr_in, softbuf);
+  // LDS staging buffer: the largest rate-matched length in the batch (known from host descriptors or `limits`), capped.
+  uint32_t max_E = RDM_LDS_BYTES;
+  if (!descs_on_device) {
+    max_E = 0;
+    for (uint32_t i = 0; i < n; ++i)
+      max_E = descs[i].E > max_E ? descs[i].E : max_E;
+  } else if (limits) {
+    max_E = limits->max_E;
+  }
+  const int lds_bytes = (int)(((max_E > (uint32_t)RDM_LDS_BYTES ? 0u : max_E) + 15u) & ~15u);
+  hipLaunchKernelGGL(rate_dematch_kernel, dim3(n), dim3(256), lds_bytes, s, (const miphy_ldpc_rdm_desc*)d_descs, llr_in, softbuf, lds_bytes);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

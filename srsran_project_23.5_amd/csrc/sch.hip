@@ -287,7 +287,7 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
   std::vector<tb_asm_desc>         asmd(n);
   std::vector<uint64_t>            tmp_off(n);
   uint64_t                         tmp_bytes = 0;
-  uint32_t                         max_Z = 2, max_in_len = 0;
+  uint32_t                         max_Z = 2, max_in_len = 0, max_E = 0;
   for (uint32_t t = 0; t < n; ++t) {
     const miphy_pusch_tb_desc& d = tbs[t];
     seg_t                      sg;
@@ -322,6 +322,7 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
       r.nof_filler_bits = (uint16_t)sg.nof_filler_bits, r.Nref = d.Nref, r.E = E;
       r.in_offset = d.llr_offset + cw_off, r.out_offset = (uint64_t)slot * HARQ_CB_STRIDE;
       MIPHY_REQUIRE(E > 0, "pusch_decode: TB %u: empty codeblock", t);
+      max_E = E > max_E ? E : max_E;
       rdm.push_back(r);
       miphy_ldpc_dec_desc q = {};
       q.bg = d.bg, q.crc_poly = (uint8_t)sg.crc_poly, q.Z = (uint16_t)sg.Z, q.max_iter = d.nof_ldpc_iterations;
@@ -370,7 +371,8 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
   MIPHY_HIP_CHECK(hipStreamSynchronize(s));
   if (!reset_slots.empty())
     hipLaunchKernelGGL(harq_reset_kernel, dim3((unsigned)(reset_slots.size() + 255) / 256), dim3(256), 0, s, d_reset, (uint32_t)reset_slots.size(), harq_crc_ok);
-  if ((rc = miphy_ldpc_rate_dematch_batch(ctx, d_rdm, 1, ncb, llrs, harq_softbits, s)))
+  miphy_ldpc_rdm_limits rlim = {max_E};
+  if ((rc = miphy_ldpc_rate_dematch_batch(ctx, d_rdm, 1, ncb, llrs, harq_softbits, &rlim, s)))
     return rc;
   miphy_ldpc_dec_limits lim = {max_Z, max_in_len};
   if ((rc = miphy_ldpc_decode_launch(ctx, d_dec, 1, ncb, harq_softbits, harq_msgs, d_iters, &lim, d_slots, harq_crc_ok, s)))

@@ -32,8 +32,10 @@ def lib():
         l.miphy_destroy.argtypes = [C.c_void_p]
         l.miphy_ldpc_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
-        for name in ("miphy_ldpc_rate_dematch_batch", "miphy_ldpc_rate_match_batch", "miphy_ldpc_encode_batch"):
+        for name in ("miphy_ldpc_rate_match_batch", "miphy_ldpc_encode_batch"):
             getattr(l, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_ldpc_rate_dematch_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p]
         l.miphy_dft_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         for name in ("miphy_ofdm_demodulate_slots", "miphy_ofdm_modulate_slots"):
             getattr(l, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -206,9 +208,11 @@ class Context:
                                             lim, _stream_ptr(stream)))
 
     # ------------------------------------------------------------------ LDPC rate (de)matching, encoder, CRC
-    def ldpc_rate_dematch_batch(self, descs, llr_in, softbuf, stream=None):
+    def ldpc_rate_dematch_batch(self, descs, llr_in, softbuf, stream=None, max_E=None):
+        """max_E: optional bound on the rate-matched length for device-resident descriptors."""
         descs, n, ptr, on_dev = self._descs(descs, LdpcRdmDesc)
-        check(lib().miphy_ldpc_rate_dematch_batch(self.h, ptr, on_dev, n, _dptr(llr_in), _dptr(softbuf), _stream_ptr(stream)))
+        lim = (C.c_uint32 * 1)(int(max_E)) if max_E is not None else None
+        check(lib().miphy_ldpc_rate_dematch_batch(self.h, ptr, on_dev, n, _dptr(llr_in), _dptr(softbuf), lim, _stream_ptr(stream)))
 
     def ldpc_rate_match_batch(self, descs, cb_in, out, stream=None):
         descs, n, ptr, on_dev = self._descs(descs, LdpcRdmDesc)
