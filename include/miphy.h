@@ -86,6 +86,9 @@ int miphy_ldpc_decode_batch(miphy_ctx*                 ctx,
                             int32_t*                   iters,    /* device, n entries */
                             const miphy_ldpc_dec_limits* limits, /* may be NULL */
                             void*                      stream);
+/* Test / A-B knob: 0 = automatic choice, 1 = one-row-per-lane kernel, 2 = packed two-rows-per-lane kernel (even Z only).
+ * Both kernels produce identical results. */
+void miphy_debug_force_ldpc_kernel(int mode);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * LDPC rate dematcher  --  replaces srsran::ldpc_rate_dematcher::rate_dematch

@@ -15,6 +15,7 @@
 //   * hard decision + CRC run in-kernel: each lane reduces one 32-bit word of the message to a partial remainder,
 //     multiplies it by x^(32k) mod P and the partial remainders are XOR-reduced with wavefront shuffles.
 #include "miphy_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -368,6 +369,13 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 
 } // namespace
 
+static int g_force_kernel = 0; // 0 auto, 1 scalar, 2 packed (miphy_debug_force_ldpc_kernel)
+
+extern "C" void miphy_debug_force_ldpc_kernel(int mode)
+{
+  g_force_kernel = mode;
+}
+
 int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
                              const miphy_ldpc_dec_desc*   descs,
                              int                          descs_on_device,
@@ -389,8 +397,10 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   // (the reference asserts the same conditions, ldpc_decoder_impl.cpp:66-84); for device descriptors the caller
   // vouches for validity and may pass `limits` (worst case assumed otherwise).
   int    max_threads = 64;
+  bool   all_even     = true;   // the packed kernel pairs rows l and l + Z/2
   int    max_nodes[2] = {0, 0}; // per base graph: largest ceil((in_len + 2Z) / Z)
   auto   account      = [&](unsigned bg, unsigned Z, unsigned in_len) {
+    all_even &= (Z % 2 == 0);
     const int nodes   = (int)((in_len + 2 * Z + Z - 1) / Z);
     const int threads = ((Z + 63) / 64) * 64;
     max_threads       = threads > max_threads ? threads : max_threads;
@@ -433,6 +443,29 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   int         rc      = miphy_stage_descs(ctx, descs, descs_on_device, sizeof(miphy_ldpc_dec_desc) * (size_t)n, s, &d_descs);
   if (rc)
     return rc;
+  // Kernel choice: the packed two-rows-per-lane kernel pays off once a codeblock spans at least two wavefronts.
+  // MIPHY_LDPC_KERNEL=scalar|packed or miphy_debug_force_ldpc_kernel() override (test / A-B knob).
+  static const char* force = getenv("MIPHY_LDPC_KERNEL");
+  bool               use_pk = max_threads >= 128 && all_even && (!descs_on_device || limits);
+  if ((force && force[0] == 's') || g_force_kernel == 1)
+    use_pk = false;
+  if ((force && force[0] == 'p') || g_force_kernel == 2)
+    use_pk = all_even && (!descs_on_device || limits);
+  if (use_pk) {
+    const int pk_threads = ((max_threads / 2 + 63) / 64) * 64; // max_threads >= max Z, a multiple of 64
+    size_t    pk_lds     = 0;
+    for (int b = 0; b < 2; ++b) {
+      if (!max_nodes[b])
+        continue;
+      const int bgK = b ? 10 : 22, bgM = b ? 42 : 46;
+      int       lay = nodes_all - bgK;
+      lay           = lay < 4 ? 4 : (lay > bgM ? bgM : lay);
+      const size_t l = miphy_ldpc_pk_lds_bytes(bgK, lay, (size_t)max_threads);
+      pk_lds         = l > pk_lds ? l : pk_lds;
+    }
+    return miphy_ldpc_pk_launch((const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, n, pk_threads, pk_lds, llr, out_bits, iters, nodes_all, harq_slot,
+                                harq_crc_ok, s);
+  }
   static thread_local size_t lds_set = 0;
   if (max_lds > lds_set) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));

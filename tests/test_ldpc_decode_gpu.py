@@ -7,6 +7,15 @@ from oracle_lib import (ALL_Z, BG_K, BG_NS, CRC16, CRC24A, CRC24B, o_crc_bits, o
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "scalar", "packed"], autouse=True)
+def ldpc_kernel(request):
+    """Every test of this file runs with the automatic kernel choice and with each of the two decoder kernels forced."""
+    import miphy
+    miphy.lib().miphy_debug_force_ldpc_kernel({"auto": 0, "scalar": 1, "packed": 2}[request.param])
+    yield request.param
+    miphy.lib().miphy_debug_force_ldpc_kernel(0)
+
+
 def noisy_llr(cw, sigma, rng):
     y = (1.0 - 2.0 * (cw & 1)) + sigma * rng.standard_normal(cw.size)
     return np.round(np.clip(4 * y, -20, 20) / 20 * 120).astype(np.int8)
