@@ -8,6 +8,7 @@
 #include "fft_device.h"
 #include "miphy_ext.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -26,41 +27,81 @@ __device__ __forceinline__ uint32_t x2_step28(uint32_t s)
   return ((s >> 3) ^ (s >> 2) ^ (s >> 1) ^ s) & 0x0fffffffu;
 }
 
-// Writes c(0..nbits-1) bit-packed LSB-first into `out` (32-bit words). Single thread.
-__device__ void gold_bits(uint32_t c_init, int nbits, uint32_t* out)
+// State of both LFSRs after the Nc = 1600 warm-up, as 31-bit windows. x1 starts from a constant, so its state is a
+// constant; x2's state is linear in c_init: the XOR of one precomputed column per set bit of c_init.
+struct gold_jump {
+  uint32_t x1_1600;
+  uint32_t x2_col[31];
+};
+
+__host__ __device__ inline void gold_jump_init(gold_jump& g)
 {
-  uint32_t s1 = 1u, s2 = c_init & 0x7fffffffu;
-  // advance both registers by Nc = 1600 = 57 * 28 + 4
-  for (int i = 0; i < 57; ++i) {
-    const uint32_t n1 = x1_step28(s1), n2 = x2_step28(s2);
-    s1 = ((s1 >> 28) | (n1 << 3)) & 0x7fffffffu;
-    s2 = ((s2 >> 28) | (n2 << 3)) & 0x7fffffffu;
-  }
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t b1 = ((s1 >> 3) ^ s1) & 1u, b2 = ((s2 >> 3) ^ (s2 >> 2) ^ (s2 >> 1) ^ s2) & 1u;
-    s1 = (s1 >> 1) | (b1 << 30);
-    s2 = (s2 >> 1) | (b2 << 30);
-  }
-  // now s1, s2 hold x(1600..1630); emit 28 bits per step
-  int      pos = 0;
-  uint64_t acc = 0;
-  int      have = 0, w = 0;
-  while (pos < nbits) {
-    const uint32_t c28 = (s1 ^ s2) & 0x0fffffffu; // c(pos..pos+27)
-    acc |= (uint64_t)c28 << have;
+  auto adv = [](uint32_t s1, bool is_x2) {
+    for (int i = 0; i < 1600; ++i) {
+      const uint32_t b = is_x2 ? (((s1 >> 3) ^ (s1 >> 2) ^ (s1 >> 1) ^ s1) & 1u) : (((s1 >> 3) ^ s1) & 1u);
+      s1               = (s1 >> 1) | (b << 30);
+    }
+    return s1;
+  };
+  g.x1_1600 = adv(1u, false);
+  for (int k = 0; k < 31; ++k)
+    g.x2_col[k] = adv(1u << k, true);
+}
+
+// Head of one LFSR sequence: its first `head` (<= 31) 32-bit words from the 31-bit state window `s` (28 bits per step).
+__device__ __forceinline__ void lfsr_head(uint32_t s, bool is_x2, int head, uint32_t* w)
+{
+  uint64_t acc  = 0;
+  int      have = 0, k = 0;
+  while (k < head) {
+    acc |= (uint64_t)(s & 0x0fffffffu) << have;
     have += 28;
-    pos += 28;
-    while (have >= 32) {
-      out[w++] = (uint32_t)acc;
+    if (have >= 32) {
+      w[k++] = (uint32_t)acc;
       acc >>= 32;
       have -= 32;
     }
-    const uint32_t n1 = x1_step28(s1), n2 = x2_step28(s2);
-    s1 = ((s1 >> 28) | (n1 << 3)) & 0x7fffffffu;
-    s2 = ((s2 >> 28) | (n2 << 3)) & 0x7fffffffu;
+    const uint32_t n = is_x2 ? x2_step28(s) : x1_step28(s);
+    s                = ((s >> 28) | (n << 3)) & 0x7fffffffu;
   }
-  if (have > 0)
-    out[w++] = (uint32_t)acc;
+}
+
+// Gold sequences c(0..nbits-1) of `nseq` initial values (one per DM-RS symbol), bit-packed LSB-first, 104 words apart in
+// `out`. Cooperative over the workgroup: 2*nseq lanes produce the 31-word heads of x1/x2; the Frobenius identity
+// p(D)^32 = p(D^32) then turns the bit recurrences into WORD recurrences that reach 28 words back,
+//   W1[i] = W1[i-28] ^ W1[i-31],   W2[i] = W2[i-28] ^ W2[i-29] ^ W2[i-30] ^ W2[i-31],
+// so 28 new words per sequence are produced per step by 28 lanes. tmp: nseq x 2 x 104 words of LDS scratch.
+__device__ __forceinline__ void gold_bits_block(const gold_jump& gj, const uint32_t* c_init, int nseq, int nbits, uint32_t* out, uint32_t* tmp,
+                                                int tid, int nt)
+{
+  const int nwords = (nbits + 31) >> 5;
+  const int head   = nwords < 31 ? nwords : 31;
+  if (tid < 2 * nseq) {
+    const int  q = tid >> 1;
+    const bool is_x2 = tid & 1;
+    uint32_t   st = gj.x1_1600;
+    if (is_x2) {
+      st = 0;
+      for (int k = 0; k < 31; ++k)
+        st ^= ((c_init[q] >> k) & 1u) ? gj.x2_col[k] : 0u;
+    }
+    lfsr_head(st, is_x2, head, tmp + (2 * q + (is_x2 ? 1 : 0)) * 104);
+  }
+  __syncthreads();
+  for (int i0 = 31; i0 < nwords; i0 += 28) {
+    if (tid < 2 * nseq * 28) {
+      const int qs = tid / 28, j = tid - qs * 28, i = i0 + j;
+      uint32_t* w  = tmp + qs * 104;
+      if (i < nwords)
+        w[i] = (qs & 1) ? (w[i - 28] ^ w[i - 29] ^ w[i - 30] ^ w[i - 31]) : (w[i - 28] ^ w[i - 31]);
+    }
+    __syncthreads();
+  }
+  for (int k = tid; k < nseq * nwords; k += nt) {
+    const int q = k / nwords, i = k - q * nwords;
+    out[q * 104 + i] = tmp[(2 * q) * 104 + i] ^ tmp[(2 * q + 1) * 104 + i];
+  }
+  __syncthreads();
 }
 
 __device__ __forceinline__ float block_sum(float v, float* red, int tid)
@@ -75,7 +116,9 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid)
   return red[0] + red[1] + red[2] + red[3];
 }
 
+
 __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job* __restrict__ jobs,
+                                                    const gold_jump* __restrict__ gj,
                                                     const cplx* __restrict__ tw,
                                                     const float2* __restrict__ grid,
                                                     float2* __restrict__ ce_out,
@@ -83,15 +126,17 @@ __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job*
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cplx*     fbuf   = reinterpret_cast<cplx*>(smem);                  // 4096 cplx: IDFT buffer, later interpolated response
-  cplx*     lse    = fbuf + CE_DFT;                                   // MAX_PILOTS
+  cplx*     lse    = fbuf + fft_lds_bytes(CE_DFT) / 8;                // MAX_PILOTS
   uint32_t* cbits  = reinterpret_cast<uint32_t*>(lse + MAX_PILOTS);   // 4 symbols x 104 words
-  uint16_t* prb_of = reinterpret_cast<uint16_t*>(cbits + 4 * 104);    // allocated PRB list (<= 275)
+  uint32_t* gtmp   = cbits + 4 * 104;                                 // Gold scratch: 4 symbols x 2 x 104 words
+  uint16_t* prb_of = reinterpret_cast<uint16_t*>(gtmp + 4 * 208);     // allocated PRB list (<= 275)
   float*    red    = reinterpret_cast<float*>(prb_of + 276);          // reductions
   int*      ired   = reinterpret_cast<int*>(red + 8);
 
   const miphy_pusch_chest_job job = jobs[blockIdx.x];
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int port = blockIdx.y, layer = blockIdx.z;
+  const int port = blockIdx.y % 4, layer = blockIdx.y / 4;
+  const int sgrp = blockIdx.z, ngrp = gridDim.z; // symbol group: stores OFDM symbols l with l % ngrp == sgrp; group 0 owns the scalars
   if (port >= job.nof_rx_ports || layer >= job.nof_tx_layers)
     return;
   const int nprb_grid = job.grid_nof_prb, nsc = nprb_grid * 12;
@@ -105,21 +150,29 @@ __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job*
         dsym[nds] = l;
       ++nds;
     }
-  // Allocated PRB list (compact), built by thread 0 of each wave-uniform pass.
+  // Allocated PRB list (compact): PRB r goes to slot popcount(mask bits below r).
+  for (int r = tid; r < nprb_grid; r += nt) {
+    const int wd = r >> 6, bt = r & 63;
+    if ((job.rb_mask[wd] >> bt) & 1ull) {
+      int idx = __popcll(job.rb_mask[wd] & ((1ull << bt) - 1ull));
+      for (int w = 0; w < wd; ++w)
+        idx += __popcll(job.rb_mask[w]);
+      prb_of[idx] = (uint16_t)r;
+    }
+  }
   if (tid == 0) {
     int c = 0;
-    for (int r = 0; r < nprb_grid; ++r)
-      if ((job.rb_mask[r >> 6] >> (r & 63)) & 1ull)
-        prb_of[c++] = (uint16_t)r;
+    for (int w = 0; w < 5; ++w)
+      c += __popcll(w * 64 < nprb_grid ? (job.rb_mask[w] & ((nprb_grid - w * 64 >= 64) ? ~0ull : ((1ull << (nprb_grid - w * 64)) - 1ull))) : 0ull);
     ired[0] = c;
   }
-  // Gold sequences, one thread per DM-RS symbol (dmrs_pusch_estimator_impl.cpp:158-162).
-  if (tid < nds && tid < 4) {
-    const uint64_t t      = ((uint64_t)(14u * job.slot_in_frame + (uint32_t)dsym[tid] + 1u) * (2ull * job.scrambling_id + 1ull)) % (1ull << 31);
-    const uint32_t c_init = (uint32_t)((t * (1ull << 17) + (2ull * job.scrambling_id + (job.n_scid ? 1u : 0u))) % (1ull << 31));
-    gold_bits(c_init, 12 * nprb_grid, cbits + tid * 104);
+  // Gold sequences of the DM-RS symbols (dmrs_pusch_estimator_impl.cpp:158-162).
+  uint32_t c_init[4] = {0, 0, 0, 0};
+  for (int q = 0; q < nds && q < 4; ++q) {
+    const uint64_t t = ((uint64_t)(14u * job.slot_in_frame + (uint32_t)dsym[q] + 1u) * (2ull * job.scrambling_id + 1ull)) % (1ull << 31);
+    c_init[q]        = (uint32_t)((t * (1ull << 17) + (2ull * job.scrambling_id + (job.n_scid ? 1u : 0u))) % (1ull << 31));
   }
-  __syncthreads();
+  gold_bits_block(*gj, c_init, min(nds, 4), 12 * nprb_grid, cbits, gtmp, tid, nt);
   const int nprb = ired[0];
   const int np   = nprb * 6;
   const int delta = (layer >> 1) & 1;             // RE pattern: even subcarriers for ports 0,1 ; odd for 2,3
@@ -154,9 +207,9 @@ __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job*
   const float rsrp_sum = block_sum(rsrp_acc, red, tid) / (float)nds;
   __syncthreads();
 
-  // ---- noise (:271-310): per-PRB mean of the estimates, predicted observation, residual power
+  // ---- noise (:271-310): per-PRB mean of the estimates, predicted observation, residual power (symbol group 0 only)
   float noise_acc = 0.f;
-  for (int i = tid; i < np; i += nt) {
+  for (int i = tid; i < ((sgrp == 0) ? np : 0); i += nt) {
     const int b = (i / 6) * 6;
     cplx      avg = {0.f, 0.f};
 #pragma unroll
@@ -179,23 +232,25 @@ __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job*
   const float noise_sum = block_sum(noise_acc, red, tid); // = sum over symbols of |pred|^2 ; x window / np applied below
 
   // ---- time alignment (:312-347): zero-padded IDFT of the LS estimates at their RE positions
-  for (int i = tid; i < CE_DFT; i += nt)
+  float ta_samples = 0.f;
+  if (sgrp == 0) {
+  for (int i = tid; i < (int)(fft_lds_bytes(CE_DFT) / 8); i += nt)
     fbuf[i] = {0.f, 0.f};
   __syncthreads();
   for (int i = tid; i < np; i += nt)
-    fbuf[prb_of[i / 6] * 12 + 2 * (i % 6) + delta] = lse[i];
+    fbuf[fpad(prb_of[i / 6] * 12 + 2 * (i % 6) + delta)] = lse[i];
   __syncthreads();
   fft_lds<true>(fbuf, CE_DFT, tw, tid, nt);
   // arg-max of |.|^2 over the first / last HALF_CP taps (first occurrence wins, like std::max_element)
   float best = -1.f;
   int   bidx = 0x7fffffff;
   if (tid < HALF_CP) {
-    const cplx v = fbuf[tid];
+    const cplx v = fbuf[fpad(tid)];
     best = v.x * v.x + v.y * v.y;
     bidx = tid;
   } else if (tid < 2 * HALF_CP - 0 && tid >= HALF_CP && tid < 256) {
     const int  k = tid - HALF_CP; // 0..111 ; the remaining taps are handled below
-    const cplx v = fbuf[CE_DFT - HALF_CP + k];
+    const cplx v = fbuf[fpad(CE_DFT - HALF_CP + k)];
     best = v.x * v.x + v.y * v.y;
     bidx = HALF_CP + k;
   }
@@ -204,7 +259,7 @@ __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job*
   int   bidx2 = 0x7fffffff;
   if (tid + 256 < 2 * HALF_CP) {
     const int  k = tid + 256 - HALF_CP;
-    const cplx v = fbuf[CE_DFT - HALF_CP + k];
+    const cplx v = fbuf[fpad(CE_DFT - HALF_CP + k)];
     best2 = v.x * v.x + v.y * v.y;
     bidx2 = HALF_CP + k;
   }
@@ -223,8 +278,9 @@ __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job*
   const float md = __uint_as_float((unsigned)(keys[0] >> 32)), ma = __uint_as_float((unsigned)(keys[1] >> 32));
   const int   id = (int)(0xffffffffu - (unsigned)(keys[0] & 0xffffffffu));
   const int   ia = (int)(0xffffffffu - (unsigned)(keys[1] & 0xffffffffu)) - HALF_CP;
-  const float ta_samples = (md >= ma) ? (float)id : -(float)(HALF_CP - ia);
+  ta_samples = (md >= ma) ? (float)id : -(float)(HALF_CP - ia);
   __syncthreads();
+  } // sgrp == 0
 
   // ---- linear interpolation over the concatenated allocated PRBs (interpolator_linear_impl.cpp:58-78; offset = delta,
   // stride 2, edges held) written straight to every OFDM symbol of the allocation (:216-224).
@@ -248,11 +304,12 @@ __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job*
     const int    r   = prb_of[k / 12];
     const size_t col = (size_t)r * 12 + (k % 12);
     for (int l = first; l < nsymb_out; ++l)
-      dst0[(size_t)l * nsc + col] = make_float2(v.x, v.y);
+      if (l % ngrp == sgrp)
+        dst0[(size_t)l * nsc + col] = make_float2(v.x, v.y);
   }
 
   // ---- side-band scalars (:118-144)
-  if (tid == 0) {
+  if (tid == 0 && sgrp == 0) {
     const float ndp  = (float)(np * nds);
     const float rsrp = rsrp_sum / ndp;
     const float epre = epre_sum / ndp;
@@ -316,8 +373,20 @@ extern "C" int miphy_dmrs_pusch_estimate_batch(miphy_ctx*                   ctx,
   const void* d_jobs = nullptr;
   if ((rc = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_pusch_chest_job) * (size_t)n, s, &d_jobs)))
     return rc;
-  const size_t lds = (size_t)CE_DFT * 8 + (size_t)MAX_PILOTS * 8 + 4 * 104 * 4 + 276 * 2 + 64 + 64;
-  hipLaunchKernelGGL(chest_kernel, dim3(n, max_ports, max_layers), dim3(256), lds, s, (const miphy_pusch_chest_job*)d_jobs, (const cplx*)tw,
+  const size_t lds = fft_lds_bytes(CE_DFT) + (size_t)MAX_PILOTS * 8 + 4 * 104 * 4 + 4 * 208 * 4 + 276 * 2 + 64 + 64;
+  if (!ctx->ext->d_gold) {
+    gold_jump gj;
+    gold_jump_init(gj);
+    MIPHY_HIP_CHECK(hipMalloc(&ctx->ext->d_gold, sizeof(gj)));
+    MIPHY_HIP_CHECK(hipMemcpy(ctx->ext->d_gold, &gj, sizeof(gj), hipMemcpyHostToDevice));
+    ctx->ext->to_free.push_back(ctx->ext->d_gold);
+  }
+  // Small batches cannot fill 256 CUs with one workgroup per (job, port, layer): split the broadcast store over symbol groups.
+  static const char* genv = getenv("MIPHY_CHEST_GROUPS");
+  int                ngrp = genv ? atoi(genv) : 1; // measured: splitting does not pay once the per-workgroup prologue is parallel
+  ngrp                    = ngrp < 1 ? 1 : (ngrp > 14 ? 14 : ngrp);
+  hipLaunchKernelGGL(chest_kernel, dim3(n, 4 * max_layers, ngrp), dim3(256), lds, s, (const miphy_pusch_chest_job*)d_jobs,
+                     (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw,
                      (const float2*)grid, (float2*)ce, scalars);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;

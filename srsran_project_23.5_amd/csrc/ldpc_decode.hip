@@ -226,7 +226,6 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   const int                 bgi = (dsc.bg == 1) ? 0 : 1;
   const int                 bgK = bgi ? 10 : 22;
   const int                 bgM = bgi ? 42 : 46;
-  const int                 NF  = bgK + bgM;
   const int                 K   = bgK * Z;
   const int                 zp  = tab->z_pos[Z];
 

@@ -18,13 +18,13 @@ __global__ void __launch_bounds__(256) dft_kernel(const float2* __restrict__ in,
   const float2* src = in + (size_t)blockIdx.x * N;
   float2*       dst = out + (size_t)blockIdx.x * N;
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
-    float2 v = src[i];
-    x[i]     = {v.x, v.y};
+    float2 v   = src[i];
+    x[fpad(i)] = {v.x, v.y};
   }
   __syncthreads();
   fft_lds<INV>(x, N, tw, threadIdx.x, blockDim.x);
   for (int i = threadIdx.x; i < N; i += blockDim.x)
-    dst[i] = make_float2(x[i].x, x[i].y);
+    dst[i] = make_float2(x[fpad(i)].x, x[fpad(i)].y);
 }
 
 __global__ void __launch_bounds__(256) ofdm_demod_kernel(const miphy_ofdm_job* __restrict__ jobs,
@@ -42,9 +42,18 @@ __global__ void __launch_bounds__(256) ofdm_demod_kernel(const miphy_ofdm_job* _
   const int            sym = (int)job.slot_index * 14 + l;
   // FFT window: starts `window_offset` samples before the end of the cyclic prefix (demodulator_impl.cpp:115).
   const float2* src = samples + job.samples_offset + plan->sym_off[sym] + plan->cp_len[sym] - plan->window_offset;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) {
-    float2 v = src[i];
-    x[i]     = {v.x, v.y};
+  if ((((uintptr_t)src) & 15) == 0) { // 16-byte loads: two samples per lane
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    for (int i = threadIdx.x; i < N / 2; i += blockDim.x) {
+      const float4 v     = src4[i];
+      x[fpad(2 * i)]     = {v.x, v.y};
+      x[fpad(2 * i + 1)] = {v.z, v.w};
+    }
+  } else {
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      float2 v   = src[i];
+      x[fpad(i)] = {v.x, v.y};
+    }
   }
   __syncthreads();
   fft_lds<false>(x, N, tw, threadIdx.x, blockDim.x);
@@ -53,7 +62,7 @@ __global__ void __launch_bounds__(256) ofdm_demod_kernel(const miphy_ofdm_job* _
   const int  half = rg / 2;
   for (int k = threadIdx.x; k < rg; k += blockDim.x) {
     const int bin = (k < half) ? N - half + k : k - half; // demodulator_impl.cpp:131-137
-    cplx      v   = cmul(x[bin], coef);                    // sc_prod(dft_output, phase * scale)
+    cplx      v   = cmul(x[fpad(bin)], coef);              // sc_prod(dft_output, phase * scale)
     if (ramp)
       v = cmul(v, ramp[bin]);                              // window-offset phase ramp (:60-76,127-129)
     dst[k] = make_float2(v.x, v.y);
@@ -91,14 +100,14 @@ __global__ void __launch_bounds__(256) ofdm_mod_kernel(const miphy_ofdm_job* __r
       float2 g = src[i - (N - half)];
       v        = {g.x, g.y};
     }
-    x[i] = v;
+    x[fpad(i)] = v;
   }
   __syncthreads();
   fft_lds<true>(x, N, tw, threadIdx.x, blockDim.x);
   const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
   for (int i = threadIdx.x; i < N + cp; i += blockDim.x) {
     const int j = (i < cp) ? N - cp + i : i - cp; // cyclic prefix = copy of the tail (:98)
-    cplx      v = cmul(x[j], coef);
+    cplx      v = cmul(x[fpad(j)], coef);
     dst[i]      = make_float2(v.x, v.y);
   }
 }
@@ -263,9 +272,9 @@ extern "C" int miphy_dft_batch(miphy_ctx* ctx, uint32_t size, int inverse, uint3
     return rc;
   hipStream_t s = (hipStream_t)stream;
   if (inverse)
-    hipLaunchKernelGGL(dft_kernel<true>, dim3(n), dim3(threads_for(size)), size * 8, s, (const float2*)in, (float2*)out, (const cplx*)tw, (int)size);
+    hipLaunchKernelGGL(dft_kernel<true>, dim3(n), dim3(threads_for(size)), fft_lds_bytes(size), s, (const float2*)in, (float2*)out, (const cplx*)tw, (int)size);
   else
-    hipLaunchKernelGGL(dft_kernel<false>, dim3(n), dim3(threads_for(size)), size * 8, s, (const float2*)in, (float2*)out, (const cplx*)tw, (int)size);
+    hipLaunchKernelGGL(dft_kernel<false>, dim3(n), dim3(threads_for(size)), fft_lds_bytes(size), s, (const float2*)in, (float2*)out, (const cplx*)tw, (int)size);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }
@@ -299,7 +308,7 @@ extern "C" int miphy_ofdm_demodulate_slots(miphy_ctx*               ctx,
   const void* d_jobs = nullptr;
   if ((rc = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_ofdm_job) * (size_t)n, s, &d_jobs)))
     return rc;
-  hipLaunchKernelGGL(ofdm_demod_kernel, dim3(14, n), dim3(threads_for(cfg->dft_size)), cfg->dft_size * 8, s, (const miphy_ofdm_job*)d_jobs, plan,
+  hipLaunchKernelGGL(ofdm_demod_kernel, dim3(14, n), dim3(threads_for(cfg->dft_size)), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan,
                      (const cplx*)tw, (const cplx*)ramp, (const float2*)samples, (float2*)grid);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
@@ -333,7 +342,7 @@ extern "C" int miphy_ofdm_modulate_slots(miphy_ctx*               ctx,
   const void* d_jobs = nullptr;
   if ((rc = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_ofdm_job) * (size_t)n, s, &d_jobs)))
     return rc;
-  hipLaunchKernelGGL(ofdm_mod_kernel, dim3(14, n), dim3(threads_for(cfg->dft_size)), cfg->dft_size * 8, s, (const miphy_ofdm_job*)d_jobs, plan,
+  hipLaunchKernelGGL(ofdm_mod_kernel, dim3(14, n), dim3(threads_for(cfg->dft_size)), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan,
                      (const cplx*)tw, (const float2*)grid, (float2*)samples);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
