@@ -247,6 +247,15 @@ def main():
     gbs = {k: alg[k] / (kernel_ms[k] * 1e-3) / 1e9 for k in stages}
     dom = max(kernel_ms, key=kernel_ms.get)
     achieved = gbs[dom]
+    # HBM traffic per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE collected offline in separate rocprofv3 passes on
+    # this same workload; the counters cannot be read from inside the process). Scales linearly with the slots per step.
+    traffic = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        for k, v in tj["kernels"].items():
+            traffic[k] = v["hbm_bytes_per_launch"] * S / tj["slots_per_gpu_per_step"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "LDPC info-bits/sec + OFDM slots/sec, 100 MHz n78 273-PRB grid",
         "value": value,
@@ -270,11 +279,11 @@ def main():
         "kernel_algorithmic_GBps": gbs,
         "ofdm_slots_per_s": S * world / (kernel_ms["ofdm_demod"] * 1e-3),
         "roofline_ofdm": {"kernel": "ofdm_demod", "bound": "hbm", "achieved": gbs["ofdm_demod"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": gbs["ofdm_demod"] / HBM_PEAK_GBS, "traffic": None},
+                          "frac": gbs["ofdm_demod"] / HBM_PEAK_GBS, "traffic": traffic.get("ofdm_demod")},
         "mean_ldpc_iterations": float(iters.mean()) if args.early_stop else float(args.max_iter),
         "parity_check": "%d/%d slots identical to oracle" % (ok_slots, checked),
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get(dom), "algorithmic_bytes": alg[dom],
                      "note": "LDPC decode is LDS/VALU-bound; HBM fraction reported as required"},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
