@@ -186,7 +186,8 @@ int miphy_crc_batch(miphy_ctx*            ctx,
  * DFT processor  --  replaces srsran::dft_processor (get_input/run), batched
  *   include/srsran/phy/generic_functions/dft_processor.h:34-73, lib/phy/generic_functions/dft_processor_generic_impl.cpp.
  * Unnormalised; DIRECT uses exp(-j...), INVERSE exp(+j...). `n` transforms stored back to back (size cf_t each).
- * Supported sizes this round: 2^a * 3^b <= 4096 (128 ... 4096 of the reference's 18 sizes); larger -> MIPHY_EUNSUPP. */
+ * Supported sizes: every 2^a * 3^b <= 4096 in one LDS pass, and 4608 ... 49152 of the reference's list through a four-step
+ * transform (all 18 sizes of dft_processor_generic_impl.cpp:193-210); anything else -> MIPHY_EUNSUPP. */
 int miphy_dft_batch(miphy_ctx* ctx, uint32_t size, int inverse, uint32_t n, const float* in /* device cf_t */,
                     float* out /* device cf_t */, void* stream);
 

@@ -27,6 +27,104 @@ __global__ void __launch_bounds__(256) dft_kernel(const float2* __restrict__ in,
     dst[i] = make_float2(x[fpad(i)].x, x[fpad(i)].y);
 }
 
+// ---- sizes above 4096 (up to 49152 = 192 x 256): four-step FFT through HBM. N = N1 * N2, n = N2*n1 + n2, k = k1 + N1*k2:
+//   X[k1 + N1 k2] = sum_n2 W_N^(n2 k1) W_N2^(n2 k2) [ sum_n1 x[N2 n1 + n2] W_N1^(n1 k1) ]
+// Step 1: N1-point transforms down the columns (16 adjacent columns per workgroup so that every row segment is a 128-byte
+// access), times the twiddle W_N^(n2 k1), stored as A[k1][n2]. Step 2: N2-point transforms along the rows of A, 16 rows per
+// workgroup, scattered to X[k1 + N1 k2] in 128-byte segments.
+constexpr int FS_TILE = 16;
+
+template <bool INV>
+__global__ void __launch_bounds__(256) dft_fs_step1_kernel(const float2* __restrict__ in,
+                                                           float2* __restrict__ tmp,
+                                                           const cplx* __restrict__ tw1,
+                                                           const cplx* __restrict__ twN,
+                                                           int N1,
+                                                           int N2)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cplx*         x      = reinterpret_cast<cplx*>(smem);
+  const int     stride = (int)(fft_lds_bytes(N1) / 8);
+  const size_t  N      = (size_t)N1 * N2;
+  const float2* src    = in + (size_t)blockIdx.y * N;
+  float2*       dst    = tmp + (size_t)blockIdx.y * N;
+  const int     c0     = blockIdx.x * FS_TILE;
+  for (int i = threadIdx.x; i < FS_TILE * N1; i += blockDim.x) {
+    const int n1 = i / FS_TILE, c = i % FS_TILE;
+    const float2 v = src[(size_t)N2 * n1 + c0 + c];
+    x[c * stride + fpad(n1)] = {v.x, v.y};
+  }
+  __syncthreads();
+  for (int c = 0; c < FS_TILE; ++c)
+    fft_lds<INV>(x + c * stride, N1, tw1, threadIdx.x, blockDim.x);
+  for (int i = threadIdx.x; i < FS_TILE * N1; i += blockDim.x) {
+    const int k1 = i / FS_TILE, c = i % FS_TILE;
+    const int n2 = c0 + c;
+    const cplx w = cconj_if<INV>(twN[(size_t)n2 * k1 % N]);
+    const cplx v = cmul(x[c * stride + fpad(k1)], w);
+    dst[(size_t)k1 * N2 + n2] = make_float2(v.x, v.y);
+  }
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(256)
+dft_fs_step2_kernel(const float2* __restrict__ tmp, float2* __restrict__ out, const cplx* __restrict__ tw2, int N1, int N2)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cplx*         x      = reinterpret_cast<cplx*>(smem);
+  const int     stride = (int)(fft_lds_bytes(N2) / 8);
+  const size_t  N      = (size_t)N1 * N2;
+  const float2* src    = tmp + (size_t)blockIdx.y * N;
+  float2*       dst    = out + (size_t)blockIdx.y * N;
+  const int     r0     = blockIdx.x * FS_TILE;
+  for (int i = threadIdx.x; i < FS_TILE * N2; i += blockDim.x) {
+    const int r = i / N2, n2 = i % N2;
+    const float2 v = src[(size_t)(r0 + r) * N2 + n2];
+    x[r * stride + fpad(n2)] = {v.x, v.y};
+  }
+  __syncthreads();
+  for (int r = 0; r < FS_TILE; ++r)
+    fft_lds<INV>(x + r * stride, N2, tw2, threadIdx.x, blockDim.x);
+  for (int i = threadIdx.x; i < FS_TILE * N2; i += blockDim.x) {
+    const int k2 = i / FS_TILE, r = i % FS_TILE;
+    const cplx v = x[r * stride + fpad(k2)];
+    dst[(size_t)N1 * k2 + r0 + r] = make_float2(v.x, v.y);
+  }
+}
+
+// Factorisation (both factors multiples of the 16-wide tile) used for the large sizes of the reference's list (dft_processor_generic_impl.cpp:193-210).
+bool four_step_factors(uint32_t N, uint32_t& N1, uint32_t& N2)
+{
+  switch (N) {
+    case 4608:
+      N1 = 48, N2 = 96;
+      return true;
+    case 6144:
+      N1 = 64, N2 = 96;
+      return true;
+    case 9216:
+      N1 = 96, N2 = 96;
+      return true;
+    case 12288:
+      N1 = 96, N2 = 128;
+      return true;
+    case 18432:
+      N1 = 96, N2 = 192;
+      return true;
+    case 24576:
+      N1 = 128, N2 = 192;
+      return true;
+    case 36864:
+      N1 = 192, N2 = 192;
+      return true;
+    case 49152:
+      N1 = 192, N2 = 256;
+      return true;
+    default:
+      return false;
+  }
+}
+
 __global__ void __launch_bounds__(256) ofdm_demod_kernel(const miphy_ofdm_job* __restrict__ jobs,
                                                          const ofdm_plan_dev* __restrict__ plan,
                                                          const cplx* __restrict__ tw,
@@ -260,8 +358,36 @@ extern "C" uint32_t miphy_ofdm_slot_size(const miphy_ofdm_config* c, uint32_t sl
 extern "C" int miphy_dft_batch(miphy_ctx* ctx, uint32_t size, int inverse, uint32_t n, const float* in, float* out, void* stream)
 {
   MIPHY_REQUIRE(ctx && in && out, "miphy_dft_batch: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t    N1 = 0, N2 = 0;
+  if (!size_supported(size) && four_step_factors(size, N1, N2)) {
+    if (n == 0)
+      return MIPHY_OK;
+    MIPHY_REQUIRE(n <= 65535, "miphy_dft_batch: at most 65535 transforms of size %u per call", size);
+    const float *tw1 = nullptr, *tw2 = nullptr, *twN = nullptr;
+    int          rc;
+    if ((rc = miphy_get_twiddles(ctx, N1, &tw1)) || (rc = miphy_get_twiddles(ctx, N2, &tw2)) || (rc = miphy_get_twiddles(ctx, size, &twN)))
+      return rc;
+    void* tmp = nullptr;
+    if ((rc = miphy_get_workspace(ctx, (size_t)n * size * 8, s, &tmp)))
+      return rc;
+    const size_t lds1 = FS_TILE * fft_lds_bytes(N1), lds2 = FS_TILE * fft_lds_bytes(N2);
+    if (inverse) {
+      hipLaunchKernelGGL(dft_fs_step1_kernel<true>, dim3(N2 / FS_TILE, n), dim3(256), lds1, s, (const float2*)in, (float2*)tmp, (const cplx*)tw1,
+                         (const cplx*)twN, (int)N1, (int)N2);
+      hipLaunchKernelGGL(dft_fs_step2_kernel<true>, dim3(N1 / FS_TILE, n), dim3(256), lds2, s, (const float2*)tmp, (float2*)out, (const cplx*)tw2, (int)N1,
+                         (int)N2);
+    } else {
+      hipLaunchKernelGGL(dft_fs_step1_kernel<false>, dim3(N2 / FS_TILE, n), dim3(256), lds1, s, (const float2*)in, (float2*)tmp, (const cplx*)tw1,
+                         (const cplx*)twN, (int)N1, (int)N2);
+      hipLaunchKernelGGL(dft_fs_step2_kernel<false>, dim3(N1 / FS_TILE, n), dim3(256), lds2, s, (const float2*)tmp, (float2*)out, (const cplx*)tw2, (int)N1,
+                         (int)N2);
+    }
+    MIPHY_HIP_CHECK(hipGetLastError());
+    return MIPHY_OK;
+  }
   if (!size_supported(size)) {
-    miphy_set_error("miphy_dft_batch: size %u not supported this round (2^a*3^b <= 4096)", size);
+    miphy_set_error("miphy_dft_batch: size %u not supported (2^a*3^b <= 4096, or one of 4608 ... 49152)", size);
     return MIPHY_EUNSUPP;
   }
   if (n == 0)
@@ -270,7 +396,6 @@ extern "C" int miphy_dft_batch(miphy_ctx* ctx, uint32_t size, int inverse, uint3
   int          rc = miphy_get_twiddles(ctx, size, &tw);
   if (rc)
     return rc;
-  hipStream_t s = (hipStream_t)stream;
   if (inverse)
     hipLaunchKernelGGL(dft_kernel<true>, dim3(n), dim3(threads_for(size)), fft_lds_bytes(size), s, (const float2*)in, (float2*)out, (const cplx*)tw, (int)size);
   else
