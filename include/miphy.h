@@ -366,6 +366,24 @@ typedef struct {
 int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs /* host */, uint32_t n, const uint8_t* tb_in /* device */,
                              uint8_t* codeword_out /* device */, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * PBCH encoder  --  replaces srsran::pbch_encoder::encode
+ *   include/srsran/phy/upper/channel_processors/pbch_encoder.h:53-80, lib/phy/upper/channel_processors/pbch_encoder_impl.cpp:41-190
+ * (payload interleaving G(j) with SFN / half-frame / SSB-index bits, Gold-sequence scrambling, CRC24C, CRC interleaver,
+ * polar chain K = 56, E = 864). The 32-bit payload generation and scrambling are bit bookkeeping done on the host; CRC,
+ * interleaving and the polar chain run on the device. msgs: host array; out: n x 864 bytes (one bit per byte), device. */
+typedef struct {
+  uint32_t N_id;        /* physical cell identifier */
+  uint32_t ssb_idx;
+  uint32_t L_max;       /* 4, 8 or 64 */
+  uint32_t hrf;         /* half-frame flag */
+  uint32_t sfn;
+  uint32_t k_ssb;
+  uint8_t  payload[32]; /* one bit per byte (only the first 24 are used, like the reference) */
+} miphy_pbch_msg;
+
+int miphy_pbch_encode_batch(miphy_ctx* ctx, const miphy_pbch_msg* msgs /* host */, uint32_t n, uint8_t* out /* device */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,4 +162,10 @@ for i, (A, AL) in enumerate([(12, 1), (40, 2), (70, 8), (128, 16)]):
     rnti = int(rng.integers(0, 65536))
     d["pdcch_pay_%d" % i], d["pdcch_out_%d" % i] = pay, O.r_pdcch_encode(pay, rnti, 108 * AL)
     d["pdcch_meta_%d" % i] = np.array([A, 108 * AL, rnti], dtype=np.int64)
+for i in range(6):
+    L_max = [4, 8, 64][i % 3]
+    a = (int(rng.integers(0, 1008)), int(rng.integers(0, L_max)), L_max, int(rng.integers(0, 2)), int(rng.integers(0, 1024)),
+         int(rng.integers(0, 12 if L_max == 64 else 24)))
+    pay = rng.integers(0, 2, 32, dtype=np.uint8)
+    d["pbch_meta_%d" % i], d["pbch_pay_%d" % i], d["pbch_out_%d" % i] = np.array(a, dtype=np.int64), pay, O.r_pbch_encode(*a, pay)
 save("polar", **d)

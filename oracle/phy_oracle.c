@@ -1359,3 +1359,44 @@ int orc_pdcch_encode(const uint8_t* payload, unsigned A, unsigned rnti, unsigned
   orc_polar_interleave(c + 24, cp, K, 0);
   return orc_polar_encode_chain(K, E, 9, 0, cp, out, 0, 0) > 0 ? 0 : -1;
 }
+
+/* pbch_encoder_impl.cpp:41-190 */
+int orc_pbch_encode(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, unsigned sfn, unsigned k_ssb, const uint8_t* payload, uint8_t* out)
+{
+  static const uint8_t G[32] = {16, 23, 18, 17, 8, 30, 10, 6, 24, 7, 0, 5, 3, 2, 1, 4, 9, 11, 12, 13, 14, 15, 19, 20, 21, 22, 25, 26, 27, 28, 29, 31};
+  uint8_t  a[32] = {0}, ap[32], k[56], kp[56];
+  unsigned j_sfn = 0, j_other = 14;
+  for (unsigned i = 0; i < 24; ++i) {
+    if (i >= 1 && i < 7)
+      a[G[j_sfn++]] = payload[i];
+    else
+      a[G[j_other++]] = payload[i];
+  }
+  for (int b = 3; b >= 0; --b)
+    a[G[j_sfn++]] = (uint8_t)((sfn >> b) & 1u);
+  a[G[10]] = hrf ? 1 : 0;
+  if (L_max == 64) {
+    a[G[11]] = (ssb_idx >> 5) & 1u, a[G[12]] = (ssb_idx >> 4) & 1u, a[G[13]] = (ssb_idx >> 3) & 1u;
+  } else {
+    a[G[11]] = (k_ssb >> 4) & 1u, a[G[12]] = 0, a[G[13]] = 0;
+  }
+  unsigned M = (L_max == 64) ? 26 : 29;
+  unsigned v = 2u * a[G[7]] + a[G[8]];
+  uint8_t  c[32];
+  orc_gold_sequence(N_id, M * v, 32, c);
+  for (unsigned i = 0, j = 0; i < 32; ++i) {
+    uint8_t s_i = c[j];
+    int     ssb = (i == G[11] || i == G[12] || i == G[13]) && L_max == 64;
+    if (ssb || i == G[10] || i == G[8] || i == G[7])
+      s_i = 0;
+    else
+      ++j;
+    ap[i] = a[i] ^ s_i;
+  }
+  memcpy(k, ap, 32);
+  uint32_t crc = orc_crc_bits(ORC_CRC24C, ap, 32);
+  for (unsigned i = 0; i < 24; ++i)
+    k[32 + i] = (uint8_t)((crc >> (23 - i)) & 1u);
+  orc_polar_interleave(k, kp, 56, 0);
+  return orc_polar_encode_chain(56, 864, 9, 0, kp, out, 0, 0) > 0 ? 0 : -1;
+}

@@ -122,6 +122,8 @@ int orc_polar_decode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, cons
 void orc_polar_interleave(const uint8_t* in, uint8_t* out, unsigned K, int rx);
 /* PDCCH: payload A bits (1 bit/byte) + rnti -> E rate-matched bits. */
 int orc_pdcch_encode(const uint8_t* payload, unsigned A, unsigned rnti, unsigned E, uint8_t* out);
+/* PBCH (pbch_encoder_impl.cpp:41-190): payload 32 bytes (first 24 used) -> 864 rate-matched bits. */
+int orc_pbch_encode(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, unsigned sfn, unsigned k_ssb, const uint8_t* payload, uint8_t* out);
 
 #ifdef __cplusplus
 }

@@ -688,4 +688,22 @@ int ref_pdcch_encode(const uint8_t* payload, unsigned A, unsigned rnti, unsigned
   return 0;
 }
 
+// ---------------------------------------------------------------- PBCH encoder
+int ref_pbch_encode(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, unsigned sfn, unsigned k_ssb, const uint8_t* payload, uint8_t* out)
+{
+  auto enc = create_pbch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_pseudo_random_generator_sw_factory(), create_polar_factory_sw())->create();
+  pbch_encoder::pbch_msg_t msg;
+  msg.N_id    = N_id;
+  msg.ssb_idx = ssb_idx;
+  msg.L_max   = L_max;
+  msg.hrf     = hrf != 0;
+  msg.sfn     = sfn;
+  msg.k_ssb   = k_ssb;
+  for (unsigned i = 0; i != pbch_encoder::A; ++i) {
+    msg.payload[i] = payload[i];
+  }
+  enc->encode(span<uint8_t>(out, pbch_encoder::E), msg);
+  return 0;
+}
+
 } // extern "C"

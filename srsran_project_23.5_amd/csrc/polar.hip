@@ -281,8 +281,9 @@ __global__ void __launch_bounds__(64) polar_encode_kernel(polar_plan p, const ui
   polar_tx_chain(p, u, m, out + cw * p.E, alloc_tap ? alloc_tap + cw * p.N : nullptr, enc_tap ? enc_tap + cw * p.N : nullptr, lane);
 }
 
+// PDCCH (ones = 24 leading ones, RNTI mask) and PBCH (ones = 0, rnti == nullptr) share the CRC24C + interleave + polar chain.
 __global__ void __launch_bounds__(64) pdcch_encode_kernel(polar_plan p, uint32_t A, const uint8_t* __restrict__ payload,
-                                                          const uint16_t* __restrict__ rnti, uint8_t* __restrict__ out)
+                                                          const uint16_t* __restrict__ rnti, uint8_t* __restrict__ out, int ones)
 {
   __shared__ uint8_t u[1024];
   __shared__ uint8_t c[24 + 164];
@@ -296,11 +297,11 @@ __global__ void __launch_bounds__(64) pdcch_encode_kernel(polar_plan p, uint32_t
   __syncthreads();
   if (lane == 0) {
     uint32_t reg = 0;
-    for (int i = 0; i < 24 + (int)A; ++i) {
+    for (int i = 24 - ones; i < 24 + (int)A; ++i) {
       reg = (reg << 1) ^ ((uint32_t)(c[i] & 1u) << 24);
       reg ^= (reg & 0x1000000u) ? 0x1B2B117u : 0u;
     }
-    const uint32_t r = rnti[cw];
+    const uint32_t r = rnti ? rnti[cw] : 0u;
     for (int i = 0; i < 24; ++i) {
       uint32_t b = (reg >> (23 - i)) & 1u;
       if (i >= 8)
@@ -498,7 +499,92 @@ extern "C" int miphy_pdcch_encode_batch(miphy_ctx*      ctx,
   int               rc   = get_plan(ctx, &code, &p);
   if (rc || n == 0)
     return rc;
-  hipLaunchKernelGGL(pdcch_encode_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, *p, A, payload, rnti, out);
+  hipLaunchKernelGGL(pdcch_encode_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, *p, A, payload, rnti, out, 24);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+namespace {
+// TS 38.211 5.2.1 Gold sequence bit c(n) on the host (PBCH scrambling needs at most a few hundred bits).
+void host_gold(uint32_t c_init, uint32_t offset, uint32_t nbits, uint8_t* out)
+{
+  const uint32_t       total = 1600 + offset + nbits + 31;
+  std::vector<uint8_t> x1(total + 31, 0), x2(total + 31, 0);
+  x1[0] = 1;
+  for (int i = 0; i < 31; ++i)
+    x2[i] = (c_init >> i) & 1u;
+  for (uint32_t n = 0; n + 31 < total + 31; ++n) {
+    x1[n + 31] = x1[n + 3] ^ x1[n];
+    x2[n + 31] = x2[n + 3] ^ x2[n + 2] ^ x2[n + 1] ^ x2[n];
+  }
+  for (uint32_t n = 0; n < nbits; ++n)
+    out[n] = x1[n + offset + 1600] ^ x2[n + offset + 1600];
+}
+} // namespace
+
+extern "C" int miphy_pbch_encode_batch(miphy_ctx* ctx, const miphy_pbch_msg* msgs, uint32_t n, uint8_t* out, void* stream)
+{
+  MIPHY_REQUIRE(ctx && msgs && out, "miphy_pbch_encode_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  // TS 38.212 Table 7.1.1-1, payload interleaver pattern G(j) (pbch_encoder_impl.cpp:33-35).
+  static const uint8_t G[32] = {16, 23, 18, 17, 8, 30, 10, 6, 24, 7, 0, 5, 3, 2, 1, 4, 9, 11, 12, 13, 14, 15, 19, 20, 21, 22, 25, 26, 27, 28, 29, 31};
+  std::vector<uint8_t> ap((size_t)n * 32);
+  for (uint32_t m = 0; m < n; ++m) {
+    const miphy_pbch_msg& msg = msgs[m];
+    MIPHY_REQUIRE(msg.N_id <= 1007, "pbch_encode: message %u: invalid N_id %u", m, msg.N_id);
+    MIPHY_REQUIRE(msg.L_max == 4 || msg.L_max == 8 || msg.L_max == 64, "pbch_encode: message %u: invalid L_max %u", m, msg.L_max);
+    uint8_t a[32] = {0};
+    // payload_generate (pbch_encoder_impl.cpp:42-86)
+    uint32_t j_sfn = 0, j_other = 14;
+    for (uint32_t i = 0; i < 24; ++i) {
+      if (i >= 1 && i < 7)
+        a[G[j_sfn++]] = msg.payload[i] & 1u;
+      else
+        a[G[j_other++]] = msg.payload[i] & 1u;
+    }
+    a[G[j_sfn++]] = (msg.sfn >> 3) & 1u;
+    a[G[j_sfn++]] = (msg.sfn >> 2) & 1u;
+    a[G[j_sfn++]] = (msg.sfn >> 1) & 1u;
+    a[G[j_sfn++]] = (msg.sfn >> 0) & 1u;
+    a[G[10]]      = msg.hrf ? 1 : 0;
+    if (msg.L_max == 64) {
+      a[G[11]] = (msg.ssb_idx >> 5) & 1u;
+      a[G[12]] = (msg.ssb_idx >> 4) & 1u;
+      a[G[13]] = (msg.ssb_idx >> 3) & 1u;
+    } else {
+      a[G[11]] = (msg.k_ssb >> 4) & 1u;
+      a[G[12]] = 0;
+      a[G[13]] = 0;
+    }
+    // scramble (pbch_encoder_impl.cpp:88-129)
+    const uint32_t M = (msg.L_max == 64) ? 32 - 6 : 32 - 3;
+    const uint32_t v = 2 * a[G[7]] + a[G[8]]; // 3rd and 2nd LSB of the SFN
+    uint8_t        c[32];
+    host_gold(msg.N_id, M * v, 32, c);
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < 32; ++i) {
+      uint8_t    s_i        = c[j];
+      const bool is_ssb_idx = (i == G[11] || i == G[12] || i == G[13]) && msg.L_max == 64;
+      if (is_ssb_idx || i == G[10] || i == G[8] || i == G[7])
+        s_i = 0;
+      else
+        ++j;
+      ap[(size_t)m * 32 + i] = a[i] ^ s_i;
+    }
+  }
+  miphy_polar_code  code = {56, 864, 9, 0};
+  const polar_plan* p    = nullptr;
+  int               rc   = get_plan(ctx, &code, &p);
+  if (rc)
+    return rc;
+  hipStream_t s  = (hipStream_t)stream;
+  void*       ws = nullptr;
+  if ((rc = miphy_get_workspace(ctx, ap.size(), s, &ws)))
+    return rc;
+  MIPHY_HIP_CHECK(hipMemcpyAsync(ws, ap.data(), ap.size(), hipMemcpyHostToDevice, s));
+  MIPHY_HIP_CHECK(hipStreamSynchronize(s)); // `ap` is a local buffer
+  hipLaunchKernelGGL(pdcch_encode_kernel, dim3(n), dim3(64), 0, s, *p, 32u, (const uint8_t*)ws, (const uint16_t*)nullptr, out, 0);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

@@ -50,6 +50,7 @@ def lib():
         l.miphy_pusch_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
         l.miphy_pdsch_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_sch_segmentation_info.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+        l.miphy_pbch_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         l.miphy_crc_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
@@ -132,6 +133,12 @@ def sch_segmentation(tb_bytes, bg):
     s = SchSegmentation()
     check(lib().miphy_sch_segmentation_info(tb_bytes, bg, C.byref(s)))
     return s
+
+
+# Mirrors miphy_pbch_msg.
+PbchMsg = np.dtype([("N_id", np.uint32), ("ssb_idx", np.uint32), ("L_max", np.uint32), ("hrf", np.uint32), ("sfn", np.uint32),
+                    ("k_ssb", np.uint32), ("payload", np.uint8, 32)], align=True)
+assert PbchMsg.itemsize == 56
 
 
 # Mirrors miphy_crc_desc.
@@ -270,3 +277,8 @@ class Context:
         tbs = np.ascontiguousarray(tbs)
         check(lib().miphy_pdsch_encode_batch(self.h, C.c_void_p(tbs.ctypes.data), tbs.size, _dptr(tb_in), _dptr(codeword_out),
                                              _stream_ptr(stream)))
+
+    def pbch_encode_batch(self, msgs, out, stream=None):
+        assert isinstance(msgs, np.ndarray) and msgs.dtype == PbchMsg
+        msgs = np.ascontiguousarray(msgs)
+        check(lib().miphy_pbch_encode_batch(self.h, C.c_void_p(msgs.ctypes.data), msgs.size, _dptr(out), _stream_ptr(stream)))

@@ -237,6 +237,14 @@ def o_pdcch_encode(payload, rnti, E):
     return out
 
 
+def o_pbch_encode(N_id, ssb_idx, L_max, hrf, sfn, k_ssb, payload):
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    out = np.zeros(864, np.uint8)
+    rc = oracle().orc_pbch_encode(C.c_uint(N_id), C.c_uint(ssb_idx), C.c_uint(L_max), int(hrf), C.c_uint(sfn), C.c_uint(k_ssb), _p(payload), _p(out))
+    assert rc == 0
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- reference wrappers
 IMPL = {"generic": 0, "avx2": 1, "avx512": 2, "auto": 3}
 
@@ -385,4 +393,11 @@ def r_pdcch_encode(payload, rnti, E):
     payload = np.ascontiguousarray(payload, dtype=np.uint8)
     out = np.zeros(E, np.uint8)
     ref().ref_pdcch_encode(_p(payload), C.c_uint(payload.size), C.c_uint(rnti), C.c_uint(E), _p(out))
+    return out
+
+
+def r_pbch_encode(N_id, ssb_idx, L_max, hrf, sfn, k_ssb, payload):
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    out = np.zeros(864, np.uint8)
+    ref().ref_pbch_encode(C.c_uint(N_id), C.c_uint(ssb_idx), C.c_uint(L_max), int(hrf), C.c_uint(sfn), C.c_uint(k_ssb), _p(payload), _p(out))
     return out

@@ -95,7 +95,7 @@ def test_host_segmentation_matches_oracle():
     import miphy
     import oracle_lib as O
     for bg, tbs_bits in ((2, 24), (2, 320), (2, 3848), (1, 3824), (1, 3848), (1, 8424), (1, 8448), (1, 42016), (1, 83976), (1, 319784),
-                         (2, 9984), (1, 1277992 - 24), (2, 3840 - 16), (2, 3840)):
+                         (2, 9984), (1, 52 * 8424 - 24), (2, 3840 - 16), (2, 3840)):
         s = miphy.sch_segmentation(tbs_bits // 8, bg)
         o = O.o_segmentation(tbs_bits // 8 * 8, bg, 2, 1, 2 * 52 * 156)
         for k in ("nof_cbs", "Z", "K", "N", "nof_filler_bits", "nof_tb_crc_bits", "nof_cb_crc_bits", "cb_info_bits", "zero_pad"):

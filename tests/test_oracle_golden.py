@@ -116,6 +116,13 @@ def test_polar_and_pdcch():
         assert np.array_equal(O.o_pdcch_encode(d["pdcch_pay_%d" % i], rnti, E), d["pdcch_out_%d" % i])
 
 
+def test_pbch():
+    d = load("polar")
+    for i in range(count(d, "pbch_pay_")):
+        a = [int(x) for x in d["pbch_meta_%d" % i]]
+        assert np.array_equal(O.o_pbch_encode(*a, d["pbch_pay_%d" % i]), d["pbch_out_%d" % i])
+
+
 def test_llr_algebra_kats():
     """Known answers of tests/unittests/phy/upper/log_likelihood_ratio_test.cpp:37-86 as they surface through the oracle's
     rate-dematcher combine (clamp to +-120) and the polar repetition combine (promotion to +-127)."""

@@ -158,3 +158,12 @@ def test_polar_chains_and_pdcch():
     for A, AL in ((12, 1), (40, 2), (70, 8), (128, 16)):
         pay = rng.integers(0, 2, A, dtype=np.uint8)
         assert np.array_equal(O.o_pdcch_encode(pay, 0x1234, 108 * AL), O.r_pdcch_encode(pay, 0x1234, 108 * AL))
+
+
+def test_pbch_encoder():
+    rng = np.random.default_rng(8)
+    for i in range(60):
+        L_max = [4, 8, 64][i % 3]
+        a = (int(rng.integers(0, 1008)), int(rng.integers(0, L_max)), L_max, int(rng.integers(0, 2)), int(rng.integers(0, 1024)),
+             int(rng.integers(0, 12 if L_max == 64 else 24)), rng.integers(0, 2, 32, dtype=np.uint8))
+        assert np.array_equal(O.o_pbch_encode(*a), O.r_pbch_encode(*a)), a[:6]

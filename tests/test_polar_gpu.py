@@ -3,7 +3,7 @@ encoder vs the CPU oracle -- bit-exact, including every intermediate tap."""
 import numpy as np
 import pytest
 
-from oracle_lib import o_pdcch_encode, o_polar_decode_chain, o_polar_encode_chain
+from oracle_lib import o_pbch_encode, o_pdcch_encode, o_polar_decode_chain, o_polar_encode_chain
 
 pytestmark = pytest.mark.gpu
 
@@ -94,3 +94,23 @@ def test_polar_invalid_code(ctx):
         miphy.PolarCode(30, 100, 9, 0).info()  # downlink needs 36 <= K <= 164 (polar_code_impl.cpp:335-341)
     with pytest.raises(RuntimeError):
         miphy.PolarCode(50, 40, 10, 0).info()  # E must exceed K
+
+
+def test_pbch_encoder_batch(ctx):
+    import torch
+    import miphy
+    rng = np.random.default_rng(43)
+    n = 64
+    msgs = np.zeros(n, dtype=miphy.PbchMsg)
+    for i in range(n):
+        L_max = [4, 8, 64][i % 3]
+        msgs[i] = (int(rng.integers(0, 1008)), int(rng.integers(0, L_max)), L_max, int(rng.integers(0, 2)), int(rng.integers(0, 1024)),
+                   int(rng.integers(0, 12 if L_max == 64 else 24)), rng.integers(0, 2, 32, dtype=np.uint8))
+    out_d = torch.zeros(n * 864, dtype=torch.uint8, device="cuda")
+    ctx.pbch_encode_batch(msgs, out_d)
+    torch.cuda.synchronize()
+    out = out_d.cpu().numpy().reshape(n, 864)
+    for i in range(n):
+        m = msgs[i]
+        exp = o_pbch_encode(int(m["N_id"]), int(m["ssb_idx"]), int(m["L_max"]), int(m["hrf"]), int(m["sfn"]), int(m["k_ssb"]), m["payload"])
+        assert np.array_equal(out[i], exp), i
