@@ -384,6 +384,22 @@ typedef struct {
 
 int miphy_pbch_encode_batch(miphy_ctx* ctx, const miphy_pbch_msg* msgs /* host */, uint32_t n, uint8_t* out /* device */, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Polar successive-cancellation LIST decoder (list size 1, 2, 4 or 8), optionally CRC-aided  --  no counterpart in the
+ * reference (its polar_decoder is the list-size-1 SSC decoder that miphy_polar_decode_batch reproduces bit for bit); this
+ * is the SCL-8 path BASELINE.json's north_star / configs[3] ask for. Same rate-dematcher and LLR algebra as the reference;
+ * path metric PM += |llr| whenever a decision disagrees with the hard decision; candidates ranked by (metric, 2*slot+flip).
+ *   crc_mode 0: msg_out = K bits of the best-metric path in K-set order (the format of miphy_polar_decode_batch);
+ *   crc_mode 1: PDCCH -- every surviving path is CRC de-interleaved (TS 38.212 5.3.1.1) and checked with CRC24C over 24
+ *               leading ones + payload and the RNTI mask (pdcch_encoder_impl.cpp:33-59 inverted); the best-metric path that
+ *               passes wins; msg_out = the K de-interleaved bits (payload then masked CRC), crc_ok_out = 1 on a pass;
+ *   crc_mode 2: PBCH -- the same without leading ones / RNTI.
+ * rnti may be NULL unless crc_mode == 1. Bit-exact against oracle/phy_oracle.c::orc_polar_scl_decode. */
+int miphy_polar_decode_list_batch(miphy_ctx* ctx, const miphy_polar_code* code, uint32_t list_size, uint32_t crc_mode, uint32_t n,
+                                  const int8_t* llr /* device, n x E */, const uint16_t* rnti /* device, n */,
+                                  uint8_t* msg_out /* device, n x K */, uint8_t* crc_ok_out /* device, n */,
+                                  int32_t* metric_out /* device, n; may be NULL */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,6 +122,15 @@ int orc_polar_decode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, cons
 void orc_polar_interleave(const uint8_t* in, uint8_t* out, unsigned K, int rx);
 /* PDCCH: payload A bits (1 bit/byte) + rnti -> E rate-matched bits. */
 int orc_pdcch_encode(const uint8_t* payload, unsigned A, unsigned rnti, unsigned E, uint8_t* out);
+/* Successive-cancellation LIST decoder (list size L in {1,2,4,8}) -- NO reference counterpart (the reference only has the
+ * list-size-1 SSC decoder above); this restates the algorithm of the HIP kernel so that the kernel can be checked bit for
+ * bit: LLR-domain path metrics (PM += |llr| when the decision disagrees with the hard decision), min-sum f, saturating g with
+ * the reference's LLR algebra, candidates ranked by (metric, 2*slot + flip), survivors renumbered by rank.
+ * crc_mode 0: best metric path, msg = K bits in K-set order. crc_mode 1 (PDCCH): candidates are de-interleaved (Pi_IL) and
+ * checked with CRC24C over 24 leading ones + payload with the RNTI mask; crc_mode 2 (PBCH): CRC24C without ones / mask.
+ * In modes 1/2 msg = the K de-interleaved bits of the selected path. Returns the chosen path's metric; *crc_ok. */
+int orc_polar_scl_decode(unsigned K, unsigned E, unsigned nMax, int ibil, unsigned L, int crc_mode, unsigned rnti, const int8_t* llr,
+                         uint8_t* msg, int* crc_ok);
 /* PBCH (pbch_encoder_impl.cpp:41-190): payload 32 bytes (first 24 used) -> 864 rate-matched bits. */
 int orc_pbch_encode(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, unsigned sfn, unsigned k_ssb, const uint8_t* payload, uint8_t* out);
 

@@ -29,6 +29,7 @@ struct polar_plan {
 
 struct miphy_ctx_ext {
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, polar_plan> polar_plans;
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, uint8_t*>   polar_kset; // per-position K-set flags (SCL)
   std::map<uint32_t, float*>                                    twiddles; // N -> device exp(-2 pi i j / N), j < N
   std::map<std::pair<uint32_t, uint32_t>, float*>               ramps;    // (N, offset) -> device window ramp
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, float, double, int>, ofdm_plan_dev*> plans;

@@ -504,6 +504,255 @@ extern "C" int miphy_pdcch_encode_batch(miphy_ctx*      ctx,
   return MIPHY_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------- SCL list decoder
+namespace {
+
+// One wavefront per codeword. LDS: channel LLRs [N] + two banks (current / scratch) of L paths x {llr[N], bl[N], u[N]}.
+//   llr: stage s node LLRs at offset 2^s (s < n), bl: left-child partial sums of stage s at offset 2^s, u: decisions.
+// All L paths advance together: a stage of size 2^s over `active` paths is one flat loop over active * 2^s lanes' worth of
+// elements; forking ranks the 2 * active candidates with wavefront shuffles and copies the survivors bank to bank.
+__global__ void __launch_bounds__(64) polar_scl_kernel(polar_plan p, int L, int crc_mode, const int8_t* __restrict__ llr_in,
+                                                       const uint16_t* __restrict__ rnti, const uint8_t* __restrict__ k_set,
+                                                       uint8_t* __restrict__ msg_out, uint8_t* __restrict__ crc_ok_out,
+                                                       int32_t* __restrict__ metric_out)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int    lane = threadIdx.x;
+  const size_t cw   = blockIdx.x;
+  const int    N = (int)p.N, n = (int)p.n, E = (int)p.E, K = (int)p.K;
+  int8_t*      ch     = reinterpret_cast<int8_t*>(smem);
+  const int    PSZ    = 3 * N; // bytes per path
+  uint8_t*     bankA  = smem + N;
+  uint8_t*     bankB  = bankA + (size_t)L * PSZ;
+  int*         pm     = reinterpret_cast<int*>(bankB + (size_t)L * PSZ); // [L]
+  int*         sel    = pm + 8;                                           // parent[8], bit[8], pm[8]
+  const int8_t* f_in  = llr_in + cw * p.E;
+  // Rate dematching (same gather as polar_decode_kernel).
+  for (int q = lane; q < N; q += 64) {
+    const int first = p.d_rx_first[q];
+    int       v;
+    if (first == -1) {
+      v = 0;
+    } else if (first == -2) {
+      v = 127;
+    } else {
+      v = f_in[p.d_rx_fidx[first]];
+      for (int k = first + N; k < E; k += N)
+        v = llr_promotion_sum(v, f_in[p.d_rx_fidx[k]]);
+    }
+    ch[q] = (int8_t)v;
+  }
+  if (lane < 8)
+    pm[lane] = 0;
+  __syncthreads();
+  uint8_t* P = bankA;
+  uint8_t* Q = bankB;
+  int      active = 1;
+  for (int i = 0; i < N; ++i) {
+    // ---- leaf LLRs
+    int t = n;
+    if (i != 0) {
+      t = __ffs(i) - 1;
+      const int sz = 1 << t;
+      for (int idx = lane; idx < active * sz; idx += 64) {
+        const int     q = idx >> t, j = idx & (sz - 1);
+        uint8_t*      a  = P + q * PSZ;
+        const int8_t* up = (t + 1 == n) ? ch : reinterpret_cast<int8_t*>(a) + 2 * sz;
+        const int     x = up[j], y = up[j + sz];
+        reinterpret_cast<int8_t*>(a)[sz + j] = (int8_t)(a[N + sz + j] ? llr_add(y, -x) : llr_add(y, x));
+      }
+      __syncthreads();
+    }
+    for (int s = t - 1; s >= 0; --s) {
+      const int sz = 1 << s;
+      for (int idx = lane; idx < active * sz; idx += 64) {
+        const int     q = idx >> s, j = idx & (sz - 1);
+        int8_t*       a  = reinterpret_cast<int8_t*>(P + q * PSZ);
+        const int8_t* up = (s + 1 == n) ? ch : a + 2 * sz;
+        a[sz + j]        = (int8_t)llr_soft_xor(up[j], up[j + sz]);
+      }
+      __syncthreads();
+    }
+    // ---- decision
+    if (!k_set[i]) {
+      if (lane < active) {
+        const int l0 = reinterpret_cast<int8_t*>(P + lane * PSZ)[1];
+        P[lane * PSZ + 2 * N + i] = 0;
+        if (l0 < 0)
+          pm[lane] -= l0;
+      }
+      __syncthreads();
+    } else {
+      const int nc = 2 * active, keep = min(nc, L);
+      int       met = 0x7fffffff, bit = 0;
+      if (lane < nc) {
+        const int q = lane >> 1, l0 = reinterpret_cast<int8_t*>(P + q * PSZ)[1];
+        const int hard = l0 <= 0, al = abs(l0);
+        met = pm[q] + ((lane & 1) ? al : 0);
+        bit = (lane & 1) ? !hard : hard;
+      }
+      int rank = 0;
+      for (int o = 0; o < nc; ++o) {
+        const int mo = __shfl(met, o);
+        rank += (mo < met) || (mo == met && o < lane);
+      }
+      __syncthreads(); // pm[] has been read by everyone
+      if (lane < nc && rank < keep) {
+        sel[rank]      = lane >> 1;
+        sel[8 + rank]  = bit;
+        pm[rank]       = met;
+      }
+      __syncthreads();
+      // survivors: bank P (parent) -> bank Q (slot), 16 bytes per lane per step
+      const int vec_per_path = PSZ >> 4;
+      for (int idx = lane; idx < keep * vec_per_path; idx += 64) {
+        const int r = idx / vec_per_path, v = idx - r * vec_per_path;
+        reinterpret_cast<uint4*>(Q + r * PSZ)[v] = reinterpret_cast<const uint4*>(P + sel[r] * PSZ)[v];
+      }
+      __syncthreads();
+      if (lane < keep)
+        Q[lane * PSZ + 2 * N + i] = (uint8_t)sel[8 + lane];
+      uint8_t* tmp = P;
+      P            = Q;
+      Q            = tmp;
+      active       = keep;
+      __syncthreads();
+    }
+    // ---- partial sums (bank Q's u area serves as the per-path working vector)
+    if (!(i & 1)) {
+      if (lane < active)
+        P[lane * PSZ + N + 1] = P[lane * PSZ + 2 * N + i];
+    } else {
+      if (lane < active)
+        Q[lane * PSZ + 2 * N] = P[lane * PSZ + 2 * N + i];
+      __syncthreads();
+      int sz = 1, s = 0;
+      while (s < n && ((i >> s) & 1)) {
+        for (int idx = lane; idx < active * sz; idx += 64) {
+          const int q = idx >> s, j = idx & (sz - 1);
+          uint8_t*  cur = Q + q * PSZ + 2 * N;
+          const uint8_t c0 = cur[j];
+          cur[sz + j]      = c0;
+          cur[j]           = c0 ^ P[q * PSZ + N + sz + j];
+        }
+        __syncthreads();
+        sz <<= 1;
+        ++s;
+      }
+      if (s < n) {
+        for (int idx = lane; idx < active * sz; idx += 64) {
+          const int q = idx >> s, j = idx & (sz - 1);
+          P[q * PSZ + N + sz + j] = Q[q * PSZ + 2 * N + j];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- selection: extract the K bits of every path (into bank Q), optional de-interleave + CRC, best metric wins
+  int      my_pm = 0x7fffffff, my_ok = 0;
+  uint8_t* cand  = Q + (lane < 8 ? lane : 0) * PSZ;     // K bits at cand[0..K), K-set order at cand[N..N+K)
+  if (lane < active) {
+    const uint8_t* u  = P + lane * PSZ + 2 * N;
+    int            iK = 0;
+    for (int i = 0; i < (int)(p.K + p.nPC); ++i)
+      if (!p.d_is_pc[i])
+        cand[N + iK++] = u[p.d_info_pos[i]];
+    my_pm = pm[lane];
+    if (crc_mode == 0) {
+      for (int k = 0; k < K; ++k)
+        cand[k] = cand[N + k];
+    } else {
+      for (int k = 0; k < K; ++k) // polar_interleaver, rx direction: out[pi(k)] = in[k]
+        cand[p.d_pi_il[k]] = cand[N + k];
+      const int A    = K - 24;
+      uint32_t  reg  = 0;
+      const int ones = (crc_mode == 1) ? 24 : 0;
+      for (int b = 0; b < ones + A; ++b) {
+        const uint32_t bitv = (b < ones) ? 1u : cand[b - ones];
+        reg                 = (reg << 1) ^ (bitv << 24);
+        reg ^= (reg & 0x1000000u) ? 0x1B2B117u : 0u;
+      }
+      uint32_t rx = 0;
+      for (int b = 0; b < 24; ++b)
+        rx = (rx << 1) | cand[A + b];
+      if (crc_mode == 1)
+        rx ^= (uint32_t)rnti[cw];
+      my_ok = (reg & 0xffffffu) == rx;
+    }
+  }
+  // winner: smallest metric among CRC passes (if any), else smallest metric; ties -> lowest slot
+  const unsigned long long okmask = __ballot(my_ok != 0);
+  const bool               any_ok = okmask != 0ull;
+  int                      key    = (lane < active && (!any_ok || my_ok)) ? my_pm : 0x7fffffff;
+  int                      best   = key, best_lane = lane;
+#pragma unroll
+  for (int off = 4; off >= 1; off >>= 1) {
+    const int ok = __shfl_xor(best, off), ol = __shfl_xor(best_lane, off);
+    if (ok < best || (ok == best && ol < best_lane)) {
+      best      = ok;
+      best_lane = ol;
+    }
+  }
+  best_lane = __shfl(best_lane, 0);
+  best      = __shfl(best, 0);
+  __syncthreads();
+  const uint8_t* win = Q + best_lane * PSZ;
+  for (int k = lane; k < K; k += 64)
+    msg_out[cw * p.K + k] = win[k];
+  if (lane == 0) {
+    crc_ok_out[cw] = any_ok ? 1 : 0;
+    if (metric_out)
+      metric_out[cw] = best;
+  }
+}
+
+} // namespace
+
+extern "C" int miphy_polar_decode_list_batch(miphy_ctx*              ctx,
+                                             const miphy_polar_code* code,
+                                             uint32_t                list_size,
+                                             uint32_t                crc_mode,
+                                             uint32_t                n,
+                                             const int8_t*           llr,
+                                             const uint16_t*         rnti,
+                                             uint8_t*                msg_out,
+                                             uint8_t*                crc_ok_out,
+                                             int32_t*                metric_out,
+                                             void*                   stream)
+{
+  MIPHY_REQUIRE(ctx && code && llr && msg_out && crc_ok_out, "miphy_polar_decode_list_batch: null argument");
+  MIPHY_REQUIRE(list_size == 1 || list_size == 2 || list_size == 4 || list_size == 8, "polar_decode_list: list size %u not in {1,2,4,8}", list_size);
+  MIPHY_REQUIRE(crc_mode <= 2, "polar_decode_list: invalid crc_mode %u", crc_mode);
+  MIPHY_REQUIRE(crc_mode != 1 || rnti, "polar_decode_list: PDCCH CRC mode needs the RNTI array");
+  MIPHY_REQUIRE(crc_mode == 0 || (code->K > 24 && code->K <= 164), "polar_decode_list: CRC-aided modes need 24 < K <= 164");
+  const polar_plan* p  = nullptr;
+  int               rc = get_plan(ctx, code, &p);
+  if (rc || n == 0)
+    return rc;
+  // K-set membership per position (frozen / information), uploaded once per plan.
+  auto key = std::make_tuple(code->K, code->E, code->nMax, code->ibil ? 1u : 0u);
+  auto it  = ctx->ext->polar_kset.find(key);
+  if (it == ctx->ext->polar_kset.end()) {
+    host_code h;
+    if ((rc = build_code(code, h)))
+      return rc;
+    uint8_t* d = nullptr;
+    if ((rc = upload(ctx, h.k_set, &d)))
+      return rc;
+    it = ctx->ext->polar_kset.emplace(key, d).first;
+  }
+  const size_t lds = (size_t)p->N + 2 * (size_t)list_size * 3 * p->N + 8 * 4 + 24 * 4 + 64;
+  static thread_local size_t lds_set = 0;
+  if (lds > lds_set) {
+    MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
+  hipLaunchKernelGGL(polar_scl_kernel, dim3(n), dim3(64), lds, (hipStream_t)stream, *p, (int)list_size, (int)crc_mode, llr, rnti, it->second, msg_out,
+                     crc_ok_out, metric_out);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
 namespace {
 // TS 38.211 5.2.1 Gold sequence bit c(n) on the host (PBCH scrambling needs at most a few hundred bits).
 void host_gold(uint32_t c_init, uint32_t offset, uint32_t nbits, uint8_t* out)

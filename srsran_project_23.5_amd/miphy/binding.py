@@ -50,6 +50,8 @@ def lib():
         l.miphy_pusch_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
         l.miphy_pdsch_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_sch_segmentation_info.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+        l.miphy_polar_decode_list_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_pbch_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         l.miphy_crc_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = l
@@ -282,3 +284,8 @@ class Context:
         assert isinstance(msgs, np.ndarray) and msgs.dtype == PbchMsg
         msgs = np.ascontiguousarray(msgs)
         check(lib().miphy_pbch_encode_batch(self.h, C.c_void_p(msgs.ctypes.data), msgs.size, _dptr(out), _stream_ptr(stream)))
+
+    def polar_decode_list_batch(self, code, list_size, crc_mode, n, llr, rnti, msg_out, crc_ok_out, metric_out=None, stream=None):
+        check(lib().miphy_polar_decode_list_batch(self.h, C.byref(code), list_size, crc_mode, n, _dptr(llr),
+                                                  _dptr(rnti) if rnti is not None else None, _dptr(msg_out), _dptr(crc_ok_out),
+                                                  _dptr(metric_out) if metric_out is not None else None, _stream_ptr(stream)))

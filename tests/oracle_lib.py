@@ -229,6 +229,16 @@ def o_polar_decode_chain(K, E, nMax, ibil, llr):
     return msg, dem[:N], u[:N]
 
 
+def o_polar_scl_decode(K, E, nMax, ibil, L, crc_mode, rnti, llr):
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    msg = np.zeros(K, np.uint8)
+    ok = C.c_int(0)
+    pm = oracle().orc_polar_scl_decode(C.c_uint(K), C.c_uint(E), C.c_uint(nMax), int(ibil), C.c_uint(L), int(crc_mode), C.c_uint(rnti),
+                                       _p(llr), _p(msg), C.byref(ok))
+    assert pm >= 0, pm
+    return msg, bool(ok.value), pm
+
+
 def o_pdcch_encode(payload, rnti, E):
     payload = np.ascontiguousarray(payload, dtype=np.uint8)
     out = np.zeros(E, np.uint8)

@@ -3,7 +3,7 @@ encoder vs the CPU oracle -- bit-exact, including every intermediate tap."""
 import numpy as np
 import pytest
 
-from oracle_lib import o_pbch_encode, o_pdcch_encode, o_polar_decode_chain, o_polar_encode_chain
+from oracle_lib import (o_pbch_encode, o_pdcch_encode, o_polar_decode_chain, o_polar_encode_chain, o_polar_scl_decode)
 
 pytestmark = pytest.mark.gpu
 
@@ -114,3 +114,76 @@ def test_pbch_encoder_batch(ctx):
         m = msgs[i]
         exp = o_pbch_encode(int(m["N_id"]), int(m["ssb_idx"]), int(m["L_max"]), int(m["hrf"]), int(m["sfn"]), int(m["k_ssb"]), m["payload"])
         assert np.array_equal(out[i], exp), i
+
+
+@pytest.mark.parametrize("A,AL,sigma", [(12, 1, 1.1), (40, 1, 0.9), (40, 2, 1.25), (70, 4, 1.6), (128, 8, 1.5), (57, 16, 2.6)])
+def test_scl_list_decoder_pdcch(ctx, A, AL, sigma):
+    """SCL (L = 1, 2, 4, 8; plain and CRC-aided) against the oracle's restatement, bit for bit incl. metric and CRC verdict
+    (BASELINE configs[3]: PDCCH aggregation levels 1-16). There is no reference counterpart for L > 1; properties checked on
+    top: CA-SCL-8 never returns a wrong payload with crc_ok, and it decodes about as many blocks as the reference-style SSC or more."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(A * 100 + AL)
+    K, E = A + 24, 108 * AL
+    code = miphy.PolarCode(K, E, 9, 0)
+    nb = 48
+    pays = rng.integers(0, 2, (nb, A), dtype=np.uint8)
+    rntis = rng.integers(0, 65536, nb).astype(np.uint16)
+    llrs = np.zeros((nb, E), np.int8)
+    for i in range(nb):
+        tx = o_pdcch_encode(pays[i], int(rntis[i]), E)
+        y = (1.0 - 2.0 * tx) + sigma * rng.standard_normal(E)
+        llrs[i] = np.round(np.clip(4 * y, -20, 20) / 20 * 120)
+    l_d = torch.from_numpy(llrs.reshape(-1)).cuda()
+    r_d = torch.from_numpy(rntis.view(np.int16)).cuda()
+    n_ca8 = n_ssc = 0
+    for L in (1, 2, 4, 8):
+        for mode in (0, 1):
+            msg_d = torch.zeros(nb * K, dtype=torch.uint8, device="cuda")
+            ok_d = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+            pm_d = torch.zeros(nb, dtype=torch.int32, device="cuda")
+            ctx.polar_decode_list_batch(code, L, mode, nb, l_d, r_d if mode == 1 else None, msg_d, ok_d, pm_d)
+            torch.cuda.synchronize()
+            msg, ok, pm = msg_d.cpu().numpy().reshape(nb, K), ok_d.cpu().numpy(), pm_d.cpu().numpy()
+            for i in range(nb):
+                em, eok, epm = o_polar_scl_decode(K, E, 9, 0, L, mode, int(rntis[i]), llrs[i])
+                assert np.array_equal(msg[i], em) and bool(ok[i]) == eok and int(pm[i]) == epm, (L, mode, i)
+                if mode == 1 and L == 8:
+                    if ok[i]:
+                        assert np.array_equal(msg[i][:A], pays[i]), "CRC-passing candidate with a wrong payload"
+                        n_ca8 += 1
+    for i in range(nb):
+        m, _, _ = o_polar_decode_chain(K, E, 9, 0, llrs[i])
+        import ctypes as C
+        from oracle_lib import oracle
+        c = np.zeros(K, np.uint8)
+        oracle().orc_polar_interleave(m.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), C.c_uint(K), 1)
+        n_ssc += int(np.array_equal(c[:A], pays[i]))
+    # statistical, not a theorem (int8 saturation / +-inf LLRs after repetition can favour the SSC rate-1 shortcut): allow 10 %
+    assert n_ca8 >= n_ssc - max(2, nb // 10), (n_ca8, n_ssc)
+
+
+def test_scl_pbch_and_uplink_codes(ctx):
+    """crc_mode 2 (PBCH, K = 56, E = 864) and plain list decoding of uplink codes with parity-check bits / all rate-matching modes."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(44)
+    for (K, E, nMax, ibil, mode) in ((56, 864, 9, 0, 2), (20, 100, 10, 1, 0), (25, 300, 10, 0, 0), (100, 200, 10, 1, 0), (500, 1500, 10, 0, 0),
+                                     (300, 400, 10, 1, 0)):
+        code = miphy.PolarCode(K, E, nMax, ibil)
+        nb = 8
+        llrs = np.zeros((nb, E), np.int8)
+        for i in range(nb):
+            msg = rng.integers(0, 2, K, dtype=np.uint8)
+            tx = o_polar_encode_chain(K, E, nMax, ibil, msg)[0]
+            y = (1.0 - 2.0 * tx) + 0.9 * rng.standard_normal(E)
+            llrs[i] = np.round(np.clip(4 * y, -20, 20) / 20 * 120)
+        msg_d = torch.zeros(nb * K, dtype=torch.uint8, device="cuda")
+        ok_d = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        pm_d = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        ctx.polar_decode_list_batch(code, 8, mode, nb, torch.from_numpy(llrs.reshape(-1)).cuda(), None, msg_d, ok_d, pm_d)
+        torch.cuda.synchronize()
+        msg, ok, pm = msg_d.cpu().numpy().reshape(nb, K), ok_d.cpu().numpy(), pm_d.cpu().numpy()
+        for i in range(nb):
+            em, eok, epm = o_polar_scl_decode(K, E, nMax, ibil, 8, mode, 0, llrs[i])
+            assert np.array_equal(msg[i], em) and bool(ok[i]) == eok and int(pm[i]) == epm, (K, E, i)
