@@ -312,6 +312,26 @@ static void test_ofdm_and_estimator(std::shared_ptr<miphy::context> c)
   printf("ofdm (de)modulator + dmrs_pusch_estimator done, failures so far %d\n", failures);
 }
 
+static void test_dft(std::shared_ptr<miphy::context> c)
+{
+  generic_dft_factory              ref_f;
+  miphy::dft_processor_factory_hip hip_f(c);
+  std::uniform_real_distribution<float> u(-1.F, 1.F);
+  for (unsigned N : {128U, 384U, 1536U, 4096U, 6144U, 49152U}) {
+    for (auto dir : {dft_processor::direction::DIRECT, dft_processor::direction::INVERSE}) {
+      dft_processor::configuration cfg;
+      cfg.size = N, cfg.dir = dir;
+      auto d1 = ref_f.create(cfg), d2 = hip_f.create(cfg);
+      for (unsigned i = 0; i != N; ++i) {
+        d1->get_input()[i] = d2->get_input()[i] = cf_t(u(rgen), u(rgen));
+      }
+      float e = rel_err(d2->run(), d1->run());
+      CHECK(e < 6e-6F, "dft size %u rel err %g", N, e);
+    }
+  }
+  printf("dft_processor done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -343,6 +363,7 @@ int main()
   test_rate_matching(c);
   test_sch(c);
   test_ofdm_and_estimator(c);
+  test_dft(c);
   test_pdcch(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);

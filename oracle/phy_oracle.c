@@ -1406,7 +1406,7 @@ int orc_pbch_encode(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, un
   return orc_polar_encode_chain(56, 864, 9, 0, kp, out, 0, 0) > 0 ? 0 : -1;
 }
 
-/* ------------------------------------------------------------------------------------------------ SCL (no reference
+/* ------------------------------------------------------------------------------------------------ SCL -- PARITY UNPINNED (no reference
  * counterpart; restatement of srsran_project_23.5_amd/csrc/polar_scl.hip for bit-exact checking) */
 typedef struct {
   int8_t  llr[1024];  /* stage s at offset 2^s, size 2^s (s < n) */

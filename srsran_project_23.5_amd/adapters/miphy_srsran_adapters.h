@@ -14,6 +14,7 @@
 #define __HIP_PLATFORM_AMD__ 1
 #endif
 #include "miphy.h"
+#include "srsran/phy/generic_functions/generic_functions_factories.h"
 #include "srsran/phy/lower/modulation/modulation_factories.h"
 #include "srsran/phy/support/resource_grid.h"
 #include "srsran/phy/upper/channel_coding/channel_coding_factories.h"
@@ -340,6 +341,47 @@ public:
         stats.ldpc_decoder_stats.update(r.iters_max);
       }
     }
+  }
+
+private:
+  std::shared_ptr<context> c;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- DFT
+/// srsran::dft_processor over miphy_dft_batch (include/srsran/phy/generic_functions/dft_processor.h:34-73). Like the
+/// reference implementations it owns its input and output buffers and hands out views.
+class dft_processor_hip : public srsran::dft_processor
+{
+public:
+  dft_processor_hip(std::shared_ptr<context> c, const configuration& cfg) : c(std::move(c)), dir(cfg.dir), in(cfg.size), out(cfg.size) {}
+  direction                        get_direction() const override { return dir; }
+  unsigned                         get_size() const override { return in.size(); }
+  srsran::span<srsran::cf_t>       get_input() override { return in; }
+  srsran::span<const srsran::cf_t> run() override
+  {
+    const size_t bytes = in.size() * sizeof(srsran::cf_t);
+    auto*        d_in  = static_cast<float*>(c->buf(0, bytes));
+    auto*        d_out = static_cast<float*>(c->buf(1, bytes));
+    c->h2d(d_in, in.data(), bytes);
+    context::check(miphy_dft_batch(c->ctx, in.size(), dir == direction::INVERSE, 1, d_in, d_out, c->stream), "dft");
+    c->d2h(out.data(), d_out, bytes);
+    c->sync();
+    return out;
+  }
+
+private:
+  std::shared_ptr<context>  c;
+  direction                 dir;
+  std::vector<srsran::cf_t> in, out;
+};
+
+class dft_processor_factory_hip : public srsran::dft_processor_factory
+{
+public:
+  explicit dft_processor_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  std::unique_ptr<srsran::dft_processor> create(const srsran::dft_processor::configuration& cfg) override
+  {
+    return std::make_unique<dft_processor_hip>(c, cfg);
   }
 
 private:
