@@ -1,13 +1,11 @@
-// LDPC decoder, packed variant: every lane owns TWO lifted check rows (l and l + ceil(Z/2)) and processes them with the
-// packed 16-bit VALU instructions of CDNA (v_pk_add/sub/min/max/ashr/lshl_i16), halving both the instruction count per
-// codeblock and the number of wavefronts a codeblock occupies. Same arithmetic contract as ldpc_decode.hip (reference:
+// LDPC decoder, packed variant: every lane owns TWO lifted check rows (l and l + Z/2) and processes them with the packed
+// 16-bit VALU instructions of CDNA (v_pk_add/sub/min/max/mad), halving both the instruction count per codeblock and the
+// number of wavefronts a codeblock occupies. Same arithmetic contract as ldpc_decode.hip (reference:
 // ldpc_decoder_impl.cpp:60-146 + ldpc_decoder_avx2.cpp:66-243, avx2_support.h:65-106); results are bit-identical.
 //
-// Per (layer, lane) state, all fields duplicated for the two rows in the low / high half-word:
-//   Wm  : [7:0] scaled min1, [15:8] scaled min2  |  same for row B in [31:16]
-//   Wi0 : bit j (and 16 + j) = edge j is the argmin edge, j < 16 ; Wi1: edges 16.. (degree 19 rows only)
-//   Ws0 : bit j (and 16 + j) = sign of the outgoing c2v message of edge j ; Ws1: edges 16..
-// A mask for edge j is obtained for both rows at once with two packed shifts (lshl by 15-j, ashr by 15).
+// Check-to-variable messages are kept EXPLICITLY in LDS, one int8 per (edge, row): for wave w the block of edge e is
+// 128 bytes = [64 x row-A byte][64 x row-B byte], so a lane's accesses are byte loads / stores with an immediate offset
+// (no VALU work to rebuild a message from compressed min/argmin/sign state, which dominated the earlier formulation).
 #include "miphy_internal.h"
 
 namespace {
@@ -38,52 +36,28 @@ __device__ __forceinline__ s16x2 pk_ashr15(s16x2 a)
 {
   return a >> splat(15);
 }
-// Both half-words: bit `bit` -> all-ones / all-zeros mask.
-// Hides how a lane mask was produced: otherwise LLVM rewrites "mask & x" into per-half compare + select, which has no
-// packed form and costs 4-5 instructions instead of one.
-__device__ __forceinline__ uint32_t opaque(uint32_t m)
+// two sign-extended bytes -> one register with two int16 (bytes 1:0 of each source)
+__device__ __forceinline__ s16x2 pk_pair(int lo, int hi)
 {
-  asm("" : "+v"(m));
-  return m;
-}
-__device__ __forceinline__ uint32_t pk_bit_mask(uint32_t w, int bit)
-{
-  return opaque(as_u(pk_ashr15(as_s2(w) << splat(15 - bit))));
+  return as_s2(__builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u));
 }
 
 constexpr int LLR_MAX = 120;
 constexpr int LLR_INF = 127;
-constexpr int INF_INT = 255;
-
-// 0/1 per half-word from bit `bit` (and 16 + bit) of w.
-__device__ __forceinline__ uint32_t pk_bit01(uint32_t w, int bit)
-{
-  return (w >> bit) & 0x00010001u;
-}
-// a * b + c per half-word (low 16 bits).
-__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)
-{
-  return as_u(as_s2(a) * as_s2(b) + as_s2(c));
-}
+constexpr int INF_MUL = 255; // an infinite soft bit (|s| > 120) becomes a message of magnitude >= 255 + 24
 
 template <int D, bool FIRST>
 __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
-                                               uint32_t&       Wm,
-                                               uint32_t&       Wi0,
-                                               uint32_t&       Wi1,
-                                               uint32_t&       Ws0,
-                                               uint32_t&       Ws1,
+                                               int8_t* __restrict__ c2v, // this lane's row-A byte of edge 0 of the layer
                                                const uint32_t* __restrict__ edges,
                                                int l,
                                                int H,
                                                int Z)
 {
-  uint32_t v2c[D];
+  s16x2    v2c[D];
   uint32_t adrA[D], adrB[D];
   s16x2    mag1 = splat(LLR_MAX), mag2 = splat(LLR_MAX);
   uint32_t spx  = 0;
-  const uint32_t m1p = Wm & 0x00ff00ffu;
-  const uint32_t dm  = as_u(as_s2((Wm >> 8) & 0x00ff00ffu) - as_s2(m1p));
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     const uint32_t e  = edges[j];
@@ -95,28 +69,19 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
     const uint32_t aA = base + pA, aB = base + pB;
     adrA[j]           = aA;
     adrB[j]           = aB;
-    // two sign-extended bytes -> one register with two int16 (bytes 1:0 of each source)
-    const s16x2 s = as_s2(__builtin_amdgcn_perm((uint32_t)(int)soft[aB], (uint32_t)(int)soft[aA], 0x05040100u));
-    s16x2       v;
-    if (FIRST) {
-      v = s;
-    } else {
-      const uint32_t im01 = (j < 16) ? pk_bit01(Wi0, j) : pk_bit01(Wi1, j - 16);
-      const uint32_t mag  = pk_mad(im01, dm, m1p);                 // argmin edge ? min2 : min1
-      const uint32_t s01  = (j < 16) ? pk_bit01(Ws0, j) : pk_bit01(Ws1, j - 16);
-      const uint32_t f    = pk_mad(s01, as_u(splat(-2)), as_u(splat(1))); // +1 / -1
-      const s16x2    c    = as_s2(mag) * as_s2(f);
-      v                   = pk_min(pk_max(s - c, splat(-LLR_MAX)), splat(LLR_MAX));
+    const s16x2 s  = pk_pair(soft[aA], soft[aB]);
+    // |s| > 120: infinite soft bit -> "infinite" message with the same sign: d != 0 only then, and 255 * d dominates.
+    const s16x2 sc = pk_min(pk_max(s, splat(-LLR_MAX)), splat(LLR_MAX));
+    const s16x2 d  = s - sc;
+    s16x2       t  = sc;
+    if (!FIRST) {
+      const s16x2 c = pk_pair(c2v[128 * j], c2v[128 * j + 64]);
+      t             = pk_min(pk_max(sc - c, splat(-LLR_MAX)), splat(LLR_MAX));
     }
-    // |s| > 120: infinite soft bit -> infinite message with the same sign (carried as +-INF_INT, see ldpc_decode.hip).
-    const s16x2    as_   = pk_max(s, -s);
-    const uint32_t infm  = opaque(as_u(pk_ashr15(splat(LLR_MAX) - as_)));
-    const uint32_t vinf  = as_u(pk_ashr15(s)) ^ as_u(splat(INF_INT));
-    const uint32_t vu    = (as_u(v) & ~infm) | (vinf & infm);
-    v2c[j]               = vu;
-    spx ^= vu;
-    const s16x2 vv   = as_s2(vu);
-    const s16x2 av   = pk_max(vv, -vv);
+    const s16x2 v = d * splat(INF_MUL) + t;
+    v2c[j]        = v;
+    spx ^= as_u(v);
+    const s16x2 av   = pk_max(v, -v);
     const s16x2 help = pk_max(mag1, av);
     mag1             = pk_min(mag1, av);
     mag2             = pk_min(mag2, help);
@@ -124,71 +89,57 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
   // Scaling by 0.8 = floor(x * 52428 / 65536), per row (avx2_support.h:65-106).
   const uint32_t s1A = ((uint32_t)(uint16_t)mag1.x * 52428u) >> 16, s1B = ((uint32_t)(uint16_t)mag1.y * 52428u) >> 16;
   const uint32_t s2A = ((uint32_t)(uint16_t)mag2.x * 52428u) >> 16, s2B = ((uint32_t)(uint16_t)mag2.y * 52428u) >> 16;
-  const uint32_t s1p = s1A | (s1B << 16);
-  const uint32_t ds  = as_u(as_s2(s2A | (s2B << 16)) - as_s2(s1p));
+  const s16x2    s2p = as_s2(s2A | (s2B << 16));
+  const s16x2    dsp = as_s2(s1A | (s1B << 16)) - s2p; // min1 - min2 (scaled), <= 0
   const uint32_t spm = spx & 0x80008000u;
-  uint32_t       ni0 = 0, ni1 = 0, ns0 = 0, ns1 = 0;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    const s16x2    v    = as_s2(v2c[j]);
-    const s16x2    av   = pk_max(v, -v);
-    // 1 where |v| == min1 (ties make min1 == min2): (|v| - min1 - 1) is negative only then
-    const uint32_t im01 = (as_u((av - mag1) - splat(1)) >> 15) & 0x00010001u;
-    const uint32_t mag  = pk_mad(im01, ds, s1p);
-    const uint32_t s01  = ((v2c[j] ^ spm) >> 15) & 0x00010001u; // sign of the product of all other messages
-    const uint32_t f    = pk_mad(s01, as_u(splat(-2)), as_u(splat(1)));
-    const s16x2    c    = as_s2(mag) * as_s2(f);
-    if (j < 16) {
-      ni0 |= im01 << j;
-      ns0 |= s01 << j;
-    } else {
-      ni1 |= im01 << (j - 16);
-      ns1 |= s01 << (j - 16);
-    }
+    const s16x2 v  = v2c[j];
+    const s16x2 av = pk_max(v, -v);
+    // x = 0 where |v| == min1 (this edge provided the minimum, or ties it: then min1 == min2), 1 elsewhere
+    const s16x2 x   = pk_min(av - mag1, splat(1));
+    const s16x2 mag = x * dsp + s2p;
+    const s16x2 m   = pk_ashr15(as_s2(as_u(v) ^ spm)); // -1 where the product of the signs of all OTHER messages is negative
+    const s16x2 c   = as_s2(as_u(mag) ^ as_u(m)) - m;
+    const uint32_t cu = as_u(c);
+    c2v[128 * j]      = (int8_t)cu;
+    c2v[128 * j + 64] = (int8_t)(cu >> 16);
     const uint32_t r = as_u(pk_min(pk_max(c + v, splat(-LLR_INF)), splat(LLR_INF)));
     soft[adrA[j]]    = (int8_t)r;
     soft[adrB[j]]    = (int8_t)(r >> 16);
   }
-  Wm  = s1A | (s2A << 8) | (s1B << 16) | (s2B << 24);
-  Wi0 = ni0;
-  Ws0 = ns0;
-  if (D > 16) {
-    Wi1 = ni1;
-    Ws1 = ns1;
-  }
 }
 
 template <bool FIRST>
-__device__ __forceinline__ void update_rows_pk_any(int d, int8_t* soft, uint32_t& Wm, uint32_t& Wi0, uint32_t& Wi1, uint32_t& Ws0, uint32_t& Ws1,
-                                                   const uint32_t* edges, int l, int H, int Z)
+__device__ __forceinline__ void update_rows_pk_any(int d, int8_t* soft, int8_t* c2v, const uint32_t* edges, int l, int H, int Z)
 {
   switch (d) {
     case 19:
-      update_rows_pk<19, FIRST>(soft, Wm, Wi0, Wi1, Ws0, Ws1, edges, l, H, Z);
+      update_rows_pk<19, FIRST>(soft, c2v, edges, l, H, Z);
       break;
     case 10:
-      update_rows_pk<10, FIRST>(soft, Wm, Wi0, Wi1, Ws0, Ws1, edges, l, H, Z);
+      update_rows_pk<10, FIRST>(soft, c2v, edges, l, H, Z);
       break;
     case 9:
-      update_rows_pk<9, FIRST>(soft, Wm, Wi0, Wi1, Ws0, Ws1, edges, l, H, Z);
+      update_rows_pk<9, FIRST>(soft, c2v, edges, l, H, Z);
       break;
     case 8:
-      update_rows_pk<8, FIRST>(soft, Wm, Wi0, Wi1, Ws0, Ws1, edges, l, H, Z);
+      update_rows_pk<8, FIRST>(soft, c2v, edges, l, H, Z);
       break;
     case 7:
-      update_rows_pk<7, FIRST>(soft, Wm, Wi0, Wi1, Ws0, Ws1, edges, l, H, Z);
+      update_rows_pk<7, FIRST>(soft, c2v, edges, l, H, Z);
       break;
     case 6:
-      update_rows_pk<6, FIRST>(soft, Wm, Wi0, Wi1, Ws0, Ws1, edges, l, H, Z);
+      update_rows_pk<6, FIRST>(soft, c2v, edges, l, H, Z);
       break;
     case 5:
-      update_rows_pk<5, FIRST>(soft, Wm, Wi0, Wi1, Ws0, Ws1, edges, l, H, Z);
+      update_rows_pk<5, FIRST>(soft, c2v, edges, l, H, Z);
       break;
     case 4:
-      update_rows_pk<4, FIRST>(soft, Wm, Wi0, Wi1, Ws0, Ws1, edges, l, H, Z);
+      update_rows_pk<4, FIRST>(soft, c2v, edges, l, H, Z);
       break;
     default:
-      update_rows_pk<3, FIRST>(soft, Wm, Wi0, Wi1, Ws0, Ws1, edges, l, H, Z);
+      update_rows_pk<3, FIRST>(soft, c2v, edges, l, H, Z);
       break;
   }
 }
@@ -287,15 +238,16 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   const int                 K   = bgK * Z;
   const int                 zp  = tab->z_pos[Z];
 
-  // Soft bits live in a STATIC LDS array so that its base folds into the DS instructions' offset field (a dynamic base
-  // costs one v_add per access); the state arrays stay dynamic (sized by the reachable layers).
-  __shared__ __attribute__((aligned(16))) int8_t soft[68 * MIPHY_MAX_Z];
+  // Soft bits come FIRST in the dynamic LDS block: the kernel has no static LDS, so their base is the constant 0 and folds
+  // into the DS instructions (a run-time base would cost one v_add per access). Then the check-to-variable messages,
+  // [wave][edge][row A: 64 lanes | row B: 64 lanes] bytes, then a few reduction words. Everything is sized by the layers the
+  // batch can reach, so a high-rate batch (4 layers, 76 edges) packs 4 codeblocks = 12 waves per CU.
+  int8_t*   soft       = reinterpret_cast<int8_t*>(smem);
   const int lay_alloc  = min(bgM, max(4, max_nodes - bgK));
   const int soft_bytes = ((bgK + lay_alloc) * Z + 15) & ~15;
-  // State arrays: 3 words per (layer, lane) + 2 extra words for the (at most 4) degree > 16 layers.
-  uint32_t* st  = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* stx = st + 3 * lay_alloc * H;
-  uint32_t* red = stx + 2 * 4 * H;
+  const int edges_all  = tab->row_start[bgi][lay_alloc];
+  int8_t*   c2v_lane   = reinterpret_cast<int8_t*>(smem) + soft_bytes + (tid >> 6) * (edges_all * 128) + (tid & 63);
+  uint32_t* red        = reinterpret_cast<uint32_t*>(smem + soft_bytes + (nt >> 6) * (edges_all * 128));
 
   if (harq_crc_ok && harq_crc_ok[harq_slot[blockIdx.x]]) {
     if (tid == 0)
@@ -380,27 +332,11 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       const int       d     = row_start[m + 1] - e0;
       const uint32_t* edges = edges_g + e0;
       if (tid < H) {
-        uint32_t  Wm = 0, Wi0 = 0, Wi1 = 0, Ws0 = 0, Ws1 = 0;
-        uint32_t* sp = st + (3 * m) * H + tid;
-        if (it == 0) {
-          update_rows_pk_any<true>(d, soft, Wm, Wi0, Wi1, Ws0, Ws1, edges, tid, H, Z);
-        } else {
-          Wm  = sp[0];
-          Wi0 = sp[H];
-          Ws0 = sp[2 * H];
-          if (d > 16) {
-            Wi1 = stx[(2 * m) * H + tid];
-            Ws1 = stx[(2 * m + 1) * H + tid];
-          }
-          update_rows_pk_any<false>(d, soft, Wm, Wi0, Wi1, Ws0, Ws1, edges, tid, H, Z);
-        }
-        sp[0]     = Wm;
-        sp[H]     = Wi0;
-        sp[2 * H] = Ws0;
-        if (d > 16) {
-          stx[(2 * m) * H + tid]     = Wi1;
-          stx[(2 * m + 1) * H + tid] = Ws1;
-        }
+        int8_t* cl = c2v_lane + 128 * e0;
+        if (it == 0)
+          update_rows_pk_any<true>(d, soft, cl, edges, tid, H, Z);
+        else
+          update_rows_pk_any<false>(d, soft, cl, edges, tid, H, Z);
       }
       __syncthreads();
     }
@@ -429,12 +365,12 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 
 } // namespace
 
-// LDS bytes the packed kernel needs for a given geometry (Zt >= Z of every codeblock, lay = layer bound, bgK).
-size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt)
+// LDS bytes the packed kernel needs for a given geometry (Zt >= Z of every codeblock, lay = layer bound, edges_all = edges
+// of those layers).
+size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int edges_all)
 {
-  const size_t H = (Zt + 1) / 2;
-  (void)bgK; // the soft-bit array is static
-  return (size_t)(3 * lay + 8) * H * 4 + 64;
+  const size_t waves = ((Zt + 1) / 2 + 63) / 64;
+  return ((((size_t)bgK + lay) * Zt + 15) & ~(size_t)15) + waves * (size_t)edges_all * 128 + 64;
 }
 
 int miphy_ldpc_pk_launch(const miphy_ldpc_dec_desc* d_descs, const miphy_graph_tables* tab, uint32_t n, int threads, size_t lds, const int8_t* llr,
