@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-slot latency leg (keeps profiles to the timed step only)")
     args = ap.parse_args()
 
     import torch
@@ -222,7 +223,7 @@ def main():
 
     # ---- single-slot latency of the same pipeline (one slot = 38 codeblocks: the real-time unit of work), not part of `value`
     lat_us = None
-    if rank == 0:
+    if rank == 0 and not args.no_latency:
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20

@@ -459,7 +459,7 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
       const int bgK = b ? 10 : 22, bgM = b ? 42 : 46;
       int       lay = nodes_all - bgK;
       lay           = lay < 4 ? 4 : (lay > bgM ? bgM : lay);
-      const size_t l = miphy_ldpc_pk_lds_bytes(bgK, lay, (size_t)max_threads, ctx->h_tables->row_start[b][lay]);
+      const size_t l = miphy_ldpc_pk_lds_bytes(bgK, lay, (size_t)max_threads, ctx->h_tables->pair_start[b][lay]);
       pk_lds         = l > pk_lds ? l : pk_lds;
     }
     return miphy_ldpc_pk_launch((const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, n, pk_threads, pk_lds, llr, out_bits, iters, nodes_all, harq_slot,

@@ -3,9 +3,12 @@
 // number of wavefronts a codeblock occupies. Same arithmetic contract as ldpc_decode.hip (reference:
 // ldpc_decoder_impl.cpp:60-146 + ldpc_decoder_avx2.cpp:66-243, avx2_support.h:65-106); results are bit-identical.
 //
-// Check-to-variable messages are kept EXPLICITLY in LDS, one int8 per (edge, row): for wave w the block of edge e is
-// 128 bytes = [64 x row-A byte][64 x row-B byte], so a lane's accesses are byte loads / stores with an immediate offset
-// (no VALU work to rebuild a message from compressed min/argmin/sign state, which dominated the earlier formulation).
+// Check-to-variable messages are kept EXPLICITLY in LDS, one int8 per (edge, row), no VALU work to rebuild a message from
+// compressed min/argmin/sign state (which dominated an earlier formulation). A lane packs the messages of two consecutive
+// edges into one dword {A(j+1), A(j), B(j+1), B(j)} (bytes 0..3): edge j sits in the odd bytes, where v_perm_b32 can
+// sign-extend it to two int16 in ONE instruction; edge j+1 needs one extra shift. Per wave the dwords of an edge pair are
+// 64 consecutive words: conflict-free, immediate offsets, and only one LDS read and one LDS write per TWO edges (measured on
+// gfx950: a DS write costs ~5 cycles of the CU's LDS pipe whatever its width, a read ~2.8 -- tools/lds_probe.hip).
 #include "miphy_internal.h"
 
 namespace {
@@ -41,6 +44,22 @@ __device__ __forceinline__ s16x2 pk_pair(int lo, int hi)
 {
   return as_s2(__builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u));
 }
+// Message dword {A1, A0, B1, B0} (bytes 0..3) -> edge 0 = (sext A0, sext B0), edge 1 = (sext A1, sext B1).
+// v_perm_b32 selectors 8 / 9 replicate the sign of byte 1 / 3 of the low source (10 / 11: of the high source).
+__device__ __forceinline__ s16x2 c2v_even(uint32_t w)
+{
+  return as_s2(__builtin_amdgcn_perm(w, w, 0x09030801u));
+}
+__device__ __forceinline__ s16x2 c2v_odd(uint32_t w)
+{
+  const uint32_t h = w << 8; // bytes {0, A1, A0, B1}: A1 -> byte 1, B1 -> byte 3
+  return as_s2(__builtin_amdgcn_perm(h, h, 0x09030801u));
+}
+__device__ __forceinline__ uint32_t c2v_pack(s16x2 c0, s16x2 c1)
+{
+  // {S0 = c0 -> bytes 4..7, S1 = c1 -> bytes 0..3}: out = {c1.A, c0.A, c1.B, c0.B}
+  return __builtin_amdgcn_perm(as_u(c0), as_u(c1), 0x06020400u);
+}
 
 constexpr int LLR_MAX = 120;
 constexpr int LLR_INF = 127;
@@ -48,13 +67,13 @@ constexpr int INF_MUL = 255; // an infinite soft bit (|s| > 120) becomes a messa
 
 template <int D, bool FIRST>
 __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
-                                               int8_t* __restrict__ c2v, // this lane's row-A byte of edge 0 of the layer
+                                               uint32_t* __restrict__ c2v, // this lane's message dword of edges 0,1 of the layer
                                                const uint32_t* __restrict__ edges,
                                                int l,
                                                int H,
                                                int Z)
 {
-  s16x2    v2c[D];
+  s16x2    v2c[D], mabs[D];
   uint32_t adrA[D], adrB[D];
   s16x2    mag1 = splat(LLR_MAX), mag2 = splat(LLR_MAX);
   uint32_t spx  = 0;
@@ -75,13 +94,15 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
     const s16x2 d  = s - sc;
     s16x2       t  = sc;
     if (!FIRST) {
-      const s16x2 c = pk_pair(c2v[128 * j], c2v[128 * j + 64]);
-      t             = pk_min(pk_max(sc - c, splat(-LLR_MAX)), splat(LLR_MAX));
+      const uint32_t w = c2v[64 * (j >> 1)];
+      const s16x2    c = (j & 1) ? c2v_odd(w) : c2v_even(w);
+      t                = pk_min(pk_max(sc - c, splat(-LLR_MAX)), splat(LLR_MAX));
     }
     const s16x2 v = d * splat(INF_MUL) + t;
     v2c[j]        = v;
     spx ^= as_u(v);
     const s16x2 av   = pk_max(v, -v);
+    mabs[j]          = av;
     const s16x2 help = pk_max(mag1, av);
     mag1             = pk_min(mag1, av);
     mag2             = pk_min(mag2, help);
@@ -89,21 +110,26 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
   // Scaling by 0.8 = floor(x * 52428 / 65536), per row (avx2_support.h:65-106).
   const uint32_t s1A = ((uint32_t)(uint16_t)mag1.x * 52428u) >> 16, s1B = ((uint32_t)(uint16_t)mag1.y * 52428u) >> 16;
   const uint32_t s2A = ((uint32_t)(uint16_t)mag2.x * 52428u) >> 16, s2B = ((uint32_t)(uint16_t)mag2.y * 52428u) >> 16;
-  const s16x2    s2p = as_s2(s2A | (s2B << 16));
-  const s16x2    dsp = as_s2(s1A | (s1B << 16)) - s2p; // min1 - min2 (scaled), <= 0
-  const uint32_t spm = spx & 0x80008000u;
+  // The product of ALL signs is folded into the two candidate magnitudes once per layer; an edge then only applies its own sign.
+  const s16x2 pm  = pk_ashr15(as_s2(spx));
+  const s16x2 s2u = as_s2(s2A | (s2B << 16));
+  const s16x2 s1u = as_s2(s1A | (s1B << 16));
+  const s16x2 s2p = as_s2(as_u(s2u) ^ as_u(pm)) - pm;
+  const s16x2 dsp = (as_s2(as_u(s1u) ^ as_u(pm)) - pm) - s2p; // +-(min1 - min2), scaled
+  s16x2 cprev = splat(0);
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    const s16x2 v  = v2c[j];
-    const s16x2 av = pk_max(v, -v);
+    const s16x2 v = v2c[j];
     // x = 0 where |v| == min1 (this edge provided the minimum, or ties it: then min1 == min2), 1 elsewhere
-    const s16x2 x   = pk_min(av - mag1, splat(1));
+    const s16x2 x   = pk_min(mabs[j] - mag1, splat(1));
     const s16x2 mag = x * dsp + s2p;
-    const s16x2 m   = pk_ashr15(as_s2(as_u(v) ^ spm)); // -1 where the product of the signs of all OTHER messages is negative
+    const s16x2 m   = pk_ashr15(v); // -1 where this edge's own message is negative
     const s16x2 c   = as_s2(as_u(mag) ^ as_u(m)) - m;
-    const uint32_t cu = as_u(c);
-    c2v[128 * j]      = (int8_t)cu;
-    c2v[128 * j + 64] = (int8_t)(cu >> 16);
+    if (j & 1)
+      c2v[64 * (j >> 1)] = c2v_pack(cprev, c);
+    else if (j == D - 1)
+      c2v[64 * (j >> 1)] = c2v_pack(c, c);
+    cprev = c;
     const uint32_t r = as_u(pk_min(pk_max(c + v, splat(-LLR_INF)), splat(LLR_INF)));
     soft[adrA[j]]    = (int8_t)r;
     soft[adrB[j]]    = (int8_t)(r >> 16);
@@ -111,7 +137,7 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
 }
 
 template <bool FIRST>
-__device__ __forceinline__ void update_rows_pk_any(int d, int8_t* soft, int8_t* c2v, const uint32_t* edges, int l, int H, int Z)
+__device__ __forceinline__ void update_rows_pk_any(int d, int8_t* soft, uint32_t* c2v, const uint32_t* edges, int l, int H, int Z)
 {
   switch (d) {
     case 19:
@@ -214,7 +240,7 @@ __device__ __forceinline__ uint32_t block_crc(const int8_t* soft, const miphy_gr
 }
 
 #ifndef LDPC_PK_MIN_WAVES
-#define LDPC_PK_MIN_WAVES 4
+#define LDPC_PK_MIN_WAVES 3
 #endif
 __global__ void __launch_bounds__(192, LDPC_PK_MIN_WAVES)
 ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
@@ -240,14 +266,14 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 
   // Soft bits come FIRST in the dynamic LDS block: the kernel has no static LDS, so their base is the constant 0 and folds
   // into the DS instructions (a run-time base would cost one v_add per access). Then the check-to-variable messages,
-  // [wave][edge][row A: 64 lanes | row B: 64 lanes] bytes, then a few reduction words. Everything is sized by the layers the
-  // batch can reach, so a high-rate batch (4 layers, 76 edges) packs 4 codeblocks = 12 waves per CU.
+  // [wave][edge pair][64 lanes] dwords, then a few reduction words. Everything is sized by the layers the batch can reach, so
+  // a high-rate batch (4 layers, 76 edges) packs 4 codeblocks = 12 waves per CU.
   int8_t*   soft       = reinterpret_cast<int8_t*>(smem);
   const int lay_alloc  = min(bgM, max(4, max_nodes - bgK));
   const int soft_bytes = ((bgK + lay_alloc) * Z + 15) & ~15;
-  const int edges_all  = tab->row_start[bgi][lay_alloc];
-  int8_t*   c2v_lane   = reinterpret_cast<int8_t*>(smem) + soft_bytes + (tid >> 6) * (edges_all * 128) + (tid & 63);
-  uint32_t* red        = reinterpret_cast<uint32_t*>(smem + soft_bytes + (nt >> 6) * (edges_all * 128));
+  const int pairs_all  = tab->pair_start[bgi][lay_alloc];
+  uint32_t* c2v_lane   = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (tid >> 6) * (pairs_all * 64) + (tid & 63);
+  uint32_t* red        = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (nt >> 6) * (pairs_all * 64);
 
   if (harq_crc_ok && harq_crc_ok[harq_slot[blockIdx.x]]) {
     if (tid == 0)
@@ -314,7 +340,8 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   const int nof_layers = cb_len / Z - bgK;
 
   const uint32_t* edges_g   = tab->edge[bgi][zp];
-  const uint16_t* row_start = tab->row_start[bgi];
+  const uint16_t* row_start  = tab->row_start[bgi];
+  const uint16_t* pair_start = tab->pair_start[bgi];
   uint32_t        poly = 0, order = 0;
   int             L = 0;
   if (use_crc) {
@@ -332,7 +359,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       const int       d     = row_start[m + 1] - e0;
       const uint32_t* edges = edges_g + e0;
       if (tid < H) {
-        int8_t* cl = c2v_lane + 128 * e0;
+        uint32_t* cl = c2v_lane + 64 * pair_start[m];
         if (it == 0)
           update_rows_pk_any<true>(d, soft, cl, edges, tid, H, Z);
         else
@@ -365,12 +392,12 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 
 } // namespace
 
-// LDS bytes the packed kernel needs for a given geometry (Zt >= Z of every codeblock, lay = layer bound, edges_all = edges
-// of those layers).
-size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int edges_all)
+// LDS bytes the packed kernel needs for a given geometry (Zt >= Z of every codeblock, lay = layer bound, pairs_all = message
+// dwords per lane of those layers).
+size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all)
 {
   const size_t waves = ((Zt + 1) / 2 + 63) / 64;
-  return ((((size_t)bgK + lay) * Zt + 15) & ~(size_t)15) + waves * (size_t)edges_all * 128 + 64;
+  return ((((size_t)bgK + lay) * Zt + 15) & ~(size_t)15) + waves * (size_t)pairs_all * 256 + 64;
 }
 
 int miphy_ldpc_pk_launch(const miphy_ldpc_dec_desc* d_descs, const miphy_graph_tables* tab, uint32_t n, int threads, size_t lds, const int8_t* llr,

@@ -75,6 +75,11 @@ static void build_tables(miphy_graph_tables* t)
     t->row_start[0][m] = NR_LDPC_BG1_ROW_START[m];
   for (int m = 0; m <= NR_LDPC_BG2_M; ++m)
     t->row_start[1][m] = NR_LDPC_BG2_ROW_START[m];
+  for (int b = 0; b < 2; ++b) {
+    t->pair_start[b][0] = 0;
+    for (int m = 0; m < (b ? NR_LDPC_BG2_M : NR_LDPC_BG1_M); ++m)
+      t->pair_start[b][m + 1] = (uint16_t)(t->pair_start[b][m] + (t->row_start[b][m + 1] - t->row_start[b][m] + 1) / 2);
+  }
   static const uint32_t POLY[5]  = {0x1864CFB, 0x1800063, 0x1B2B117, 0x11021, 0xE21};
   static const uint32_t ORDER[5] = {24, 24, 24, 16, 11};
   for (int p = 0; p < 5; ++p) {

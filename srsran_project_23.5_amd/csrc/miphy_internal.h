@@ -16,6 +16,7 @@
 struct miphy_graph_tables {
   uint32_t edge[2][MIPHY_NOF_Z][MIPHY_MAX_EDGES];
   uint16_t row_start[2][48];
+  uint16_t pair_start[2][48]; // prefix sum of ceil(degree / 2) over the layers (packed decoder message storage)
   uint16_t z_pos[MIPHY_MAX_Z + 1]; // position of Z in the list of lifting sizes, 0xffff if invalid
   uint8_t  i_ls[MIPHY_MAX_Z + 1];  // lifting-size set index
   // CRC: pow32[p][k] = x^(32k) mod poly_p for k in [0, 320); poly/order per id.
@@ -70,6 +71,6 @@ int miphy_ldpc_decode_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* descs, i
 int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out);
 
 // Packed (two rows per lane) LDPC decoder kernel, ldpc_decode_pk.hip.
-size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int edges_all);
+size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all);
 int    miphy_ldpc_pk_launch(const miphy_ldpc_dec_desc* d_descs, const miphy_graph_tables* tab, uint32_t n, int threads, size_t lds, const int8_t* llr,
                             uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s);

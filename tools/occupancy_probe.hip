@@ -44,7 +44,7 @@ int main(int argc, char** argv)
   rec*      d;
   hipMalloc(&d, n * sizeof(rec));
   std::vector<rec> h(n);
-  const int dyns[] = {0, 8192, 15424, 20000, 27000, 38000, 54000};
+  const int dyns[] = {4608, 5632, 6656, 8704, 10752, 11776, 12800, 13120, 13824, 14848};
   hipFuncSetAttribute((const void*)probe<26112>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 - 26112);
   hipFuncSetAttribute((const void*)probe<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 - 256);
   for (int variant = 0; variant < 2; ++variant)
