@@ -10,6 +10,7 @@
 // 64 consecutive words: conflict-free, immediate offsets, and only one LDS read and one LDS write per TWO edges (measured on
 // gfx950: a DS write costs ~5 cycles of the CU's LDS pipe whatever its width, a read ~2.8 -- tools/lds_probe.hip).
 #include "miphy_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -68,33 +69,48 @@ constexpr int INF_MUL = 255; // an infinite soft bit (|s| > 120) becomes a messa
 template <int D, bool FIRST>
 __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
                                                uint32_t* __restrict__ c2v, // this lane's message dword of edges 0,1 of the layer
-                                               const uint32_t* __restrict__ edges,
+                                               const uint32_t* __restrict__ edges, // {shift, column*Z} per edge
                                                int l,
                                                int H,
                                                int Z)
 {
   s16x2    v2c[D], mabs[D];
   uint32_t adrA[D], adrB[D];
+  int      rawA[D], rawB[D];
+  uint32_t cw[(D + 1) / 2];
+  // Stage A: every address of the layer, then every LDS read of the layer in one go (2 soft bits per edge + the old
+  // messages): the latency of the LDS pipe is paid once per layer instead of once per group of edges.
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    uint32_t pA = (uint32_t)l + edges[2 * j];
+    pA          = min(pA, pA - (uint32_t)Z);
+    uint32_t pB = pA + (uint32_t)H;
+    pB          = min(pB, pB - (uint32_t)Z);
+    adrA[j]     = edges[2 * j + 1] + pA;
+    adrB[j]     = edges[2 * j + 1] + pB;
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    rawA[j] = soft[adrA[j]];
+    rawB[j] = soft[adrB[j]];
+  }
+  if (!FIRST) {
+#pragma unroll
+    for (int jj = 0; jj < (D + 1) / 2; ++jj)
+      cw[jj] = c2v[64 * jj];
+  }
+  __builtin_amdgcn_sched_barrier(0);
   s16x2    mag1 = splat(LLR_MAX), mag2 = splat(LLR_MAX);
   uint32_t spx  = 0;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    const uint32_t e  = edges[j];
-    uint32_t       pA = (uint32_t)l + (e >> 16);
-    pA                = min(pA, pA - (uint32_t)Z);
-    uint32_t pB       = pA + (uint32_t)H;
-    pB                = min(pB, pB - (uint32_t)Z);
-    const uint32_t base = e & 0xffffu;
-    const uint32_t aA = base + pA, aB = base + pB;
-    adrA[j]           = aA;
-    adrB[j]           = aB;
-    const s16x2 s  = pk_pair(soft[aA], soft[aB]);
+    const s16x2 s = pk_pair(rawA[j], rawB[j]);
     // |s| > 120: infinite soft bit -> "infinite" message with the same sign: d != 0 only then, and 255 * d dominates.
     const s16x2 sc = pk_min(pk_max(s, splat(-LLR_MAX)), splat(LLR_MAX));
     const s16x2 d  = s - sc;
     s16x2       t  = sc;
     if (!FIRST) {
-      const uint32_t w = c2v[64 * (j >> 1)];
+      const uint32_t w = cw[j >> 1];
       const s16x2    c = (j & 1) ? c2v_odd(w) : c2v_even(w);
       t                = pk_min(pk_max(sc - c, splat(-LLR_MAX)), splat(LLR_MAX));
     }
@@ -339,7 +355,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   cb_len     = ((cb_len + Z - 1) / Z) * Z;
   const int nof_layers = cb_len / Z - bgK;
 
-  const uint32_t* edges_g   = tab->edge[bgi][zp];
+  const uint32_t* edges_g   = tab->edge_sb[bgi][zp];
   const uint16_t* row_start  = tab->row_start[bgi];
   const uint16_t* pair_start = tab->pair_start[bgi];
   uint32_t        poly = 0, order = 0;
@@ -357,7 +373,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     for (int m = 0; m < nof_layers; ++m) {
       const int       e0    = row_start[m];
       const int       d     = row_start[m + 1] - e0;
-      const uint32_t* edges = edges_g + e0;
+      const uint32_t* edges = edges_g + 2 * e0;
       if (tid < H) {
         uint32_t* cl = c2v_lane + 64 * pair_start[m];
         if (it == 0)
@@ -403,6 +419,9 @@ size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all)
 int miphy_ldpc_pk_launch(const miphy_ldpc_dec_desc* d_descs, const miphy_graph_tables* tab, uint32_t n, int threads, size_t lds, const int8_t* llr,
                          uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s)
 {
+  static const char* pad = getenv("MIPHY_LDPC_PAD_LDS"); // occupancy experiments only
+  if (pad)
+    lds += (size_t)atoi(pad);
   static thread_local size_t lds_set = 0;
   if (lds > lds_set) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_pk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -71,6 +71,12 @@ static void build_tables(miphy_graph_tables* t)
     for (int e = 0; e < NR_LDPC_BG2_NOF_EDGES; ++e)
       t->edge[1][p][e] = (uint32_t)(NR_LDPC_BG2_COL[e] * Z) | ((uint32_t)(NR_LDPC_BG2_SHIFT[ils][e] % Z) << 16);
   }
+  for (int b = 0; b < 2; ++b)
+    for (int p = 0; p < MIPHY_NOF_Z; ++p)
+      for (int e = 0; e < (b ? NR_LDPC_BG2_NOF_EDGES : NR_LDPC_BG1_NOF_EDGES); ++e) {
+        t->edge_sb[b][p][2 * e]     = t->edge[b][p][e] >> 16;
+        t->edge_sb[b][p][2 * e + 1] = t->edge[b][p][e] & 0xffffu;
+      }
   for (int m = 0; m <= NR_LDPC_BG1_M; ++m)
     t->row_start[0][m] = NR_LDPC_BG1_ROW_START[m];
   for (int m = 0; m <= NR_LDPC_BG2_M; ++m)

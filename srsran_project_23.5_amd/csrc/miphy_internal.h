@@ -15,6 +15,7 @@
 // high 16 bits = cyclic shift (already reduced modulo Z).
 struct miphy_graph_tables {
   uint32_t edge[2][MIPHY_NOF_Z][MIPHY_MAX_EDGES];
+  uint32_t edge_sb[2][MIPHY_NOF_Z][2 * MIPHY_MAX_EDGES]; // the same, unpacked: {shift, column*Z} per edge (scalar operands as loaded)
   uint16_t row_start[2][48];
   uint16_t pair_start[2][48]; // prefix sum of ceil(degree / 2) over the layers (packed decoder message storage)
   uint16_t z_pos[MIPHY_MAX_Z + 1]; // position of Z in the list of lifting sizes, 0xffff if invalid
