@@ -49,11 +49,33 @@ __device__ __forceinline__ int combine(int a, int b)
 // thread then produces 16 consecutive output positions and writes them with one 16-byte store; the (rare) positions the
 // reference leaves untouched fall back to byte stores.
 constexpr int RDM_LDS_BYTES = 60 * 1024;
+constexpr int RDM_SLOW_CAP  = 16;
 
 struct rdm_ctx {
   rm_geom g;
   bool    nd, wrapped, tail_on;
   int     k0p, tail_start;
+};
+
+// Where the LLR of rank index i (position in the de-interleaved sequence, 0 <= i < E) lives.
+struct raw_access { // interleaved input as received: in[p * mod + q] with i = q * Kq + p
+  const int8_t* in;
+  int           Kq, mod;
+  __device__ __forceinline__ int operator()(int i) const
+  {
+    const int q = i / Kq;
+    return in[(i - q * Kq) * mod + q];
+  }
+};
+struct image_access { // LDS image laid out like the output buffer (single-pass geometry only), see rate_dematch_kernel
+  const int8_t* img;
+  int           r0, f0, F, jbase, f1, gapcut;
+  __device__ __forceinline__ int slot(int j) const { return j - jbase - ((j >= f1) ? gapcut : 0); }
+  __device__ __forceinline__ int operator()(int i) const
+  {
+    const int r = r0 + i;
+    return img[slot((r < f0) ? r : r + F)];
+  }
 };
 
 // Value of output position j. Returns false when the reference leaves the position untouched.
@@ -78,8 +100,7 @@ __device__ __forceinline__ bool rdm_value(const rdm_ctx& c, const IN& in, const 
       if (i0 >= 0) {
         has0 = i0 < g.E;
         if (has0) {
-          const int q = i0 / g.Kq;
-          acc         = in[(i0 - q * g.Kq) * g.mod + q];
+          acc         = in(i0);
           write       = true;
           i_next      = i0 + g.L;
         }
@@ -108,18 +129,71 @@ __device__ __forceinline__ bool rdm_value(const rdm_ctx& c, const IN& in, const 
       acc = out[j];
   }
   for (int i = i_next; i < g.E; i += g.L) {
-    const int q = i / g.Kq;
-    acc         = combine(acc, in[(i - q * g.Kq) * g.mod + q]);
-    write       = true;
+    acc   = combine(acc, in(i));
+    write = true;
   }
   result = acc;
   return write;
+}
+
+// De-interleaving stage: input byte k = p * MOD + q is the LLR of rank index i = q * Kq + p, which goes to image slot
+// rank + (rank >= f0 ? adj : 0) - jbase (single-pass geometry: see image_access). A lane takes 16 consecutive input bytes;
+// for the power-of-two modulation orders these are 16 / MOD whole symbols, so that per bit plane q the slot is one add away
+// from a per-plane scalar and the symbols of a lane land on consecutive bytes.
+template <int MOD>
+__device__ __forceinline__ void stage_image(const image_access& img, const int8_t* __restrict__ in, int8_t* __restrict__ lds, int nq, const rm_geom& g,
+                                            int tid, int nt)
+{
+  const uint4* src = reinterpret_cast<const uint4*>(in);
+  const int    adj = g.F - img.gapcut;
+  if (MOD == 6) {
+    for (int v = tid; v < nq; v += nt) {
+      const uint4    x    = src[v];
+      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+      int            p    = (16 * v) / 6;
+      int            q    = 16 * v - p * 6;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const int r                              = g.r0 + q * g.Kq + p;
+        lds[r - img.jbase + ((r >= g.f0) ? adj : 0)] = (int8_t)(w[b >> 2] >> (8 * (b & 3)));
+        if (++q == 6) {
+          q = 0;
+          ++p;
+        }
+      }
+    }
+  } else {
+    constexpr int SYM = 16 / MOD; // symbols per 16-byte vector
+    for (int v = tid; v < nq; v += nt) {
+      const uint4    x    = src[v];
+      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+      const int      p0   = v * SYM;
+#pragma unroll
+      for (int q = 0; q < MOD; ++q) {
+        const int r0q = g.r0 + q * g.Kq - img.jbase; // uniform
+        const int lim = g.f0 - g.r0 - q * g.Kq;      // uniform: symbols p >= lim of this plane lie behind the filler gap
+#pragma unroll
+        for (int sy = 0; sy < SYM; ++sy) {
+          const int p = p0 + sy;
+          const int b = sy * MOD + q;
+          lds[r0q + p + ((p >= lim) ? adj : 0)] = (int8_t)(w[b >> 2] >> (8 * (b & 3)));
+        }
+      }
+    }
+  }
+  for (int k = (nq << 4) + tid; k < g.E; k += nt) {
+    const int p = k / MOD, q = k - p * MOD;
+    const int r = g.r0 + q * g.Kq + p;
+    lds[r - img.jbase + ((r >= g.f0) ? adj : 0)] = in[k];
+  }
 }
 
 __global__ void __launch_bounds__(256)
 rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t* __restrict__ in_base, int8_t* __restrict__ out_base, int lds_bytes)
 {
   extern __shared__ __attribute__((aligned(16))) int8_t lds_in[];
+  __shared__ int            slow_list[RDM_SLOW_CAP];
+  __shared__ int            slow_n;
   const miphy_ldpc_rdm_desc d = descs[blockIdx.x];
   rdm_ctx                   c;
   c.g                         = make_geom(d);
@@ -147,10 +221,46 @@ rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t*
   c.tail_on    = c.nd && !c.wrapped && idx_end != 0;
   c.tail_start = g.N - (g.Ncb - idx_end);
 
-  const int  tid     = threadIdx.x, nt = blockDim.x;
-  const bool use_lds = g.E <= lds_bytes;
-  if (use_lds) {
-    if ((((uintptr_t)in) & 15) == 0) {
+  const int  tid    = threadIdx.x, nt = blockDim.x;
+  const bool single = g.E <= cap0; // E does not wrap around the circular buffer: the overwhelmingly common case
+  // Staging. Single-pass geometry: the input is DE-INTERLEAVED while it is staged, straight into an LDS image of the output
+  // buffer (slot(j) keeps j mod 16, the filler gap is cut down to its length mod 16), so that the output phase is a copy of
+  // aligned 16-byte LDS vectors -- byte gathers out of an interleaved LDS copy put all 64 lanes on one bank.
+  // Otherwise (wrap-around combining) the input is staged as received and gathered.
+  const int    j_first = (g.r0 < g.f0) ? g.r0 : g.r0 + g.F;
+  image_access img;
+  img.img    = lds_in;
+  img.r0     = g.r0;
+  img.f0     = g.f0;
+  img.F      = g.F;
+  img.f1     = g.f1;
+  img.jbase  = j_first & ~15;
+  img.gapcut = (j_first < g.f0) ? (g.F & ~15) : 0;
+  const bool use_img = single && g.E + 64 <= lds_bytes;
+  const bool use_lds = use_img || g.E <= lds_bytes;
+  const bool in_vec  = (((uintptr_t)in) & 15) == 0;
+  if (use_img) {
+    const int nq = in_vec ? (g.E >> 4) : 0;
+    switch (g.mod) {
+      case 8:
+        stage_image<8>(img, in, lds_in, nq, g, tid, nt);
+        break;
+      case 6:
+        stage_image<6>(img, in, lds_in, nq, g, tid, nt);
+        break;
+      case 4:
+        stage_image<4>(img, in, lds_in, nq, g, tid, nt);
+        break;
+      case 2:
+        stage_image<2>(img, in, lds_in, nq, g, tid, nt);
+        break;
+      default:
+        stage_image<1>(img, in, lds_in, nq, g, tid, nt);
+        break;
+    }
+    __syncthreads();
+  } else if (use_lds) {
+    if (in_vec) {
       const uint4* src = reinterpret_cast<const uint4*>(in);
       uint4*       dst = reinterpret_cast<uint4*>(lds_in);
       const int    nq  = g.E >> 4;
@@ -164,13 +274,91 @@ rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t*
     }
     __syncthreads();
   }
+  if (use_img && (((uintptr_t)out) & 15) == 0) {
+    // Output phase, single-pass geometry. The buffer is a fixed sequence of (possibly empty) intervals, in this order:
+    //   [0,z) cleared | [z,sA) untouched | [sA,eA) data | [eA,f0) untouched | [f0,f1) fillers | [f1,sB) untouched |
+    //   [sB,eB) data | [eB,t) untouched | [t,N) cleared                     (rdm_value above, restated per region)
+    // In combining mode nothing is cleared and the fillers stay. Whole 16-byte vectors inside one interval are produced by a
+    // loop without per-vector classification; the (at most 9) vectors that straddle a boundary run the byte-wise rule on
+    // 16 lanes side by side.
+    const int r_end = g.r0 + g.E;
+    int       B[10];
+    B[0] = 0;
+    B[1] = (c.k0p < g.f0) ? c.k0p : g.f0;
+    B[2] = (g.r0 < g.f0) ? g.r0 : g.f0;
+    B[3] = (g.r0 < g.f0) ? min(g.f0, r_end) : g.f0;
+    B[4] = g.f0;
+    B[5] = g.f1;
+    B[6] = max(g.f1, g.r0 + g.F);
+    B[7] = max(B[6], r_end + g.F);
+    B[8] = c.tail_on ? max(B[7], c.tail_start) : g.N;
+    B[9] = g.N;
+    if (tid == 0) {
+      int n = 0, last = -1;
+#pragma unroll
+      for (int k = 1; k <= 9; ++k) {
+        const int bp = B[k];
+        if ((bp & 15) != 0 && bp <= g.N && (bp >> 4) != last) {
+          last           = bp >> 4;
+          slow_list[n++] = last;
+        }
+      }
+      slow_n = n;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int vs = (B[k] + 15) >> 4, ve = B[k + 1] >> 4;
+      if (ve <= vs)
+        continue;
+      uint4* dst = reinterpret_cast<uint4*>(out);
+      if (k == 2 || k == 6) {
+        // data: the image keeps j mod 16, behind the filler gap it is shifted by gapcut (a multiple of 16)
+        const uint4* srcv = reinterpret_cast<const uint4*>(lds_in + (vs << 4) - img.jbase - ((k == 6) ? img.gapcut : 0)) - vs;
+        if (c.nd) {
+          for (int v = vs + tid; v < ve; v += nt)
+            dst[v] = srcv[v];
+        } else {
+          for (int v = vs + tid; v < ve; v += nt) {
+            const uint4    x = srcv[v], old = dst[v];
+            const uint32_t xw[4] = {x.x, x.y, x.z, x.w}, ow[4] = {old.x, old.y, old.z, old.w};
+            uint32_t       w[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              uint32_t r = 0;
+#pragma unroll
+              for (int b = 0; b < 4; ++b)
+                r |= (uint32_t)(combine((int)(int8_t)(ow[kk] >> (8 * b)), (int)(int8_t)(xw[kk] >> (8 * b))) & 0xff) << (8 * b);
+              w[kk] = r;
+            }
+            dst[v] = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        }
+      } else if (c.nd && (k == 0 || k == 8 || k == 4)) {
+        const uint32_t f = (k == 4) ? 0x7f7f7f7fu : 0u;
+        for (int v = vs + tid; v < ve; v += nt)
+          dst[v] = make_uint4(f, f, f, f);
+      }
+    }
+    __syncthreads();
+    const int n = slow_n;
+    for (int idx = tid; idx < 16 * n; idx += nt) {
+      const int j = (slow_list[idx >> 4] << 4) + (idx & 15);
+      int       r = 0;
+      if (j < g.N && rdm_value(c, img, out, j, r))
+        out[j] = (int8_t)r;
+    }
+    return;
+  }
+  raw_access raw;
+  raw.in  = use_lds ? lds_in : in;
+  raw.Kq  = g.Kq;
+  raw.mod = g.mod;
+
   const bool vec_out = (((uintptr_t)out) & 15) == 0;
   const int  nvec    = (g.N + 15) >> 4;
-  // Single-pass geometry (E does not wrap around the circular buffer): the overwhelmingly common case. Rank interval
-  // [r0, r0 + E) holds the data; a 16-byte output vector that lies entirely inside it, or entirely outside every written /
-  // cleared / combined region, takes a fast path with one division per vector.
-  const bool single = g.E <= cap0;
-  const int  r_end  = g.r0 + g.E;
+  // A 16-byte output vector that lies entirely inside the data interval (ranks [r0, r0 + E)), or entirely outside every
+  // written / cleared / combined region, takes a fast path.
+  const int r_end = g.r0 + g.E;
   for (int v = tid; v < nvec; v += nt) {
     const int j0 = v << 4;
     if (single && vec_out && j0 + 16 <= g.N) {
@@ -179,24 +367,36 @@ rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t*
       if (no_fill && j1 < g.Ncb) {
         const int ra = (j0 < g.f0) ? j0 : j0 - g.F, rb = ra + 15;
         if (ra >= g.r0 && rb < r_end) { // all data
-          int      i = ra - g.r0;
-          int      q = i / g.Kq;
-          int      p = i - q * g.Kq;
-          uint32_t w[4] = {0, 0, 0, 0};
-          uint4    old  = make_uint4(0, 0, 0, 0);
-          if (!c.nd)
-            old = *reinterpret_cast<const uint4*>(out + j0);
-          const uint32_t ow[4] = {old.x, old.y, old.z, old.w};
+          uint32_t w[4];
+          if (use_img) {
+            const uint4 x = *reinterpret_cast<const uint4*>(lds_in + img.slot(j0));
+            w[0] = x.x, w[1] = x.y, w[2] = x.z, w[3] = x.w;
+          } else {
+            int i = ra - g.r0;
+            int q = i / g.Kq;
+            int p = i - q * g.Kq;
+            w[0] = w[1] = w[2] = w[3] = 0;
 #pragma unroll
-          for (int b = 0; b < 16; ++b) {
-            int x = use_lds ? (int)lds_in[p * g.mod + q] : (int)in[p * g.mod + q];
-            if (!c.nd)
-              x = combine((int)(int8_t)(ow[b >> 2] >> (8 * (b & 3))), x);
-            w[b >> 2] |= (uint32_t)(x & 0xff) << (8 * (b & 3));
-            ++p;
-            if (p == g.Kq) {
-              p = 0;
-              ++q;
+            for (int b = 0; b < 16; ++b) {
+              const int x = raw.in[p * g.mod + q];
+              w[b >> 2] |= (uint32_t)(x & 0xff) << (8 * (b & 3));
+              ++p;
+              if (p == g.Kq) {
+                p = 0;
+                ++q;
+              }
+            }
+          }
+          if (!c.nd) {
+            const uint4    old   = *reinterpret_cast<const uint4*>(out + j0);
+            const uint32_t ow[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              uint32_t r = 0;
+#pragma unroll
+              for (int b = 0; b < 4; ++b)
+                r |= (uint32_t)(combine((int)(int8_t)(ow[k] >> (8 * b)), (int)(int8_t)(w[k] >> (8 * b))) & 0xff) << (8 * b);
+              w[k] = r;
             }
           }
           *reinterpret_cast<uint4*>(out + j0) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -228,7 +428,7 @@ rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t*
       int       r = 0;
       bool      wr = false;
       if (j < g.N)
-        wr = use_lds ? rdm_value(c, lds_in, out, j, r) : rdm_value(c, in, out, j, r);
+        wr = use_img ? rdm_value(c, img, out, j, r) : rdm_value(c, raw, out, j, r);
       keep |= (wr ? 0u : 1u) << b;
       w[b >> 2] |= (uint32_t)(r & 0xff) << (8 * (b & 3));
     }
@@ -311,7 +511,8 @@ extern "C" int miphy_ldpc_rate_dematch_batch(miphy_ctx*                 ctx,
   } else if (limits) {
     max_E = limits->max_E;
   }
-  const int lds_bytes = (int)(((max_E > (uint32_t)RDM_LDS_BYTES ? 0u : max_E) + 15u) & ~15u);
+  // + 64: the LDS image of the single-pass path keeps the output alignment (see rate_dematch_kernel)
+  const int lds_bytes = (max_E > (uint32_t)RDM_LDS_BYTES) ? 0 : (int)((max_E + 64u + 15u) & ~15u);
   hipLaunchKernelGGL(rate_dematch_kernel, dim3(n), dim3(256), lds_bytes, s, (const miphy_ldpc_rdm_desc*)d_descs, llr_in, softbuf, lds_bytes);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
