@@ -8,6 +8,7 @@
 // form, the (de)interleaver index, the circular-buffer rank (fillers skipped positionally) and the wrap-around passes,
 // so both directions are pure HBM-bound gathers with coalesced writes.
 #include "miphy_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -140,47 +141,66 @@ __device__ __forceinline__ bool rdm_value(const rdm_ctx& c, const IN& in, const 
 // rank + (rank >= f0 ? adj : 0) - jbase (single-pass geometry: see image_access). A lane takes 16 consecutive input bytes;
 // for the power-of-two modulation orders these are 16 / MOD whole symbols, so that per bit plane q the slot is one add away
 // from a per-plane scalar and the symbols of a lane land on consecutive bytes.
-template <int MOD>
-__device__ __forceinline__ void stage_image(const image_access& img, const int8_t* __restrict__ in, int8_t* __restrict__ lds, int nq, const rm_geom& g,
-                                            int tid, int nt)
+// 16 input bytes at byte offset 16 * v of a stream with ANY alignment: one dword-aligned 16-byte load plus the following dword,
+// funnel-shifted by the (uniform) misalignment mb = address & 3. The caller keeps 16 * v + 20 - mb <= E.
+struct __attribute__((packed, aligned(4))) rdm_u4 {
+  uint32_t x, y, z, w;
+};
+__device__ __forceinline__ uint4 load_in16(const int8_t* __restrict__ in, int mb, int v)
 {
-  const uint4* src = reinterpret_cast<const uint4*>(in);
-  const int    adj = g.F - img.gapcut;
+  const uint32_t* p4 = reinterpret_cast<const uint32_t*>(in - mb) + 4 * v;
+  const rdm_u4    a  = *reinterpret_cast<const rdm_u4*>(p4);
+  if (mb == 0)
+    return make_uint4(a.x, a.y, a.z, a.w);
+  const uint32_t e = p4[4];
+  return make_uint4(__builtin_amdgcn_alignbyte(a.y, a.x, mb), __builtin_amdgcn_alignbyte(a.z, a.y, mb), __builtin_amdgcn_alignbyte(a.w, a.z, mb),
+                    __builtin_amdgcn_alignbyte(e, a.w, mb));
+}
+
+constexpr int RDM_PRE = 4; // input vectors per lane that are in flight while the constant regions are being written
+template <int MOD>
+__device__ __forceinline__ void stage_vector(const image_access& img, int8_t* __restrict__ lds, const rm_geom& g, int adj, int v, const uint4& x)
+{
+  const uint32_t w[4] = {x.x, x.y, x.z, x.w};
   if (MOD == 6) {
-    for (int v = tid; v < nq; v += nt) {
-      const uint4    x    = src[v];
-      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
-      int            p    = (16 * v) / 6;
-      int            q    = 16 * v - p * 6;
+    int p = (16 * v) / 6;
+    int q = 16 * v - p * 6;
 #pragma unroll
-      for (int b = 0; b < 16; ++b) {
-        const int r                              = g.r0 + q * g.Kq + p;
-        lds[r - img.jbase + ((r >= g.f0) ? adj : 0)] = (int8_t)(w[b >> 2] >> (8 * (b & 3)));
-        if (++q == 6) {
-          q = 0;
-          ++p;
-        }
+    for (int b = 0; b < 16; ++b) {
+      const int r                                  = g.r0 + q * g.Kq + p;
+      lds[r - img.jbase + ((r >= g.f0) ? adj : 0)] = (int8_t)(w[b >> 2] >> (8 * (b & 3)));
+      if (++q == 6) {
+        q = 0;
+        ++p;
       }
     }
   } else {
     constexpr int SYM = 16 / MOD; // symbols per 16-byte vector
-    for (int v = tid; v < nq; v += nt) {
-      const uint4    x    = src[v];
-      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
-      const int      p0   = v * SYM;
+    const int     p0  = v * SYM;
 #pragma unroll
-      for (int q = 0; q < MOD; ++q) {
-        const int r0q = g.r0 + q * g.Kq - img.jbase; // uniform
-        const int lim = g.f0 - g.r0 - q * g.Kq;      // uniform: symbols p >= lim of this plane lie behind the filler gap
+    for (int q = 0; q < MOD; ++q) {
+      const int r0q = g.r0 + q * g.Kq - img.jbase; // uniform
+      const int lim = g.f0 - g.r0 - q * g.Kq;      // uniform: symbols p >= lim of this plane lie behind the filler gap
 #pragma unroll
-        for (int sy = 0; sy < SYM; ++sy) {
-          const int p = p0 + sy;
-          const int b = sy * MOD + q;
-          lds[r0q + p + ((p >= lim) ? adj : 0)] = (int8_t)(w[b >> 2] >> (8 * (b & 3)));
-        }
+      for (int sy = 0; sy < SYM; ++sy) {
+        const int p = p0 + sy;
+        const int b = sy * MOD + q;
+        lds[r0q + p + ((p >= lim) ? adj : 0)] = (int8_t)(w[b >> 2] >> (8 * (b & 3)));
       }
     }
   }
+}
+template <int MOD>
+__device__ __forceinline__ void stage_image(const image_access& img, const int8_t* __restrict__ in, int8_t* __restrict__ lds, int nq, const rm_geom& g,
+                                            int tid, int nt, int mb, const uint4 (&pre)[RDM_PRE])
+{
+  const int adj = g.F - img.gapcut;
+#pragma unroll
+  for (int k = 0; k < RDM_PRE; ++k)
+    if (tid + k * nt < nq)
+      stage_vector<MOD>(img, lds, g, adj, tid + k * nt, pre[k]);
+  for (int v = tid + RDM_PRE * nt; v < nq; v += nt)
+    stage_vector<MOD>(img, lds, g, adj, v, load_in16(in, mb, v));
   for (int k = (nq << 4) + tid; k < g.E; k += nt) {
     const int p = k / MOD, q = k - p * MOD;
     const int r = g.r0 + q * g.Kq + p;
@@ -239,23 +259,56 @@ rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t*
   const bool use_img = single && g.E + 64 <= lds_bytes;
   const bool use_lds = use_img || g.E <= lds_bytes;
   const bool in_vec  = (((uintptr_t)in) & 15) == 0;
+  // Region boundaries of the single-pass output (see the output phase below).
+  const int r_end = g.r0 + g.E;
+  int       B[10];
+  B[0] = 0;
+  B[1] = (c.k0p < g.f0) ? c.k0p : g.f0;
+  B[2] = (g.r0 < g.f0) ? g.r0 : g.f0;
+  B[3] = (g.r0 < g.f0) ? min(g.f0, r_end) : g.f0;
+  B[4] = g.f0;
+  B[5] = g.f1;
+  B[6] = max(g.f1, g.r0 + g.F);
+  B[7] = max(B[6], r_end + g.F);
+  B[8] = c.tail_on ? max(B[7], c.tail_start) : g.N;
+  B[9] = g.N;
+  const bool fast_out = use_img && (((uintptr_t)out) & 15) == 0;
   if (use_img) {
-    const int nq = in_vec ? (g.E >> 4) : 0;
+    const int mb = (int)(((uintptr_t)in) & 3);
+    const int nq = (mb == 0) ? (g.E >> 4) : ((g.E >= 4) ? ((g.E - 4) >> 4) : 0);
+    uint4     pre[RDM_PRE];
+#pragma unroll
+    for (int k = 0; k < RDM_PRE; ++k)
+      pre[k] = (tid + k * nt < nq) ? load_in16(in, mb, tid + k * nt) : make_uint4(0, 0, 0, 0);
+    // While the input is in flight: the regions that do not depend on it (cleared ranges and fillers, copy mode only).
+    if (fast_out && c.nd) {
+      uint4* dst = reinterpret_cast<uint4*>(out);
+#pragma unroll
+      for (int k = 0; k <= 8; k += 4) {
+        const int      vs = (B[k] + 15) >> 4, ve = B[k + 1] >> 4;
+        const uint32_t f  = (k == 4) ? 0x7f7f7f7fu : 0u;
+        // streaming stores: most of this is the never-transmitted tail of the circular buffer, nobody reads it back soon
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 fv = {f, f, f, f};
+        for (int v = vs + tid; v < ve; v += nt)
+          __builtin_nontemporal_store(fv, reinterpret_cast<u32x4*>(dst) + v);
+      }
+    }
     switch (g.mod) {
       case 8:
-        stage_image<8>(img, in, lds_in, nq, g, tid, nt);
+        stage_image<8>(img, in, lds_in, nq, g, tid, nt, mb, pre);
         break;
       case 6:
-        stage_image<6>(img, in, lds_in, nq, g, tid, nt);
+        stage_image<6>(img, in, lds_in, nq, g, tid, nt, mb, pre);
         break;
       case 4:
-        stage_image<4>(img, in, lds_in, nq, g, tid, nt);
+        stage_image<4>(img, in, lds_in, nq, g, tid, nt, mb, pre);
         break;
       case 2:
-        stage_image<2>(img, in, lds_in, nq, g, tid, nt);
+        stage_image<2>(img, in, lds_in, nq, g, tid, nt, mb, pre);
         break;
       default:
-        stage_image<1>(img, in, lds_in, nq, g, tid, nt);
+        stage_image<1>(img, in, lds_in, nq, g, tid, nt, mb, pre);
         break;
     }
     __syncthreads();
@@ -274,25 +327,14 @@ rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t*
     }
     __syncthreads();
   }
-  if (use_img && (((uintptr_t)out) & 15) == 0) {
+  if (fast_out) {
     // Output phase, single-pass geometry. The buffer is a fixed sequence of (possibly empty) intervals, in this order:
     //   [0,z) cleared | [z,sA) untouched | [sA,eA) data | [eA,f0) untouched | [f0,f1) fillers | [f1,sB) untouched |
     //   [sB,eB) data | [eB,t) untouched | [t,N) cleared                     (rdm_value above, restated per region)
-    // In combining mode nothing is cleared and the fillers stay. Whole 16-byte vectors inside one interval are produced by a
+    // (the cleared ranges and the fillers were written above, under the input loads). In combining mode nothing is cleared and
+    // the fillers stay. Whole 16-byte vectors inside one interval are produced by a
     // loop without per-vector classification; the (at most 9) vectors that straddle a boundary run the byte-wise rule on
     // 16 lanes side by side.
-    const int r_end = g.r0 + g.E;
-    int       B[10];
-    B[0] = 0;
-    B[1] = (c.k0p < g.f0) ? c.k0p : g.f0;
-    B[2] = (g.r0 < g.f0) ? g.r0 : g.f0;
-    B[3] = (g.r0 < g.f0) ? min(g.f0, r_end) : g.f0;
-    B[4] = g.f0;
-    B[5] = g.f1;
-    B[6] = max(g.f1, g.r0 + g.F);
-    B[7] = max(B[6], r_end + g.F);
-    B[8] = c.tail_on ? max(B[7], c.tail_start) : g.N;
-    B[9] = g.N;
     if (tid == 0) {
       int n = 0, last = -1;
 #pragma unroll
@@ -306,37 +348,31 @@ rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t*
       slow_n = n;
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 2; k <= 6; k += 4) {
       const int vs = (B[k] + 15) >> 4, ve = B[k + 1] >> 4;
       if (ve <= vs)
         continue;
       uint4* dst = reinterpret_cast<uint4*>(out);
-      if (k == 2 || k == 6) {
-        // data: the image keeps j mod 16, behind the filler gap it is shifted by gapcut (a multiple of 16)
-        const uint4* srcv = reinterpret_cast<const uint4*>(lds_in + (vs << 4) - img.jbase - ((k == 6) ? img.gapcut : 0)) - vs;
-        if (c.nd) {
-          for (int v = vs + tid; v < ve; v += nt)
-            dst[v] = srcv[v];
-        } else {
-          for (int v = vs + tid; v < ve; v += nt) {
-            const uint4    x = srcv[v], old = dst[v];
-            const uint32_t xw[4] = {x.x, x.y, x.z, x.w}, ow[4] = {old.x, old.y, old.z, old.w};
-            uint32_t       w[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              uint32_t r = 0;
-#pragma unroll
-              for (int b = 0; b < 4; ++b)
-                r |= (uint32_t)(combine((int)(int8_t)(ow[kk] >> (8 * b)), (int)(int8_t)(xw[kk] >> (8 * b))) & 0xff) << (8 * b);
-              w[kk] = r;
-            }
-            dst[v] = make_uint4(w[0], w[1], w[2], w[3]);
-          }
-        }
-      } else if (c.nd && (k == 0 || k == 8 || k == 4)) {
-        const uint32_t f = (k == 4) ? 0x7f7f7f7fu : 0u;
+      // data: the image keeps j mod 16, behind the filler gap it is shifted by gapcut (a multiple of 16)
+      const uint4* srcv = reinterpret_cast<const uint4*>(lds_in + (vs << 4) - img.jbase - ((k == 6) ? img.gapcut : 0)) - vs;
+      if (c.nd) {
         for (int v = vs + tid; v < ve; v += nt)
-          dst[v] = make_uint4(f, f, f, f);
+          dst[v] = srcv[v];
+      } else {
+        for (int v = vs + tid; v < ve; v += nt) {
+          const uint4    x = srcv[v], old = dst[v];
+          const uint32_t xw[4] = {x.x, x.y, x.z, x.w}, ow[4] = {old.x, old.y, old.z, old.w};
+          uint32_t       w[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              r |= (uint32_t)(combine((int)(int8_t)(ow[kk] >> (8 * b)), (int)(int8_t)(xw[kk] >> (8 * b))) & 0xff) << (8 * b);
+            w[kk] = r;
+          }
+          dst[v] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
       }
     }
     __syncthreads();
@@ -358,7 +394,6 @@ rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t*
   const int  nvec    = (g.N + 15) >> 4;
   // A 16-byte output vector that lies entirely inside the data interval (ranks [r0, r0 + E)), or entirely outside every
   // written / cleared / combined region, takes a fast path.
-  const int r_end = g.r0 + g.E;
   for (int v = tid; v < nvec; v += nt) {
     const int j0 = v << 4;
     if (single && vec_out && j0 + 16 <= g.N) {
