@@ -259,6 +259,45 @@ int miphy_dmrs_pusch_estimate_batch(miphy_ctx* ctx, const miphy_pusch_chest_job*
                                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * PUSCH demodulator  --  replaces srsran::pusch_demodulator::demodulate (the block between the channel estimator
+ * and the decoder), i.e. channel_equalizer::equalize + demodulation_mapper::demodulate_soft + descrambling in one pass
+ *   include/srsran/phy/upper/channel_processors/pusch_demodulator.h:40-108
+ *   lib/phy/upper/channel_processors/pusch_demodulator_impl.cpp:31-152, pusch_demodulator_impl.h:74-172
+ *   lib/phy/upper/equalization/channel_equalizer_zf_impl.cpp:123-162, equalize_zf_1xn.h:42-158
+ *   lib/phy/upper/channel_modulation/demodulation_mapper_impl.cpp:34-106 and demodulation_mapper_q*.cpp
+ * One transmit layer (the reference asserts the same, pusch_demodulator_impl.cpp:83), 1..4 receive ports, pi/2-BPSK .. 256QAM,
+ * DM-RS type 1 or 2, no UCI placeholders, no EVM report. One job = one PUSCH transmission; the LLRs are the codeword in the order
+ * the decoder expects (symbol-major, subcarrier ascending). The channel estimate and the noise variance are read where
+ * miphy_dmrs_pusch_estimate_batch wrote them (layer 0 block; noise variance of rx port 0: scalars[scalars_offset + 2]). */
+typedef struct {
+  uint32_t rnti;
+  uint32_t n_id;           /* scrambling identity, c_init = rnti * 2^15 + n_id */
+  uint8_t  mod;            /* bits per symbol: 1 (pi/2-BPSK), 2, 4, 6, 8 */
+  uint8_t  nof_rx_ports;   /* 1..4, port p is grid port rx_ports[p] */
+  uint8_t  start_symbol;
+  uint8_t  nof_symbols;
+  uint8_t  dmrs_type;      /* 1 or 2 */
+  uint8_t  nof_cdm_groups_without_data;
+  uint8_t  ce_nof_symbols; /* symbols per (port) block of the channel estimate = first_symbol + nof_symbols of the estimator job */
+  uint8_t  reserved;
+  uint8_t  rx_ports[4];
+  uint16_t dmrs_symbols_mask; /* bit l = OFDM symbol l carries DM-RS */
+  uint16_t grid_nof_prb;
+  uint32_t nof_llr;        /* codeword length; must equal miphy_pusch_demod_nof_llr() */
+  uint64_t rb_mask[5];
+  uint64_t grid_offset;    /* cf_t offset of grid port 0: [port][14][grid_nof_prb*12] */
+  uint64_t ce_offset;      /* cf_t offset of the channel estimate: [rx port][ce_nof_symbols][grid_nof_prb*12] */
+  uint64_t scalars_offset; /* float offset of the estimator scalars of this transmission */
+  uint64_t llr_offset;     /* int8 offset of the output codeword */
+} miphy_pusch_demod_job;
+
+/* Number of LLRs the allocation of `job` produces (data REs x mod); 0 on an invalid job. Host function. */
+uint32_t miphy_pusch_demod_nof_llr(const miphy_pusch_demod_job* job);
+int miphy_pusch_demodulate_batch(miphy_ctx* ctx, const miphy_pusch_demod_job* jobs, int jobs_on_device, uint32_t n,
+                                 const float* grid /* device cf_t */, const float* ce /* device cf_t */, const float* scalars /* device */,
+                                 int8_t* llr_out /* device */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Polar code chains  --  replace the chain of srsran::polar_code::set + polar_allocator::allocate + polar_encoder::encode
  * + polar_rate_matcher::rate_match (transmit) and polar_rate_dematcher::rate_dematch + polar_decoder::decode +
  * polar_deallocator::deallocate (receive), as wired in tests/unittests/phy/upper/channel_coding/polar/polar_chain_test.cpp:156-210

@@ -26,7 +26,12 @@ def noisy(cw, sigma):
     return np.round(np.clip(4 * y, -20, 20) / 20 * 120).astype(np.int8)
 
 
+ONLY = set(sys.argv[1:])  # optional: names of the fixtures to (re)write; the random stream is consumed identically either way
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrays)
     print("%-28s %7.1f KiB" % (name, os.path.getsize(path) / 1024))
@@ -169,3 +174,46 @@ for i in range(6):
     pay = rng.integers(0, 2, 32, dtype=np.uint8)
     d["pbch_meta_%d" % i], d["pbch_pay_%d" % i], d["pbch_out_%d" % i] = np.array(a, dtype=np.int64), pay, O.r_pbch_encode(*a, pay)
 save("polar", **d)
+
+# ------------------------------------------------------------------ PUSCH demodulator: soft demapper alone + whole block
+d = {}
+for i, mod in enumerate((1, 2, 4, 6, 8)):
+    n = 1200 + 3  # not a multiple of the AVX2 batch: the reference's scalar tail runs too
+    bits = rng.integers(0, 2, n * mod, dtype=np.uint8)
+    x = O.nr_modulate(bits, mod) + ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.12).astype(np.complex64)
+    nv = rng.uniform(0.004, 0.3, n).astype(np.float32)
+    nv[::97], nv[5::101], nv[11::107] = 0, np.inf, -1  # the reference maps all of these to LLR 0
+    d["dm_sym_%d" % i], d["dm_nv_%d" % i], d["dm_llr_%d" % i] = x, nv, O.r_demodulate_soft(mod, x, nv)
+    d["dm_meta_%d" % i] = np.array([mod], dtype=np.int64)
+for i, (mod, ports, cdm, nprb_grid, start, nof, dsyms) in enumerate([(8, 1, 2, 12, 0, 14, (2,)), (6, 2, 1, 10, 1, 13, (2, 11)), (4, 4, 2, 8, 2, 10, (3, 7)),
+                                                                      (2, 1, 1, 11, 0, 14, (2, 7, 11)), (1, 2, 2, 6, 0, 12, (2,)),
+                                                                      (8, 2, 2, 9, 0, 14, (2, 11))]):
+    nsc = nprb_grid * 12
+    rb = (rng.uniform(size=nprb_grid) < 0.8).astype(np.uint8)
+    rb[0] = 1
+    dm = np.zeros(14, np.uint8)
+    dm[list(dsyms)] = 1
+    n_re = O.pusch_nof_re(start, nof, dm, 0, cdm, rb)
+    bits = rng.integers(0, 2, n_re * mod, dtype=np.uint8)
+    h = ((rng.standard_normal((ports, 1, nsc)) + 1j * rng.standard_normal((ports, 1, nsc))) * 0.7).astype(np.complex64) * np.ones((1, 14, 1), np.complex64)
+    grid = ((rng.standard_normal((ports, 14, nsc)) + 1j * rng.standard_normal((ports, 14, nsc))) * 0.05).astype(np.complex64)
+    x = O.nr_modulate(bits, mod)
+    k = 0
+    for sy in range(start, start + nof):  # place the symbols where the demodulator will look for them
+        for r in range(nprb_grid):
+            if not rb[r]:
+                continue
+            for q in range(12):
+                if dm[sy] and (q % 2) < cdm:
+                    continue
+                grid[:, sy, r * 12 + q] += h[:, sy, r * 12 + q] * x[k]
+                k += 1
+    assert k == n_re
+    ce = (h + ((rng.standard_normal(h.shape) + 1j * rng.standard_normal(h.shape)) * 0.01)).astype(np.complex64)
+    ce[0, start, 5] = 0  # a dead estimate: with one port the reference outputs LLR 0 there
+    rnti, n_id, noise_var = int(rng.integers(1, 65536)), int(rng.integers(0, 1024)), 0.005
+    d["grid_%d" % i], d["ce_%d" % i], d["rb_%d" % i], d["dm_%d" % i] = grid, ce, rb, dm
+    d["meta_%d" % i] = np.array([rnti, n_id, mod, start, nof, cdm, noise_var], dtype=np.float64)
+    d["llr_%d" % i] = O.r_pusch_demodulate(rnti, n_id, mod, start, nof, dm, 0, cdm, rb, grid, ce, noise_var)
+    d["bits_%d" % i] = bits
+save("pusch_demod", **d)

@@ -1543,3 +1543,159 @@ int orc_polar_scl_decode(unsigned K, unsigned E, unsigned nMax, int ibil, unsign
   free(P < Q ? P : Q);
   return pm;
 }
+
+/* ================================================================================================= PUSCH demodulator
+ * pusch_demodulator_impl.cpp:31-152 (RE extraction pusch_demodulator_impl.h:74-172, equalise, soft-demap, descramble),
+ * channel_equalizer_zf_impl.cpp:123-162 + equalize_zf_1xn.h:42-158 (one transmit layer, any number of ports),
+ * demodulation_mapper_impl.cpp:34-106 and demodulation_mapper_{qpsk,qam16,qam64,qam256}.cpp (AVX2 arithmetic: reciprocal noise by
+ * an exact division, interval index = floor(x * (1/width)), (slope*x + intercept) * rcp_noise, quantisation = scale, clip to
+ * +-120, round to nearest even: avx2_helpers.h:103-157,164-236), descrambling with c_init = rnti * 2^15 + n_id.
+ * Floating point: every operation is a single correctly rounded IEEE operation in the order written here (no contraction:
+ * this file is compiled for baseline x86-64 without FMA); the reference's AVX2 equaliser uses the approximate _mm256_rcp_ps and
+ * its build may contract a*b+c, so reference LLRs can differ by one quantisation step (stated tolerance: +-1, see the tests). */
+#include "../srsran_project_23.5_amd/csrc/tables/nr_demod_tables.h"
+
+static int8_t demod_quantize(float v, float range_limit)
+{
+  float s = v * (120.0f / range_limit);
+  if (s > 120.0f)
+    s = 120.0f;
+  if (s < -120.0f)
+    s = -120.0f;
+  float r = rintf(s); /* round to nearest even */
+  if (!(r <= 120.0f && r >= -120.0f))
+    return 0; /* NaN */
+  return (int8_t)r;
+}
+
+static float demod_interval(float x, float rcp_noise, float rcp_width, int count, const float* slope, const float* intercept)
+{
+  int idx = (int)floorf(x * rcp_width) + count / 2;
+  idx     = idx < 0 ? 0 : (idx > count - 1 ? count - 1 : idx);
+  float t = slope[idx] * x;
+  t       = t + intercept[idx];
+  return t * rcp_noise;
+}
+
+/* One equalised symbol -> mod LLRs (before descrambling). sym_idx only matters for pi/2-BPSK. */
+static void demod_symbol(int mod, float re, float im, float nvar, unsigned sym_idx, int8_t* out)
+{
+  if (mod == 1) { /* pi/2-BPSK, demodulation_mapper_impl.cpp:34-81 */
+    float l = 0.f;
+    if (nvar > 0) {
+      float a = (sym_idx & 1u) ? im : re, b = (sym_idx & 1u) ? -re : im;
+      l       = 2.0f * (float)M_SQRT2 * (a + b) / nvar;
+    }
+    /* scalar quantiser of the reference for this modulation (log_likelihood_ratio.cpp:87-96) */
+    float c = l;
+    if (fabsf(l) > 24.f)
+      c = copysignf(24.f, l);
+    out[0] = (nvar > 0) ? (int8_t)roundf(c / 24.f * 120.f) : 0;
+    return;
+  }
+  float rcp = (nvar > 0) ? 1.0f / nvar : 0.0f;
+  float x[2] = {re, im};
+  if (mod == 2) {
+    for (int d = 0; d < 2; ++d)
+      out[d] = demod_quantize((NR_DEMOD_QPSK_GAIN * x[d]) * rcp, 24.f);
+  } else if (mod == 4) {
+    for (int d = 0; d < 2; ++d) {
+      float first  = NR_DEMOD_QAM16_GAIN * x[d];
+      float second = 2.0f * first - copysignf(0.8f, x[d]);
+      float l01    = (fabsf(x[d]) > NR_DEMOD_QAM16_THRESHOLD) ? second : first;
+      float l23    = 0.8f - fabsf(first);
+      out[d]       = demod_quantize(l01 * rcp, 20.f);
+      out[2 + d]   = demod_quantize(l23 * rcp, 20.f);
+    }
+  } else if (mod == 6) {
+    for (int d = 0; d < 2; ++d) {
+      out[d]     = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM64_B0_RCP_WIDTH, NR_DEMOD_QAM64_B0_COUNT, NR_DEMOD_QAM64_B0_SLOPE, NR_DEMOD_QAM64_B0_INTERCEPT), 20.f);
+      out[2 + d] = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM64_B1_RCP_WIDTH, NR_DEMOD_QAM64_B1_COUNT, NR_DEMOD_QAM64_B1_SLOPE, NR_DEMOD_QAM64_B1_INTERCEPT), 20.f);
+      out[4 + d] = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM64_B2_RCP_WIDTH, NR_DEMOD_QAM64_B2_COUNT, NR_DEMOD_QAM64_B2_SLOPE, NR_DEMOD_QAM64_B2_INTERCEPT), 20.f);
+    }
+  } else {
+    for (int d = 0; d < 2; ++d) {
+      out[d]     = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM256_B0_RCP_WIDTH, NR_DEMOD_QAM256_B0_COUNT, NR_DEMOD_QAM256_B0_SLOPE, NR_DEMOD_QAM256_B0_INTERCEPT), 20.f);
+      out[2 + d] = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM256_B1_RCP_WIDTH, NR_DEMOD_QAM256_B1_COUNT, NR_DEMOD_QAM256_B1_SLOPE, NR_DEMOD_QAM256_B1_INTERCEPT), 20.f);
+      out[4 + d] = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM256_B2_RCP_WIDTH, NR_DEMOD_QAM256_B2_COUNT, NR_DEMOD_QAM256_B2_SLOPE, NR_DEMOD_QAM256_B2_INTERCEPT), 20.f);
+      out[6 + d] = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM256_B3_RCP_WIDTH, NR_DEMOD_QAM256_B3_COUNT, NR_DEMOD_QAM256_B3_SLOPE, NR_DEMOD_QAM256_B3_INTERCEPT), 20.f);
+    }
+  }
+}
+
+void orc_demodulate_soft(int mod, unsigned nsym, const float* symbols, const float* noise_vars, int8_t* llr)
+{
+  for (unsigned i = 0; i < nsym; ++i)
+    demod_symbol(mod, symbols[2 * i], symbols[2 * i + 1], noise_vars[i], i, llr + (size_t)i * (unsigned)mod);
+}
+
+/* 12-bit mask of the resource elements of a PRB that carry DM-RS (dmrs_mapping.h:76-92). */
+static unsigned dmrs_prb_mask(int type2, unsigned nof_cdm_groups_without_data)
+{
+  unsigned m = 0;
+  for (unsigned k = 0; k < 12; ++k) {
+    unsigned set = !type2 ? ((k % 2) < nof_cdm_groups_without_data) : ((k % 6) < 2 * nof_cdm_groups_without_data);
+    m |= set << k;
+  }
+  return m;
+}
+
+int orc_pusch_demodulate(unsigned rnti, unsigned n_id, int mod, unsigned start_symbol, unsigned nof_symbols, const uint8_t* dmrs_symbols_mask,
+                         int dmrs_type2, unsigned nof_cdm_groups_without_data, const uint8_t* rb_mask, unsigned nof_prb_grid,
+                         unsigned nof_rx_ports, const float* grid, const float* ce, unsigned ce_nof_symbols, float noise_var, int8_t* llr_out,
+                         float* eq_out, float* nvar_out)
+{
+  const unsigned nsc   = nof_prb_grid * 12;
+  const unsigned dmask = dmrs_prb_mask(dmrs_type2, nof_cdm_groups_without_data);
+  unsigned       n     = 0;
+  for (unsigned sy = start_symbol; sy < start_symbol + nof_symbols; ++sy) {
+    for (unsigned rb = 0; rb < nof_prb_grid; ++rb) {
+      if (!rb_mask[rb])
+        continue;
+      for (unsigned k = 0; k < 12; ++k) {
+        if (dmrs_symbols_mask[sy] && ((dmask >> k) & 1u))
+          continue;
+        const unsigned sc = rb * 12 + k;
+        /* equalize_zf_1xn.h:120-158 */
+        float ch_mod_sq = 0.f, acc_re = 0.f, acc_im = 0.f;
+        for (unsigned p = 0; p < nof_rx_ports; ++p) {
+          const float* y = grid + 2 * ((size_t)(p * 14 + sy) * nsc + sc);
+          const float* h = ce + 2 * ((size_t)(p * ce_nof_symbols + sy) * nsc + sc);
+          float        t = h[0] * h[0];
+          float        u = h[1] * h[1];
+          ch_mod_sq      = ch_mod_sq + (t + u);
+          /* y * conj(h) */
+          float a = y[0] * h[0], b = y[1] * h[1], c = y[1] * h[0], d = y[0] * h[1];
+          acc_re  = acc_re + (a + b);
+          acc_im  = acc_im + (c - d);
+        }
+        const float d_pinv = 1.0f * ch_mod_sq;
+        float       z_re = 0.f, z_im = 0.f, nv = INFINITY;
+        const float rcpd = 1.0f / d_pinv;
+        const float v    = rcpd * (noise_var / 1.0f);
+        if (d_pinv > 0.f && d_pinv < INFINITY && v > 0.f && v < INFINITY) {
+          z_re = acc_re * rcpd;
+          z_im = acc_im * rcpd;
+          nv   = v;
+        }
+        if (eq_out) {
+          eq_out[2 * n]     = z_re;
+          eq_out[2 * n + 1] = z_im;
+        }
+        if (nvar_out)
+          nvar_out[n] = nv;
+        demod_symbol(mod, z_re, z_im, nv, n, llr_out + (size_t)n * (unsigned)mod);
+        ++n;
+      }
+    }
+  }
+  /* descrambling (pusch_demodulator_impl.cpp:99-152, no UCI placeholders) */
+  const unsigned nbits = n * (unsigned)mod;
+  uint8_t*       c     = (uint8_t*)malloc(nbits ? nbits : 1);
+  orc_gold_sequence((rnti << 15) + n_id, 0, nbits, c);
+  for (unsigned i = 0; i < nbits; ++i)
+    if (c[i])
+      llr_out[i] = (int8_t)-llr_out[i];
+  free(c);
+  return (int)nbits;
+}

@@ -134,6 +134,19 @@ int orc_polar_scl_decode(unsigned K, unsigned E, unsigned nMax, int ibil, unsign
 /* PBCH (pbch_encoder_impl.cpp:41-190): payload 32 bytes (first 24 used) -> 864 rate-matched bits. */
 int orc_pbch_encode(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, unsigned sfn, unsigned k_ssb, const uint8_t* payload, uint8_t* out);
 
+
+/* ------------------------------------------------------------------------------------------------ PUSCH demodulator
+ * Soft demapper alone: symbols cf_t, one noise variance per symbol, mod in {1 (pi/2-BPSK), 2, 4, 6, 8} -> nsym*mod int8 LLRs. */
+void orc_demodulate_soft(int mod, unsigned nsym, const float* symbols, const float* noise_vars, int8_t* llr);
+/* Whole demodulator for one transmit layer: RE extraction (DM-RS symbols keep the REs outside the CDM groups without data),
+ * ZF/MRC equalisation over nof_rx_ports, soft demapping, descrambling (c_init = rnti*2^15 + n_id). grid: [port][14][nsc] cf_t,
+ * ce: [port][ce_nof_symbols][nsc] cf_t (absolute symbol index), noise_var: estimator's value for port 0. Returns the number of
+ * LLRs written. eq_out / nvar_out (optional): equalised symbols and post-equalisation noise variances. */
+int orc_pusch_demodulate(unsigned rnti, unsigned n_id, int mod, unsigned start_symbol, unsigned nof_symbols, const uint8_t* dmrs_symbols_mask,
+                         int dmrs_type2, unsigned nof_cdm_groups_without_data, const uint8_t* rb_mask, unsigned nof_prb_grid,
+                         unsigned nof_rx_ports, const float* grid, const float* ce, unsigned ce_nof_symbols, float noise_var, int8_t* llr_out,
+                         float* eq_out, float* nvar_out);
+
 #ifdef __cplusplus
 }
 #endif

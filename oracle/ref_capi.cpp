@@ -17,6 +17,8 @@
 #include "srsran/phy/lower/modulation/modulation_factories.h"
 #include "srsran/phy/support/support_factories.h"
 #include "srsran/phy/upper/channel_estimation.h"
+#include "srsran/phy/upper/channel_modulation/channel_modulation_factories.h"
+#include "srsran/phy/upper/equalization/equalization_factories.h"
 #include "srsran/phy/upper/sequence_generators/sequence_generator_factories.h"
 #include "srsran/phy/upper/signal_processors/signal_processor_factories.h"
 #include "lib/phy/generic_functions/dft_processor_generic_impl.h"
@@ -596,6 +598,121 @@ int ref_dmrs_pusch_estimate(unsigned       numerology,
       sc[3]     = ce.get_snr(p, ly);
       sc[4]     = (float)ce.get_time_alignment(p, ly).to_seconds();
     }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- PUSCH demodulator
+static modulation_scheme mod_from_bits(int mod)
+{
+  switch (mod) {
+    case 1:
+      return modulation_scheme::PI_2_BPSK;
+    case 2:
+      return modulation_scheme::QPSK;
+    case 4:
+      return modulation_scheme::QAM16;
+    case 6:
+      return modulation_scheme::QAM64;
+    default:
+      return modulation_scheme::QAM256;
+  }
+}
+
+// Soft demapper alone (demodulation_mapper_impl.cpp:83-106).
+int ref_demodulate_soft(int mod, unsigned nsym, const float* symbols, const float* noise_vars, int8_t* llr)
+{
+  auto demod = create_channel_modulation_sw_factory()->create_demodulation_mapper();
+  std::vector<log_likelihood_ratio> out(size_t(nsym) * mod);
+  demod->demodulate_soft(out,
+                         span<const cf_t>(reinterpret_cast<const cf_t*>(symbols), nsym),
+                         span<const float>(noise_vars, nsym),
+                         mod_from_bits(mod));
+  for (size_t i = 0; i != out.size(); ++i) {
+    llr[i] = out[i].to_value_type();
+  }
+  return 0;
+}
+
+// Modulation mapper (TX side, modulation_mapper_impl.cpp) - only used to build stimuli. bits: one bit per byte.
+int ref_modulate(int mod, unsigned nsym, const uint8_t* bits, float* symbols)
+{
+  auto               mapper = create_channel_modulation_sw_factory()->create_modulation_mapper();
+  dynamic_bit_buffer packed(nsym * mod);
+  for (unsigned i = 0; i != nsym * (unsigned)mod; ++i) {
+    packed.insert(bits[i] & 1u, i, 1);
+  }
+  mapper->modulate(span<cf_t>(reinterpret_cast<cf_t*>(symbols), nsym), packed, mod_from_bits(mod));
+  return 0;
+}
+
+// pusch_demodulator_impl::demodulate, one transmit layer. grid_in: [nof_rx_ports][14][nsc]; ce_in: [nof_rx_ports][ce_nof_symbols][nsc].
+int ref_pusch_demodulate(unsigned       rnti,
+                         unsigned       n_id,
+                         int            mod,
+                         unsigned       start_symbol,
+                         unsigned       nof_symbols,
+                         const uint8_t* dmrs_symbols_mask,
+                         int            dmrs_type2,
+                         unsigned       nof_cdm_groups_without_data,
+                         const uint8_t* rb_mask,
+                         unsigned       nof_prb_grid,
+                         unsigned       nof_rx_ports,
+                         const float*   grid_in,
+                         const float*   ce_in,
+                         unsigned       ce_nof_symbols,
+                         float          noise_var,
+                         int8_t*        llr_out,
+                         unsigned       nof_llr)
+{
+  auto dem = create_pusch_demodulator_factory_sw(
+                 create_channel_equalizer_factory_zf(), create_channel_modulation_sw_factory(), create_pseudo_random_generator_sw_factory())
+                 ->create();
+  unsigned nsc  = nof_prb_grid * 12;
+  auto     grid = create_resource_grid(nof_rx_ports, 14, nsc);
+  for (unsigned p = 0; p != nof_rx_ports; ++p) {
+    for (unsigned l = 0; l != 14; ++l) {
+      grid->put(p, l, 0, span<const cf_t>(reinterpret_cast<const cf_t*>(grid_in) + (size_t(p) * 14 + l) * nsc, nsc));
+    }
+  }
+  channel_estimate::channel_estimate_dimensions dims;
+  dims.nof_prb       = nof_prb_grid;
+  dims.nof_symbols   = ce_nof_symbols;
+  dims.nof_rx_ports  = nof_rx_ports;
+  dims.nof_tx_layers = 1;
+  channel_estimate ce(dims);
+  for (unsigned p = 0; p != nof_rx_ports; ++p) {
+    for (unsigned l = 0; l != ce_nof_symbols; ++l) {
+      span<cf_t> v = ce.get_symbol_ch_estimate(l, p, 0);
+      std::memcpy(v.data(), ce_in + 2 * ((size_t(p) * ce_nof_symbols + l) * nsc), sizeof(cf_t) * nsc);
+    }
+    ce.set_noise_variance(noise_var, p, 0);
+  }
+  pusch_demodulator::configuration cfg;
+  cfg.rnti    = rnti;
+  cfg.rb_mask = bounded_bitset<MAX_RB>(nof_prb_grid);
+  for (unsigned r = 0; r != nof_prb_grid; ++r) {
+    if (rb_mask[r]) {
+      cfg.rb_mask.set(r);
+    }
+  }
+  cfg.modulation         = mod_from_bits(mod);
+  cfg.start_symbol_index = start_symbol;
+  cfg.nof_symbols        = nof_symbols;
+  for (unsigned l = 0; l != 14; ++l) {
+    cfg.dmrs_symb_pos[l] = dmrs_symbols_mask[l] != 0;
+  }
+  cfg.dmrs_config_type            = dmrs_type2 ? dmrs_type::TYPE2 : dmrs_type::TYPE1;
+  cfg.nof_cdm_groups_without_data = nof_cdm_groups_without_data;
+  cfg.n_id                        = n_id;
+  cfg.nof_tx_layers               = 1;
+  for (unsigned p = 0; p != nof_rx_ports; ++p) {
+    cfg.rx_ports.push_back(p);
+  }
+  std::vector<log_likelihood_ratio> out(nof_llr);
+  dem->demodulate(out, *grid, ce, cfg);
+  for (unsigned i = 0; i != nof_llr; ++i) {
+    llr_out[i] = out[i].to_value_type();
   }
   return 0;
 }

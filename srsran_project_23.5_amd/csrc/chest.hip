@@ -6,6 +6,7 @@
 // Everything stays on chip: Gold-sequence pilots are generated into LDS (28 bits per LFSR step), the LS estimates and the
 // IDFT buffer live in LDS, HBM sees the DM-RS resource elements once and the estimate once.
 #include "fft_device.h"
+#include "gold_device.h"
 #include "miphy_ext.h"
 #include <cmath>
 #include <cstdlib>
@@ -15,56 +16,6 @@ namespace {
 constexpr int CE_DFT = 4096;                       // port_channel_estimator_average_impl::DFT_SIZE
 constexpr int HALF_CP = ((144 / 2) * CE_DFT) / 2048; // 144
 constexpr int MAX_PILOTS = 275 * 6;
-
-// Gold sequence of TS 38.211 5.2.1 produced 28 bits per step: x(n+31+k) only depends on x(n+k), x(n+3+k) (x1) or
-// x(n+k..n+3+k) (x2) for k <= 27, so a 31-bit window yields the next 28 bits with shifts and XORs.
-__device__ __forceinline__ uint32_t x1_step28(uint32_t s)
-{ // s: bits n..n+30 ; returns bits n+31..n+58 in [27:0]
-  return ((s >> 3) ^ s) & 0x0fffffffu;
-}
-__device__ __forceinline__ uint32_t x2_step28(uint32_t s)
-{
-  return ((s >> 3) ^ (s >> 2) ^ (s >> 1) ^ s) & 0x0fffffffu;
-}
-
-// State of both LFSRs after the Nc = 1600 warm-up, as 31-bit windows. x1 starts from a constant, so its state is a
-// constant; x2's state is linear in c_init: the XOR of one precomputed column per set bit of c_init.
-struct gold_jump {
-  uint32_t x1_1600;
-  uint32_t x2_col[31];
-};
-
-__host__ __device__ inline void gold_jump_init(gold_jump& g)
-{
-  auto adv = [](uint32_t s1, bool is_x2) {
-    for (int i = 0; i < 1600; ++i) {
-      const uint32_t b = is_x2 ? (((s1 >> 3) ^ (s1 >> 2) ^ (s1 >> 1) ^ s1) & 1u) : (((s1 >> 3) ^ s1) & 1u);
-      s1               = (s1 >> 1) | (b << 30);
-    }
-    return s1;
-  };
-  g.x1_1600 = adv(1u, false);
-  for (int k = 0; k < 31; ++k)
-    g.x2_col[k] = adv(1u << k, true);
-}
-
-// Head of one LFSR sequence: its first `head` (<= 31) 32-bit words from the 31-bit state window `s` (28 bits per step).
-__device__ __forceinline__ void lfsr_head(uint32_t s, bool is_x2, int head, uint32_t* w)
-{
-  uint64_t acc  = 0;
-  int      have = 0, k = 0;
-  while (k < head) {
-    acc |= (uint64_t)(s & 0x0fffffffu) << have;
-    have += 28;
-    if (have >= 32) {
-      w[k++] = (uint32_t)acc;
-      acc >>= 32;
-      have -= 32;
-    }
-    const uint32_t n = is_x2 ? x2_step28(s) : x1_step28(s);
-    s                = ((s >> 28) | (n << 3)) & 0x7fffffffu;
-  }
-}
 
 // Gold sequences c(0..nbits-1) of `nseq` initial values (one per DM-RS symbol), bit-packed LSB-first, 104 words apart in
 // `out`. Cooperative over the workgroup: 2*nseq lanes produce the 31-word heads of x1/x2; the Frobenius identity
@@ -375,11 +326,9 @@ extern "C" int miphy_dmrs_pusch_estimate_batch(miphy_ctx*                   ctx,
     return rc;
   const size_t lds = fft_lds_bytes(CE_DFT) + (size_t)MAX_PILOTS * 8 + 4 * 104 * 4 + 4 * 208 * 4 + 276 * 2 + 64 + 64;
   if (!ctx->ext->d_gold) {
-    gold_jump gj;
-    gold_jump_init(gj);
-    MIPHY_HIP_CHECK(hipMalloc(&ctx->ext->d_gold, sizeof(gj)));
-    MIPHY_HIP_CHECK(hipMemcpy(ctx->ext->d_gold, &gj, sizeof(gj), hipMemcpyHostToDevice));
-    ctx->ext->to_free.push_back(ctx->ext->d_gold);
+    int rc = miphy_get_gold_tables(ctx, nullptr);
+    if (rc)
+      return rc;
   }
   // Small batches cannot fill 256 CUs with one workgroup per (job, port, layer): split the broadcast store over symbol groups.
   static const char* genv = getenv("MIPHY_CHEST_GROUPS");

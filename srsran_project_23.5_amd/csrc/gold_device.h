@@ -1,0 +1,133 @@
+// Gold sequence (TS 38.211 5.2.1) helpers shared by the DM-RS estimator and the PUSCH demodulator.
+#pragma once
+#include "miphy_internal.h"
+
+// Gold sequence of TS 38.211 5.2.1 produced 28 bits per step: x(n+31+k) only depends on x(n+k), x(n+3+k) (x1) or
+// x(n+k..n+3+k) (x2) for k <= 27, so a 31-bit window yields the next 28 bits with shifts and XORs.
+__device__ __forceinline__ uint32_t x1_step28(uint32_t s)
+{ // s: bits n..n+30 ; returns bits n+31..n+58 in [27:0]
+  return ((s >> 3) ^ s) & 0x0fffffffu;
+}
+__device__ __forceinline__ uint32_t x2_step28(uint32_t s)
+{
+  return ((s >> 3) ^ (s >> 2) ^ (s >> 1) ^ s) & 0x0fffffffu;
+}
+
+// State of both LFSRs after the Nc = 1600 warm-up, as 31-bit windows. x1 starts from a constant, so its state is a
+// constant; x2's state is linear in c_init: the XOR of one precomputed column per set bit of c_init.
+struct gold_jump {
+  uint32_t x1_1600;
+  uint32_t x2_col[31];
+};
+
+__host__ __device__ inline void gold_jump_init(gold_jump& g)
+{
+  auto adv = [](uint32_t s1, bool is_x2) {
+    for (int i = 0; i < 1600; ++i) {
+      const uint32_t b = is_x2 ? (((s1 >> 3) ^ (s1 >> 2) ^ (s1 >> 1) ^ s1) & 1u) : (((s1 >> 3) ^ s1) & 1u);
+      s1               = (s1 >> 1) | (b << 30);
+    }
+    return s1;
+  };
+  g.x1_1600 = adv(1u, false);
+  for (int k = 0; k < 31; ++k)
+    g.x2_col[k] = adv(1u << k, true);
+}
+
+// Head of one LFSR sequence: its first `head` (<= 31) 32-bit words from the 31-bit state window `s` (28 bits per step).
+__device__ __forceinline__ void lfsr_head(uint32_t s, bool is_x2, int head, uint32_t* w)
+{
+  uint64_t acc  = 0;
+  int      have = 0, k = 0;
+  while (k < head) {
+    acc |= (uint64_t)(s & 0x0fffffffu) << have;
+    have += 28;
+    if (have >= 32) {
+      w[k++] = (uint32_t)acc;
+      acc >>= 32;
+      have -= 32;
+    }
+    const uint32_t n = is_x2 ? x2_step28(s) : x1_step28(s);
+    s                = ((s >> 28) | (n << 3)) & 0x7fffffffu;
+  }
+}
+
+
+// Jump-ahead: the 31-bit window s (bit i = x(n+i)) advances by one position through a linear map M; pow[k] holds the columns
+// of M^(2^k), so any offset costs one matrix-vector product (31 conditional XORs) per set bit of the offset.
+constexpr int GOLD_POW = 26; // offsets below 2^26
+struct gold_tables {
+  gold_jump j; // state after the Nc = 1600 warm-up (first member: the estimator only needs this part)
+  uint32_t  x1_pow[GOLD_POW][31];
+  uint32_t  x2_pow[GOLD_POW][31];
+};
+
+__host__ __device__ inline uint32_t gold_mat_apply(const uint32_t* cols, uint32_t v)
+{
+  uint32_t r = 0;
+  for (int i = 0; i < 31; ++i)
+    r ^= ((v >> i) & 1u) ? cols[i] : 0u;
+  return r;
+}
+
+inline void gold_tables_init(gold_tables& t)
+{
+  gold_jump_init(t.j);
+  for (int i = 0; i < 31; ++i) {
+    const uint32_t e = 1u << i;
+    t.x1_pow[0][i]   = (e >> 1) | ((((e >> 3) ^ e) & 1u) << 30);
+    t.x2_pow[0][i]   = (e >> 1) | ((((e >> 3) ^ (e >> 2) ^ (e >> 1) ^ e) & 1u) << 30);
+  }
+  for (int k = 1; k < GOLD_POW; ++k)
+    for (int i = 0; i < 31; ++i) {
+      t.x1_pow[k][i] = gold_mat_apply(t.x1_pow[k - 1], t.x1_pow[k - 1][i]);
+      t.x2_pow[k][i] = gold_mat_apply(t.x2_pow[k - 1], t.x2_pow[k - 1][i]);
+    }
+}
+
+// 31-bit windows of x1 / x2 at sequence position `offset` of c(n) (i.e. LFSR position 1600 + offset).
+__device__ __forceinline__ uint32_t gold_state(const gold_tables& t, bool is_x2, uint32_t c_init, uint32_t offset)
+{
+  uint32_t st = t.j.x1_1600;
+  if (is_x2) {
+    st = 0;
+    for (int k = 0; k < 31; ++k)
+      st ^= ((c_init >> k) & 1u) ? t.j.x2_col[k] : 0u;
+  }
+  for (int k = 0; k < GOLD_POW; ++k)
+    if ((offset >> k) & 1u)
+      st = gold_mat_apply(is_x2 ? t.x2_pow[k] : t.x1_pow[k], st);
+  return st;
+}
+
+// c(offset .. offset + nbits - 1), bit-packed LSB first into out[0 .. nwords), for ONE long sequence, cooperatively over the
+// workgroup: two lanes produce the 31-word heads, then the word recurrences (see chest.hip) give 28 words per step and LFSR.
+// w1 / w2: LDS scratch of nwords words each; out may alias w1.
+__device__ __forceinline__ void gold_long_block(const gold_tables& t, uint32_t c_init, uint32_t offset, int nwords, uint32_t* w1, uint32_t* w2,
+                                                uint32_t* out, int tid, int nt)
+{
+  const int head = nwords < 31 ? nwords : 31;
+  if (tid < 2) {
+    const bool is_x2 = tid & 1;
+    lfsr_head(gold_state(t, is_x2, c_init, offset), is_x2, head, is_x2 ? w2 : w1);
+  }
+  __syncthreads();
+  for (int i0 = 31; i0 < nwords; i0 += 28) {
+    if (tid < 56) {
+      const int j = tid % 28, i = i0 + j;
+      if (i < nwords) {
+        if (tid < 28)
+          w1[i] = w1[i - 28] ^ w1[i - 31];
+        else
+          w2[i] = w2[i - 28] ^ w2[i - 29] ^ w2[i - 30] ^ w2[i - 31];
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < nwords; i += nt)
+    out[i] = w1[i] ^ w2[i];
+  __syncthreads();
+}
+
+// Device copy of the tables, created on first use and cached in the context.
+int miphy_get_gold_tables(miphy_ctx* ctx, const gold_tables** out);

@@ -181,3 +181,26 @@ int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out)
   *out = ctx->d_work;
   return MIPHY_OK;
 }
+
+#include "gold_device.h"
+#include "miphy_ext.h"
+int miphy_get_gold_tables(miphy_ctx* ctx, const gold_tables** out)
+{
+  if (!ctx->ext->d_gold) {
+    gold_tables* t = new gold_tables;
+    gold_tables_init(*t);
+    hipError_t e = hipMalloc(&ctx->ext->d_gold, sizeof(gold_tables));
+    if (e == hipSuccess)
+      e = hipMemcpy(ctx->ext->d_gold, t, sizeof(gold_tables), hipMemcpyHostToDevice);
+    delete t;
+    if (e != hipSuccess) {
+      miphy_set_error("gold tables: %s", hipGetErrorString(e));
+      ctx->ext->d_gold = nullptr;
+      return MIPHY_EHIP;
+    }
+    ctx->ext->to_free.push_back(ctx->ext->d_gold);
+  }
+  if (out)
+    *out = (const gold_tables*)ctx->ext->d_gold;
+  return MIPHY_OK;
+}

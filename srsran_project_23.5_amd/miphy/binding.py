@@ -54,6 +54,10 @@ def lib():
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_pbch_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         l.miphy_crc_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_pusch_demodulate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p]
+        l.miphy_pusch_demod_nof_llr.argtypes = [C.c_void_p]
+        l.miphy_pusch_demod_nof_llr.restype = C.c_uint32
         _lib = l
     return _lib
 
@@ -96,6 +100,21 @@ PuschChestJob = np.dtype([("numerology", np.uint32), ("slot_in_frame", np.uint32
                           ("scalars_offset", np.uint64)], align=True)
 assert PuschChestJob.itemsize == 96, PuschChestJob.itemsize
 assert PuschChestJob.fields["rb_mask"][1] == 32 and PuschChestJob.fields["symbols_mask"][1] == 28
+
+
+# Mirrors miphy_pusch_demod_job.
+PuschDemodJob = np.dtype([("rnti", np.uint32), ("n_id", np.uint32), ("mod", np.uint8), ("nof_rx_ports", np.uint8), ("start_symbol", np.uint8),
+                          ("nof_symbols", np.uint8), ("dmrs_type", np.uint8), ("nof_cdm_groups_without_data", np.uint8),
+                          ("ce_nof_symbols", np.uint8), ("reserved", np.uint8), ("rx_ports", np.uint8, 4), ("dmrs_symbols_mask", np.uint16),
+                          ("grid_nof_prb", np.uint16), ("nof_llr", np.uint32), ("rb_mask", np.uint64, 5), ("grid_offset", np.uint64),
+                          ("ce_offset", np.uint64), ("scalars_offset", np.uint64), ("llr_offset", np.uint64)], align=True)
+assert PuschDemodJob.itemsize == 104 and PuschDemodJob.fields["rb_mask"][1] == 32, PuschDemodJob.itemsize
+
+
+def pusch_demod_nof_llr(job):
+    """Codeword length (data REs x bits per symbol) of one PuschDemodJob record (host computation in the library)."""
+    a = np.ascontiguousarray(np.asarray(job, dtype=PuschDemodJob).reshape(1))
+    return int(lib().miphy_pusch_demod_nof_llr(a.ctypes.data_as(C.c_void_p)))
 
 
 class PolarCode(C.Structure):
@@ -246,6 +265,11 @@ class Context:
     def ofdm_modulate_slots(self, cfg, jobs, grid, samples, stream=None):
         jobs, n, ptr, on_dev = self._descs(jobs, OfdmJob)
         check(lib().miphy_ofdm_modulate_slots(self.h, C.byref(cfg), ptr, on_dev, n, _dptr(grid), _dptr(samples), _stream_ptr(stream)))
+
+    # ------------------------------------------------------------------ PUSCH demodulator (equalise + soft-demap + descramble)
+    def pusch_demodulate_batch(self, jobs, grid, ce, scalars, llr, stream=None):
+        jobs, n, ptr, on_dev = self._descs(jobs, PuschDemodJob)
+        check(lib().miphy_pusch_demodulate_batch(self.h, ptr, on_dev, n, _dptr(grid), _dptr(ce), _dptr(scalars), _dptr(llr), _stream_ptr(stream)))
 
     # ------------------------------------------------------------------ DM-RS PUSCH channel estimator
     def dmrs_pusch_estimate_batch(self, jobs, grid, ce, scalars, stream=None):

@@ -411,3 +411,79 @@ def r_pbch_encode(N_id, ssb_idx, L_max, hrf, sfn, k_ssb, payload):
     out = np.zeros(864, np.uint8)
     ref().ref_pbch_encode(C.c_uint(N_id), C.c_uint(ssb_idx), C.c_uint(L_max), int(hrf), C.c_uint(sfn), C.c_uint(k_ssb), _p(payload), _p(out))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ PUSCH demodulator
+def nr_modulate(bits, mod):
+    """TS 38.211 5.1 mapper (numpy, float32): bits one per element -> complex64 symbols. mod in {1 (pi/2-BPSK), 2, 4, 6, 8}."""
+    b = np.asarray(bits, dtype=np.float32).reshape(-1, mod)
+    s = 1.0 - 2.0 * b
+    if mod == 1:
+        i = np.arange(b.shape[0])
+        z = (s[:, 0] + 1j * s[:, 0]) / np.sqrt(2.0)
+        return (z * np.exp(1j * (np.pi / 2) * (i % 2))).astype(np.complex64)
+    if mod == 2:
+        return ((s[:, 0] + 1j * s[:, 1]) / np.sqrt(2.0)).astype(np.complex64)
+    if mod == 4:
+        return ((s[:, 0] * (2 - s[:, 2]) + 1j * s[:, 1] * (2 - s[:, 3])) / np.sqrt(10.0)).astype(np.complex64)
+    if mod == 6:
+        return ((s[:, 0] * (4 - s[:, 2] * (2 - s[:, 4])) + 1j * s[:, 1] * (4 - s[:, 3] * (2 - s[:, 5]))) / np.sqrt(42.0)).astype(np.complex64)
+    return ((s[:, 0] * (8 - s[:, 2] * (4 - s[:, 4] * (2 - s[:, 6]))) + 1j * s[:, 1] * (8 - s[:, 3] * (4 - s[:, 5] * (2 - s[:, 7])))) /
+            np.sqrt(170.0)).astype(np.complex64)
+
+
+def o_demodulate_soft(mod, symbols, noise_vars):
+    sym = np.ascontiguousarray(symbols, dtype=np.complex64)
+    nv = np.ascontiguousarray(noise_vars, dtype=np.float32)
+    out = np.zeros(sym.size * mod, dtype=np.int8)
+    oracle().orc_demodulate_soft(int(mod), C.c_uint(sym.size), _p(sym), _p(nv), _p(out))
+    return out
+
+
+def r_demodulate_soft(mod, symbols, noise_vars):
+    sym = np.ascontiguousarray(symbols, dtype=np.complex64)
+    nv = np.ascontiguousarray(noise_vars, dtype=np.float32)
+    out = np.zeros(sym.size * mod, dtype=np.int8)
+    assert ref().ref_demodulate_soft(int(mod), C.c_uint(sym.size), _p(sym), _p(nv), _p(out)) == 0
+    return out
+
+
+def r_modulate(mod, bits):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    out = np.zeros(bits.size // mod, dtype=np.complex64)
+    assert ref().ref_modulate(int(mod), C.c_uint(out.size), _p(bits), _p(out)) == 0
+    return out
+
+
+def pusch_nof_re(start, nof, dmrs_mask, type2, cdm, rb_mask):
+    per_dmrs = 12 - (cdm * (4 if type2 else 6))
+    nprb = int(np.count_nonzero(rb_mask))
+    return sum(nprb * (per_dmrs if dmrs_mask[s] else 12) for s in range(start, start + nof))
+
+
+def _demod_args(rnti, n_id, mod, start, nof, dmrs_mask, type2, cdm, rb_mask, grid, ce, noise_var):
+    dm = np.ascontiguousarray(dmrs_mask, dtype=np.uint8)
+    rb = np.ascontiguousarray(rb_mask, dtype=np.uint8)
+    g = np.ascontiguousarray(grid, dtype=np.complex64)  # [ports][14][nsc]
+    h = np.ascontiguousarray(ce, dtype=np.complex64)    # [ports][ce_syms][nsc]
+    assert g.ndim == 3 and g.shape[1] == 14 and h.ndim == 3 and h.shape[0] == g.shape[0] and h.shape[2] == g.shape[2]
+    n = pusch_nof_re(start, nof, dm, type2, cdm, rb)
+    llr = np.zeros(n * mod, dtype=np.int8)
+    args = [C.c_uint(rnti), C.c_uint(n_id), int(mod), C.c_uint(start), C.c_uint(nof), _p(dm), int(type2), C.c_uint(cdm), _p(rb),
+            C.c_uint(rb.size), C.c_uint(g.shape[0]), _p(g), _p(h), C.c_uint(h.shape[1]), C.c_float(noise_var), _p(llr)]
+    return args, llr, n, (dm, rb, g, h)
+
+
+def o_pusch_demodulate(*a):
+    args, llr, n, keep = _demod_args(*a)
+    eq = np.zeros(n, dtype=np.complex64)
+    nv = np.zeros(n, dtype=np.float32)
+    got = oracle().orc_pusch_demodulate(*args, _p(eq), _p(nv))
+    assert got == llr.size, (got, llr.size)
+    return llr, eq, nv
+
+
+def r_pusch_demodulate(*a):
+    args, llr, n, keep = _demod_args(*a)
+    assert ref().ref_pusch_demodulate(*args, C.c_uint(llr.size)) == 0
+    return llr

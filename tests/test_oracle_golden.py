@@ -143,3 +143,26 @@ def test_llr_algebra_kats():
     assert dem.size == 512
     # the sub-block interleaver maps positions 0, 1, 2 to themselves (P(0) = 0)
     assert dem[0] == 127 and dem[1] == -127 and dem[2] == 0
+
+
+def test_pusch_demodulator():
+    """Soft demapper and whole PUSCH demodulator against reference-produced LLRs. Stated tolerance: at most one quantisation step
+    (the reference equalises with the approximate _mm256_rcp_ps and its build may contract a*b+c), and at least 99 % of the LLRs
+    identical (97 % at the high SNR of these stimuli, where the LLR magnitudes are large); the demapper alone (same inputs, exact arithmetic on both sides) must agree on > 99.99 %."""
+    d = load("pusch_demod")
+    for i in range(count(d, "dm_sym_")):
+        mod = int(d["dm_meta_%d" % i][0])
+        got, ref = O.o_demodulate_soft(mod, d["dm_sym_%d" % i], d["dm_nv_%d" % i]), d["dm_llr_%d" % i]
+        diff = np.abs(got.astype(int) - ref.astype(int))
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.9999, (mod, diff.max(), (diff == 0).mean())
+    for i in range(count(d, "grid_")):
+        rnti, n_id, mod, start, nof, cdm, nv = d["meta_%d" % i]
+        got, eq, nvar = O.o_pusch_demodulate(int(rnti), int(n_id), int(mod), int(start), int(nof), d["dm_%d" % i], 0, int(cdm), d["rb_%d" % i],
+                                             d["grid_%d" % i], d["ce_%d" % i], float(nv))
+        ref = d["llr_%d" % i]
+        diff = np.abs(got.astype(int) - ref.astype(int))
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.97, (i, diff.max(), (diff == 0).mean())
+        # the stimulus carries known (unscrambled) bits at high SNR: hard decisions of the descrambled LLRs = bits xor c(n)
+        bits = d["bits_%d" % i] ^ O.o_gold((int(rnti) << 15) + int(n_id), 0, got.size)
+        nz = got != 0
+        assert ((got < 0).astype(np.uint8)[nz] == bits[nz]).mean() > (0.999 if mod <= 4 else 0.9)  # 64/256QAM: the stimulus noise flips some LSBs

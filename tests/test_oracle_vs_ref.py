@@ -167,3 +167,34 @@ def test_pbch_encoder():
         a = (int(rng.integers(0, 1008)), int(rng.integers(0, L_max)), L_max, int(rng.integers(0, 2)), int(rng.integers(0, 1024)),
              int(rng.integers(0, 12 if L_max == 64 else 24)), rng.integers(0, 2, 32, dtype=np.uint8))
         assert np.array_equal(O.o_pbch_encode(*a), O.r_pbch_encode(*a)), a[:6]
+
+
+def test_pusch_demodulator():
+    """Oracle restatement vs the reference demodulation mapper (all modulations, abnormal noise variances) and vs the whole
+    pusch_demodulator_impl (1-4 ports, both CDM settings, partial allocations). Tolerance: one quantisation step."""
+    rng = np.random.default_rng(77)
+    for mod in (1, 2, 4, 6, 8):
+        n = 20000 + 3
+        bits = rng.integers(0, 2, n * mod, dtype=np.uint8)
+        assert np.abs(O.nr_modulate(bits, mod) - O.r_modulate(mod, bits)).max() < 3e-7  # the test-side mapper is the reference's
+        x = O.nr_modulate(bits, mod) + ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.15).astype(np.complex64)
+        nv = rng.uniform(0.005, 0.2, n).astype(np.float32)
+        nv[::97], nv[5::101], nv[7::103], nv[11::107] = 0, np.inf, np.nan, -1
+        o, r = O.o_demodulate_soft(mod, x, nv), O.r_demodulate_soft(mod, x, nv)
+        diff = np.abs(o.astype(int) - r.astype(int))
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.9999, (mod, diff.max(), (diff == 0).mean())
+    for mod, ports, cdm, type2 in ((8, 1, 2, 0), (6, 2, 1, 0), (4, 4, 2, 0), (2, 1, 1, 0), (1, 2, 2, 0), (6, 1, 1, 1), (4, 2, 3, 1), (8, 3, 2, 1)):
+        nprb = 25
+        nsc = nprb * 12
+        rb = np.zeros(nprb, np.uint8)
+        rb[3:20] = 1
+        rb[21] = 1
+        dm = np.zeros(14, np.uint8)
+        dm[[2, 11]] = 1
+        grid = (rng.standard_normal((ports, 14, nsc)) + 1j * rng.standard_normal((ports, 14, nsc))).astype(np.complex64)
+        ce = (rng.standard_normal((ports, 14, nsc)) + 1j * rng.standard_normal((ports, 14, nsc))).astype(np.complex64)
+        ce[0, 5, 40] = 0
+        args = (0x4601, 935, mod, 1, 13, dm, type2, cdm, rb, grid, ce, 0.05)
+        (o, eq, nv), r = O.o_pusch_demodulate(*args), O.r_pusch_demodulate(*args)
+        diff = np.abs(o.astype(int) - r.astype(int))
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.99, (mod, ports, diff.max(), (diff == 0).mean())
