@@ -7,6 +7,8 @@
 #include "lib/phy/generic_functions/dft_processor_generic_impl.h"
 #include "miphy_srsran_adapters.h"
 #include "srsran/phy/support/support_factories.h"
+#include "srsran/phy/upper/channel_modulation/channel_modulation_factories.h"
+#include "srsran/phy/upper/equalization/equalization_factories.h"
 #include "srsran/phy/upper/rx_softbuffer_pool.h"
 #include "srsran/phy/upper/sequence_generators/sequence_generator_factories.h"
 #include "srsran/phy/upper/unique_rx_softbuffer.h"
@@ -332,6 +334,75 @@ static void test_dft(std::shared_ptr<miphy::context> c)
   printf("dft_processor done, failures so far %d\n", failures);
 }
 
+// pusch_demodulator: the reference object (ZF equaliser + AVX2 demapper + descrambler) and the HIP adapter on the same grid and
+// channel estimate. Tolerance: one LLR quantisation step (the reference equalises with the approximate reciprocal instruction).
+static void test_pusch_demodulator(std::shared_ptr<miphy::context> c)
+{
+  auto d_ref = create_pusch_demodulator_factory_sw(
+                   create_channel_equalizer_factory_zf(), create_channel_modulation_sw_factory(), create_pseudo_random_generator_sw_factory())
+                   ->create();
+  auto d_hip = miphy::create_pusch_demodulator_factory_hip(c)->create();
+  std::normal_distribution<float> n(0.F, 0.7071F);
+  struct tc {
+    modulation_scheme mod;
+    unsigned          rb, ports, cdm;
+  };
+  for (const tc& t : {tc{modulation_scheme::QAM256, 273, 1, 2}, tc{modulation_scheme::QAM64, 106, 2, 1}, tc{modulation_scheme::QAM16, 52, 4, 2},
+                      tc{modulation_scheme::QPSK, 25, 1, 1}}) {
+    unsigned nsc  = t.rb * 12;
+    auto     grid = create_resource_grid(t.ports, 14, nsc);
+    channel_estimate::channel_estimate_dimensions dims;
+    dims.nof_prb = t.rb, dims.nof_symbols = 14, dims.nof_rx_ports = t.ports, dims.nof_tx_layers = 1;
+    channel_estimate  ce(dims);
+    std::vector<cf_t> tmp(nsc);
+    for (unsigned p = 0; p != t.ports; ++p) {
+      for (unsigned l = 0; l != 14; ++l) {
+        for (auto& v : tmp) {
+          v = cf_t(n(rgen), n(rgen));
+        }
+        grid->put(p, l, 0, tmp);
+        auto h = ce.get_symbol_ch_estimate(l, p, 0);
+        for (auto& v : h) {
+          v = cf_t(n(rgen), n(rgen));
+        }
+      }
+      ce.set_noise_variance(0.07F, p, 0);
+    }
+    pusch_demodulator::configuration cfg;
+    cfg.rnti    = 0x4601;
+    cfg.rb_mask = bounded_bitset<MAX_RB>(t.rb);
+    cfg.rb_mask.fill(t.rb > 30 ? 3 : 0, t.rb - 1, true);
+    cfg.modulation         = t.mod;
+    cfg.start_symbol_index = 0;
+    cfg.nof_symbols        = 14;
+    cfg.dmrs_symb_pos      = {};
+    cfg.dmrs_symb_pos[2]   = true;
+    cfg.dmrs_symb_pos[11]  = (t.rb != 273);
+    cfg.dmrs_config_type   = dmrs_type::TYPE1;
+    cfg.nof_cdm_groups_without_data = t.cdm;
+    cfg.n_id               = 935;
+    cfg.nof_tx_layers      = 1;
+    for (unsigned p = 0; p != t.ports; ++p) {
+      cfg.rx_ports.push_back(p);
+    }
+    unsigned nprb = cfg.rb_mask.count(), ndm = (t.rb != 273) ? 2 : 1;
+    unsigned nre  = nprb * (12 * (14 - ndm) + (12 - 6 * t.cdm) * ndm);
+    unsigned nllr = nre * get_bits_per_symbol(t.mod);
+    std::vector<log_likelihood_ratio> a(nllr), b(nllr);
+    d_ref->demodulate(a, *grid, ce, cfg);
+    d_hip->demodulate(b, *grid, ce, cfg);
+    unsigned same = 0, worst = 0;
+    for (unsigned i = 0; i != nllr; ++i) {
+      unsigned d = std::abs(a[i].to_int() - b[i].to_int());
+      same += (d == 0);
+      worst = std::max(worst, d);
+    }
+    CHECK(worst <= 1, "pusch_demodulator: LLR differs by %u (rb %u)", worst, t.rb);
+    CHECK(same > nllr * 0.98, "pusch_demodulator: only %u of %u LLRs identical (rb %u)", same, nllr, t.rb);
+  }
+  printf("pusch_demodulator done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -365,6 +436,7 @@ int main()
   test_ofdm_and_estimator(c);
   test_dft(c);
   test_pdcch(c);
+  test_pusch_demodulator(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);
     return 1;

@@ -544,6 +544,80 @@ private:
   std::vector<srsran::cf_t> host, ce_host;
 };
 
+// ---------------------------------------------------------------------------------------------------------------- PUSCH demodulator
+/// srsran::pusch_demodulator over miphy_pusch_demodulate_batch (pusch_demodulator.h:105-108): equaliser, soft demapper and
+/// descrambler of pusch_demodulator_impl in one device pass. No UCI placeholders, no EVM report (status.evm stays empty).
+class pusch_demodulator_hip : public srsran::pusch_demodulator
+{
+public:
+  explicit pusch_demodulator_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  demodulation_status demodulate(srsran::span<srsran::log_likelihood_ratio> codeword,
+                                 const srsran::resource_grid_reader&        grid,
+                                 const srsran::channel_estimate&            estimates,
+                                 const configuration&                       config) override
+  {
+    srsran_assert(config.nof_tx_layers == 1, "Only a single transmit layer is supported.");
+    bool has_placeholders = false;
+    config.placeholders.for_each(config.modulation, config.nof_tx_layers, [&has_placeholders](unsigned, unsigned) { has_placeholders = true; });
+    if (has_placeholders) {
+      srsran::report_fatal_error("pusch_demodulator_hip: UCI placeholders are not supported.");
+    }
+    const unsigned nprb = config.rb_mask.size(), nsc = nprb * 12, nports = config.rx_ports.size();
+    const unsigned nsymb = config.start_symbol_index + config.nof_symbols;
+    miphy_pusch_demod_job j = {};
+    j.rnti                  = config.rnti;
+    j.n_id                  = config.n_id;
+    j.mod                   = srsran::get_bits_per_symbol(config.modulation);
+    j.nof_rx_ports          = nports;
+    j.start_symbol          = config.start_symbol_index;
+    j.nof_symbols           = config.nof_symbols;
+    j.dmrs_type             = (config.dmrs_config_type == srsran::dmrs_type::TYPE1) ? 1 : 2;
+    j.nof_cdm_groups_without_data = config.nof_cdm_groups_without_data;
+    j.ce_nof_symbols        = nsymb;
+    j.grid_nof_prb          = nprb;
+    for (unsigned p = 0; p != nports; ++p) {
+      j.rx_ports[p] = p; // the staging grid below is already ordered by rx_ports
+    }
+    for (unsigned l = 0; l != 14; ++l) {
+      if (config.dmrs_symb_pos[l]) {
+        j.dmrs_symbols_mask |= static_cast<uint16_t>(1U << l);
+      }
+    }
+    config.rb_mask.for_each(0, nprb, [&j](unsigned r) { j.rb_mask[r >> 6] |= 1ULL << (r & 63); });
+    j.nof_llr = codeword.size(); // validated against the allocation by the library, like pusch_demodulator_impl.cpp:76-80
+    host.resize(static_cast<size_t>(nports) * 14 * nsc);
+    for (unsigned p = 0; p != nports; ++p) {
+      for (unsigned l = 0; l != 14; ++l) {
+        grid.get(srsran::span<srsran::cf_t>(host.data() + (static_cast<size_t>(p) * 14 + l) * nsc, nsc), config.rx_ports[p], l, 0);
+      }
+    }
+    ce_host.resize(static_cast<size_t>(nports) * nsymb * nsc);
+    for (unsigned p = 0; p != nports; ++p) {
+      for (unsigned l = 0; l != nsymb; ++l) {
+        auto v = estimates.get_symbol_ch_estimate(l, p, 0);
+        std::memcpy(ce_host.data() + (static_cast<size_t>(p) * nsymb + l) * nsc, v.data(), nsc * sizeof(srsran::cf_t));
+      }
+    }
+    float sc[5] = {0, 0, estimates.get_noise_variance(0, 0), 0, 0};
+    auto* d_g   = static_cast<float*>(c->buf(0, host.size() * sizeof(srsran::cf_t)));
+    auto* d_ce  = static_cast<float*>(c->buf(1, ce_host.size() * sizeof(srsran::cf_t)));
+    auto* d_sc  = static_cast<float*>(c->buf(2, sizeof(sc)));
+    auto* d_llr = static_cast<int8_t*>(c->buf(3, codeword.size() + 16));
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    c->h2d(d_ce, ce_host.data(), ce_host.size() * sizeof(srsran::cf_t));
+    c->h2d(d_sc, sc, sizeof(sc));
+    context::check(miphy_pusch_demodulate_batch(c->ctx, &j, 0, 1, d_g, d_ce, d_sc, d_llr, c->stream), "pusch_demodulate");
+    static_assert(sizeof(srsran::log_likelihood_ratio) == 1, "LLRs are int8");
+    c->d2h(codeword.data(), d_llr, codeword.size());
+    c->sync();
+    return {};
+  }
+
+private:
+  std::shared_ptr<context>  c;
+  std::vector<srsran::cf_t> host, ce_host;
+};
+
 // ---------------------------------------------------------------------------------------------------------------- PDCCH
 /// srsran::pdcch_encoder over miphy_pdcch_encode_batch (pdcch_encoder.h:53).
 class pdcch_encoder_hip : public srsran::pdcch_encoder
@@ -588,6 +662,7 @@ MIPHY_SIMPLE_FACTORY(pdsch_encoder_factory_hip, pdsch_encoder_factory, pdsch_enc
 MIPHY_SIMPLE_FACTORY(pusch_decoder_factory_hip, pusch_decoder_factory, pusch_decoder, pusch_decoder_hip)
 MIPHY_SIMPLE_FACTORY(dmrs_pusch_estimator_factory_hip, dmrs_pusch_estimator_factory, dmrs_pusch_estimator, dmrs_pusch_estimator_hip)
 MIPHY_SIMPLE_FACTORY(pdcch_encoder_factory_hip, pdcch_encoder_factory, pdcch_encoder, pdcch_encoder_hip)
+MIPHY_SIMPLE_FACTORY(pusch_demodulator_factory_hip, pusch_demodulator_factory, pusch_demodulator, pusch_demodulator_hip)
 #undef MIPHY_SIMPLE_FACTORY
 
 /// The string-selected factory functions of the reference (channel_coding_factories.cpp:86-180) gain a "hip" case that
@@ -623,6 +698,11 @@ inline std::shared_ptr<srsran::dmrs_pusch_estimator_factory> create_dmrs_pusch_e
 inline std::shared_ptr<srsran::pdcch_encoder_factory> create_pdcch_encoder_factory_hip(std::shared_ptr<context> c)
 {
   return std::make_shared<pdcch_encoder_factory_hip>(std::move(c));
+}
+/// Replaces create_pusch_demodulator_factory_sw(equalizer, demodulation, prg) (channel_processor_factories.h:256-259).
+inline std::shared_ptr<srsran::pusch_demodulator_factory> create_pusch_demodulator_factory_hip(std::shared_ptr<context> c)
+{
+  return std::make_shared<pusch_demodulator_factory_hip>(std::move(c));
 }
 
 /// OFDM factories take a configuration per product (modulation_factories.h:34-76).

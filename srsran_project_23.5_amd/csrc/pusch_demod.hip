@@ -9,8 +9,8 @@
 //   descrambling: c_init = rnti * 2^15 + n_id, TS 38.211 6.3.1.1 (no UCI placeholders).
 // The equalised symbols and noise variances never leave registers; HBM sees the grid and the channel estimate once and the LLRs
 // once. The descrambling sequence of the symbol is produced in LDS by jumping the two LFSRs to the symbol's first bit
-// (gold_device.h). Floating point: single IEEE operations in the order of oracle/phy_oracle.c (no contraction), exact division,
-// so the LLRs equal the oracle's bit for bit; against the reference's AVX2 build they are within one quantisation step.
+// (gold_device.h). Floating point: single IEEE operations in a fixed order (no contraction), exact division,
+// so the LLRs are reproducible bit for bit by a scalar CPU restatement; against the reference AVX2 build they are within one step.
 #define NR_DEMOD_TABLE_ATTR __device__
 #include "gold_device.h"
 #include "miphy_ext.h"
@@ -112,7 +112,7 @@ __device__ __forceinline__ void demod_body(const miphy_pusch_demod_job& job, con
   for (int r = tid; r < n_re; r += nt) {
     const int prb = prb_of[r / npp], k = r - (r / npp) * npp;
     const int sc  = prb * 12 + pos[k];
-    // equalize_zf_1xn.h:120-158 (same operation order as oracle/phy_oracle.c)
+    // equalize_zf_1xn.h:120-158
     float ch_mod_sq = 0.f, acc_re = 0.f, acc_im = 0.f;
     for (int p = 0; p < job.nof_rx_ports; ++p) {
       const float2 y = g[((size_t)job.rx_ports[p] * 14 + sy) * nsc + sc];
