@@ -84,7 +84,13 @@ __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job*
   float*    red    = reinterpret_cast<float*>(prb_of + 276);          // reductions
   int*      ired   = reinterpret_cast<int*>(red + 8);
 
-  const miphy_pusch_chest_job job = jobs[blockIdx.x];
+  // Read field by field (uniform loads); the arrays go through LDS / a packed word: a private copy of the descriptor indexed at
+  // run time would live in scratch memory.
+  const miphy_pusch_chest_job& job = jobs[blockIdx.x];
+  __shared__ uint64_t rbm[5];
+  if (threadIdx.x < 5)
+    rbm[threadIdx.x] = job.rb_mask[threadIdx.x];
+  __syncthreads();
   const int tid = threadIdx.x, nt = blockDim.x;
   const int port = blockIdx.y % 4, layer = blockIdx.y / 4;
   const int sgrp = blockIdx.z, ngrp = gridDim.z; // symbol group: stores OFDM symbols l with l % ngrp == sgrp; group 0 owns the scalars
@@ -104,17 +110,17 @@ __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job*
   // Allocated PRB list (compact): PRB r goes to slot popcount(mask bits below r).
   for (int r = tid; r < nprb_grid; r += nt) {
     const int wd = r >> 6, bt = r & 63;
-    if ((job.rb_mask[wd] >> bt) & 1ull) {
-      int idx = __popcll(job.rb_mask[wd] & ((1ull << bt) - 1ull));
+    if ((rbm[wd] >> bt) & 1ull) {
+      int idx = __popcll(rbm[wd] & ((1ull << bt) - 1ull));
       for (int w = 0; w < wd; ++w)
-        idx += __popcll(job.rb_mask[w]);
+        idx += __popcll(rbm[w]);
       prb_of[idx] = (uint16_t)r;
     }
   }
   if (tid == 0) {
     int c = 0;
     for (int w = 0; w < 5; ++w)
-      c += __popcll(w * 64 < nprb_grid ? (job.rb_mask[w] & ((nprb_grid - w * 64 >= 64) ? ~0ull : ((1ull << (nprb_grid - w * 64)) - 1ull))) : 0ull);
+      c += __popcll(w * 64 < nprb_grid ? (rbm[w] & ((nprb_grid - w * 64 >= 64) ? ~0ull : ((1ull << (nprb_grid - w * 64)) - 1ull))) : 0ull);
     ired[0] = c;
   }
   // Gold sequences of the DM-RS symbols (dmrs_pusch_estimator_impl.cpp:158-162).
@@ -129,7 +135,7 @@ __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job*
   const int delta = (layer >> 1) & 1;             // RE pattern: even subcarriers for ports 0,1 ; odd for 2,3
   const float wf1 = (layer & 1) ? -1.f : 1.f;     // frequency weight on odd pilots (layers > 0)
   const float amp = 0.70710678118654752440f;
-  const float2* g = grid + job.grid_offset + (size_t)job.rx_ports[port] * 14 * nsc;
+  const float2* g = grid + job.grid_offset + (size_t)(((uint32_t)job.rx_ports[0] | ((uint32_t)job.rx_ports[1] << 8) | ((uint32_t)job.rx_ports[2] << 16) | ((uint32_t)job.rx_ports[3] << 24)) >> (8 * port) & 0xffu) * 14 * nsc;
   const float   beta = job.scaling;
 
   // ---- LS estimate, EPRE (port_channel_estimator_average_impl.cpp:180-201)

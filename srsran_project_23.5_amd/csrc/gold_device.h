@@ -100,30 +100,49 @@ __device__ __forceinline__ uint32_t gold_state(const gold_tables& t, bool is_x2,
   return st;
 }
 
-// c(offset .. offset + nbits - 1), bit-packed LSB first into out[0 .. nwords), for ONE long sequence, cooperatively over the
-// workgroup: two lanes produce the 31-word heads, then the word recurrences (see chest.hip) give 28 words per step and LFSR.
+// c(offset .. offset + nbits - 1), bit-packed LSB first into out[0 .. nwords), for ONE long sequence. All of it runs on the first
+// wavefront, x1 on lanes 0-31 and x2 on lanes 32-63, without workgroup barriers: the jump to `offset` is a chain of matrix-vector
+// products in which lane i contributes column i and a 5-step XOR butterfly adds them up; lane 0 of each half produces the 31-word
+// head; then the word recurrences (see chest.hip) give 28 words per step and LFSR on lanes 0-27 of each half (LDS accesses of one
+// wavefront are executed in order). The other wavefronts only join at the final barrier.
 // w1 / w2: LDS scratch of nwords words each; out may alias w1.
 __device__ __forceinline__ void gold_long_block(const gold_tables& t, uint32_t c_init, uint32_t offset, int nwords, uint32_t* w1, uint32_t* w2,
                                                 uint32_t* out, int tid, int nt)
 {
   const int head = nwords < 31 ? nwords : 31;
-  if (tid < 2) {
-    const bool is_x2 = tid & 1;
-    lfsr_head(gold_state(t, is_x2, c_init, offset), is_x2, head, is_x2 ? w2 : w1);
+  if (tid < 64) {
+    const bool is_x2 = tid >= 32;
+    const int  lane  = tid & 31;
+    auto       xor32 = [](uint32_t v) {
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1)
+        v ^= __shfl_xor(v, o); // stays inside the 32-lane half
+      return v;
+    };
+    uint32_t st = t.j.x1_1600;
+    if (is_x2)
+      st = xor32((lane < 31 && ((c_init >> lane) & 1u)) ? t.j.x2_col[lane] : 0u);
+    // all columns this lane may need are fetched up front (independent loads: one memory latency instead of one per set bit)
+    uint32_t cols[GOLD_POW];
+#pragma unroll
+    for (int k = 0; k < GOLD_POW; ++k)
+      cols[k] = (lane < 31 && ((offset >> k) & 1u)) ? (is_x2 ? t.x2_pow[k][lane] : t.x1_pow[k][lane]) : 0u;
+#pragma unroll
+    for (int k = 0; k < GOLD_POW; ++k)
+      if ((offset >> k) & 1u) // uniform
+        st = xor32(((st >> lane) & 1u) ? cols[k] : 0u);
+    volatile uint32_t* w = is_x2 ? w2 : w1;
+    if (lane == 0)
+      lfsr_head(st, is_x2, head, is_x2 ? w2 : w1);
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 31; i0 < nwords; i0 += 28) {
+      const int i = i0 + lane;
+      if (lane < 28 && i < nwords)
+        w[i] = is_x2 ? (w[i - 28] ^ w[i - 29] ^ w[i - 30] ^ w[i - 31]) : (w[i - 28] ^ w[i - 31]);
+      __builtin_amdgcn_wave_barrier();
+    }
   }
   __syncthreads();
-  for (int i0 = 31; i0 < nwords; i0 += 28) {
-    if (tid < 56) {
-      const int j = tid % 28, i = i0 + j;
-      if (i < nwords) {
-        if (tid < 28)
-          w1[i] = w1[i - 28] ^ w1[i - 31];
-        else
-          w2[i] = w2[i - 28] ^ w2[i - 29] ^ w2[i - 30] ^ w2[i - 31];
-      }
-    }
-    __syncthreads();
-  }
   for (int i = tid; i < nwords; i += nt)
     out[i] = w1[i] ^ w2[i];
   __syncthreads();

@@ -21,6 +21,7 @@ namespace {
 
 constexpr int MAX_SYM_WORDS = 832; // 275 PRB * 12 RE * 8 bit / 32 = 825 words (+ 1 guard word)
 
+// Quantisation of avx2_helpers.h:103-157: scale, clip to +-120, round to nearest even, NaN -> 0.
 __device__ __forceinline__ int demod_quantize(float v, float scale)
 {
 #pragma clang fp contract(off)
@@ -30,24 +31,59 @@ __device__ __forceinline__ int demod_quantize(float v, float scale)
   const float r = rintf(s);
   return (r <= 120.0f && r >= -120.0f) ? (int)r : 0; // NaN -> 0
 }
-
-__device__ __forceinline__ float demod_interval(float x, float rcp_noise, float rcp_width, int count, const float* slope, const float* intercept)
+// Same for a value that is known not to be NaN (the caller checks the inputs once per resource element).
+__device__ __forceinline__ int demod_quantize_fast(float v, float scale)
 {
 #pragma clang fp contract(off)
-  int idx = (int)floorf(x * rcp_width) + count / 2;
-  idx     = idx < 0 ? 0 : (idx > count - 1 ? count - 1 : idx);
-  float t = slope[idx] * x;
-  t       = t + intercept[idx];
+  return (int)rintf(__builtin_amdgcn_fmed3f(v * scale, -120.0f, 120.0f));
+}
+
+// LDS copy of the interval tables of one modulation: level k (bits 2k, 2k+1) at tab[16 k ...], {slope, intercept} pairs.
+template <int MOD>
+__device__ __forceinline__ void demod_tables_to_lds(float2* tab, int tid)
+{
+  if (MOD == 6) {
+    if (tid < 8)
+      tab[tid] = make_float2(NR_DEMOD_QAM64_B0_SLOPE[tid], NR_DEMOD_QAM64_B0_INTERCEPT[tid]);
+    else if (tid < 16)
+      tab[16 + tid - 8] = make_float2(NR_DEMOD_QAM64_B1_SLOPE[tid - 8], NR_DEMOD_QAM64_B1_INTERCEPT[tid - 8]);
+    else if (tid < 20)
+      tab[32 + tid - 16] = make_float2(NR_DEMOD_QAM64_B2_SLOPE[tid - 16], NR_DEMOD_QAM64_B2_INTERCEPT[tid - 16]);
+  } else if (MOD == 8) {
+    if (tid < 16)
+      tab[tid] = make_float2(NR_DEMOD_QAM256_B0_SLOPE[tid], NR_DEMOD_QAM256_B0_INTERCEPT[tid]);
+    else if (tid < 32)
+      tab[tid] = make_float2(NR_DEMOD_QAM256_B1_SLOPE[tid - 16], NR_DEMOD_QAM256_B1_INTERCEPT[tid - 16]);
+    else if (tid < 48)
+      tab[tid] = make_float2(NR_DEMOD_QAM256_B2_SLOPE[tid - 32], NR_DEMOD_QAM256_B2_INTERCEPT[tid - 32]);
+    else if (tid < 56)
+      tab[tid] = make_float2(NR_DEMOD_QAM256_B3_SLOPE[tid - 48], NR_DEMOD_QAM256_B3_INTERCEPT[tid - 48]);
+  }
+}
+
+__device__ __forceinline__ int demod_interval_idx(float x, float rcp_width, int count)
+{
+#pragma clang fp contract(off)
+  const int idx = (int)floorf(x * rcp_width) + count / 2;
+  return idx < 0 ? 0 : (idx > count - 1 ? count - 1 : idx);
+}
+__device__ __forceinline__ float demod_interval_at(float x, float rcp_noise, float2 si)
+{
+#pragma clang fp contract(off)
+  float t = si.x * x;
+  t       = t + si.y;
   return t * rcp_noise;
 }
 
-// One equalised symbol -> MOD LLRs, packed one per byte (LSB = first bit) into 64 bits.
-template <int MOD>
-__device__ __forceinline__ uint64_t demod_symbol(float re, float im, float nvar, unsigned sym_idx)
+// One equalised symbol -> MOD LLRs in l[]. FAST: no NaN can appear (finite symbol, finite reciprocal noise), which allows the
+// one-instruction clamp; otherwise the exact NaN-preserving sequence of the reference is used.
+template <int MOD, bool FAST>
+__device__ __forceinline__ void demod_symbol(float re, float im, float nvar, unsigned sym_idx, const float2* tab, int* l)
 {
 #pragma clang fp contract(off)
-  int l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define Q(v, sc) (FAST ? demod_quantize_fast((v), (sc)) : demod_quantize((v), (sc)))
   if (MOD == 1) {
+    l[0] = 0;
     if (nvar > 0.f) {
       const float a = (sym_idx & 1u) ? im : re, b = (sym_idx & 1u) ? -re : im;
       const float v = NR_DEMOD_QPSK_GAIN * (a + b) / nvar;
@@ -56,37 +92,37 @@ __device__ __forceinline__ uint64_t demod_symbol(float re, float im, float nvar,
         c = copysignf(24.f, v);
       l[0] = (int)roundf(c / 24.f * 120.f);
     }
-  } else {
-    const float rcp  = (nvar > 0.f) ? 1.0f / nvar : 0.0f;
-    const float x[2] = {re, im};
+    return;
+  }
+  const float rcp  = (nvar > 0.f) ? 1.0f / nvar : 0.0f;
+  const float x[2] = {re, im};
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      if (MOD == 2) {
-        l[d] = demod_quantize((NR_DEMOD_QPSK_GAIN * x[d]) * rcp, 120.0f / 24.f);
-      } else if (MOD == 4) {
-        const float first  = NR_DEMOD_QAM16_GAIN * x[d];
-        const float second = 2.0f * first - copysignf(0.8f, x[d]);
-        const float l01    = (fabsf(x[d]) > NR_DEMOD_QAM16_THRESHOLD) ? second : first;
-        const float l23    = 0.8f - fabsf(first);
-        l[d]               = demod_quantize(l01 * rcp, 120.0f / 20.f);
-        l[2 + d]           = demod_quantize(l23 * rcp, 120.0f / 20.f);
-      } else if (MOD == 6) {
-        l[d]     = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM64_B0_RCP_WIDTH, NR_DEMOD_QAM64_B0_COUNT, NR_DEMOD_QAM64_B0_SLOPE, NR_DEMOD_QAM64_B0_INTERCEPT), 6.0f);
-        l[2 + d] = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM64_B1_RCP_WIDTH, NR_DEMOD_QAM64_B1_COUNT, NR_DEMOD_QAM64_B1_SLOPE, NR_DEMOD_QAM64_B1_INTERCEPT), 6.0f);
-        l[4 + d] = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM64_B2_RCP_WIDTH, NR_DEMOD_QAM64_B2_COUNT, NR_DEMOD_QAM64_B2_SLOPE, NR_DEMOD_QAM64_B2_INTERCEPT), 6.0f);
-      } else {
-        l[d]     = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM256_B0_RCP_WIDTH, NR_DEMOD_QAM256_B0_COUNT, NR_DEMOD_QAM256_B0_SLOPE, NR_DEMOD_QAM256_B0_INTERCEPT), 6.0f);
-        l[2 + d] = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM256_B1_RCP_WIDTH, NR_DEMOD_QAM256_B1_COUNT, NR_DEMOD_QAM256_B1_SLOPE, NR_DEMOD_QAM256_B1_INTERCEPT), 6.0f);
-        l[4 + d] = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM256_B2_RCP_WIDTH, NR_DEMOD_QAM256_B2_COUNT, NR_DEMOD_QAM256_B2_SLOPE, NR_DEMOD_QAM256_B2_INTERCEPT), 6.0f);
-        l[6 + d] = demod_quantize(demod_interval(x[d], rcp, NR_DEMOD_QAM256_B3_RCP_WIDTH, NR_DEMOD_QAM256_B3_COUNT, NR_DEMOD_QAM256_B3_SLOPE, NR_DEMOD_QAM256_B3_INTERCEPT), 6.0f);
-      }
+  for (int d = 0; d < 2; ++d) {
+    if (MOD == 2) {
+      l[d] = Q((NR_DEMOD_QPSK_GAIN * x[d]) * rcp, 120.0f / 24.f);
+    } else if (MOD == 4) {
+      const float first  = NR_DEMOD_QAM16_GAIN * x[d];
+      const float second = 2.0f * first - copysignf(0.8f, x[d]);
+      const float l01    = (fabsf(x[d]) > NR_DEMOD_QAM16_THRESHOLD) ? second : first;
+      const float l23    = 0.8f - fabsf(first);
+      l[d]               = Q(l01 * rcp, 6.0f);
+      l[2 + d]           = Q(l23 * rcp, 6.0f);
+    } else if (MOD == 6) {
+      const int i0 = demod_interval_idx(x[d], NR_DEMOD_QAM64_B0_RCP_WIDTH, 8); // bits 0-3 share the grid of 8 intervals
+      const int i2 = demod_interval_idx(x[d], NR_DEMOD_QAM64_B2_RCP_WIDTH, 4);
+      l[d]         = Q(demod_interval_at(x[d], rcp, tab[i0]), 6.0f);
+      l[2 + d]     = Q(demod_interval_at(x[d], rcp, tab[16 + i0]), 6.0f);
+      l[4 + d]     = Q(demod_interval_at(x[d], rcp, tab[32 + i2]), 6.0f);
+    } else {
+      const int i0 = demod_interval_idx(x[d], NR_DEMOD_QAM256_B0_RCP_WIDTH, 16); // bits 0-5 share the grid of 16 intervals
+      const int i3 = demod_interval_idx(x[d], NR_DEMOD_QAM256_B3_RCP_WIDTH, 8);
+      l[d]         = Q(demod_interval_at(x[d], rcp, tab[i0]), 6.0f);
+      l[2 + d]     = Q(demod_interval_at(x[d], rcp, tab[16 + i0]), 6.0f);
+      l[4 + d]     = Q(demod_interval_at(x[d], rcp, tab[32 + i0]), 6.0f);
+      l[6 + d]     = Q(demod_interval_at(x[d], rcp, tab[48 + i3]), 6.0f);
     }
   }
-  uint64_t out = 0;
-#pragma unroll
-  for (int b = 0; b < MOD; ++b)
-    out |= (uint64_t)(uint8_t)(int8_t)l[b] << (8 * b);
-  return out;
+#undef Q
 }
 
 // 12-bit mask of the REs of a PRB that carry DM-RS (dmrs_mapping.h:76-92).
@@ -98,30 +134,50 @@ __device__ __forceinline__ unsigned dmrs_prb_mask(int type, unsigned cdm)
   return m;
 }
 
+struct demod_args {
+  int           nsc, nports, ce_nof_symbols;
+  uint32_t      rxp; // rx_ports[0..3], one byte each
+  const float2* grid;
+  const float2* ce;
+  int8_t*       llr;
+  float         noise_var;
+};
+
 template <int MOD>
-__device__ __forceinline__ void demod_body(const miphy_pusch_demod_job& job, const uint16_t* prb_of, const uint8_t* pos, int npp, int n_re, int prefix,
-                                           int sy, const uint32_t* cw, const float2* __restrict__ grid, const float2* __restrict__ ce, float noise_var,
-                                           int8_t* __restrict__ llr, int tid, int nt)
+__device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* prb_of, const uint8_t* pos, int npp, int n_re, int prefix, int sy,
+                                           const uint32_t* cw, const float2* tab, int tid, int nt)
 {
 #pragma clang fp contract(off)
-  const int     nsc = job.grid_nof_prb * 12;
-  const float2* g   = grid + job.grid_offset;
-  const float2* h   = ce + job.ce_offset;
-  int8_t*       o   = llr + job.llr_offset + (size_t)prefix * MOD;
-  const bool    aligned = ((uintptr_t)o % (MOD == 8 ? 8 : MOD == 4 ? 4 : MOD == 1 ? 1 : 2)) == 0;
+  const int   nsc = a.nsc, nports = a.nports;
+  const float noise_var = a.noise_var;
+  // per-port row pointers of this OFDM symbol
+  const float2* gp[4];
+  const float2* hp[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    gp[p] = a.grid + ((size_t)((a.rxp >> (8 * p)) & 0xffu) * 14 + sy) * nsc;
+    hp[p] = a.ce + ((size_t)p * a.ce_nof_symbols + sy) * nsc;
+  }
+  int8_t*    o       = a.llr + (size_t)prefix * MOD;
+  const bool aligned = ((uintptr_t)o % (MOD == 8 ? 8 : MOD == 4 ? 4 : MOD == 1 ? 1 : 2)) == 0;
+  const uint32_t npp_magic = (uint32_t)((0x100000000ull + (uint32_t)npp - 1u) / (uint32_t)npp); // r / npp for r < 2^16
   for (int r = tid; r < n_re; r += nt) {
-    const int prb = prb_of[r / npp], k = r - (r / npp) * npp;
+    const int pi  = (int)__umulhi((uint32_t)r, npp_magic);
+    const int prb = prb_of[pi], k = r - pi * npp;
     const int sc  = prb * 12 + pos[k];
     // equalize_zf_1xn.h:120-158
     float ch_mod_sq = 0.f, acc_re = 0.f, acc_im = 0.f;
-    for (int p = 0; p < job.nof_rx_ports; ++p) {
-      const float2 y = g[((size_t)job.rx_ports[p] * 14 + sy) * nsc + sc];
-      const float2 c = h[((size_t)p * job.ce_nof_symbols + sy) * nsc + sc];
-      const float  t = c.x * c.x, u = c.y * c.y;
-      ch_mod_sq      = ch_mod_sq + (t + u);
-      const float a = y.x * c.x, b = y.y * c.y, cc = y.y * c.x, d = y.x * c.y;
-      acc_re        = acc_re + (a + b);
-      acc_im        = acc_im + (cc - d);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (p < nports) {
+        const float2 y = gp[p][sc];
+        const float2 c = hp[p][sc];
+        const float  t = c.x * c.x, u = c.y * c.y;
+        ch_mod_sq      = ch_mod_sq + (t + u);
+        const float a = y.x * c.x, b = y.y * c.y, cc = y.y * c.x, d = y.x * c.y;
+        acc_re        = acc_re + (a + b);
+        acc_im        = acc_im + (cc - d);
+      }
     }
     const float d_pinv = 1.0f * ch_mod_sq;
     const float rcpd   = 1.0f / d_pinv;
@@ -132,19 +188,26 @@ __device__ __forceinline__ void demod_body(const miphy_pusch_demod_job& job, con
       z_im = acc_im * rcpd;
       nv   = v;
     }
-    uint64_t w = demod_symbol<MOD>(z_re, z_im, nv, (unsigned)(prefix + r));
+    int l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // NaNs can only come from a non-finite symbol or an infinite reciprocal noise variance (0 * inf): rare, exact path.
+    const float rcp_chk = (nv > 0.f) ? 1.0f / nv : 0.0f;
+    if (fabsf(z_re) < INFINITY && fabsf(z_im) < INFINITY && rcp_chk < INFINITY)
+      demod_symbol<MOD, true>(z_re, z_im, nv, (unsigned)(prefix + r), tab, l);
+    else
+      demod_symbol<MOD, false>(z_re, z_im, nv, (unsigned)(prefix + r), tab, l);
     // descramble: bit b of this RE is sequence bit (prefix + r) * MOD + b; cw holds the bits of this OFDM symbol from r = 0
     const int      bi   = r * MOD;
     const uint64_t two  = (uint64_t)cw[bi >> 5] | ((uint64_t)cw[(bi >> 5) + 1] << 32);
     const uint32_t bits = (uint32_t)(two >> (bi & 31));
 #pragma unroll
     for (int b = 0; b < MOD; ++b) {
-      if ((bits >> b) & 1u) {
-        const uint64_t m = 0xffull << (8 * b);
-        const uint64_t n = (uint64_t)(uint8_t)(-(int8_t)(w >> (8 * b))) << (8 * b);
-        w                = (w & ~m) | n;
-      }
+      const int m = -(int)((bits >> b) & 1u); // 0 / -1
+      l[b]        = (l[b] ^ m) - m;
     }
+    uint64_t w = 0;
+#pragma unroll
+    for (int b = 0; b < MOD; ++b)
+      w |= (uint64_t)(uint8_t)(int8_t)l[b] << (8 * b);
     int8_t* q = o + (size_t)r * MOD;
     if (aligned) {
       if (MOD == 8)
@@ -174,31 +237,41 @@ __global__ void __launch_bounds__(256) pusch_demod_kernel(const miphy_pusch_demo
   __shared__ uint16_t prb_of[276];
   __shared__ uint8_t  pos[12];
   __shared__ int      nprb_s;
-  const miphy_pusch_demod_job job = jobs[blockIdx.x];
-  const int                   sy  = blockIdx.y;
-  const int                   tid = threadIdx.x, nt = blockDim.x;
-  if (sy < job.start_symbol || sy >= job.start_symbol + job.nof_symbols)
+  __shared__ float2   tab[64];
+  __shared__ uint64_t rbm[5];
+  // The descriptor is read field by field (uniform scalar loads) and its arrays go through LDS: a private copy indexed at
+  // run time would live in scratch memory, and every dependent access to it costs a memory round trip.
+  const miphy_pusch_demod_job* __restrict__ jp = jobs + blockIdx.x;
+  const int sy  = blockIdx.y;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int start_symbol = jp->start_symbol, nof_symbols = jp->nof_symbols;
+  if (sy < start_symbol || sy >= start_symbol + nof_symbols)
     return;
-  const unsigned dmask   = dmrs_prb_mask(job.dmrs_type, job.nof_cdm_groups_without_data);
-  const int      per_dm  = 12 - __popc(dmask);
-  const bool     is_dmrs = (job.dmrs_symbols_mask >> sy) & 1;
-  const int      npp     = is_dmrs ? per_dm : 12; // data REs per PRB in this symbol
+  const unsigned dmask     = dmrs_prb_mask(jp->dmrs_type, jp->nof_cdm_groups_without_data);
+  const int      per_dm    = 12 - __popc(dmask);
+  const unsigned dmrs_syms = jp->dmrs_symbols_mask;
+  const bool     is_dmrs   = (dmrs_syms >> sy) & 1;
+  const int      npp       = is_dmrs ? per_dm : 12; // data REs per PRB in this symbol
   if (npp == 0)
     return;
-  const int nprb_grid = job.grid_nof_prb;
+  const int nprb_grid = jp->grid_nof_prb;
+  if (tid < 5)
+    rbm[tid] = jp->rb_mask[tid];
+  __syncthreads();
   for (int r = tid; r < nprb_grid; r += nt) {
     const int wd = r >> 6, bt = r & 63;
-    if ((job.rb_mask[wd] >> bt) & 1ull) {
-      int idx = __popcll(job.rb_mask[wd] & ((1ull << bt) - 1ull));
+    const uint64_t m = rbm[wd];
+    if ((m >> bt) & 1ull) {
+      int idx = __popcll(m & ((1ull << bt) - 1ull));
       for (int w = 0; w < wd; ++w)
-        idx += __popcll(job.rb_mask[w]);
+        idx += __popcll(rbm[w]);
       prb_of[idx] = (uint16_t)r;
     }
   }
   if (tid == 0) {
     int c = 0;
     for (int w = 0; w < 5; ++w)
-      c += __popcll(w * 64 < nprb_grid ? (job.rb_mask[w] & ((nprb_grid - w * 64 >= 64) ? ~0ull : ((1ull << (nprb_grid - w * 64)) - 1ull))) : 0ull);
+      c += __popcll(w * 64 < nprb_grid ? (rbm[w] & ((nprb_grid - w * 64 >= 64) ? ~0ull : ((1ull << (nprb_grid - w * 64)) - 1ull))) : 0ull);
     nprb_s = c;
     int k  = 0;
     for (int q = 0; q < 12; ++q)
@@ -208,28 +281,40 @@ __global__ void __launch_bounds__(256) pusch_demod_kernel(const miphy_pusch_demo
   __syncthreads();
   const int nprb = nprb_s;
   int       prefix = 0; // data REs of the transmission before this symbol
-  for (int s = job.start_symbol; s < sy; ++s)
-    prefix += nprb * (((job.dmrs_symbols_mask >> s) & 1) ? per_dm : 12);
+  for (int s = start_symbol; s < sy; ++s)
+    prefix += nprb * (((dmrs_syms >> s) & 1) ? per_dm : 12);
   const int n_re   = nprb * npp;
-  const int mod    = job.mod;
+  const int mod    = jp->mod;
   const int nwords = ((n_re * mod + 31) >> 5) + 1; // + 1: the 64-bit window of the last RE
-  gold_long_block(*gt, (job.rnti << 15) + job.n_id, (uint32_t)prefix * (uint32_t)mod, nwords, w1, w2, w1, tid, nt);
-  const float noise_var = scalars[job.scalars_offset + 2];
+  gold_long_block(*gt, (jp->rnti << 15) + jp->n_id, (uint32_t)prefix * (uint32_t)mod, nwords, w1, w2, w1, tid, nt);
+  demod_args a;
+  a.nsc            = nprb_grid * 12;
+  a.nports         = jp->nof_rx_ports;
+  a.ce_nof_symbols = jp->ce_nof_symbols;
+  a.rxp            = (uint32_t)jp->rx_ports[0] | ((uint32_t)jp->rx_ports[1] << 8) | ((uint32_t)jp->rx_ports[2] << 16) | ((uint32_t)jp->rx_ports[3] << 24);
+  a.grid           = grid + jp->grid_offset;
+  a.ce             = ce + jp->ce_offset;
+  a.llr            = llr + jp->llr_offset;
+  a.noise_var      = scalars[jp->scalars_offset + 2];
   switch (mod) {
     case 8:
-      demod_body<8>(job, prb_of, pos, npp, n_re, prefix, sy, w1, grid, ce, noise_var, llr, tid, nt);
+      demod_tables_to_lds<8>(tab, tid);
+      __syncthreads();
+      demod_body<8>(a, prb_of, pos, npp, n_re, prefix, sy, w1, tab, tid, nt);
       break;
     case 6:
-      demod_body<6>(job, prb_of, pos, npp, n_re, prefix, sy, w1, grid, ce, noise_var, llr, tid, nt);
+      demod_tables_to_lds<6>(tab, tid);
+      __syncthreads();
+      demod_body<6>(a, prb_of, pos, npp, n_re, prefix, sy, w1, tab, tid, nt);
       break;
     case 4:
-      demod_body<4>(job, prb_of, pos, npp, n_re, prefix, sy, w1, grid, ce, noise_var, llr, tid, nt);
+      demod_body<4>(a, prb_of, pos, npp, n_re, prefix, sy, w1, tab, tid, nt);
       break;
     case 2:
-      demod_body<2>(job, prb_of, pos, npp, n_re, prefix, sy, w1, grid, ce, noise_var, llr, tid, nt);
+      demod_body<2>(a, prb_of, pos, npp, n_re, prefix, sy, w1, tab, tid, nt);
       break;
     default:
-      demod_body<1>(job, prb_of, pos, npp, n_re, prefix, sy, w1, grid, ce, noise_var, llr, tid, nt);
+      demod_body<1>(a, prb_of, pos, npp, n_re, prefix, sy, w1, tab, tid, nt);
       break;
   }
 }
