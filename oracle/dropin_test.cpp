@@ -403,6 +403,146 @@ static void test_pusch_demodulator(std::shared_ptr<miphy::context> c)
   printf("pusch_demodulator done, failures so far %d\n", failures);
 }
 
+// The seam the gNB actually uses: srsran::pusch_processor built by the reference's own create_pusch_processor_factory_sw, once
+// from the reference's software factories and once from the HIP factories (estimator, demodulator, decoder), on a slot that the
+// reference's transmit blocks produced (PDSCH encoder + modulator + DM-RS processor: CP-OFDM uplink has the same structure).
+namespace {
+struct notifier_spy : public pusch_processor_result_notifier {
+  channel_state_information   csi;
+  pusch_processor_result_data sch;
+  bool                        got_csi = false, got_sch = false, got_uci = false;
+  void on_csi(const channel_state_information& c) override { csi = c, got_csi = true; }
+  void on_uci(const pusch_processor_result_control&) override { got_uci = true; }
+  void on_sch(const pusch_processor_result_data& d) override { sch = d, got_sch = true; }
+};
+} // namespace
+
+static std::unique_ptr<pusch_processor> make_processor(std::shared_ptr<miphy::context> c, bool hip)
+{
+  auto prg  = create_pseudo_random_generator_sw_factory();
+  auto crcf = create_crc_calculator_factory_sw("auto");
+  pusch_decoder_factory_sw_configuration dc;
+  dc.crc_factory       = crcf;
+  dc.decoder_factory   = create_ldpc_decoder_factory_sw("avx2");
+  dc.dematcher_factory = create_ldpc_rate_dematcher_factory_sw("avx2");
+  dc.segmenter_factory = create_ldpc_segmenter_rx_factory_sw();
+  uci_decoder_factory_sw_configuration uc;
+  uc.decoder_factory = create_short_block_detector_factory_sw();
+  pusch_processor_factory_sw_configuration pc;
+  pc.estimator_factory   = hip ? miphy::create_dmrs_pusch_estimator_factory_hip(c)
+                               : create_dmrs_pusch_estimator_factory_sw(prg, create_port_channel_estimator_factory_sw(std::make_shared<generic_dft_factory>()));
+  pc.demodulator_factory = hip ? miphy::create_pusch_demodulator_factory_hip(c)
+                               : create_pusch_demodulator_factory_sw(create_channel_equalizer_factory_zf(), create_channel_modulation_sw_factory(), prg);
+  pc.demux_factory       = create_ulsch_demultiplex_factory_sw();
+  pc.decoder_factory     = hip ? miphy::create_pusch_decoder_factory_hip(c) : create_pusch_decoder_factory_sw(dc);
+  pc.uci_dec_factory     = create_uci_decoder_factory_sw(uc);
+  pc.ch_estimate_dimensions.nof_prb = MAX_RB, pc.ch_estimate_dimensions.nof_symbols = MAX_NSYMB_PER_SLOT;
+  pc.ch_estimate_dimensions.nof_rx_ports = 1, pc.ch_estimate_dimensions.nof_tx_layers = 1;
+  pc.dec_nof_iterations = 6, pc.dec_enable_early_stop = true;
+  return create_pusch_processor_factory_sw(pc)->create();
+}
+
+static void test_pusch_processor(std::shared_ptr<miphy::context> c)
+{
+  auto prg  = create_pseudo_random_generator_sw_factory();
+  auto crcf = create_crc_calculator_factory_sw("auto");
+  pdsch_encoder_factory_sw_configuration ec;
+  ec.encoder_factory      = create_ldpc_encoder_factory_sw("avx2");
+  ec.rate_matcher_factory = create_ldpc_rate_matcher_factory_sw();
+  ec.segmenter_factory    = create_ldpc_segmenter_tx_factory_sw(crcf);
+  auto enc   = create_pdsch_encoder_factory_sw(ec)->create();
+  auto mod   = create_pdsch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg)->create();
+  auto dmrs  = create_dmrs_pdsch_processor_factory_sw(prg)->create();
+  auto p_ref = make_processor(c, false), p_hip = make_processor(c, true);
+  struct tc {
+    modulation_scheme mod;
+    unsigned          nprb, rb_start, tbs;
+    float             sigma;
+  };
+  std::uniform_int_distribution<int> byte(0, 255);
+  const float                        dmrs_amp = convert_dB_to_amplitude(3.0F);
+  for (const tc& t : {tc{modulation_scheme::QAM256, 273, 0, 319784, 0.015F}, tc{modulation_scheme::QAM64, 52, 10, 42016, 0.03F},
+                      tc{modulation_scheme::QPSK, 25, 3, 3848, 0.2F}}) {
+    const unsigned grid_rb = t.rb_start + t.nprb, nsc = grid_rb * 12, Qm = get_bits_per_symbol(t.mod);
+    const unsigned nre = t.nprb * 156, G = nre * Qm;
+    std::vector<uint8_t> tb(t.tbs / 8);
+    for (auto& b : tb) {
+      b = byte(rgen);
+    }
+    segmenter_config sc;
+    sc.base_graph = (t.tbs > 3824) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+    sc.rv = 0, sc.mod = t.mod, sc.Nref = 0, sc.nof_layers = 1, sc.nof_ch_symbols = nre;
+    std::vector<uint8_t> cw(G);
+    enc->encode(cw, tb, sc);
+    dynamic_bit_buffer packed(G);
+    for (unsigned i = 0; i != G; ++i) {
+      packed.insert(cw[i] & 1U, i, 1);
+    }
+    auto grid = create_resource_grid(1, 14, nsc);
+    grid->set_all_zero();
+    symbol_slot_mask dm(14);
+    dm.set(2);
+    pdsch_modulator::config_t mc;
+    mc.rnti = 0x4601, mc.bwp_size_rb = grid_rb, mc.bwp_start_rb = 0, mc.modulation1 = t.mod, mc.modulation2 = t.mod;
+    mc.freq_allocation    = rb_allocation::make_type1(t.rb_start, t.nprb);
+    mc.start_symbol_index = 0, mc.nof_symbols = 14, mc.dmrs_symb_pos = dm, mc.dmrs_config_type = dmrs_type::TYPE1;
+    mc.nof_cdm_groups_without_data = 2, mc.n_id = 935, mc.scaling = 1.0F, mc.pmi = 0;
+    mc.ports.push_back(0);
+    std::vector<bit_buffer> cws;
+    cws.emplace_back(packed);
+    mod->modulate(*grid, cws, mc);
+    dmrs_pdsch_processor::config_t dc;
+    dc.slot = slot_point(1, 7), dc.reference_point_k_rb = 0, dc.type = dmrs_type::TYPE1, dc.scrambling_id = 42, dc.n_scid = false;
+    dc.amplitude = dmrs_amp, dc.symbols_mask = dm;
+    dc.rb_mask   = bounded_bitset<MAX_RB>(grid_rb);
+    dc.rb_mask.fill(t.rb_start, t.rb_start + t.nprb, true);
+    dc.ports.push_back(0);
+    dmrs->map(*grid, dc);
+    std::normal_distribution<float> n(0.F, t.sigma * 0.7071F);
+    std::vector<cf_t>               row(nsc);
+    for (unsigned l = 0; l != 14; ++l) {
+      grid->get(row, 0, l, 0);
+      for (auto& v : row) {
+        v += cf_t(n(rgen), n(rgen));
+      }
+      grid->put(0, l, 0, row);
+    }
+    pusch_processor::pdu_t pdu;
+    pdu.slot = slot_point(1, 7), pdu.rnti = 0x4601, pdu.bwp_size_rb = grid_rb, pdu.bwp_start_rb = 0, pdu.cp = cyclic_prefix::NORMAL;
+    pdu.mcs_descr.modulation = t.mod, pdu.mcs_descr.target_code_rate = 0.5F;
+    pdu.codeword.emplace();
+    pdu.codeword.value().rv = 0, pdu.codeword.value().ldpc_base_graph = sc.base_graph, pdu.codeword.value().new_data = true;
+    pdu.uci = {};
+    pdu.uci.alpha_scaling = 1.0F, pdu.uci.beta_offset_harq_ack = 20.0F, pdu.uci.beta_offset_csi_part1 = 6.25F, pdu.uci.beta_offset_csi_part2 = 6.25F;
+    pdu.n_id = 935, pdu.nof_tx_layers = 1;
+    pdu.rx_ports.push_back(0);
+    pdu.dmrs_symbol_mask = dm, pdu.dmrs = dmrs_type::TYPE1, pdu.scrambling_id = 42, pdu.n_scid = false, pdu.nof_cdm_groups_without_data = 2;
+    pdu.freq_alloc = rb_allocation::make_type1(t.rb_start, t.nprb);
+    pdu.start_symbol_index = 0, pdu.nof_symbols = 14, pdu.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8;
+    unsigned nof_cbs = ldpc::compute_nof_codeblocks(units::bits(t.tbs), sc.base_graph);
+    rx_softbuffer_pool_config pc;
+    pc.max_codeblock_size = ldpc::MAX_CODEBLOCK_SIZE, pc.max_softbuffers = 2, pc.max_nof_codeblocks = 128, pc.expire_timeout_slots = 1000;
+    auto                     pool1 = create_rx_softbuffer_pool(pc), pool2 = create_rx_softbuffer_pool(pc);
+    rx_softbuffer_identifier id;
+    id.rnti = 1, id.harq_ack_id = 0;
+    auto sb1 = pool1->reserve_softbuffer(slot_point(1, 7), id, nof_cbs), sb2 = pool2->reserve_softbuffer(slot_point(1, 7), id, nof_cbs);
+    std::vector<uint8_t> o1(tb.size(), 0), o2(tb.size(), 0);
+    notifier_spy         n1, n2;
+    p_ref->process(o1, sb1.get(), n1, *grid, pdu);
+    p_hip->process(o2, sb2.get(), n2, *grid, pdu);
+    CHECK(n1.got_sch && n2.got_sch && n1.got_csi && n2.got_csi && !n1.got_uci && !n2.got_uci, "pusch_processor: notifications differ");
+    CHECK(n1.sch.data.tb_crc_ok && n2.sch.data.tb_crc_ok, "pusch_processor: TB CRC ref %d hip %d (nprb %u)", (int)n1.sch.data.tb_crc_ok,
+          (int)n2.sch.data.tb_crc_ok, t.nprb);
+    CHECK(o1 == tb && o2 == tb, "pusch_processor: transport block mismatch (nprb %u)", t.nprb);
+    CHECK(n1.sch.data.nof_codeblocks_total == n2.sch.data.nof_codeblocks_total, "pusch_processor: codeblock count mismatch");
+    CHECK(std::abs(n1.csi.epre_dB - n2.csi.epre_dB) < 1e-3F && std::abs(n1.csi.rsrp_dB - n2.csi.rsrp_dB) < 1e-3F &&
+              std::abs(n1.csi.sinr_dB - n2.csi.sinr_dB) < 1e-2F,
+          "pusch_processor: CSI differs: epre %g/%g rsrp %g/%g sinr %g/%g", n1.csi.epre_dB, n2.csi.epre_dB, n1.csi.rsrp_dB, n2.csi.rsrp_dB,
+          n1.csi.sinr_dB, n2.csi.sinr_dB);
+  }
+  printf("pusch_processor (reference factory, HIP estimator + demodulator + decoder) done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -437,6 +577,7 @@ int main()
   test_dft(c);
   test_pdcch(c);
   test_pusch_demodulator(c);
+  test_pusch_processor(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);
     return 1;
