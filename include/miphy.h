@@ -298,6 +298,70 @@ int miphy_pusch_demodulate_batch(miphy_ctx* ctx, const miphy_pusch_demod_job* jo
                                  int8_t* llr_out /* device */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * PDSCH modulator and PDSCH DM-RS  --  replace srsran::pdsch_modulator::modulate and srsran::dmrs_pdsch_processor::map
+ * (after the encoder, before the OFDM modulator)
+ *   include/srsran/phy/upper/channel_processors/pdsch_modulator.h:40-99, lib/.../pdsch_modulator_impl.cpp:30-282
+ *   lib/phy/upper/channel_modulation/modulation_mapper_impl.cpp:31-146
+ *   include/srsran/phy/upper/signal_processors/dmrs_pdsch_processor.h:36-66, lib/.../dmrs_pdsch_processor_impl.cpp:30-169
+ * Modulator: one codeword on one layer, PRBs mapped in ascending order (what 23.5 supports: its layer mapper and its
+ * non-contiguous mapping path are broken, see csrc/pdsch_mod.hip); DM-RS pattern of the bandwidth part and up to four reserved RE
+ * patterns are skipped. The codeword is one bit per byte (the layout miphy_pdsch_encode_batch writes). Only the mapped REs of
+ * the grid are written. */
+typedef struct {
+  uint64_t prb_mask[5]; /* PRBs (grid numbering) the pattern applies to */
+  uint16_t re_mask;     /* bit k = subcarrier k of each of these PRBs */
+  uint16_t symbols;     /* bit l = OFDM symbol l */
+  uint32_t pad;
+} miphy_re_pattern;
+
+typedef struct {
+  uint32_t rnti;
+  uint32_t n_id;
+  float    scaling;        /* applied when std::isnormal(scaling), like the reference */
+  uint8_t  mod;            /* bits per symbol: 1 (pi/2-BPSK), 2, 4, 6, 8 */
+  uint8_t  port;           /* grid port of the (single) layer */
+  uint8_t  start_symbol;
+  uint8_t  nof_symbols;
+  uint8_t  dmrs_type;      /* 1 or 2 */
+  uint8_t  nof_cdm_groups_without_data;
+  uint8_t  nof_reserved;   /* 0..4 */
+  uint8_t  reserved0;
+  uint16_t dmrs_symbols_mask;
+  uint16_t grid_nof_prb;
+  uint16_t bwp_start_rb;   /* the DM-RS pattern covers [bwp_start_rb, bwp_start_rb + bwp_size_rb) */
+  uint16_t bwp_size_rb;
+  uint32_t nof_bits;       /* codeword length; must equal miphy_pdsch_mod_nof_re() * mod */
+  uint64_t rb_mask[5];     /* allocated PRBs, grid numbering (rb_allocation::get_prb_mask) */
+  miphy_re_pattern reserved[4];
+  uint64_t cw_offset;      /* byte offset of the codeword (one bit per byte) */
+  uint64_t grid_offset;    /* cf_t offset of grid port 0: [port][14][grid_nof_prb*12] */
+} miphy_pdsch_mod_job;
+
+uint32_t miphy_pdsch_mod_nof_re(const miphy_pdsch_mod_job* job); /* host: data REs of the allocation; 0 on an invalid job */
+int miphy_pdsch_modulate_batch(miphy_ctx* ctx, const miphy_pdsch_mod_job* jobs, int jobs_on_device, uint32_t n,
+                               const uint8_t* codewords /* device */, float* grid /* device cf_t */, void* stream);
+
+typedef struct {
+  uint32_t slot_in_frame;         /* slot.slot_index() */
+  uint32_t reference_point_k_rb;
+  uint32_t scrambling_id;
+  float    amplitude;             /* linear amplitude of the DM-RS (the sequence is +-amplitude/sqrt(2)) */
+  uint8_t  dmrs_type;             /* 1 or 2 */
+  uint8_t  n_scid;
+  uint8_t  nof_ports;             /* DM-RS ports 1000 .. 1000 + nof_ports - 1 */
+  uint8_t  reserved0;
+  uint8_t  ports[12];             /* grid port of each DM-RS port */
+  uint16_t symbols_mask;
+  uint16_t grid_nof_prb;
+  uint32_t pad;
+  uint64_t rb_mask[5];
+  uint64_t grid_offset;           /* cf_t offset of grid port 0 */
+} miphy_dmrs_pdsch_job;
+
+int miphy_dmrs_pdsch_map_batch(miphy_ctx* ctx, const miphy_dmrs_pdsch_job* jobs, int jobs_on_device, uint32_t n, float* grid /* device cf_t */,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Polar code chains  --  replace the chain of srsran::polar_code::set + polar_allocator::allocate + polar_encoder::encode
  * + polar_rate_matcher::rate_match (transmit) and polar_rate_dematcher::rate_dematch + polar_decoder::decode +
  * polar_deallocator::deallocate (receive), as wired in tests/unittests/phy/upper/channel_coding/polar/polar_chain_test.cpp:156-210

@@ -217,3 +217,39 @@ for i, (mod, ports, cdm, nprb_grid, start, nof, dsyms) in enumerate([(8, 1, 2, 1
     d["llr_%d" % i] = O.r_pusch_demodulate(rnti, n_id, mod, start, nof, dm, 0, cdm, rb, grid, ce, noise_var)
     d["bits_%d" % i] = bits
 save("pusch_demod", **d)
+
+# ------------------------------------------------------------------ PDSCH modulator + PDSCH DM-RS
+d = {}
+for i, mod in enumerate((1, 2, 4, 6, 8)):
+    bits = rng.integers(0, 2, 509 * mod, dtype=np.uint8)
+    d["map_bits_%d" % i], d["map_sym_%d" % i], d["map_meta_%d" % i] = bits, O.r_modulate(mod, bits), np.array([mod], dtype=np.int64)
+for i, (mod, nprb_grid, bwp_start, bwp_size, v0, v1, start, nof, dsyms, type2, cdm, nres, scaling, port, ngp) in enumerate([
+        (8, 24, 0, 24, 0, 24, 0, 14, (2,), 0, 2, 0, 1.0, 0, 1), (6, 40, 6, 30, 3, 25, 2, 12, (2, 11), 0, 1, 2, 0.7, 1, 2),
+        (4, 30, 4, 26, 0, 26, 1, 13, (3,), 1, 2, 1, 1.0, 3, 4), (2, 20, 0, 20, 7, 8, 0, 14, (2, 7), 1, 1, 4, float("nan"), 2, 3),
+        (1, 16, 2, 12, 1, 9, 0, 14, (2,), 0, 2, 0, 1.0, 0, 1)]):
+    dm = np.zeros(14, np.uint8)
+    dm[list(dsyms)] = 1
+    vrb = np.zeros(bwp_size, np.uint8)
+    vrb[v0:v1] = 1
+    reserved = [((rng.uniform(size=nprb_grid) < 0.5).astype(np.uint8), int(rng.integers(1, 4096)), int(rng.integers(1, 1 << 14))) for _ in range(nres)]
+    pl = O.r_prb_indices(bwp_start, bwp_size, vrb, 0)
+    nre = O.pdsch_nof_re(pl, start, nof, dm, type2, cdm, bwp_start, bwp_size, reserved)
+    cw = rng.integers(0, 2, nre * mod, dtype=np.uint8)
+    rnti, n_id = int(rng.integers(1, 65536)), int(rng.integers(0, 1024))
+    grid, pl2 = O.r_pdsch_modulate(rnti, n_id, scaling, 1, [mod], [cw], start, nof, dm, type2, cdm, bwp_start, bwp_size, vrb, 0, reserved, [port],
+                                   nprb_grid, ngp)
+    d["pm_cw_%d" % i], d["pm_grid_%d" % i], d["pm_prb_%d" % i], d["pm_dm_%d" % i] = cw, grid, pl2, dm
+    d["pm_res_prb_%d" % i] = np.array([r[0] for r in reserved], dtype=np.uint8).reshape(nres, nprb_grid)
+    d["pm_res_re_%d" % i] = np.array([[r[1], r[2]] for r in reserved], dtype=np.int64).reshape(nres, 2)
+    d["pm_meta_%d" % i] = np.array([rnti, n_id, scaling, mod, start, nof, type2, cdm, bwp_start, bwp_size, port, nprb_grid, ngp], dtype=np.float64)
+for i, (type2, nports, ref_pt, syms, nprb) in enumerate([(0, 4, 0, (2, 3), 24), (1, 6, 5, (2,), 30), (0, 8, 2, (2, 3, 10, 11), 20), (1, 12, 0, (4, 5), 12)]):
+    rb = np.zeros(nprb, np.uint8)
+    rb[ref_pt + 1: ref_pt + 9] = 1
+    rb[nprb - 2] = 1
+    sm = np.zeros(14, np.uint8)
+    sm[list(syms)] = 1
+    slot, scr, nscid, amp = int(rng.integers(0, 20)), int(rng.integers(0, 65536)), int(rng.integers(0, 2)), float(rng.uniform(0.5, 2.0))
+    d["dd_grid_%d" % i] = O.r_dmrs_pdsch_map(1, slot, ref_pt, type2, scr, nscid, amp, sm, rb, list(range(nports)), nports)
+    d["dd_rb_%d" % i], d["dd_sm_%d" % i] = rb, sm
+    d["dd_meta_%d" % i] = np.array([slot, ref_pt, type2, scr, nscid, amp, nports], dtype=np.float64)
+save("pdsch_mod", **d)

@@ -1699,3 +1699,145 @@ int orc_pusch_demodulate(unsigned rnti, unsigned n_id, int mod, unsigned start_s
   free(c);
   return (int)nbits;
 }
+
+/* ================================================================================================= PDSCH modulator + DM-RS
+ * modulation_mapper_impl.cpp:31-146 (constellation = integer level * sqrtf(1 / average power), TS 38.211 5.1),
+ * pdsch_modulator_impl.cpp:30-282 (scramble with c_init = rnti*2^15 + q*2^14 + n_id, modulate, optional scaling, codeword-to-layer
+ * mapping with the reference's rule "two codewords from four layers on", mapping to the allocated PRBs in the given order skipping
+ * the DM-RS pattern of the bandwidth part and the reserved RE patterns), dmrs_pdsch_processor_impl.cpp:30-169 + dmrs_helper.h:44-96. */
+static float mod_scale(int mod)
+{
+  /* average power of the integer constellation: 2 (QPSK), 10, 42, 170 -> scaling = sqrt(1 / avg) in single precision */
+  const float avg = (mod == 2) ? 2.f : (mod == 4) ? 10.f : (mod == 6) ? 42.f : 170.f;
+  return sqrtf(1.0f / avg);
+}
+
+/* bits: one bit per byte, first bit = most significant. */
+static void mod_symbol(int mod, const uint8_t* b, unsigned sym_idx, float* re, float* im)
+{
+  if (mod == 1) { /* pi/2-BPSK: even (s, s), odd (-s, s) with s = +-1/sqrt(2) */
+    const float v = (float)M_SQRT1_2;
+    const float s = (b[0] & 1u) ? -v : v;
+    *re           = (sym_idx & 1u) ? -s : s;
+    *im           = s;
+    return;
+  }
+  int lr = 0, li = 0;
+  const int h = mod / 2;
+  /* x = (1-2b0)[2^(h-1) - (1-2b2)[2^(h-2) - ...]], real part from the even bits, imaginary part from the odd ones */
+  for (int j = h - 1; j >= 0; --j) {
+    const int sr = 1 - 2 * (int)(b[2 * j] & 1u), si = 1 - 2 * (int)(b[2 * j + 1] & 1u);
+    const int w  = 1 << (h - 1 - j);
+    lr           = sr * (w - lr);
+    li           = si * (w - li);
+  }
+  const float sc = mod_scale(mod);
+  *re            = (float)lr * sc;
+  *im            = (float)li * sc;
+}
+
+void orc_modulate(int mod, unsigned nsym, const uint8_t* bits, float* symbols)
+{
+  for (unsigned i = 0; i < nsym; ++i)
+    mod_symbol(mod, bits + (size_t)i * (unsigned)mod, i, symbols + 2 * i, symbols + 2 * i + 1);
+}
+
+int orc_pdsch_modulate(unsigned rnti, unsigned n_id, float scaling, unsigned nof_layers, const int* mod, const uint8_t* cw0, unsigned nbits0,
+                       const uint8_t* cw1, unsigned nbits1, unsigned start_symbol, unsigned nof_symbols, const uint8_t* dmrs_symbols_mask,
+                       int dmrs_type2, unsigned nof_cdm_groups_without_data, unsigned bwp_start_rb, unsigned bwp_size_rb, const uint16_t* prb_list,
+                       unsigned nof_prb, unsigned nof_reserved, const uint8_t* res_prb_mask, const uint16_t* res_re_mask,
+                       const uint16_t* res_symbols, const uint8_t* ports, unsigned nof_prb_grid, float* grid)
+{
+  const unsigned nsc      = nof_prb_grid * 12;
+  const unsigned nof_cw   = (nof_layers >= 4) ? 2 : 1;
+  const unsigned lcw[2]   = {nof_layers / nof_cw, nof_layers - nof_layers / nof_cw};
+  const uint8_t* cw[2]    = {cw0, cw1};
+  const unsigned nbits[2] = {nbits0, nbits1};
+  const unsigned dmask    = dmrs_prb_mask(dmrs_type2, nof_cdm_groups_without_data);
+  uint8_t*       c[2]     = {NULL, NULL};
+  for (unsigned q = 0; q < nof_cw; ++q) {
+    c[q] = (uint8_t*)malloc(nbits[q] ? nbits[q] : 1);
+    orc_gold_sequence((rnti << 15) + (q << 14) + n_id, 0, nbits[q], c[q]);
+  }
+  unsigned i_re = 0;
+  int      rc   = 0;
+  for (unsigned sy = start_symbol; sy < start_symbol + nof_symbols; ++sy) {
+    for (unsigned pi = 0; pi < nof_prb; ++pi) {
+      const unsigned rb = prb_list[pi];
+      for (unsigned k = 0; k < 12; ++k) {
+        int excluded = dmrs_symbols_mask[sy] && ((dmask >> k) & 1u) && rb >= bwp_start_rb && rb < bwp_start_rb + bwp_size_rb;
+        for (unsigned r = 0; r < nof_reserved; ++r)
+          excluded |= res_prb_mask[(size_t)r * nof_prb_grid + rb] && ((res_re_mask[r] >> k) & 1u) && ((res_symbols[r] >> sy) & 1u);
+        if (excluded)
+          continue;
+        for (unsigned ly = 0; ly < nof_layers; ++ly) {
+          const unsigned q = (ly < lcw[0]) ? 0 : 1;
+          const unsigned d = (q == 0) ? lcw[0] * i_re + ly : lcw[1] * i_re + (ly - lcw[0]);
+          const unsigned m = (unsigned)mod[q];
+          if ((size_t)(d + 1) * m > nbits[q]) {
+            rc = -1;
+            continue;
+          }
+          uint8_t b[8];
+          for (unsigned t = 0; t < m; ++t)
+            b[t] = (cw[q][(size_t)d * m + t] ^ c[q][(size_t)d * m + t]) & 1u;
+          float re, im;
+          mod_symbol((int)m, b, d, &re, &im);
+          if (isnormal(scaling)) {
+            re = re * scaling;
+            im = im * scaling;
+          }
+          float* o = grid + 2 * (((size_t)ports[ly] * 14 + sy) * nsc + rb * 12 + k);
+          o[0]     = re;
+          o[1]     = im;
+        }
+        ++i_re;
+      }
+    }
+  }
+  for (unsigned q = 0; q < nof_cw; ++q) {
+    if ((size_t)i_re * lcw[q] * (unsigned)mod[q] != nbits[q])
+      rc = -1; /* pdsch_modulator_impl.cpp:222-225: every element of every layer must be mapped */
+    free(c[q]);
+  }
+  return rc ? rc : (int)i_re;
+}
+
+int orc_dmrs_pdsch_map(unsigned slot_in_frame, unsigned reference_point_k_rb, int type2, unsigned scrambling_id, int n_scid, float amplitude,
+                       const uint8_t* symbols_mask, const uint8_t* rb_mask, unsigned nof_prb_grid, unsigned nof_ports, const uint8_t* ports, float* grid)
+{
+  const unsigned nsc = nof_prb_grid * 12, npr = type2 ? 4 : 6;
+  const float    amp = (float)(M_SQRT1_2 * (double)amplitude);
+  uint8_t*       c   = (uint8_t*)malloc(2 * npr * nof_prb_grid + 1);
+  for (unsigned sy = 0; sy < 14; ++sy) {
+    if (!symbols_mask[sy])
+      continue;
+    const unsigned long long t = ((unsigned long long)(14 * slot_in_frame + sy + 1) * (2ull * scrambling_id + 1)) % (1ull << 31);
+    const unsigned c_init      = (unsigned)((t * (1ull << 17) + (2ull * scrambling_id + (n_scid ? 1 : 0))) % (1ull << 31));
+    orc_gold_sequence(c_init, 0, 2 * npr * nof_prb_grid, c);
+    const unsigned l_prime = (sy != 0 && symbols_mask[sy - 1]) ? 1 : 0;
+    for (unsigned p = 0; p < nof_ports; ++p) {
+      const unsigned delta = !type2 ? (p / 2) % 2 : 2 * ((p / 2) % 3);
+      const float    wf1   = (p % 2) ? -1.f : 1.f;
+      const float    wt    = (l_prime && p >= (type2 ? 6u : 4u)) ? -1.f : 1.f;
+      unsigned       i     = 0; /* index in the generated sequence (allocated PRBs only) */
+      for (unsigned rb = reference_point_k_rb; rb < nof_prb_grid; ++rb) {
+        if (!rb_mask[rb])
+          continue;
+        for (unsigned q = 0; q < npr; ++q, ++i) {
+          const unsigned g  = (rb - reference_point_k_rb) * npr + q; /* sequence position counted from the reference point */
+          const unsigned k  = !type2 ? 2 * q : (q < 2 ? q : 4 + q);     /* type 1: 0,2,..,10 ; type 2: 0,1,6,7 */
+          float          re = c[2 * g] ? -amp : amp, im = c[2 * g + 1] ? -amp : amp;
+          const float    w  = wt * ((i & 1u) ? wf1 : 1.f);
+          re                = re * w;
+          im                = im * w;
+          float* o          = grid + 2 * (((size_t)ports[p] * 14 + sy) * nsc + rb * 12 + k + delta);
+          o[0]              = re;
+          o[1]              = im;
+        }
+      }
+    }
+  }
+  free(c);
+  return 0;
+}

@@ -147,6 +147,22 @@ int orc_pusch_demodulate(unsigned rnti, unsigned n_id, int mod, unsigned start_s
                          unsigned nof_rx_ports, const float* grid, const float* ce, unsigned ce_nof_symbols, float noise_var, int8_t* llr_out,
                          float* eq_out, float* nvar_out);
 
+/* ------------------------------------------------------------------------------------------------ PDSCH modulator + DM-RS
+ * Modulation mapper: bits one per byte -> cf_t symbols (mod 1 = pi/2-BPSK, 2, 4, 6, 8). */
+void orc_modulate(int mod, unsigned nsym, const uint8_t* bits, float* symbols);
+/* pdsch_modulator::modulate. cw0/cw1: codewords, one bit per byte; mod[2]; prb_list: allocated PRBs in mapping order; reserved patterns:
+ * res_prb_mask [nof_reserved][nof_prb_grid] bytes, res_re_mask (12 bits), res_symbols (14 bits); ports[layer] = grid port.
+ * grid: [ports][14][nof_prb_grid*12] cf_t, only the mapped REs are written. Returns the number of REs per layer, or -1 when the
+ * codeword lengths do not match the allocation. */
+int orc_pdsch_modulate(unsigned rnti, unsigned n_id, float scaling, unsigned nof_layers, const int* mod, const uint8_t* cw0, unsigned nbits0,
+                       const uint8_t* cw1, unsigned nbits1, unsigned start_symbol, unsigned nof_symbols, const uint8_t* dmrs_symbols_mask,
+                       int dmrs_type2, unsigned nof_cdm_groups_without_data, unsigned bwp_start_rb, unsigned bwp_size_rb, const uint16_t* prb_list,
+                       unsigned nof_prb, unsigned nof_reserved, const uint8_t* res_prb_mask, const uint16_t* res_re_mask,
+                       const uint16_t* res_symbols, const uint8_t* ports, unsigned nof_prb_grid, float* grid);
+/* dmrs_pdsch_processor::map. ports[p] = grid port of the p-th DM-RS port (1000 + p). */
+int orc_dmrs_pdsch_map(unsigned slot_in_frame, unsigned reference_point_k_rb, int type2, unsigned scrambling_id, int n_scid, float amplitude,
+                       const uint8_t* symbols_mask, const uint8_t* rb_mask, unsigned nof_prb_grid, unsigned nof_ports, const uint8_t* ports, float* grid);
+
 #ifdef __cplusplus
 }
 #endif

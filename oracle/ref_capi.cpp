@@ -717,6 +717,180 @@ int ref_pusch_demodulate(unsigned       rnti,
   return 0;
 }
 
+// ---------------------------------------------------------------- PDSCH modulator + DM-RS PDSCH
+// vrb_mask: [bwp_size] bytes (type-0 allocation relative to the BWP); interleaved: 0 = none, 1 = create_interleaved_other(L_i = 2).
+// grid_out: [nof_grid_ports][14][nof_prb_grid*12] (zero where nothing was mapped); prb_list_out: the PRB indices in mapping order.
+int ref_pdsch_modulate(unsigned        rnti,
+                       unsigned        n_id,
+                       float           scaling,
+                       unsigned        nof_layers,
+                       const int*      mod,
+                       const uint8_t*  cw0,
+                       unsigned        nbits0,
+                       const uint8_t*  cw1,
+                       unsigned        nbits1,
+                       unsigned        start_symbol,
+                       unsigned        nof_symbols,
+                       const uint8_t*  dmrs_symbols_mask,
+                       int             dmrs_type2,
+                       unsigned        nof_cdm_groups_without_data,
+                       unsigned        bwp_start_rb,
+                       unsigned        bwp_size_rb,
+                       const uint8_t*  vrb_mask,
+                       int             interleaved,
+                       unsigned        nof_reserved,
+                       const uint8_t*  res_prb_mask,
+                       const uint16_t* res_re_mask,
+                       const uint16_t* res_symbols,
+                       const uint8_t*  ports,
+                       unsigned        nof_prb_grid,
+                       unsigned        nof_grid_ports,
+                       float*          grid_out,
+                       uint16_t*       prb_list_out,
+                       unsigned*       nof_prb_out)
+{
+  auto     m    = create_pdsch_modulator_factory_sw(create_channel_modulation_sw_factory(), create_pseudo_random_generator_sw_factory())->create();
+  unsigned nsc  = nof_prb_grid * 12;
+  auto     grid = create_resource_grid(nof_grid_ports, 14, nsc);
+  grid->set_all_zero();
+  pdsch_modulator::config_t cfg;
+  cfg.rnti = rnti, cfg.bwp_size_rb = bwp_size_rb, cfg.bwp_start_rb = bwp_start_rb;
+  cfg.modulation1 = mod_from_bits(mod[0]), cfg.modulation2 = mod_from_bits(mod[1]);
+  bounded_bitset<MAX_RB> vrb(bwp_size_rb);
+  for (unsigned r = 0; r != bwp_size_rb; ++r) {
+    if (vrb_mask[r]) {
+      vrb.set(r);
+    }
+  }
+  optional<vrb_to_prb_mapper> mapper;
+  if (interleaved) {
+    mapper.emplace(vrb_to_prb_mapper::create_interleaved_other(bwp_start_rb, bwp_size_rb, 2));
+  }
+  cfg.freq_allocation    = rb_allocation::make_type0(vrb, mapper);
+  cfg.start_symbol_index = start_symbol, cfg.nof_symbols = nof_symbols;
+  cfg.dmrs_symb_pos      = symbol_slot_mask(14);
+  for (unsigned l = 0; l != 14; ++l) {
+    if (dmrs_symbols_mask[l]) {
+      cfg.dmrs_symb_pos.set(l);
+    }
+  }
+  cfg.dmrs_config_type            = dmrs_type2 ? dmrs_type::TYPE2 : dmrs_type::TYPE1;
+  cfg.nof_cdm_groups_without_data = nof_cdm_groups_without_data;
+  cfg.n_id = n_id, cfg.scaling = scaling, cfg.pmi = 0;
+  for (unsigned r = 0; r != nof_reserved; ++r) {
+    re_pattern pat;
+    pat.prb_mask = bounded_bitset<MAX_RB>(nof_prb_grid);
+    for (unsigned b = 0; b != nof_prb_grid; ++b) {
+      if (res_prb_mask[size_t(r) * nof_prb_grid + b]) {
+        pat.prb_mask.set(b);
+      }
+    }
+    for (unsigned k = 0; k != 12; ++k) {
+      pat.re_mask.set(k, (res_re_mask[r] >> k) & 1U);
+    }
+    pat.symbols = symbol_slot_mask(14);
+    for (unsigned l = 0; l != 14; ++l) {
+      pat.symbols.set(l, (res_symbols[r] >> l) & 1U);
+    }
+    cfg.reserved.merge(pat);
+  }
+  for (unsigned l = 0; l != nof_layers; ++l) {
+    cfg.ports.push_back(ports[l]);
+  }
+  std::vector<dynamic_bit_buffer> packed;
+  const uint8_t*                  cws[2] = {cw0, cw1};
+  unsigned                        nb[2]  = {nbits0, nbits1};
+  unsigned                        ncw    = (nof_layers >= 4) ? 2 : 1;
+  for (unsigned q = 0; q != ncw; ++q) {
+    packed.emplace_back(nb[q]);
+    for (unsigned i = 0; i != nb[q]; ++i) {
+      packed.back().insert(cws[q][i] & 1U, i, 1);
+    }
+  }
+  std::vector<bit_buffer> views;
+  for (auto& b : packed) {
+    views.emplace_back(b);
+  }
+  m->modulate(*grid, views, cfg);
+  for (unsigned p = 0; p != nof_grid_ports; ++p) {
+    for (unsigned l = 0; l != 14; ++l) {
+      grid->get(span<cf_t>(reinterpret_cast<cf_t*>(grid_out) + (size_t(p) * 14 + l) * nsc, nsc), p, l, 0);
+    }
+  }
+  // The contiguous mapping path (the only one that works in 23.5) walks rb_allocation::get_prb_mask in ascending order.
+  auto     pm = cfg.freq_allocation.get_prb_mask(bwp_start_rb, bwp_size_rb);
+  unsigned n  = 0;
+  pm.for_each(0, pm.size(), [&](unsigned r) { prb_list_out[n++] = r; });
+  *nof_prb_out = n;
+  return 0;
+}
+
+// Allocated PRBs (rb_allocation::get_prb_mask, ascending) of a type-0 allocation inside a bandwidth part.
+int ref_prb_indices(unsigned bwp_start_rb, unsigned bwp_size_rb, const uint8_t* vrb_mask, int interleaved, uint16_t* out, unsigned* n_out)
+{
+  bounded_bitset<MAX_RB> vrb(bwp_size_rb);
+  for (unsigned r = 0; r != bwp_size_rb; ++r) {
+    if (vrb_mask[r]) {
+      vrb.set(r);
+    }
+  }
+  optional<vrb_to_prb_mapper> mapper;
+  if (interleaved) {
+    mapper.emplace(vrb_to_prb_mapper::create_interleaved_other(bwp_start_rb, bwp_size_rb, 2));
+  }
+  auto     pm = rb_allocation::make_type0(vrb, mapper).get_prb_mask(bwp_start_rb, bwp_size_rb);
+  unsigned n  = 0;
+  pm.for_each(0, pm.size(), [&](unsigned r) { out[n++] = r; });
+  *n_out = n;
+  return 0;
+}
+
+int ref_dmrs_pdsch_map(unsigned       numerology,
+                       unsigned       slot_index,
+                       unsigned       reference_point_k_rb,
+                       int            type2,
+                       unsigned       scrambling_id,
+                       int            n_scid,
+                       float          amplitude,
+                       const uint8_t* symbols_mask,
+                       const uint8_t* rb_mask,
+                       unsigned       nof_prb_grid,
+                       unsigned       nof_ports,
+                       const uint8_t* ports,
+                       unsigned       nof_grid_ports,
+                       float*         grid_out)
+{
+  auto     d    = create_dmrs_pdsch_processor_factory_sw(create_pseudo_random_generator_sw_factory())->create();
+  unsigned nsc  = nof_prb_grid * 12;
+  auto     grid = create_resource_grid(nof_grid_ports, 14, nsc);
+  grid->set_all_zero();
+  dmrs_pdsch_processor::config_t cfg;
+  cfg.slot = slot_point(numerology, slot_index), cfg.reference_point_k_rb = reference_point_k_rb;
+  cfg.type = type2 ? dmrs_type::TYPE2 : dmrs_type::TYPE1, cfg.scrambling_id = scrambling_id, cfg.n_scid = n_scid != 0, cfg.amplitude = amplitude;
+  cfg.symbols_mask = symbol_slot_mask(14);
+  for (unsigned l = 0; l != 14; ++l) {
+    if (symbols_mask[l]) {
+      cfg.symbols_mask.set(l);
+    }
+  }
+  cfg.rb_mask = bounded_bitset<MAX_RB>(nof_prb_grid);
+  for (unsigned r = 0; r != nof_prb_grid; ++r) {
+    if (rb_mask[r]) {
+      cfg.rb_mask.set(r);
+    }
+  }
+  for (unsigned p = 0; p != nof_ports; ++p) {
+    cfg.ports.push_back(ports[p]);
+  }
+  d->map(*grid, cfg);
+  for (unsigned p = 0; p != nof_grid_ports; ++p) {
+    for (unsigned l = 0; l != 14; ++l) {
+      grid->get(span<cf_t>(reinterpret_cast<cf_t*>(grid_out) + (size_t(p) * 14 + l) * nsc, nsc), p, l, 0);
+    }
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------- polar
 // Code construction: fills N, nPC, K_set (N bytes), PC_set (up to 3), F_set (N bytes), blk_interleaver (N uint16).
 int ref_polar_code(unsigned K, unsigned E, unsigned nMax, int ibil, unsigned* n_out, unsigned* npc_out, uint8_t* k_set, uint16_t* pc_set,

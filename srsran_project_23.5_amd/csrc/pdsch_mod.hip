@@ -1,0 +1,333 @@
+// PDSCH modulator and PDSCH DM-RS mapping: the transmit-side counterpart of pusch_demod.hip.
+//
+// Behaviour contract:
+//   lib/phy/upper/channel_processors/pdsch_modulator_impl.cpp:30-282 (scrambling c_init = rnti * 2^15 + q * 2^14 + n_id, modulation,
+//   optional scaling, mapping to the allocated PRBs in ascending order skipping the DM-RS pattern of the bandwidth part and the
+//   reserved RE patterns), lib/phy/upper/channel_modulation/modulation_mapper_impl.cpp:31-146 (constellation = integer level *
+//   sqrtf(1 / average power)), lib/phy/upper/signal_processors/dmrs_pdsch_processor_impl.cpp:30-169 + dmrs_helper.h:44-96.
+// One transmit layer / one codeword and contiguous (ascending) PRB mapping: the 23.5 reference cannot do more -- its layer mapper
+// indexes out of bounds for more than one layer (pdsch_modulator_impl.cpp:80-103) and its non-contiguous mapping path writes a
+// single PRB (map_to_prb_other). One workgroup per (transmission, OFDM symbol); every resource element is written once, with the
+// exact single-precision value of the reference (level * scale [* scaling]).
+#include "gold_device.h"
+#include "miphy_ext.h"
+#include <cmath>
+
+namespace {
+
+constexpr int MAX_SYM_WORDS = 832;
+
+__device__ __forceinline__ unsigned dmrs_prb_mask(int type, unsigned cdm)
+{
+  unsigned m = 0;
+  for (unsigned k = 0; k < 12; ++k)
+    m |= ((type == 1) ? ((k % 2) < cdm) : ((k % 6) < 2 * cdm)) ? (1u << k) : 0u;
+  return m;
+}
+
+// Allocated-PRB list (compact, ascending) from a 275-bit mask held in LDS; returns the number of allocated PRBs through *count.
+__device__ __forceinline__ void build_prb_list(const uint64_t* rbm, int nprb_grid, int first_rb, uint16_t* prb_of, int* count, int tid, int nt)
+{
+  for (int r = tid; r < nprb_grid; r += nt) {
+    const int      wd = r >> 6, bt = r & 63;
+    const uint64_t m  = rbm[wd];
+    if (r >= first_rb && ((m >> bt) & 1ull)) {
+      int idx = __popcll(m & ((1ull << bt) - 1ull));
+      for (int w = 0; w < wd; ++w)
+        idx += __popcll(rbm[w]);
+      prb_of[idx] = (uint16_t)r;
+    }
+  }
+  if (tid == 0) {
+    int c = 0;
+    for (int w = 0; w < 5; ++w)
+      c += __popcll(w * 64 < nprb_grid ? (rbm[w] & ((nprb_grid - w * 64 >= 64) ? ~0ull : ((1ull << (nprb_grid - w * 64)) - 1ull))) : 0ull);
+    *count = c;
+  }
+}
+
+// Constellation point of `mod` scrambled bits, TS 38.211 5.1 (b0 = first bit = most significant bit of the reference's table index).
+__device__ __forceinline__ float2 map_symbol(int mod, const uint32_t bits /* bit t = t-th bit of the symbol */, unsigned sym_idx)
+{
+  if (mod == 1) {
+    const float v = 0.70710678118654752440f;
+    const float s = (bits & 1u) ? -v : v;
+    return make_float2((sym_idx & 1u) ? -s : s, s);
+  }
+  int       lr = 0, li = 0;
+  const int h  = mod >> 1;
+  for (int j = h - 1; j >= 0; --j) {
+    const int sr = 1 - 2 * (int)((bits >> (2 * j)) & 1u), si = 1 - 2 * (int)((bits >> (2 * j + 1)) & 1u);
+    const int w  = 1 << (h - 1 - j);
+    lr           = sr * (w - lr);
+    li           = si * (w - li);
+  }
+  const float avg = (mod == 2) ? 2.f : (mod == 4) ? 10.f : (mod == 6) ? 42.f : 170.f;
+  const float sc  = sqrtf(1.0f / avg); // constant folded per modulation: correctly rounded division and square root
+  return make_float2((float)lr * sc, (float)li * sc);
+}
+
+__global__ void __launch_bounds__(256) pdsch_mod_kernel(const miphy_pdsch_mod_job* __restrict__ jobs, const gold_tables* __restrict__ gt,
+                                                        const uint8_t* __restrict__ cw_base, float2* __restrict__ grid)
+{
+  __shared__ uint32_t w1[MAX_SYM_WORDS], w2[MAX_SYM_WORDS];
+  __shared__ uint16_t prb_of[276];
+  __shared__ uint16_t keep_of[276];  // per allocated PRB: 12-bit mask of the REs that carry data in this symbol
+  __shared__ uint16_t off_of[276];   // per allocated PRB: index of its first data RE within the symbol
+  __shared__ uint64_t rbm[5], resm[4][5];
+  __shared__ int      nprb_s, red[8];
+  const miphy_pdsch_mod_job* __restrict__ jp = jobs + blockIdx.x;
+  const int sy  = blockIdx.y;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int start_symbol = jp->start_symbol, nof_symbols = jp->nof_symbols;
+  if (sy < start_symbol || sy >= start_symbol + nof_symbols)
+    return;
+  const unsigned dmask     = dmrs_prb_mask(jp->dmrs_type, jp->nof_cdm_groups_without_data);
+  const unsigned dmrs_syms = jp->dmrs_symbols_mask;
+  const int      nprb_grid = jp->grid_nof_prb, nres = jp->nof_reserved;
+  const int      bwp0 = jp->bwp_start_rb, bwp1 = bwp0 + jp->bwp_size_rb;
+  if (tid < 5)
+    rbm[tid] = jp->rb_mask[tid];
+  if (tid >= 32 && tid < 32 + 5 * nres)
+    resm[(tid - 32) / 5][(tid - 32) % 5] = jp->reserved[(tid - 32) / 5].prb_mask[(tid - 32) % 5];
+  __syncthreads();
+  build_prb_list(rbm, nprb_grid, 0, prb_of, &nprb_s, tid, nt);
+  __syncthreads();
+  const int nprb = nprb_s;
+  // reserved patterns: re_mask / symbols per pattern (uniform registers)
+  unsigned res_re[4] = {0, 0, 0, 0}, res_sy[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (r < nres) {
+      res_re[r] = jp->reserved[r].re_mask;
+      res_sy[r] = jp->reserved[r].symbols;
+    }
+  // data REs per PRB for every symbol up to this one: `before` = REs of the transmission in earlier symbols (this lane's PRBs)
+  int before = 0;
+  for (int s = start_symbol; s <= sy; ++s) {
+    for (int i = tid; i < nprb; i += nt) {
+      const int rb = prb_of[i];
+      unsigned  ex = (((dmrs_syms >> s) & 1u) && rb >= bwp0 && rb < bwp1) ? dmask : 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r < nres && ((res_sy[r] >> s) & 1u) && ((resm[r][rb >> 6] >> (rb & 63)) & 1ull))
+          ex |= res_re[r];
+      const unsigned keep = ~ex & 0xfffu;
+      if (s < sy)
+        before += __popc(keep);
+      else
+        keep_of[i] = (uint16_t)keep;
+    }
+  }
+  // block sum of `before`
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1)
+    before += __shfl_xor(before, o);
+  if ((tid & 63) == 0)
+    red[tid >> 6] = before;
+  __syncthreads();
+  const int prefix = red[0] + red[1] + red[2] + red[3];
+  // exclusive scan of the per-PRB counts of this symbol (<= 275 entries: one wavefront, 5 entries per lane)
+  if (tid < 64) {
+    int c[5], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int i = tid * 5 + q;
+      c[q]        = (i < nprb) ? __popc((unsigned)keep_of[i]) : 0;
+      sum += c[q];
+    }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o);
+      inc += (tid >= o) ? v : 0;
+    }
+    int run = inc - sum;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int i = tid * 5 + q;
+      if (i < nprb)
+        off_of[i] = (uint16_t)run;
+      run += c[q];
+    }
+    if (tid == 63)
+      red[4] = inc;
+  }
+  __syncthreads();
+  const int n_re = red[4];
+  if (n_re == 0)
+    return;
+  const int mod    = jp->mod;
+  const int nwords = ((n_re * mod + 31) >> 5) + 1;
+  gold_long_block(*gt, (jp->rnti << 15) + jp->n_id, (uint32_t)prefix * (uint32_t)mod, nwords, w1, w2, w1, tid, nt);
+  const float    scaling = jp->scaling;
+  const bool     scale   = isnormal(scaling);
+  const uint8_t* cw      = cw_base + jp->cw_offset;
+  float2*        g       = grid + jp->grid_offset + ((size_t)jp->port * 14 + sy) * (nprb_grid * 12);
+  for (int idx = tid; idx < nprb * 12; idx += nt) {
+    const int      i = idx / 12, k = idx - i * 12;
+    const unsigned keep = keep_of[i];
+    if (!((keep >> k) & 1u))
+      continue;
+    const int      j  = off_of[i] + __popc(keep & ((1u << k) - 1u)); // RE index within the symbol
+    const size_t   d  = (size_t)prefix + j;                           // symbol index within the codeword
+    const int      bi = j * mod;
+    const uint64_t two = (uint64_t)w1[bi >> 5] | ((uint64_t)w1[(bi >> 5) + 1] << 32);
+    const uint32_t cb  = (uint32_t)(two >> (bi & 31)); // scrambling bits of this RE, bit t = t-th bit
+    uint32_t       nat = 0;                            // scrambled bits, bit t = t-th bit of the symbol (b0 first)
+    for (int t = 0; t < mod; ++t)
+      nat |= ((uint32_t)(cw[d * mod + t] & 1u) ^ ((cb >> t) & 1u)) << t;
+    float2 x = map_symbol(mod, nat, (unsigned)d);
+    if (scale) {
+      x.x = x.x * scaling;
+      x.y = x.y * scaling;
+    }
+    g[prb_of[i] * 12 + k] = x;
+  }
+}
+
+__global__ void __launch_bounds__(256) dmrs_pdsch_kernel(const miphy_dmrs_pdsch_job* __restrict__ jobs, const gold_tables* __restrict__ gt,
+                                                         float2* __restrict__ grid)
+{
+  __shared__ uint32_t w1[128], w2[128];
+  __shared__ uint16_t prb_of[276];
+  __shared__ uint64_t rbm[5];
+  __shared__ int      nprb_s;
+  const miphy_dmrs_pdsch_job* __restrict__ jp = jobs + blockIdx.x;
+  const int      sy   = blockIdx.y;
+  const int      tid  = threadIdx.x, nt = blockDim.x;
+  const unsigned syms = jp->symbols_mask;
+  if (!((syms >> sy) & 1u))
+    return;
+  const int nprb_grid = jp->grid_nof_prb, ref = jp->reference_point_k_rb;
+  const bool type2 = jp->dmrs_type == 2;
+  const int  npr   = type2 ? 4 : 6;
+  if (tid < 5) { // PRBs below the reference point are never generated (dmrs_helper.h:53)
+    uint64_t m = jp->rb_mask[tid];
+    for (int b = 0; b < 64; ++b)
+      if (tid * 64 + b < ref)
+        m &= ~(1ull << b);
+    rbm[tid] = m;
+  }
+  __syncthreads();
+  build_prb_list(rbm, nprb_grid, 0, prb_of, &nprb_s, tid, nt);
+  const uint64_t t      = ((uint64_t)(14u * jp->slot_in_frame + (uint32_t)sy + 1u) * (2ull * jp->scrambling_id + 1ull)) % (1ull << 31);
+  const uint32_t c_init = (uint32_t)((t * (1ull << 17) + (2ull * jp->scrambling_id + (jp->n_scid ? 1u : 0u))) % (1ull << 31));
+  const int      nbits  = 2 * npr * (nprb_grid - ref);
+  __syncthreads();
+  gold_long_block(*gt, c_init, 0, ((nbits + 31) >> 5) + 1, w1, w2, w1, tid, nt);
+  const int   nprb    = nprb_s;
+  const float amp     = (float)(0.70710678118654752440 * (double)jp->amplitude);
+  const int   l_prime = (sy != 0 && ((syms >> (sy - 1)) & 1u)) ? 1 : 0;
+  const int   nports  = jp->nof_ports;
+  for (int idx = tid; idx < nprb * npr; idx += nt) {
+    const int i = idx / npr, q = idx - i * npr;
+    const int rb = prb_of[i];
+    const int gI = (rb - ref) * npr + q;                 // position in the sequence, counted from the reference point
+    const int k  = !type2 ? 2 * q : (q < 2 ? q : 4 + q); // type 1: 0,2,..,10 ; type 2: 0,1,6,7
+    const float re0 = ((w1[(2 * gI) >> 5] >> ((2 * gI) & 31)) & 1u) ? -amp : amp;
+    const float im0 = ((w1[(2 * gI + 1) >> 5] >> ((2 * gI + 1) & 31)) & 1u) ? -amp : amp;
+    for (int p = 0; p < nports; ++p) {
+      const int   delta = !type2 ? (p >> 1) & 1 : 2 * ((p >> 1) % 3);
+      const float wf1   = (p & 1) ? -1.f : 1.f;
+      const float wt    = (l_prime && p >= (type2 ? 6 : 4)) ? -1.f : 1.f;
+      const float w     = wt * ((idx & 1) ? wf1 : 1.f); // idx = index in the generated sequence (allocated PRBs only)
+      grid[jp->grid_offset + ((size_t)jp->ports[p] * 14 + sy) * (nprb_grid * 12) + rb * 12 + k + delta] = make_float2(re0 * w, im0 * w);
+    }
+  }
+}
+
+uint32_t host_nof_re(const miphy_pdsch_mod_job& j)
+{
+  unsigned dm = 0;
+  for (unsigned k = 0; k < 12; ++k)
+    dm |= ((j.dmrs_type == 1) ? ((k % 2) < j.nof_cdm_groups_without_data) : ((k % 6) < 2u * j.nof_cdm_groups_without_data)) ? (1u << k) : 0u;
+  uint32_t n = 0;
+  for (unsigned s = j.start_symbol; s < (unsigned)j.start_symbol + j.nof_symbols && s < 14; ++s)
+    for (unsigned rb = 0; rb < j.grid_nof_prb; ++rb) {
+      if (!((j.rb_mask[rb >> 6] >> (rb & 63)) & 1ull))
+        continue;
+      unsigned ex = (((j.dmrs_symbols_mask >> s) & 1u) && rb >= j.bwp_start_rb && rb < (unsigned)j.bwp_start_rb + j.bwp_size_rb) ? dm : 0u;
+      for (unsigned r = 0; r < j.nof_reserved && r < 4; ++r)
+        if (((j.reserved[r].symbols >> s) & 1u) && ((j.reserved[r].prb_mask[rb >> 6] >> (rb & 63)) & 1ull))
+          ex |= j.reserved[r].re_mask;
+      n += (uint32_t)__builtin_popcount(~ex & 0xfffu);
+    }
+  return n;
+}
+
+} // namespace
+
+extern "C" uint32_t miphy_pdsch_mod_nof_re(const miphy_pdsch_mod_job* j)
+{
+  if (!j || (j->dmrs_type != 1 && j->dmrs_type != 2) || j->grid_nof_prb > 275 || j->nof_reserved > 4)
+    return 0;
+  return host_nof_re(*j);
+}
+
+extern "C" int miphy_pdsch_modulate_batch(miphy_ctx* ctx, const miphy_pdsch_mod_job* jobs, int jobs_on_device, uint32_t n, const uint8_t* codewords,
+                                          float* grid, void* stream)
+{
+  MIPHY_REQUIRE(ctx && jobs && codewords && grid, "miphy_pdsch_modulate_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  MIPHY_REQUIRE(n <= 65535, "pdsch_modulate: batch too large (max 65535 transmissions per call)");
+  if (!jobs_on_device) {
+    for (uint32_t i = 0; i < n; ++i) {
+      const miphy_pdsch_mod_job& j = jobs[i];
+      MIPHY_REQUIRE(j.mod == 1 || j.mod == 2 || j.mod == 4 || j.mod == 6 || j.mod == 8, "pdsch_modulate: job %u: invalid modulation order %u", i, j.mod);
+      MIPHY_REQUIRE(j.nof_symbols >= 1 && j.start_symbol + j.nof_symbols <= 14, "pdsch_modulate: job %u: invalid time allocation", i);
+      MIPHY_REQUIRE(j.dmrs_type == 1 || j.dmrs_type == 2, "pdsch_modulate: job %u: invalid DM-RS type", i);
+      MIPHY_REQUIRE(j.nof_cdm_groups_without_data >= 1 && j.nof_cdm_groups_without_data <= (j.dmrs_type == 1 ? 2 : 3),
+                    "pdsch_modulate: job %u: invalid number of CDM groups without data", i);
+      MIPHY_REQUIRE(j.grid_nof_prb >= 1 && j.grid_nof_prb <= 275 && j.bwp_start_rb + j.bwp_size_rb <= 275, "pdsch_modulate: job %u: invalid grid / BWP", i);
+      MIPHY_REQUIRE(j.nof_reserved <= 4, "pdsch_modulate: job %u: at most 4 reserved RE patterns (re_pattern_list::MAX_RE_PATTERN)", i);
+      MIPHY_REQUIRE(j.n_id < 1024 && j.rnti < 65536, "pdsch_modulate: job %u: invalid scrambling identifiers", i);
+      MIPHY_REQUIRE(j.port < 16, "pdsch_modulate: job %u: invalid port", i);
+      // pdsch_modulator_impl.cpp:158-160: every element of the layer must be mapped
+      MIPHY_REQUIRE(j.nof_bits == host_nof_re(j) * j.mod, "pdsch_modulate: job %u: codeword of %u bits, the allocation holds %u", i, j.nof_bits,
+                    host_nof_re(j) * j.mod);
+    }
+  }
+  hipStream_t        s  = (hipStream_t)stream;
+  const gold_tables* gt = nullptr;
+  int                rc = miphy_get_gold_tables(ctx, &gt);
+  if (rc)
+    return rc;
+  const void* d_jobs = nullptr;
+  rc                 = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_pdsch_mod_job) * (size_t)n, s, &d_jobs);
+  if (rc)
+    return rc;
+  hipLaunchKernelGGL(pdsch_mod_kernel, dim3(n, 14), dim3(256), 0, s, (const miphy_pdsch_mod_job*)d_jobs, gt, codewords, (float2*)grid);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_dmrs_pdsch_map_batch(miphy_ctx* ctx, const miphy_dmrs_pdsch_job* jobs, int jobs_on_device, uint32_t n, float* grid, void* stream)
+{
+  MIPHY_REQUIRE(ctx && jobs && grid, "miphy_dmrs_pdsch_map_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  MIPHY_REQUIRE(n <= 65535, "dmrs_pdsch_map: batch too large (max 65535 transmissions per call)");
+  if (!jobs_on_device) {
+    for (uint32_t i = 0; i < n; ++i) {
+      const miphy_dmrs_pdsch_job& j = jobs[i];
+      MIPHY_REQUIRE(j.dmrs_type == 1 || j.dmrs_type == 2, "dmrs_pdsch_map: job %u: invalid DM-RS type", i);
+      MIPHY_REQUIRE(j.nof_ports >= 1 && j.nof_ports <= (j.dmrs_type == 1 ? 8 : 12), "dmrs_pdsch_map: job %u: invalid number of ports", i);
+      MIPHY_REQUIRE(j.grid_nof_prb >= 1 && j.grid_nof_prb <= 275 && j.reference_point_k_rb < j.grid_nof_prb, "dmrs_pdsch_map: job %u: invalid grid", i);
+      MIPHY_REQUIRE(j.symbols_mask < (1u << 14), "dmrs_pdsch_map: job %u: invalid symbol mask", i);
+    }
+  }
+  hipStream_t        s  = (hipStream_t)stream;
+  const gold_tables* gt = nullptr;
+  int                rc = miphy_get_gold_tables(ctx, &gt);
+  if (rc)
+    return rc;
+  const void* d_jobs = nullptr;
+  rc                 = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_dmrs_pdsch_job) * (size_t)n, s, &d_jobs);
+  if (rc)
+    return rc;
+  hipLaunchKernelGGL(dmrs_pdsch_kernel, dim3(n, 14), dim3(256), 0, s, (const miphy_dmrs_pdsch_job*)d_jobs, gt, (float2*)grid);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}

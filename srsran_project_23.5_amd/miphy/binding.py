@@ -56,6 +56,10 @@ def lib():
         l.miphy_crc_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_pusch_demodulate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p]
+        l.miphy_pdsch_modulate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_dmrs_pdsch_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+        l.miphy_pdsch_mod_nof_re.argtypes = [C.c_void_p]
+        l.miphy_pdsch_mod_nof_re.restype = C.c_uint32
         l.miphy_pusch_demod_nof_llr.argtypes = [C.c_void_p]
         l.miphy_pusch_demod_nof_llr.restype = C.c_uint32
         _lib = l
@@ -115,6 +119,27 @@ def pusch_demod_nof_llr(job):
     """Codeword length (data REs x bits per symbol) of one PuschDemodJob record (host computation in the library)."""
     a = np.ascontiguousarray(np.asarray(job, dtype=PuschDemodJob).reshape(1))
     return int(lib().miphy_pusch_demod_nof_llr(a.ctypes.data_as(C.c_void_p)))
+
+
+# Mirrors miphy_re_pattern / miphy_pdsch_mod_job / miphy_dmrs_pdsch_job.
+RePattern = np.dtype([("prb_mask", np.uint64, 5), ("re_mask", np.uint16), ("symbols", np.uint16), ("pad", np.uint32)], align=True)
+PdschModJob = np.dtype([("rnti", np.uint32), ("n_id", np.uint32), ("scaling", np.float32), ("mod", np.uint8), ("port", np.uint8),
+                        ("start_symbol", np.uint8), ("nof_symbols", np.uint8), ("dmrs_type", np.uint8), ("nof_cdm_groups_without_data", np.uint8),
+                        ("nof_reserved", np.uint8), ("reserved0", np.uint8), ("dmrs_symbols_mask", np.uint16), ("grid_nof_prb", np.uint16),
+                        ("bwp_start_rb", np.uint16), ("bwp_size_rb", np.uint16), ("nof_bits", np.uint32), ("rb_mask", np.uint64, 5),
+                        ("reserved", RePattern, 4), ("cw_offset", np.uint64), ("grid_offset", np.uint64)], align=True)
+assert RePattern.itemsize == 48 and PdschModJob.itemsize == 280 and PdschModJob.fields["rb_mask"][1] == 32, PdschModJob.itemsize
+DmrsPdschJob = np.dtype([("slot_in_frame", np.uint32), ("reference_point_k_rb", np.uint32), ("scrambling_id", np.uint32), ("amplitude", np.float32),
+                         ("dmrs_type", np.uint8), ("n_scid", np.uint8), ("nof_ports", np.uint8), ("reserved0", np.uint8), ("ports", np.uint8, 12),
+                         ("symbols_mask", np.uint16), ("grid_nof_prb", np.uint16), ("pad", np.uint32), ("rb_mask", np.uint64, 5),
+                         ("grid_offset", np.uint64)], align=True)
+assert DmrsPdschJob.itemsize == 88 and DmrsPdschJob.fields["rb_mask"][1] == 40, DmrsPdschJob.itemsize
+
+
+def pdsch_mod_nof_re(job):
+    """Data REs of one PdschModJob record (host computation in the library)."""
+    a = np.ascontiguousarray(np.asarray(job, dtype=PdschModJob).reshape(1))
+    return int(lib().miphy_pdsch_mod_nof_re(a.ctypes.data_as(C.c_void_p)))
 
 
 class PolarCode(C.Structure):
@@ -265,6 +290,15 @@ class Context:
     def ofdm_modulate_slots(self, cfg, jobs, grid, samples, stream=None):
         jobs, n, ptr, on_dev = self._descs(jobs, OfdmJob)
         check(lib().miphy_ofdm_modulate_slots(self.h, C.byref(cfg), ptr, on_dev, n, _dptr(grid), _dptr(samples), _stream_ptr(stream)))
+
+    # ------------------------------------------------------------------ PDSCH modulator / PDSCH DM-RS
+    def pdsch_modulate_batch(self, jobs, codewords, grid, stream=None):
+        jobs, n, ptr, on_dev = self._descs(jobs, PdschModJob)
+        check(lib().miphy_pdsch_modulate_batch(self.h, ptr, on_dev, n, _dptr(codewords), _dptr(grid), _stream_ptr(stream)))
+
+    def dmrs_pdsch_map_batch(self, jobs, grid, stream=None):
+        jobs, n, ptr, on_dev = self._descs(jobs, DmrsPdschJob)
+        check(lib().miphy_dmrs_pdsch_map_batch(self.h, ptr, on_dev, n, _dptr(grid), _stream_ptr(stream)))
 
     # ------------------------------------------------------------------ PUSCH demodulator (equalise + soft-demap + descramble)
     def pusch_demodulate_batch(self, jobs, grid, ce, scalars, llr, stream=None):

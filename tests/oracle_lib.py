@@ -487,3 +487,101 @@ def r_pusch_demodulate(*a):
     args, llr, n, keep = _demod_args(*a)
     assert ref().ref_pusch_demodulate(*args, C.c_uint(llr.size)) == 0
     return llr
+
+
+# ------------------------------------------------------------------------------------------------ PDSCH modulator + DM-RS
+def o_modulate(mod, bits):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    out = np.zeros(bits.size // mod, dtype=np.complex64)
+    oracle().orc_modulate(int(mod), C.c_uint(out.size), _p(bits), _p(out))
+    return out
+
+
+def _reserved_args(reserved, nprb_grid):
+    """reserved: list of (prb_mask bytes [nprb_grid], re_mask 12 bits, symbols 14 bits)."""
+    n = len(reserved)
+    pm = np.zeros((max(n, 1), nprb_grid), dtype=np.uint8)
+    rm = np.zeros(max(n, 1), dtype=np.uint16)
+    sm = np.zeros(max(n, 1), dtype=np.uint16)
+    for i, (p, r, s) in enumerate(reserved):
+        pm[i], rm[i], sm[i] = p, r, s
+    return n, pm, rm, sm
+
+
+def o_pdsch_modulate(rnti, n_id, scaling, nof_layers, mods, cws, start, nof, dmrs_mask, type2, cdm, bwp_start, bwp_size, prb_list, reserved,
+                     ports, nprb_grid, grid):
+    """grid: complex64 [nof_grid_ports][14][nsc], updated in place (only the mapped REs). Returns the number of REs per layer."""
+    mod = (C.c_int * 2)(int(mods[0]), int(mods[1] if len(mods) > 1 else mods[0]))
+    cw0 = np.ascontiguousarray(cws[0], dtype=np.uint8)
+    cw1 = np.ascontiguousarray(cws[1] if len(cws) > 1 else np.zeros(1, np.uint8), dtype=np.uint8)
+    dm = np.ascontiguousarray(dmrs_mask, dtype=np.uint8)
+    pl = np.ascontiguousarray(prb_list, dtype=np.uint16)
+    n, pm, rm, sm = _reserved_args(reserved, nprb_grid)
+    pt = np.ascontiguousarray(ports, dtype=np.uint8)
+    assert grid.dtype == np.complex64 and grid.flags.c_contiguous
+    return oracle().orc_pdsch_modulate(C.c_uint(rnti), C.c_uint(n_id), C.c_float(scaling), C.c_uint(nof_layers), mod, _p(cw0), C.c_uint(cw0.size),
+                                       _p(cw1), C.c_uint(cw1.size if len(cws) > 1 else 0), C.c_uint(start), C.c_uint(nof), _p(dm), int(type2),
+                                       C.c_uint(cdm), C.c_uint(bwp_start), C.c_uint(bwp_size), _p(pl), C.c_uint(pl.size), C.c_uint(n), _p(pm),
+                                       _p(rm), _p(sm), _p(pt), C.c_uint(nprb_grid), _p(grid))
+
+
+def r_pdsch_modulate(rnti, n_id, scaling, nof_layers, mods, cws, start, nof, dmrs_mask, type2, cdm, bwp_start, bwp_size, vrb_mask, interleaved,
+                     reserved, ports, nprb_grid, nof_grid_ports):
+    """Returns (grid [nof_grid_ports][14][nsc], prb_list in mapping order)."""
+    mod = (C.c_int * 2)(int(mods[0]), int(mods[1] if len(mods) > 1 else mods[0]))
+    cw0 = np.ascontiguousarray(cws[0], dtype=np.uint8)
+    cw1 = np.ascontiguousarray(cws[1] if len(cws) > 1 else np.zeros(1, np.uint8), dtype=np.uint8)
+    dm = np.ascontiguousarray(dmrs_mask, dtype=np.uint8)
+    vm = np.ascontiguousarray(vrb_mask, dtype=np.uint8)
+    n, pm, rm, sm = _reserved_args(reserved, nprb_grid)
+    pt = np.ascontiguousarray(ports, dtype=np.uint8)
+    grid = np.zeros((nof_grid_ports, 14, nprb_grid * 12), dtype=np.complex64)
+    pl = np.zeros(275, dtype=np.uint16)
+    npl = C.c_uint(0)
+    rc = ref().ref_pdsch_modulate(C.c_uint(rnti), C.c_uint(n_id), C.c_float(scaling), C.c_uint(nof_layers), mod, _p(cw0), C.c_uint(cw0.size), _p(cw1),
+                                  C.c_uint(cw1.size if len(cws) > 1 else 0), C.c_uint(start), C.c_uint(nof), _p(dm), int(type2), C.c_uint(cdm),
+                                  C.c_uint(bwp_start), C.c_uint(bwp_size), _p(vm), int(interleaved), C.c_uint(n), _p(pm), _p(rm), _p(sm), _p(pt),
+                                  C.c_uint(nprb_grid), C.c_uint(nof_grid_ports), _p(grid), _p(pl), C.byref(npl))
+    assert rc == 0
+    return grid, pl[:npl.value].copy()
+
+
+def o_dmrs_pdsch_map(slot_in_frame, ref_point, type2, scr_id, n_scid, amplitude, symbols_mask, rb_mask, ports, grid):
+    sm = np.ascontiguousarray(symbols_mask, dtype=np.uint8)
+    rb = np.ascontiguousarray(rb_mask, dtype=np.uint8)
+    pt = np.ascontiguousarray(ports, dtype=np.uint8)
+    assert grid.dtype == np.complex64 and grid.flags.c_contiguous
+    return oracle().orc_dmrs_pdsch_map(C.c_uint(slot_in_frame), C.c_uint(ref_point), int(type2), C.c_uint(scr_id), int(n_scid), C.c_float(amplitude),
+                                       _p(sm), _p(rb), C.c_uint(rb.size), C.c_uint(pt.size), _p(pt), _p(grid))
+
+
+def r_dmrs_pdsch_map(numerology, slot_index, ref_point, type2, scr_id, n_scid, amplitude, symbols_mask, rb_mask, ports, nof_grid_ports):
+    sm = np.ascontiguousarray(symbols_mask, dtype=np.uint8)
+    rb = np.ascontiguousarray(rb_mask, dtype=np.uint8)
+    pt = np.ascontiguousarray(ports, dtype=np.uint8)
+    grid = np.zeros((nof_grid_ports, 14, rb.size * 12), dtype=np.complex64)
+    assert ref().ref_dmrs_pdsch_map(C.c_uint(numerology), C.c_uint(slot_index), C.c_uint(ref_point), int(type2), C.c_uint(scr_id), int(n_scid),
+                                    C.c_float(amplitude), _p(sm), _p(rb), C.c_uint(rb.size), C.c_uint(pt.size), _p(pt), C.c_uint(nof_grid_ports),
+                                    _p(grid)) == 0
+    return grid
+
+
+def r_prb_indices(bwp_start, bwp_size, vrb_mask, interleaved):
+    vm = np.ascontiguousarray(vrb_mask, dtype=np.uint8)
+    pl = np.zeros(275, dtype=np.uint16)
+    n = C.c_uint(0)
+    assert ref().ref_prb_indices(C.c_uint(bwp_start), C.c_uint(bwp_size), _p(vm), int(interleaved), _p(pl), C.byref(n)) == 0
+    return pl[:n.value].copy()
+
+
+def pdsch_nof_re(prb_list, start, nof, dmrs_mask, type2, cdm, bwp_start, bwp_size, reserved):
+    """Data REs per layer of a PDSCH allocation (brute force, mirrors pdsch_modulator_impl.cpp:102-160)."""
+    n = 0
+    for sy in range(start, start + nof):
+        for rb in prb_list:
+            for k in range(12):
+                ex = bool(dmrs_mask[sy]) and (((k % 6) < 2 * cdm) if type2 else ((k % 2) < cdm)) and bwp_start <= rb < bwp_start + bwp_size
+                for (pm, rm, sm) in reserved:
+                    ex = ex or (bool(pm[rb]) and bool((rm >> k) & 1) and bool((sm >> sy) & 1))
+                n += 0 if ex else 1
+    return n

@@ -75,8 +75,8 @@ def test_binding_struct_sizes_match_header():
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(miphy_ldpc_dec_desc), sizeof(miphy_ldpc_rdm_desc), sizeof(miphy_ldpc_enc_desc),
          sizeof(miphy_crc_desc), sizeof(miphy_ofdm_job), sizeof(miphy_ofdm_config), sizeof(miphy_pusch_chest_job), sizeof(miphy_polar_code));
-  printf("%zu %zu %zu %zu %zu\n", sizeof(miphy_pusch_tb_desc), sizeof(miphy_pusch_result), sizeof(miphy_pdsch_tb_desc), sizeof(miphy_sch_segmentation),
-         sizeof(miphy_pusch_demod_job));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(miphy_pusch_tb_desc), sizeof(miphy_pusch_result), sizeof(miphy_pdsch_tb_desc),
+         sizeof(miphy_sch_segmentation), sizeof(miphy_pusch_demod_job), sizeof(miphy_re_pattern), sizeof(miphy_pdsch_mod_job), sizeof(miphy_dmrs_pdsch_job));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -88,7 +88,7 @@ int main(void) {
     mine = [miphy.LdpcDecDesc.itemsize, miphy.LdpcRdmDesc.itemsize, miphy.LdpcEncDesc.itemsize, miphy.CrcDesc.itemsize,
             miphy.OfdmJob.itemsize, ctypes.sizeof(miphy.OfdmConfig), miphy.PuschChestJob.itemsize, ctypes.sizeof(miphy.PolarCode),
             miphy.PuschTbDesc.itemsize, miphy.PuschResult.itemsize, miphy.PdschTbDesc.itemsize, ctypes.sizeof(miphy.binding.SchSegmentation),
-            miphy.PuschDemodJob.itemsize]
+            miphy.PuschDemodJob.itemsize, miphy.RePattern.itemsize, miphy.PdschModJob.itemsize, miphy.DmrsPdschJob.itemsize]
     assert sizes == mine, (sizes, mine)
 
 
