@@ -14,6 +14,7 @@
 #include "srsran/phy/upper/unique_rx_softbuffer.h"
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <random>
 
 using namespace srsran;
@@ -543,6 +544,87 @@ static void test_pusch_processor(std::shared_ptr<miphy::context> c)
   printf("pusch_processor (reference factory, HIP estimator + demodulator + decoder) done, failures so far %d\n", failures);
 }
 
+// pdsch_modulator + dmrs_pdsch_processor: reference software blocks vs the HIP adapters writing into identical grids; exact equality.
+static void test_pdsch_modulator_and_dmrs(std::shared_ptr<miphy::context> c)
+{
+  auto prg   = create_pseudo_random_generator_sw_factory();
+  auto m_ref = create_pdsch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg)->create();
+  auto m_hip = miphy::create_pdsch_modulator_factory_hip(c)->create();
+  auto d_ref = create_dmrs_pdsch_processor_factory_sw(prg)->create();
+  auto d_hip = miphy::create_dmrs_pdsch_processor_factory_hip(c)->create();
+  struct tc {
+    modulation_scheme mod;
+    unsigned          bwp_start, bwp_size, rb_start, rb_count, cdm;
+    float             scaling;
+    bool              with_reserved;
+  };
+  std::uniform_int_distribution<int> bit(0, 1);
+  for (const tc& t : {tc{modulation_scheme::QAM256, 0, 273, 0, 273, 2, 1.0F, false}, tc{modulation_scheme::QAM64, 10, 96, 4, 70, 1, 0.5F, true},
+                      tc{modulation_scheme::QPSK, 0, 25, 3, 9, 2, 1.0F, true}}) {
+    const unsigned grid_rb = t.bwp_start + t.bwp_size, nsc = grid_rb * 12;
+    auto           g1 = create_resource_grid(2, 14, nsc), g2 = create_resource_grid(2, 14, nsc);
+    g1->set_all_zero();
+    g2->set_all_zero();
+    symbol_slot_mask dm(14);
+    dm.set(2);
+    dm.set(11);
+    pdsch_modulator::config_t mc;
+    mc.rnti = 0x1234, mc.bwp_size_rb = t.bwp_size, mc.bwp_start_rb = t.bwp_start, mc.modulation1 = t.mod, mc.modulation2 = t.mod;
+    mc.freq_allocation    = rb_allocation::make_type1(t.rb_start, t.rb_count);
+    mc.start_symbol_index = 1, mc.nof_symbols = 13, mc.dmrs_symb_pos = dm, mc.dmrs_config_type = dmrs_type::TYPE1;
+    mc.nof_cdm_groups_without_data = t.cdm, mc.n_id = 77, mc.scaling = t.scaling, mc.pmi = 0;
+    mc.ports.push_back(1);
+    if (t.with_reserved) {
+      re_prb_mask rm;
+      rm.set(1);
+      rm.set(7);
+      symbol_slot_mask sm(14);
+      sm.set(4);
+      sm.set(5);
+      mc.reserved.merge(re_pattern(t.bwp_start + t.rb_start, t.bwp_start + t.rb_start + t.rb_count, 2, rm, sm));
+    }
+    // count the data REs the way the modulator will, to size the codeword
+    bounded_bitset<MAX_RB>     prb = mc.freq_allocation.get_prb_mask(t.bwp_start, t.bwp_size);
+    bounded_bitset<MAX_RB* NRE> base = prb.kronecker_product<NRE>(~re_prb_mask());
+    re_pattern                  dpat = mc.dmrs_config_type.get_dmrs_pattern(t.bwp_start, t.bwp_size, t.cdm, dm);
+    unsigned                    nre  = 0;
+    for (unsigned l = mc.start_symbol_index; l != mc.start_symbol_index + mc.nof_symbols; ++l) {
+      bounded_bitset<MAX_RB* NRE> msk = base;
+      dpat.get_exclusion_mask(msk, l);
+      mc.reserved.get_exclusion_mask(msk, l);
+      nre += msk.count();
+    }
+    unsigned           nbits = nre * get_bits_per_symbol(t.mod);
+    dynamic_bit_buffer packed(nbits);
+    for (unsigned i = 0; i != nbits; ++i) {
+      packed.insert(bit(rgen), i, 1);
+    }
+    std::vector<bit_buffer> cws;
+    cws.emplace_back(packed);
+    m_ref->modulate(*g1, cws, mc);
+    m_hip->modulate(*g2, cws, mc);
+    dmrs_pdsch_processor::config_t dc;
+    dc.slot = slot_point(1, 13), dc.reference_point_k_rb = 0, dc.type = dmrs_type::TYPE1, dc.scrambling_id = 321, dc.n_scid = true;
+    dc.amplitude = 1.4125F, dc.symbols_mask = dm;
+    dc.rb_mask   = prb;
+    dc.ports.push_back(1);
+    dc.ports.push_back(0);
+    d_ref->map(*g1, dc);
+    d_hip->map(*g2, dc);
+    std::vector<cf_t> a(nsc), b(nsc);
+    unsigned          bad = 0;
+    for (unsigned p = 0; p != 2; ++p) {
+      for (unsigned l = 0; l != 14; ++l) {
+        g1->get(a, p, l, 0);
+        g2->get(b, p, l, 0);
+        bad += std::memcmp(a.data(), b.data(), nsc * sizeof(cf_t)) != 0;
+      }
+    }
+    CHECK(bad == 0, "pdsch_modulator / dmrs_pdsch_processor: %u (port, symbol) rows differ (rb_count %u)", bad, t.rb_count);
+  }
+  printf("pdsch_modulator + dmrs_pdsch_processor done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -578,6 +660,7 @@ int main()
   test_pdcch(c);
   test_pusch_demodulator(c);
   test_pusch_processor(c);
+  test_pdsch_modulator_and_dmrs(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);
     return 1;

@@ -23,6 +23,9 @@
 #include "srsran/phy/upper/rx_softbuffer.h"
 #include "srsran/phy/upper/signal_processors/signal_processor_factories.h"
 #include "srsran/support/error_handling.h"
+#include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstring>
 #include <hip/hip_runtime_api.h>
 #include <memory>
@@ -618,6 +621,175 @@ private:
   std::vector<srsran::cf_t> host, ce_host;
 };
 
+// ---------------------------------------------------------------------------------------------------------------- PDSCH modulator / DM-RS
+/// srsran::pdsch_modulator over miphy_pdsch_modulate_batch (pdsch_modulator.h:98). One codeword on one layer, contiguous
+/// allocation -- the configurations the 23.5 software modulator handles correctly.
+class pdsch_modulator_hip : public srsran::pdsch_modulator
+{
+public:
+  explicit pdsch_modulator_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void modulate(srsran::resource_grid_writer& grid, srsran::span<const srsran::bit_buffer> codewords, const config_t& config) override
+  {
+    srsran_assert(config.ports.size() == 1 && codewords.size() == 1, "Only one layer / one codeword is supported.");
+    srsran_assert(config.freq_allocation.is_contiguous(), "Only contiguous allocations are supported.");
+    const srsran::bounded_bitset<srsran::MAX_RB> prb = config.freq_allocation.get_prb_mask(config.bwp_start_rb, config.bwp_size_rb);
+    const unsigned                               nprb = prb.size(), nsc = nprb * 12;
+    miphy_pdsch_mod_job j = {};
+    j.rnti = config.rnti, j.n_id = config.n_id, j.scaling = config.scaling;
+    j.mod  = srsran::get_bits_per_symbol(config.modulation1);
+    j.port = 0; // the staging grid has a single port
+    j.start_symbol = config.start_symbol_index, j.nof_symbols = config.nof_symbols;
+    j.dmrs_type    = (config.dmrs_config_type == srsran::dmrs_type::TYPE1) ? 1 : 2;
+    j.nof_cdm_groups_without_data = config.nof_cdm_groups_without_data;
+    j.grid_nof_prb = nprb, j.bwp_start_rb = config.bwp_start_rb, j.bwp_size_rb = config.bwp_size_rb;
+    for (unsigned l = 0; l != 14 && l != config.dmrs_symb_pos.size(); ++l) {
+      if (config.dmrs_symb_pos.test(l)) {
+        j.dmrs_symbols_mask |= static_cast<uint16_t>(1U << l);
+      }
+    }
+    prb.for_each(0, nprb, [&j](unsigned r) { j.rb_mask[r >> 6] |= 1ULL << (r & 63); });
+    // The reserved-RE list only exposes per-symbol masks: turn them back into (PRB set, RE mask, symbol set) rectangles.
+    if (config.reserved.get_nof_entries() != 0) {
+      struct rect {
+        uint16_t                 re;
+        std::array<uint64_t, 5>  prbs;
+        uint16_t                 symbols;
+      };
+      std::vector<rect> rects;
+      for (unsigned l = 0; l != 14; ++l) {
+        srsran::bounded_bitset<srsran::MAX_RB * srsran::NRE> msk(nsc);
+        msk.fill(0, nsc, true);
+        config.reserved.get_exclusion_mask(msk, l);
+        std::vector<rect> here;
+        for (unsigned r = 0; r != nprb; ++r) {
+          uint16_t v = 0;
+          for (unsigned k = 0; k != 12; ++k) {
+            v |= static_cast<uint16_t>(msk.test(r * 12 + k) ? 0U : (1U << k));
+          }
+          if (v == 0) {
+            continue;
+          }
+          auto it = std::find_if(here.begin(), here.end(), [v](const rect& x) { return x.re == v; });
+          if (it == here.end()) {
+            here.push_back(rect{v, {}, static_cast<uint16_t>(1U << l)});
+            it = here.end() - 1;
+          }
+          it->prbs[r >> 6] |= 1ULL << (r & 63);
+        }
+        for (const rect& h : here) {
+          auto it = std::find_if(rects.begin(), rects.end(), [&h](const rect& x) { return x.re == h.re && x.prbs == h.prbs; });
+          if (it == rects.end()) {
+            rects.push_back(h);
+          } else {
+            it->symbols |= h.symbols;
+          }
+        }
+      }
+      if (rects.size() > 4) {
+        srsran::report_fatal_error("pdsch_modulator_hip: the reserved RE patterns need {} rectangles, at most 4 are supported.", rects.size());
+      }
+      for (const rect& x : rects) {
+        miphy_re_pattern& o = j.reserved[j.nof_reserved++];
+        std::copy(x.prbs.begin(), x.prbs.end(), o.prb_mask);
+        o.re_mask = x.re, o.symbols = x.symbols;
+      }
+    }
+    const srsran::bit_buffer& cw = codewords[0];
+    j.nof_bits                   = cw.size();
+    bits.resize(cw.size());
+    for (unsigned i = 0; i != cw.size(); ++i) {
+      bits[i] = cw.extract<uint8_t>(i, 1);
+    }
+    host.assign(static_cast<size_t>(14) * nsc, srsran::cf_t(NAN, NAN)); // NaN marks "not written by the kernel"
+    auto* d_cw = static_cast<uint8_t*>(c->buf(0, bits.size() + 16));
+    auto* d_g  = static_cast<float*>(c->buf(1, host.size() * sizeof(srsran::cf_t)));
+    c->h2d(d_cw, bits.data(), bits.size());
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    context::check(miphy_pdsch_modulate_batch(c->ctx, &j, 0, 1, d_cw, d_g, c->stream), "pdsch_modulate");
+    c->d2h(host.data(), d_g, host.size() * sizeof(srsran::cf_t));
+    c->sync();
+    put_written(grid, config.ports[0], nsc);
+  }
+
+private:
+  void put_written(srsran::resource_grid_writer& grid, unsigned port, unsigned nsc)
+  {
+    std::vector<bool>         mask(nsc);
+    std::vector<srsran::cf_t> vals;
+    for (unsigned l = 0; l != 14; ++l) {
+      vals.clear();
+      bool any = false;
+      for (unsigned k = 0; k != nsc; ++k) {
+        const srsran::cf_t v = host[static_cast<size_t>(l) * nsc + k];
+        mask[k]              = !std::isnan(v.real());
+        if (mask[k]) {
+          vals.push_back(v);
+          any = true;
+        }
+      }
+      if (any) {
+        std::unique_ptr<bool[]> m(new bool[nsc]);
+        std::copy(mask.begin(), mask.end(), m.get());
+        grid.put(port, l, 0, srsran::span<const bool>(m.get(), nsc), vals);
+      }
+    }
+  }
+  std::shared_ptr<context>  c;
+  std::vector<uint8_t>      bits;
+  std::vector<srsran::cf_t> host;
+};
+
+/// srsran::dmrs_pdsch_processor over miphy_dmrs_pdsch_map_batch (dmrs_pdsch_processor.h:65).
+class dmrs_pdsch_processor_hip : public srsran::dmrs_pdsch_processor
+{
+public:
+  explicit dmrs_pdsch_processor_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void map(srsran::resource_grid_writer& grid, const config_t& config) override
+  {
+    const unsigned nprb = config.rb_mask.size(), nsc = nprb * 12, nports = config.ports.size();
+    miphy_dmrs_pdsch_job j = {};
+    j.slot_in_frame = config.slot.slot_index(), j.reference_point_k_rb = config.reference_point_k_rb, j.scrambling_id = config.scrambling_id;
+    j.amplitude = config.amplitude, j.dmrs_type = (config.type == srsran::dmrs_type::TYPE1) ? 1 : 2, j.n_scid = config.n_scid;
+    j.nof_ports = nports, j.grid_nof_prb = nprb;
+    for (unsigned p = 0; p != nports; ++p) {
+      j.ports[p] = p; // staging grid indexed by DM-RS port
+    }
+    for (unsigned l = 0; l != 14 && l != config.symbols_mask.size(); ++l) {
+      if (config.symbols_mask.test(l)) {
+        j.symbols_mask |= static_cast<uint16_t>(1U << l);
+      }
+    }
+    config.rb_mask.for_each(0, nprb, [&j](unsigned r) { j.rb_mask[r >> 6] |= 1ULL << (r & 63); });
+    host.assign(static_cast<size_t>(nports) * 14 * nsc, srsran::cf_t(NAN, NAN));
+    auto* d_g = static_cast<float*>(c->buf(0, host.size() * sizeof(srsran::cf_t)));
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    context::check(miphy_dmrs_pdsch_map_batch(c->ctx, &j, 0, 1, d_g, c->stream), "dmrs_pdsch_map");
+    c->d2h(host.data(), d_g, host.size() * sizeof(srsran::cf_t));
+    c->sync();
+    std::unique_ptr<bool[]>   m(new bool[nsc]);
+    std::vector<srsran::cf_t> vals;
+    for (unsigned p = 0; p != nports; ++p) {
+      for (unsigned l = 0; l != 14; ++l) {
+        vals.clear();
+        for (unsigned k = 0; k != nsc; ++k) {
+          const srsran::cf_t v = host[(static_cast<size_t>(p) * 14 + l) * nsc + k];
+          m[k]                 = !std::isnan(v.real());
+          if (m[k]) {
+            vals.push_back(v);
+          }
+        }
+        if (!vals.empty()) {
+          grid.put(config.ports[p], l, 0, srsran::span<const bool>(m.get(), nsc), vals);
+        }
+      }
+    }
+  }
+
+private:
+  std::shared_ptr<context>  c;
+  std::vector<srsran::cf_t> host;
+};
+
 // ---------------------------------------------------------------------------------------------------------------- PDCCH
 /// srsran::pdcch_encoder over miphy_pdcch_encode_batch (pdcch_encoder.h:53).
 class pdcch_encoder_hip : public srsran::pdcch_encoder
@@ -663,6 +835,8 @@ MIPHY_SIMPLE_FACTORY(pusch_decoder_factory_hip, pusch_decoder_factory, pusch_dec
 MIPHY_SIMPLE_FACTORY(dmrs_pusch_estimator_factory_hip, dmrs_pusch_estimator_factory, dmrs_pusch_estimator, dmrs_pusch_estimator_hip)
 MIPHY_SIMPLE_FACTORY(pdcch_encoder_factory_hip, pdcch_encoder_factory, pdcch_encoder, pdcch_encoder_hip)
 MIPHY_SIMPLE_FACTORY(pusch_demodulator_factory_hip, pusch_demodulator_factory, pusch_demodulator, pusch_demodulator_hip)
+MIPHY_SIMPLE_FACTORY(pdsch_modulator_factory_hip, pdsch_modulator_factory, pdsch_modulator, pdsch_modulator_hip)
+MIPHY_SIMPLE_FACTORY(dmrs_pdsch_processor_factory_hip, dmrs_pdsch_processor_factory, dmrs_pdsch_processor, dmrs_pdsch_processor_hip)
 #undef MIPHY_SIMPLE_FACTORY
 
 /// The string-selected factory functions of the reference (channel_coding_factories.cpp:86-180) gain a "hip" case that
@@ -698,6 +872,16 @@ inline std::shared_ptr<srsran::dmrs_pusch_estimator_factory> create_dmrs_pusch_e
 inline std::shared_ptr<srsran::pdcch_encoder_factory> create_pdcch_encoder_factory_hip(std::shared_ptr<context> c)
 {
   return std::make_shared<pdcch_encoder_factory_hip>(std::move(c));
+}
+/// Replace create_pdsch_modulator_factory_sw(modulation, prg) (channel_processor_factories.h:140-142) and
+/// create_dmrs_pdsch_processor_factory_sw(prg) (signal_processor_factories.h:46-47).
+inline std::shared_ptr<srsran::pdsch_modulator_factory> create_pdsch_modulator_factory_hip(std::shared_ptr<context> c)
+{
+  return std::make_shared<pdsch_modulator_factory_hip>(std::move(c));
+}
+inline std::shared_ptr<srsran::dmrs_pdsch_processor_factory> create_dmrs_pdsch_processor_factory_hip(std::shared_ptr<context> c)
+{
+  return std::make_shared<dmrs_pdsch_processor_factory_hip>(std::move(c));
 }
 /// Replaces create_pusch_demodulator_factory_sw(equalizer, demodulation, prg) (channel_processor_factories.h:256-259).
 inline std::shared_ptr<srsran::pusch_demodulator_factory> create_pusch_demodulator_factory_hip(std::shared_ptr<context> c)
