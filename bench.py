@@ -7,7 +7,8 @@ One "step" = one pass of the hot path over a batch of S synthetic uplink slots p
 bits out (OFDM demodulation -> DM-RS channel estimation -> equalise / soft-demap / descramble -> rate dematch -> LDPC decode).
 The workload is BASELINE.json configs[2]: 273-PRB PUSCH, 256QAM R=948/1024, 1 layer, 38 codeblocks (BG1, Z=384) per slot,
 TBS = 319 784 information bits per slot.  The slots are synthesised once, outside the timed region, by the transmit side of the
-same library (SCH encode, scramble, QAM map, DM-RS, OFDM modulate) plus AWGN, and are resident in HBM before timing starts.
+same library on the device (SCH encoder, PDSCH-style modulator, DM-RS mapper, OFDM modulator) plus AWGN, and are resident in HBM
+before timing starts.
 
 `value` = LDPC information bits / s over the whole step (all ranks).  Extra keys: `slots_per_s` (whole pipeline),
 per-kernel HIP-event times, `roofline` of the dominant kernel and `cpu_baseline` (reference AVX2 path from oracle/_ref
@@ -38,28 +39,38 @@ RNTI, N_ID, DMRS_SCR_ID = 0x4601, 935, 1
 DMRS_SCALING = 1.4125375  # DM-RS boosted by 3 dB with two CDM groups without data (sch_dmrs_power.h)
 
 
-def build_tx_grids(w, n_unique, seed):
-    """CPU (oracle, test infrastructure) synthesis of the transmitted resource grids: n_unique random transport blocks, SCH-encoded,
-    scrambled, 256QAM-mapped, placed on 13 data symbols, with the type-1 DM-RS of every slot of a frame on symbol 2.
-    Returns complex64 [20, 14, nsc] (slot-in-frame k carries transport block k % n_unique) and the transport blocks."""
-    import oracle_lib as O
+def build_tx_grids(ctx, miphy, torch, dev, w, n_unique, seed):
+    """Transmit side on the device (not timed): n_unique random transport blocks -> SCH encoder -> PDSCH-style modulator (scrambling,
+    256QAM, mapping around the DM-RS symbol) -> type-1 DM-RS of every slot of a frame on symbol 2 (CP-OFDM uplink has the downlink's
+    structure, so the PDSCH transmit blocks produce a valid PUSCH slot). Returns a device tensor complex64 [20 * 14 * nsc] (slot-in-frame
+    k carries transport block k % n_unique) and the transport blocks (numpy)."""
     rng = np.random.default_rng(seed)
-    G, nsc = w["nsym"] * w["mod"], w["nprb"] * 12
-    c = O.o_gold((RNTI << 15) + N_ID, 0, G)
-    x, tbs = [], []
+    G, nsc, nprb = w["nsym"] * w["mod"], w["nprb"] * 12, w["nprb"]
+    tb_bytes = w["tbs"] // 8
+    tbs = [rng.integers(0, 256, tb_bytes, dtype=np.uint8) for _ in range(n_unique)]
+    td = np.zeros(n_unique, dtype=miphy.PdschTbDesc)
     for u in range(n_unique):
-        tb = rng.integers(0, 256, w["tbs"] // 8, dtype=np.uint8)
-        cw = O.o_pdsch_encode(w["bg"], w["rv"], w["mod"], w["Nref"], w["nof_layers"], w["nsym"], tb)
-        x.append(O.nr_modulate((cw ^ c) & 1, w["mod"]))
-        tbs.append(tb)
-    grids = np.zeros((20, 14, nsc), dtype=np.complex64)
-    data_syms = [l for l in range(14) if l != 2]
+        td[u] = (w["bg"], w["rv"], w["mod"], w["nof_layers"], w["Nref"], w["nsym"], tb_bytes, u * tb_bytes, u * G)
+    cw_d = torch.zeros(n_unique * G, dtype=torch.uint8, device=dev)
+    ctx.pdsch_encode_batch(td, torch.from_numpy(np.concatenate(tbs)).to(dev), cw_d)
+    grids = torch.zeros(20 * 14 * nsc, dtype=torch.complex64, device=dev)
+    rb_words = [0xFFFFFFFFFFFFFFFF] * 4 + [(1 << (nprb - 256)) - 1]
+    mj = np.zeros(20, dtype=miphy.PdschModJob)
+    dj = np.zeros(20, dtype=miphy.DmrsPdschJob)
     for k in range(20):
-        grids[k, data_syms, :] = x[k % n_unique].reshape(13, nsc)
-        # dmrs_pusch_estimator_impl.cpp:158-162 / TS 38.211 6.4.1.1.1: c_init of (slot k, symbol 2), n_scid = 0
-        t = ((14 * k + 2 + 1) * (2 * DMRS_SCR_ID + 1)) % (1 << 31)
-        cb = O.o_gold((t * (1 << 17) + 2 * DMRS_SCR_ID) % (1 << 31), 0, 2 * (nsc // 2)).astype(np.float32)
-        grids[k, 2, 0::2] = (DMRS_SCALING / np.sqrt(2.0)) * ((1 - 2 * cb[0::2]) + 1j * (1 - 2 * cb[1::2]))
+        j = mj[k]
+        j["rnti"], j["n_id"], j["scaling"], j["mod"], j["port"], j["start_symbol"], j["nof_symbols"] = RNTI, N_ID, 1.0, w["mod"], 0, 0, 14
+        j["dmrs_type"], j["nof_cdm_groups_without_data"], j["dmrs_symbols_mask"] = 1, 2, 1 << 2
+        j["grid_nof_prb"], j["bwp_start_rb"], j["bwp_size_rb"], j["nof_bits"] = nprb, 0, nprb, G
+        j["rb_mask"] = rb_words
+        j["cw_offset"], j["grid_offset"] = (k % n_unique) * G, k * 14 * nsc
+        q = dj[k]
+        q["slot_in_frame"], q["scrambling_id"], q["amplitude"], q["dmrs_type"], q["nof_ports"] = k, DMRS_SCR_ID, DMRS_SCALING, 1, 1
+        q["symbols_mask"], q["grid_nof_prb"], q["rb_mask"], q["grid_offset"] = 1 << 2, nprb, rb_words, k * 14 * nsc
+    assert miphy.pdsch_mod_nof_re(mj[0]) * w["mod"] == G
+    ctx.pdsch_modulate_batch(mj, cw_d, grids)
+    ctx.dmrs_pdsch_map_batch(dj, grids)
+    torch.cuda.synchronize()
     return grids, tbs
 
 
@@ -144,7 +155,7 @@ def main():
     G = w["nsym"] * w["mod"]
     n_unique = 4
     nsc = w["nprb"] * 12
-    grids_tx, tbs_u = build_tx_grids(w, n_unique, seed=1234 + rank)
+    grids_tx, tbs_u = build_tx_grids(ctx, miphy, torch, dev, w, n_unique, seed=1234 + rank)
     slot_src = np.arange(S) % n_unique  # transport block carried by slot s (slot s is slot-in-frame s % 20)
 
     # ---- transmit side + channel, once, outside the timed region: OFDM modulation of the S grids on the device and AWGN
@@ -157,7 +168,7 @@ def main():
         ojobs[s] = (s * slot_samples, s * 14 * nsc, s % 2, 0)
     ojobs_d = torch.from_numpy(ojobs.view(np.uint8)).to(dev)
     samples_d = torch.zeros(S * slot_samples, dtype=torch.complex64, device=dev)
-    grid_d = torch.from_numpy(grids_tx).to(dev)[torch.arange(S, device=dev) % 20].reshape(-1).contiguous()
+    grid_d = grids_tx.reshape(20, -1)[torch.arange(S, device=dev) % 20].reshape(-1).contiguous()
     ctx.ofdm_modulate_slots(mcfg, ojobs_d, grid_d, samples_d, stream)
     g = torch.Generator(device=dev)
     g.manual_seed(99 + rank)
