@@ -355,6 +355,20 @@ def main():
             traffic[k] = v["hbm_bytes_per_launch"] * S / tj["slots_per_gpu_per_step"]
     except (OSError, KeyError, ValueError):
         pass
+    # VALU-issue roofline of the decoder (it is not an HBM kernel): wave64 VALU instructions per launch from the SQ counters of the
+    # same workload (profiles/r01_pmc_sq_v4_all_kernels.csv, SQ_INSTS_VALU; scales with the codeblocks) over the launch time, against
+    # 1024 SIMDs x (2.4 GHz / 4 cycles per wave64 instruction).
+    valu = None
+    try:
+        import csv
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_sq_v4_all_kernels.csv"))):
+            if r["kernel"] == "ldpc_decode_pk_kernel" and r["counter"] == "SQ_INSTS_VALU":
+                per_cb = float(r["mean_per_dispatch"]) / 9728.0
+                ach = per_cb * S * C / (kernel_ms["ldpc_decode"] * 1e-3) / 1e9
+                valu = {"kernel": "ldpc_decode", "bound": "valu_issue", "achieved": ach, "peak": 1024 * 2.4 / 4, "unit": "G wave-instr/s",
+                        "frac": ach / (1024 * 2.4 / 4), "valu_wave_instructions_per_codeblock": per_cb}
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "LDPC info-bits/sec + OFDM slots/sec, 100 MHz n78 273-PRB grid",
         "value": value,
@@ -380,6 +394,7 @@ def main():
         "ofdm_slots_per_s": S * world / (kernel_ms["ofdm_demod"] * 1e-3),
         "roofline_ofdm": {"kernel": "ofdm_demod", "bound": "hbm", "achieved": gbs["ofdm_demod"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": gbs["ofdm_demod"] / HBM_PEAK_GBS, "traffic": traffic.get("ofdm_demod")},
+        "roofline_valu": valu,
         "single_slot_latency_us": lat_us,
         "mean_ldpc_iterations": float(iters.mean()) if args.early_stop else float(args.max_iter),
         "parity_check": "%d/%d slots: LLRs and codeblocks identical to the oracle, transport block recovered" % (ok_slots, checked),

@@ -112,11 +112,19 @@ __device__ __forceinline__ void fft_pass(cplx* x, int N, int n, int s, const cpl
   // Butterflies per thread: the launcher guarantees N <= 16 * blockDim, i.e. nb <= MAXB * nt.
   constexpr int MAXB = (R == 8) ? 2 : (R == 4) ? 4 : (R == 2) ? 8 : 6;
   cplx          a[MAXB][R];
+  cplx          w1s[MAXB];
+  int           ps[MAXB], qs[MAXB];
+  // s is a power of two in every radix-8/4/2 pass (those run first): shift instead of a division.
+  const bool pow2  = (s & (s - 1)) == 0;
+  const int  shift = 31 - __clz(s);
 #pragma unroll
   for (int c = 0; c < MAXB; ++c) {
     const int t = tid + c * nt;
     if (t < nb) {
-      const int p = t / s, q = t - p * s;
+      const int p = pow2 ? (t >> shift) : (t / s), q = t - p * s;
+      ps[c] = p, qs[c] = q;
+      if (m > 1)
+        w1s[c] = tw[p * s]; // issued before the LDS reads and the barrier: its latency hides behind them
 #pragma unroll
       for (int k = 0; k < R; ++k)
         a[c][k] = x[fpad(q + s * (p + m * k))];
@@ -127,7 +135,7 @@ __device__ __forceinline__ void fft_pass(cplx* x, int N, int n, int s, const cpl
   for (int c = 0; c < MAXB; ++c) {
     const int t = tid + c * nt;
     if (t < nb) {
-      const int p = t / s, q = t - p * s;
+      const int p = ps[c], q = qs[c];
       cplx*     v = a[c];
       if (R == 2)
         dft2<INV>(v[0], v[1]);
@@ -138,7 +146,7 @@ __device__ __forceinline__ void fft_pass(cplx* x, int N, int n, int s, const cpl
       else
         dft8<INV>(v);
       if (m > 1) { // twiddle exp(-+ 2 pi i p k / n) = W_N^(p k s)
-        const cplx w1 = cconj_if<INV>(tw[p * s]);
+        const cplx w1 = cconj_if<INV>(w1s[c]);
         cplx       w  = w1;
 #pragma unroll
         for (int k = 1; k < R; ++k) {

@@ -4,6 +4,7 @@
 // Behaviour contract: lib/phy/lower/modulation/ofdm_demodulator_impl.cpp:93-138, ofdm_modulator_impl.cpp:55-99,
 // include/srsran/phy/lower/modulation/phase_compensation_lut.h:49-96, include/srsran/ran/cyclic_prefix.h:96-107.
 #include "fft_device.h"
+#include <cstdlib>
 #include "miphy_ext.h"
 #include <cmath>
 #include <complex>
@@ -11,7 +12,7 @@
 namespace {
 
 template <bool INV>
-__global__ void __launch_bounds__(256) dft_kernel(const float2* __restrict__ in, float2* __restrict__ out, const cplx* __restrict__ tw, int N)
+__global__ void __launch_bounds__(512) dft_kernel(const float2* __restrict__ in, float2* __restrict__ out, const cplx* __restrict__ tw, int N)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cplx*         x   = reinterpret_cast<cplx*>(smem);
@@ -125,7 +126,7 @@ bool four_step_factors(uint32_t N, uint32_t& N1, uint32_t& N2)
   }
 }
 
-__global__ void __launch_bounds__(256) ofdm_demod_kernel(const miphy_ofdm_job* __restrict__ jobs,
+__global__ void __launch_bounds__(512) ofdm_demod_kernel(const miphy_ofdm_job* __restrict__ jobs,
                                                          const ofdm_plan_dev* __restrict__ plan,
                                                          const cplx* __restrict__ tw,
                                                          const cplx* __restrict__ ramp,
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(256) ofdm_demod_kernel(const miphy_ofdm_job* _
   }
 }
 
-__global__ void __launch_bounds__(256) ofdm_mod_kernel(const miphy_ofdm_job* __restrict__ jobs,
+__global__ void __launch_bounds__(512) ofdm_mod_kernel(const miphy_ofdm_job* __restrict__ jobs,
                                                        const ofdm_plan_dev* __restrict__ plan,
                                                        const cplx* __restrict__ tw,
                                                        const float2* __restrict__ grid,
@@ -224,9 +225,13 @@ bool size_supported(uint32_t N)
 
 int threads_for(uint32_t N)
 {
-  int nt = (int)(N / 16);
-  nt     = ((nt + 63) / 64) * 64;
-  return nt < 64 ? 64 : (nt > 256 ? 256 : nt);
+  // N / 16 threads are the minimum the passes need (fft_device.h); N / 8 puts one radix-8 butterfly on every thread, which
+  // halves the latency of a pass and doubles the wavefronts a CU holds per LDS-resident transform.
+  static const char* env = getenv("MIPHY_FFT_THREADS_DIV");
+  const int          div = env ? atoi(env) : 8;
+  int                nt  = (int)(N / (div == 16 ? 16 : 8));
+  nt                     = ((nt + 63) / 64) * 64;
+  return nt < 64 ? 64 : (nt > 512 ? 512 : nt);
 }
 
 // cyclic_prefix::get_length (normal CP) in samples: (144 >> mu) (+16 for symbol 0 and 7*2^mu) kappa units.
