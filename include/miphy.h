@@ -71,7 +71,10 @@ typedef struct {
 } miphy_ldpc_dec_desc;
 
 /* Optional launch bounds for device-resident descriptors (which the host cannot inspect): the largest lifting size
- * and input length in the batch. NULL = worst case (Z = 384, full-length codeblocks: one workgroup per CU). */
+ * and input length in the batch. NULL = worst case (Z = 384, full-length codeblocks: one workgroup per CU).
+ * The library sizes its on-chip buffers for ceil((max_in_len + 2 max_Z) / max_Z) variable nodes. When the batch mixes lifting
+ * sizes, a codeblock with a smaller Z reaches more nodes per LLR: pass max_in_len = (n_max - 2) * max_Z with
+ * n_max = max over codeblocks of ceil((in_len + 2 Z) / Z). A bound that is too small corrupts the result. */
 typedef struct {
   uint32_t max_Z;
   uint32_t max_in_len;

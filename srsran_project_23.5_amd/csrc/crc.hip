@@ -2,10 +2,10 @@
 #include "crc_device.h"
 
 namespace {
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 crc_kernel(const miphy_crc_desc* __restrict__ descs, const miphy_graph_tables* __restrict__ tab, const uint8_t* __restrict__ data, uint32_t* __restrict__ out)
 {
-  __shared__ uint32_t red[4];
+  __shared__ uint32_t red[16];
   const miphy_crc_desc d    = descs[blockIdx.x];
   uint32_t             part = crc_partial(tab, (int)d.poly, data, d.bit_offset, d.nbits, threadIdx.x, blockDim.x);
 #pragma unroll
@@ -14,8 +14,12 @@ crc_kernel(const miphy_crc_desc* __restrict__ descs, const miphy_graph_tables* _
   if ((threadIdx.x & 63) == 0)
     red[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0)
-    out[blockIdx.x] = red[0] ^ red[1] ^ red[2] ^ red[3];
+  if (threadIdx.x == 0) {
+    uint32_t r = 0;
+    for (unsigned w = 0; w < blockDim.x / 64; ++w)
+      r ^= red[w];
+    out[blockIdx.x] = r;
+  }
 }
 } // namespace
 
@@ -38,7 +42,8 @@ extern "C" int miphy_crc_batch(miphy_ctx*            ctx,
   int         rc      = miphy_stage_descs(ctx, descs, descs_on_device, sizeof(miphy_crc_desc) * (size_t)n, s, &d_descs);
   if (rc)
     return rc;
-  hipLaunchKernelGGL(crc_kernel, dim3(n), dim3(256), 0, s, (const miphy_crc_desc*)d_descs, ctx->d_tables, data, checksums);
+  // Few, long messages (transport blocks): 1024 threads each; many short ones: 256 are plenty.
+  hipLaunchKernelGGL(crc_kernel, dim3(n), dim3(n <= 512 ? 1024 : 256), 0, s, (const miphy_crc_desc*)d_descs, ctx->d_tables, data, checksums);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

@@ -52,15 +52,26 @@ crc_partial(const miphy_graph_tables* tab, int p, const uint8_t* __restrict__ da
   const uint32_t w1  = min(w0 + per, nwords);
   uint32_t       reg = 0;
   uint32_t       bits_done_end = 0; // bits consumed up to the end of my run
-  for (uint32_t w = w0; w < w1; ++w) {
-    const uint32_t rem = nbits - 32 * w;
-    const int      len = rem < 32 ? (int)rem : 32;
-    const uint32_t v   = crc_load32(data, bit0 + 32ull * w);
-    for (int b = 0; b < len; ++b) {
-      reg = (reg << 1) ^ (((v >> (31 - b)) & 1u) << order);
-      reg ^= (reg & top) ? poly : 0u;
+  // Four words are fetched before any of them is consumed: one memory latency per four words instead of one per word.
+  for (uint32_t wb = w0; wb < w1; wb += 4) {
+    uint32_t v4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      v4[q] = (wb + q < w1) ? crc_load32(data, bit0 + 32ull * (wb + q)) : 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t w = wb + q;
+      if (w < w1) {
+        const uint32_t rem = nbits - 32 * w;
+        const int      len = rem < 32 ? (int)rem : 32;
+        const uint32_t v   = v4[q];
+        for (int b = 0; b < len; ++b) {
+          reg = (reg << 1) ^ (((v >> (31 - b)) & 1u) << order);
+          reg ^= (reg & top) ? poly : 0u;
+        }
+        bits_done_end = 32 * w + len;
+      }
     }
-    bits_done_end = 32 * w + len;
   }
   reg &= top - 1u;
   // Weight: x^(nbits - bits_done_end).

@@ -83,7 +83,7 @@ __global__ void harq_reset_kernel(const uint32_t* __restrict__ slots, uint32_t n
 
 // One workgroup per transport block (pusch_decoder_impl.cpp:198-222): concatenates the codeblock data bits, checks the TB
 // CRC24A when there are several codeblocks, writes the TB and the result record, resets the CRC flags on a TB CRC failure.
-__global__ void __launch_bounds__(256) pusch_tb_assemble_kernel(const tb_asm_desc* __restrict__ descs,
+__global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_desc* __restrict__ descs,
                                                                 const miphy_graph_tables* __restrict__ tab,
                                                                 const int32_t* __restrict__ iters,
                                                                 const uint8_t* __restrict__ harq_msgs,
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) pusch_tb_assemble_kernel(const tb_asm_des
                                                                 uint8_t* __restrict__ tb_out,
                                                                 miphy_pusch_result* __restrict__ results)
 {
-  __shared__ uint32_t red[8];
+  __shared__ uint32_t red[16];
   __shared__ int      all_ok;
   const tb_asm_desc d   = descs[blockIdx.x];
   const int         tid = threadIdx.x;
@@ -127,9 +127,17 @@ __global__ void __launch_bounds__(256) pusch_tb_assemble_kernel(const tb_asm_des
     return; // nothing is copied, flags stay as they are (multiple codeblocks) / tb_crc_ok = false (single codeblock)
   // tmp_tb_bits: nof_new_bits = min(free, nof_data_bits) from every codeblock message, bit-granular.
   const uint32_t nbytes = (d.tb_and_crc_bits + 7) / 8;
+  const bool     bytewise = (d.nof_data_bits % 8) == 0 || d.nof_cbs == 1; // always true for TS 38.214 transport block sizes
+  const uint32_t cb_bytes = d.nof_data_bits / 8;
   for (uint32_t b = tid; b < nbytes + 8; b += blockDim.x) {
     uint32_t v = 0;
-    if (b < nbytes) {
+    if (b < nbytes && bytewise) {
+      const uint32_t c = (d.nof_cbs == 1) ? 0u : b / cb_bytes, o = b - c * cb_bytes;
+      v                = harq_msgs[(size_t)(d.harq_cb_index + c) * HARQ_MSG_STRIDE + o];
+      const uint32_t last = d.tb_and_crc_bits - 8 * b; // bits of this byte that belong to the transport block
+      if (last < 8)
+        v &= 0xffu << (8 - last);
+    } else if (b < nbytes) {
       for (int k = 0; k < 8; ++k) {
         const uint32_t bit = 8 * b + k;
         if (bit >= d.tb_and_crc_bits)
@@ -151,7 +159,10 @@ __global__ void __launch_bounds__(256) pusch_tb_assemble_kernel(const tb_asm_des
     if ((tid & 63) == 0)
       red[tid >> 6] = part;
     __syncthreads();
-    tb_ok = ((red[0] ^ red[1] ^ red[2] ^ red[3]) == 0);
+    uint32_t r = 0;
+    for (unsigned w = 0; w < blockDim.x / 64; ++w)
+      r ^= red[w];
+    tb_ok = (r == 0);
   }
   for (uint32_t b = tid; b < d.tb_bytes; b += blockDim.x)
     tb_out[d.tb_offset + b] = tmp[b];
@@ -287,7 +298,7 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
   std::vector<tb_asm_desc>         asmd(n);
   std::vector<uint64_t>            tmp_off(n);
   uint64_t                         tmp_bytes = 0;
-  uint32_t                         max_Z = 2, max_in_len = 0, max_E = 0;
+  uint32_t                         max_Z = 2, max_nodes = 0, max_E = 0;
   for (uint32_t t = 0; t < n; ++t) {
     const miphy_pusch_tb_desc& d = tbs[t];
     seg_t                      sg;
@@ -313,7 +324,7 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
     a.tb_offset        = d.tb_offset;
     tmp_off[t]         = tmp_bytes;
     tmp_bytes += ((a.tb_and_crc_bits + 7) / 8 + 8 + 15) & ~15ull;
-    uint32_t cw_off = 0;
+    uint32_t cw_off = 0, tb_nodes = 0;
     for (uint32_t c = 0; c < sg.nof_cbs; ++c) {
       const uint32_t      E    = rm_length(sg, c, d.mod, d.nof_layers, d.nof_ch_symbols);
       const uint32_t      slot = d.harq_cb_index + c;
@@ -327,7 +338,24 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
       miphy_ldpc_dec_desc q = {};
       q.bg = d.bg, q.crc_poly = (uint8_t)sg.crc_poly, q.Z = (uint16_t)sg.Z, q.max_iter = d.nof_ldpc_iterations;
       q.nof_filler_bits = (uint16_t)sg.nof_filler_bits;
-      q.in_len          = sg.N; // the reference hands the full-length soft buffer to the decoder (pusch_decoder_impl.cpp:177,186)
+      // The reference hands the full-length soft buffer to the decoder (pusch_decoder_impl.cpp:177,186), which trims it at the
+      // last non-zero soft bit. For a first transmission with rv 0 everything behind the E rate-matched bits (+ fillers) is zero
+      // by construction, so the bound is known here: the decoder then sizes its LDS for the layers that can be reached.
+      q.in_len = sg.N;
+      {
+        // (not with a limited buffer: there the dematcher leaves part of the tail untouched, and stale soft bits of an earlier
+        // use of the HARQ slot are visible to the reference decoder)
+        const bool full_buffer = !(d.Nref > 0 && d.Nref < sg.N);
+        if (d.new_data && d.rv == 0 && full_buffer && E + sg.nof_filler_bits <= sg.N) {
+          const uint32_t need = ((E + sg.nof_filler_bits + sg.Z - 1) / sg.Z) * sg.Z;
+          const uint32_t lo   = (bgK + 2) * sg.Z;
+          q.in_len            = need < lo ? lo : (need > sg.N ? sg.N : need);
+        }
+      }
+      {
+        const uint32_t nodes = (q.in_len + 2 * sg.Z + sg.Z - 1) / sg.Z; // variable nodes this codeblock can reach
+        tb_nodes             = nodes > tb_nodes ? nodes : tb_nodes;
+      }
       q.flags           = d.use_early_stop ? 0u : 1u;
       q.llr_offset = (uint64_t)slot * HARQ_CB_STRIDE, q.out_offset = (uint64_t)slot * HARQ_MSG_STRIDE;
       dec.push_back(q);
@@ -335,12 +363,11 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
       if (d.new_data)
         reset_slots.push_back(slot);
       cw_off += E;
-      (void)bgK;
     }
     MIPHY_REQUIRE(cw_off == d.nof_ch_symbols * d.mod, "pusch_decode: TB %u: codeblock lengths (%u) do not add up to the codeword (%u)", t, cw_off,
                   d.nof_ch_symbols * d.mod);
     max_Z      = sg.Z > max_Z ? sg.Z : max_Z;
-    max_in_len = sg.N > max_in_len ? sg.N : max_in_len;
+    max_nodes  = tb_nodes > max_nodes ? tb_nodes : max_nodes;
   }
   const uint32_t ncb = (uint32_t)dec.size();
   MIPHY_REQUIRE(ncb <= 65535, "pusch_decode: %u codeblocks in one call (max 65535)", ncb);
@@ -374,10 +401,12 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
   miphy_ldpc_rdm_limits rlim = {max_E};
   if ((rc = miphy_ldpc_rate_dematch_batch(ctx, d_rdm, 1, ncb, llrs, harq_softbits, &rlim, s)))
     return rc;
-  miphy_ldpc_dec_limits lim = {max_Z, max_in_len};
+  // The decoder derives its LDS size from (max_Z, max_in_len) as ceil((max_in_len + 2 max_Z) / max_Z) nodes: hand it the node
+  // bound of the batch expressed in units of the largest lifting size (codeblocks with a smaller Z reach more nodes per LLR).
+  miphy_ldpc_dec_limits lim = {max_Z, (max_nodes - 2) * max_Z};
   if ((rc = miphy_ldpc_decode_launch(ctx, d_dec, 1, ncb, harq_softbits, harq_msgs, d_iters, &lim, d_slots, harq_crc_ok, s)))
     return rc;
-  hipLaunchKernelGGL(pusch_tb_assemble_kernel, dim3(n), dim3(256), 0, s, d_asm, ctx->d_tables, d_iters, harq_msgs, harq_crc_ok, d_tmp, d_tmpo, tb_out, results);
+  hipLaunchKernelGGL(pusch_tb_assemble_kernel, dim3(n), dim3(1024), 0, s, d_asm, ctx->d_tables, d_iters, harq_msgs, harq_crc_ok, d_tmp, d_tmpo, tb_out, results);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }
