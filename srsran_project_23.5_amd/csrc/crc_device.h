@@ -27,9 +27,13 @@ __device__ __forceinline__ uint32_t crc_load32(const uint8_t* __restrict__ data,
   return (uint32_t)(v >> (8 - sh));
 }
 
-// x^(32*k) mod poly from the power-of-two table (square-and-multiply).
+// x^(32*k) mod poly: one table entry for k < 320, one product of two entries up to k < 65536 (2 Mbit), square-and-multiply beyond.
 __device__ __forceinline__ uint32_t crc_pow32(const miphy_graph_tables* tab, int p, uint32_t k, uint32_t poly, uint32_t order)
 {
+  if (k < 320)
+    return tab->crc_pow32[p][k];
+  if (k < 65536)
+    return crc_gf2_mulmod(tab->crc_pow32[p][k & 255u], tab->crc_pow32_hi[p][k >> 8], poly, order);
   uint32_t r = 1;
   for (int b = 0; k != 0; ++b, k >>= 1)
     if (k & 1u)

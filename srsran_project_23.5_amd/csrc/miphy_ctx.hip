@@ -103,6 +103,14 @@ static void build_tables(miphy_graph_tables* t)
       t->crc_pow32[p][k] = v;
       v                  = gf2_mulmod(v, x32, POLY[p], ORDER[p]);
     }
+    {
+      const uint32_t x8192 = gf2_mulmod(t->crc_pow32[p][255], x32, POLY[p], ORDER[p]); // x^(32*256)
+      uint32_t       h     = 1;
+      for (int k = 0; k < 256; ++k) {
+        t->crc_pow32_hi[p][k] = h;
+        h                     = gf2_mulmod(h, x8192, POLY[p], ORDER[p]);
+      }
+    }
     v = x32;
     for (int b = 0; b < 24; ++b) {
       t->crc_pow2[p][b] = v;

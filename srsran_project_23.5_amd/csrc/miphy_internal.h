@@ -23,6 +23,7 @@ struct miphy_graph_tables {
   // CRC: pow32[p][k] = x^(32k) mod poly_p for k in [0, 320); poly/order per id.
   uint32_t crc_pow32[5][320];
   uint32_t crc_pow2[5][24]; // x^(32 * 2^b) mod poly
+  uint32_t crc_pow32_hi[5][256]; // x^(32 * 256 * k) mod poly: with crc_pow32[k & 255] covers messages up to 2 Mbit in one product
   uint32_t crc_poly[5];
   uint32_t crc_order[5];
 };
