@@ -448,10 +448,21 @@ extern "C" int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_des
       p.msg_offset      = msg_bytes;
       prep.push_back(p);
       tb_bit += p.take_bits;
-      miphy_ldpc_enc_desc e = {};
-      e.bg = d.bg, e.Z = (uint16_t)sg.Z, e.out_len = sg.N, e.in_offset = msg_bytes, e.out_offset = cb_bytes;
-      enc.push_back(e);
       const uint32_t      E = rm_length(sg, c, d.mod, d.nof_layers, d.nof_ch_symbols);
+      miphy_ldpc_enc_desc e = {};
+      e.bg = d.bg, e.Z = (uint16_t)sg.Z, e.in_offset = msg_bytes, e.out_offset = cb_bytes;
+      {
+        // Only the part of the circular buffer the rate matcher will read is encoded: from k0 (TS 38.212 Table 5.4.2.1-2) over E
+        // bits plus the fillers it may skip, or the whole buffer when that wraps. A high-rate codeblock needs 2 of the 42 extension
+        // nodes of base graph 1.
+        const uint32_t Ncb = (d.Nref > 0 && d.Nref < sg.N) ? d.Nref : sg.N;
+        const uint32_t num = (d.bg == 1) ? ((d.rv == 0) ? 0u : (d.rv == 1) ? 17u : (d.rv == 2) ? 33u : 56u)
+                                         : ((d.rv == 0) ? 0u : (d.rv == 1) ? 13u : (d.rv == 2) ? 25u : 43u);
+        const uint32_t k0  = (uint32_t)(((uint64_t)num * Ncb) / sg.N) * sg.Z;
+        const uint64_t end = (uint64_t)k0 + E + sg.nof_filler_bits;
+        e.out_len          = (end >= Ncb) ? Ncb : (uint32_t)end;
+      }
+      enc.push_back(e);
       miphy_ldpc_rdm_desc r = {};
       r.bg = d.bg, r.rv = d.rv, r.mod = d.mod, r.new_data = 1, r.Z = (uint16_t)sg.Z, r.nof_filler_bits = (uint16_t)sg.nof_filler_bits;
       r.Nref = d.Nref, r.E = E, r.in_offset = cb_bytes, r.out_offset = d.codeword_offset + cw_off;
