@@ -1427,8 +1427,22 @@ int orc_polar_scl_decode(unsigned K, unsigned E, unsigned nMax, int ibil, unsign
   scl_path_t* P = (scl_path_t*)calloc(2 * L, sizeof(scl_path_t));
   scl_path_t* Q = P + L;
   unsigned    active = 1;
-  for (unsigned i = 0; i < N; ++i) {
-    /* leaf LLR of every active path */
+  for (unsigned i = 0; i < N;) {
+    /* Largest aligned all-frozen block [i, i + 2^r) (a "rate-0 node"): it is processed at stage r in one step -- its path metric
+     * penalty is the sum of the negative stage-r LLRs (identical to the leaf-by-leaf sum under min-sum f and exact g). */
+    unsigned r = 0;
+    if (!c.K_set[i]) {
+      while (r < n && (i & ((2u << r) - 1u)) == 0) {
+        int frozen = 1;
+        for (unsigned j = 0; j < (2u << r) && frozen; ++j)
+          frozen = !c.K_set[i + j];
+        if (!frozen)
+          break;
+        ++r;
+      }
+    }
+    const unsigned B = 1u << r;
+    /* stage-r LLRs of every active path */
     for (unsigned p = 0; p < active; ++p) {
       scl_path_t* a = &P[p];
       unsigned    t = n;
@@ -1442,7 +1456,7 @@ int orc_polar_scl_decode(unsigned K, unsigned E, unsigned nMax, int ibil, unsign
           a->llr[(1u << t) + j] = a->bl[(1u << t) + j] ? llr_add(y, (int8_t)-x) : llr_add(y, x);
         }
       }
-      for (int s = (int)t - 1; s >= 0; --s) {
+      for (int s = (int)t - 1; s >= (int)r; --s) {
         const int8_t* up = ((unsigned)s + 1 == n) ? ch : a->llr + (2u << s);
         for (unsigned j = 0; j < (1u << s); ++j)
           a->llr[(1u << s) + j] = llr_soft_xor(up[j], up[j + (1u << s)]);
@@ -1450,10 +1464,12 @@ int orc_polar_scl_decode(unsigned K, unsigned E, unsigned nMax, int ibil, unsign
     }
     if (!c.K_set[i]) {
       for (unsigned p = 0; p < active; ++p) {
-        int l0 = P[p].llr[1];
-        P[p].u[i] = 0;
-        if (l0 < 0)
-          P[p].pm += -l0;
+        const int8_t* v = (r == n) ? ch : P[p].llr + B;
+        for (unsigned j = 0; j < B; ++j) {
+          P[p].u[i + j] = 0;
+          if (v[j] < 0)
+            P[p].pm += -v[j];
+        }
       }
     } else {
       unsigned nc = 2 * active, keep = nc < L ? nc : L;
@@ -1478,15 +1494,19 @@ int orc_polar_scl_decode(unsigned K, unsigned E, unsigned nMax, int ibil, unsign
       P = Q, Q = tmp;
       active = keep;
     }
-    /* partial sums */
+    /* partial sums of the finished block (stage r) */
     for (unsigned p = 0; p < active; ++p) {
       scl_path_t* a = &P[p];
-      if (!(i & 1u)) {
-        a->bl[1] = a->u[i];
+      if (r == n)
+        break;
+      if (!((i >> r) & 1u)) {
+        for (unsigned j = 0; j < B; ++j)
+          a->bl[B + j] = a->u[i + j];
       } else {
         uint8_t  cur[1024];
-        unsigned sz = 1, s = 0;
-        cur[0] = a->u[i];
+        unsigned sz = B, s = r;
+        for (unsigned j = 0; j < B; ++j)
+          cur[j] = a->u[i + j];
         while (s < n && ((i >> s) & 1u)) {
           for (unsigned j = 0; j < sz; ++j) {
             cur[sz + j] = cur[j];
@@ -1498,6 +1518,7 @@ int orc_polar_scl_decode(unsigned K, unsigned E, unsigned nMax, int ibil, unsign
           memcpy(a->bl + (1u << s), cur, sz);
       }
     }
+    i += B;
   }
   /* selection */
   int best = -1, best_ok = -1;

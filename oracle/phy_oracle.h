@@ -125,7 +125,8 @@ int orc_pdcch_encode(const uint8_t* payload, unsigned A, unsigned rnti, unsigned
 /* Successive-cancellation LIST decoder (list size L in {1,2,4,8}) -- NO reference counterpart (the reference only has the
  * list-size-1 SSC decoder above); this restates the algorithm of the HIP kernel so that the kernel can be checked bit for
  * bit: LLR-domain path metrics (PM += |llr| when the decision disagrees with the hard decision), min-sum f, saturating g with
- * the reference's LLR algebra, candidates ranked by (metric, 2*slot + flip), survivors renumbered by rank.
+ * the reference's LLR algebra, candidates ranked by (metric, 2*slot + flip), survivors renumbered by rank. Aligned all-frozen blocks
+ * (rate-0 nodes) are processed at their own stage: penalty = sum of the negative stage LLRs, bits and partial sums zero.
  * crc_mode 0: best metric path, msg = K bits in K-set order. crc_mode 1 (PDCCH): candidates are de-interleaved (Pi_IL) and
  * checked with CRC24C over 24 leading ones + payload with the RNTI mask; crc_mode 2 (PBCH): CRC24C without ones / mask.
  * In modes 1/2 msg = the K de-interleaved bits of the selected path. Returns the chosen path's metric; *crc_ok. */

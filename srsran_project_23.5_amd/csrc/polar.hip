@@ -526,7 +526,11 @@ __global__ void __launch_bounds__(64) polar_scl_kernel(polar_plan p, int L, int 
   uint8_t*     bankB  = bankA + (size_t)L * PSZ;
   int*         pm     = reinterpret_cast<int*>(bankB + (size_t)L * PSZ); // [L]
   int*         sel    = pm + 8;                                           // parent[8], bit[8], pm[8]
+  uint8_t*     kset   = reinterpret_cast<uint8_t*>(sel + 24);             // [N] information-set flags: one LDS read per leaf
+                                                                          // instead of a dependent global load (~1.5 us each)
   const int8_t* f_in  = llr_in + cw * p.E;
+  for (int q = lane; q < 2 * N; q += 64)
+    kset[q] = k_set[q]; // [0, N): information-set flags, [N, 2N): rate-0 block exponents
   // Rate dematching (same gather as polar_decode_kernel).
   for (int q = lane; q < N; q += 64) {
     const int first = p.d_rx_first[q];
@@ -548,8 +552,11 @@ __global__ void __launch_bounds__(64) polar_scl_kernel(polar_plan p, int L, int 
   uint8_t* P = bankA;
   uint8_t* Q = bankB;
   int      active = 1;
-  for (int i = 0; i < N; ++i) {
-    // ---- leaf LLRs
+  for (int i = 0; i < N;) {
+    // An aligned all-frozen block [i, i + 2^r) (rate-0 node) is processed at stage r in one step: its penalty is the sum of the
+    // negative stage-r LLRs, its bits and partial sums are zero.
+    const int r = kset[N + i], B = 1 << r;
+    // ---- stage-r LLRs
     int t = n;
     if (i != 0) {
       t = __ffs(i) - 1;
@@ -563,7 +570,7 @@ __global__ void __launch_bounds__(64) polar_scl_kernel(polar_plan p, int L, int 
       }
       __syncthreads();
     }
-    for (int s = t - 1; s >= 0; --s) {
+    for (int s = t - 1; s >= r; --s) {
       const int sz = 1 << s;
       for (int idx = lane; idx < active * sz; idx += 64) {
         const int     q = idx >> s, j = idx & (sz - 1);
@@ -574,12 +581,13 @@ __global__ void __launch_bounds__(64) polar_scl_kernel(polar_plan p, int L, int 
       __syncthreads();
     }
     // ---- decision
-    if (!k_set[i]) {
-      if (lane < active) {
-        const int l0 = reinterpret_cast<int8_t*>(P + lane * PSZ)[1];
-        P[lane * PSZ + 2 * N + i] = 0;
-        if (l0 < 0)
-          pm[lane] -= l0;
+    if (!kset[i]) {
+      for (int idx = lane; idx < active * B; idx += 64) {
+        const int q = idx >> r, j = idx & (B - 1);
+        const int v = (r == n) ? ch[j] : reinterpret_cast<int8_t*>(P + q * PSZ)[B + j];
+        P[q * PSZ + 2 * N + i + j] = 0;
+        if (v < 0)
+          atomicAdd(&pm[q], -v);
       }
       __syncthreads();
     } else {
@@ -618,15 +626,19 @@ __global__ void __launch_bounds__(64) polar_scl_kernel(polar_plan p, int L, int 
       active       = keep;
       __syncthreads();
     }
-    // ---- partial sums (bank Q's u area serves as the per-path working vector)
-    if (!(i & 1)) {
-      if (lane < active)
-        P[lane * PSZ + N + 1] = P[lane * PSZ + 2 * N + i];
+    // ---- partial sums of the finished block at stage r (bank Q's u area serves as the per-path working vector)
+    if (!((i >> r) & 1)) {
+      for (int idx = lane; idx < active * B; idx += 64) {
+        const int q = idx >> r, j = idx & (B - 1);
+        P[q * PSZ + N + B + j] = P[q * PSZ + 2 * N + i + j];
+      }
     } else {
-      if (lane < active)
-        Q[lane * PSZ + 2 * N] = P[lane * PSZ + 2 * N + i];
+      for (int idx = lane; idx < active * B; idx += 64) {
+        const int q = idx >> r, j = idx & (B - 1);
+        Q[q * PSZ + 2 * N + j] = P[q * PSZ + 2 * N + i + j];
+      }
       __syncthreads();
-      int sz = 1, s = 0;
+      int sz = B, s = r;
       while (s < n && ((i >> s) & 1)) {
         for (int idx = lane; idx < active * sz; idx += 64) {
           const int q = idx >> s, j = idx & (sz - 1);
@@ -647,6 +659,7 @@ __global__ void __launch_bounds__(64) polar_scl_kernel(polar_plan p, int L, int 
       }
     }
     __syncthreads();
+    i += B;
   }
   // ---- selection: extract the K bits of every path (into bank Q), optional de-interleave + CRC, best metric wins
   int      my_pm = 0x7fffffff, my_ok = 0;
@@ -736,12 +749,33 @@ extern "C" int miphy_polar_decode_list_batch(miphy_ctx*              ctx,
     host_code h;
     if ((rc = build_code(code, h)))
       return rc;
+    // followed by, per position, the exponent r of the largest aligned all-frozen block [i, i + 2^r) that starts there
+    std::vector<uint8_t> tab(h.k_set.begin(), h.k_set.end());
+    const uint32_t       Np = (uint32_t)h.k_set.size();
+    uint32_t             np = 0;
+    while ((1u << np) < Np)
+      ++np;
+    tab.resize(2 * Np, 0);
+    for (uint32_t i = 0; i < Np; ++i) {
+      uint32_t r = 0;
+      if (!h.k_set[i]) {
+        while (r < np && (i & ((2u << r) - 1u)) == 0) {
+          bool frozen = true;
+          for (uint32_t j = 0; j < (2u << r) && frozen; ++j)
+            frozen = !h.k_set[i + j];
+          if (!frozen)
+            break;
+          ++r;
+        }
+      }
+      tab[Np + i] = (uint8_t)r;
+    }
     uint8_t* d = nullptr;
-    if ((rc = upload(ctx, h.k_set, &d)))
+    if ((rc = upload(ctx, tab, &d)))
       return rc;
     it = ctx->ext->polar_kset.emplace(key, d).first;
   }
-  const size_t lds = (size_t)p->N + 2 * (size_t)list_size * 3 * p->N + 8 * 4 + 24 * 4 + 64;
+  const size_t lds = (size_t)p->N + 2 * (size_t)list_size * 3 * p->N + 8 * 4 + 24 * 4 + 2 * p->N + 64;
   static thread_local size_t lds_set = 0;
   if (lds > lds_set) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
