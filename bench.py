@@ -158,9 +158,18 @@ def main():
     ctx = miphy.Context(local_rank)
     w = pusch_workload()
     S = args.slots
-    seg = O.o_segmentation(w["tbs"], w["bg"], w["mod"], w["nof_layers"], w["nsym"])
-    C, Z, N, K, F = seg.nof_cbs, seg.Z, seg.N, seg.K, seg.nof_filler_bits
+    # Segmentation of the transport block through the library's own host logic (ldpc.h:128-207 restated in csrc/sch.hip); the
+    # rate-matched length of every codeblock is TS 38.212 5.4.2.1 (ldpc_segmenter_impl.cpp:104-141): the first codeblocks get the
+    # floor, the last ones the ceiling of the per-codeblock share of the codeword.
+    sg = miphy.sch_segmentation(w["tbs"] // 8, w["bg"])
+    C, Z, N, K, F = sg.nof_cbs, sg.Z, sg.N, sg.K, sg.nof_filler_bits
     G = w["nsym"] * w["mod"]
+    unit = w["nof_layers"] * w["mod"]
+    n_short = C - (G // unit) % C
+    seg_E = [unit * ((G // unit) // C) if c < n_short else unit * (-(-(G // unit) // C)) for c in range(C)]
+    seg_off = [sum(seg_E[:c]) for c in range(C)]
+    assert sum(seg_E) == G
+    seg_crc_poly = miphy.CRC24B if C > 1 else (miphy.CRC16 if w["tbs"] <= 3824 else miphy.CRC24A)
     n_unique = 4
     nsc = w["nprb"] * 12
     grids_tx, tbs_u = build_tx_grids(ctx, miphy, torch, dev, w, n_unique, seed=1234 + rank)
@@ -192,14 +201,14 @@ def main():
     iters_d = torch.zeros(S * C, dtype=torch.int32, device=dev)
     rdm = np.zeros(S * C, dtype=miphy.LdpcRdmDesc)
     dec = np.zeros(S * C, dtype=miphy.LdpcDecDesc)
-    crc_poly = int(seg.crc_poly)
+    crc_poly = int(seg_crc_poly)
     # The decoder only needs the part of the soft buffer the dematcher can have written (new data, rv 0: E + fillers,
     # rounded up to a node); the rest is zero, which the reference trims away itself (ldpc_decoder_impl.cpp:86-99).
-    dec_in_len = [min(N, max((22 + 2) * Z, -(-(seg.E[c] + F) // Z) * Z)) for c in range(C)]
+    dec_in_len = [min(N, max((22 + 2) * Z, -(-(seg_E[c] + F) // Z) * Z)) for c in range(C)]
     for s in range(S):
         for c in range(C):
             i = s * C + c
-            rdm[i] = (w["bg"], w["rv"], w["mod"], 1, Z, F, w["Nref"], seg.E[c], s * G + seg.cw_offset[c], i * N)
+            rdm[i] = (w["bg"], w["rv"], w["mod"], 1, Z, F, w["Nref"], seg_E[c], s * G + seg_off[c], i * N)
             dec[i] = (w["bg"], crc_poly if args.early_stop else miphy.CRC_NONE, Z, args.max_iter, F, dec_in_len[c], 0, i * N, i * (K // 8))
     rdm_d = torch.from_numpy(rdm.view(np.uint8)).to(dev)
     dec_d = torch.from_numpy(dec.view(np.uint8)).to(dev)
@@ -239,7 +248,7 @@ def main():
     G_ch = max(1, min(args.chunks, S))
     bounds = [(S * i // G_ch, S * (i + 1) // G_ch) for i in range(G_ch)]
     streams = [stream] if G_ch == 1 else [torch.cuda.Stream(), torch.cuda.Stream()]
-    max_E, dec_lim = max(seg.E[:C]), (Z, max(dec_in_len))
+    max_E, dec_lim = max(seg_E), (Z, max(dec_in_len))
 
     def step(timed):
         for ci, (a, b) in enumerate(bounds):
@@ -299,7 +308,7 @@ def main():
             ctx.ofdm_demodulate_slots(ocfg, ojobs_d[:24], samples_d, grid_d, stream)
             ctx.dmrs_pusch_estimate_batch(cjobs_d[:96], grid_d, ce_d, sc_d, stream)
             ctx.pusch_demodulate_batch(djobs_d[:104], grid_d, ce_d, sc_d, llr_d, stream)
-            ctx.ldpc_rate_dematch_batch(rdm_d[:C * 32], llr_d, softbuf_d, stream, max_E=max(seg.E[:C]))
+            ctx.ldpc_rate_dematch_batch(rdm_d[:C * 32], llr_d, softbuf_d, stream, max_E=max(seg_E))
             ctx.ldpc_decode_batch(dec_d[:C * 32], softbuf_d, bits_d, iters_d, stream, limits=(Z, max(dec_in_len)))
         ev1.record(stream)
         torch.cuda.synchronize()
