@@ -15,6 +15,7 @@
 //   * hard decision + CRC run in-kernel: each lane reduces one 32-bit word of the message to a partial remainder,
 //     multiplies it by x^(32k) mod P and the partial remainders are XOR-reduced with wavefront shuffles.
 #include "miphy_internal.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -442,17 +443,16 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   int         rc      = miphy_stage_descs(ctx, descs, descs_on_device, sizeof(miphy_ldpc_dec_desc) * (size_t)n, s, &d_descs);
   if (rc)
     return rc;
-  // Kernel choice: the packed two-rows-per-lane kernel pays off once a codeblock spans at least two wavefronts.
-  // MIPHY_LDPC_KERNEL=scalar|packed or miphy_debug_force_ldpc_kernel() override (test / A-B knob).
+  // Kernel choice. The packed kernel (two check rows per lane, explicit messages in LDS) executes ~1.6x fewer instructions per
+  // row but needs more LDS per codeblock; at low code rates / mid lifting sizes that leaves one small workgroup per CU, and the
+  // one-row-per-lane kernel (compressed messages, twice the wavefronts) wins. Both are scored by the check rows a CU holds in
+  // flight (workgroups per CU limited by LDS, wavefront slots and registers), the packed one weighted by its instruction advantage;
+  // measured crossovers: tools/ldpc_rate_sweep.py. MIPHY_LDPC_KERNEL=scalar|packed or miphy_debug_force_ldpc_kernel() override.
   static const char* force = getenv("MIPHY_LDPC_KERNEL");
-  bool               use_pk = max_threads >= 128 && all_even && (!descs_on_device || limits);
-  if ((force && force[0] == 's') || g_force_kernel == 1)
-    use_pk = false;
-  if ((force && force[0] == 'p') || g_force_kernel == 2)
-    use_pk = all_even && (!descs_on_device || limits);
-  if (use_pk) {
-    const int pk_threads = ((max_threads / 2 + 63) / 64) * 64; // max_threads >= max Z, a multiple of 64
-    size_t    pk_lds     = 0;
+  const bool         pk_ok = max_threads >= 128 && all_even && (!descs_on_device || limits);
+  const int          pk_threads = ((max_threads / 2 + 63) / 64) * 64; // max_threads >= max Z, a multiple of 64
+  size_t             pk_lds     = 0;
+  if (pk_ok) {
     for (int b = 0; b < 2; ++b) {
       if (!max_nodes[b])
         continue;
@@ -462,9 +462,23 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
       const size_t l = miphy_ldpc_pk_lds_bytes(bgK, lay, (size_t)max_threads, ctx->h_tables->pair_start[b][lay]);
       pk_lds         = l > pk_lds ? l : pk_lds;
     }
+  }
+  auto rows_in_flight = [](size_t lds, int threads, int waves_per_simd_by_regs, int rows_per_lane) {
+    const int waves = threads / 64;
+    int       wgs   = (int)((size_t)160 * 1024 / (lds ? lds : 1));
+    wgs             = std::min(wgs, 32 / waves);                          // 8 wavefront slots per SIMD
+    wgs             = std::min(wgs, 4 * waves_per_simd_by_regs / waves);  // register file
+    wgs             = std::max(wgs, 1);
+    return wgs * threads * rows_per_lane;
+  };
+  bool use_pk = pk_ok && 1.6 * rows_in_flight(pk_lds, pk_threads, 4, 2) >= 1.0 * rows_in_flight(max_lds, max_threads, 8, 1);
+  if ((force && force[0] == 's') || g_force_kernel == 1)
+    use_pk = false;
+  if ((force && force[0] == 'p') || g_force_kernel == 2)
+    use_pk = pk_ok;
+  if (use_pk)
     return miphy_ldpc_pk_launch((const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, n, pk_threads, pk_lds, llr, out_bits, iters, nodes_all, harq_slot,
                                 harq_crc_ok, s);
-  }
   static thread_local size_t lds_set = 0;
   if (max_lds > lds_set) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
