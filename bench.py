@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--snr-db", type=float, default=33.0, help="per-RE SNR of the synthesised slots")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--chunks", type=int, default=1, help="slot groups per step, alternated over two HIP streams (1 = one stream)")
+    ap.add_argument("--chunk-streams", type=int, default=2, help="1: the slot groups run back to back on one stream (cache blocking only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-slot latency leg (keeps profiles to the timed step only)")
     args = ap.parse_args()
@@ -247,7 +248,7 @@ def main():
     # decode of the other; every step still processes all S slots and the timed region ends with a device-wide sync.
     G_ch = max(1, min(args.chunks, S))
     bounds = [(S * i // G_ch, S * (i + 1) // G_ch) for i in range(G_ch)]
-    streams = [stream] if G_ch == 1 else [torch.cuda.Stream(), torch.cuda.Stream()]
+    streams = [stream] if (G_ch == 1 or args.chunk_streams == 1) else [torch.cuda.Stream(), torch.cuda.Stream()]
     max_E, dec_lim = max(seg_E), (Z, max(dec_in_len))
 
     def step(timed):

@@ -452,6 +452,47 @@ int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
                              void*                      stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * PUSCH processor  --  replaces srsran::pusch_processor::process for PDUs without UCI
+ *   include/srsran/phy/upper/channel_processors/pusch_processor.h:84-162
+ *   lib/phy/upper/channel_processors/pusch_processor_impl.cpp:108-330
+ * One call = channel estimation + demodulation + transport-block decoding of n PDUs; channel estimates and LLRs never leave the
+ * device. Restrictions of the reference apply (pusch_processor_impl.cpp:96-104): DM-RS type 1, two CDM groups without data, one
+ * transmit layer. HARQ arrays and `results` as in miphy_pusch_decode_batch; scalars_out: per PDU [4 rx ports][5] floats
+ * {rsrp, epre, noise_var, snr, time_alignment_s} of layer 0 (what channel_estimate::get_channel_state_information averages). */
+typedef struct {
+  uint32_t numerology;
+  uint32_t slot_in_frame;
+  uint32_t rnti;
+  uint32_t n_id;
+  uint32_t dmrs_scrambling_id;
+  uint32_t Nref;                /* tbs_lbrm_bytes * 8 */
+  uint32_t tb_bytes;
+  uint32_t harq_cb_index;
+  uint8_t  n_scid;
+  uint8_t  mod;                 /* bits per symbol */
+  uint8_t  nof_rx_ports;
+  uint8_t  start_symbol;
+  uint8_t  nof_symbols;
+  uint8_t  bg;                  /* codeword.ldpc_base_graph */
+  uint8_t  rv;
+  uint8_t  new_data;
+  uint8_t  rx_ports[4];
+  uint8_t  use_early_stop;
+  uint8_t  reserved0;
+  uint16_t nof_ldpc_iterations;
+  uint16_t dmrs_symbols_mask;
+  uint16_t grid_nof_prb;
+  uint32_t pad;
+  uint64_t rb_mask[5];          /* freq_alloc.get_prb_mask(bwp_start_rb, bwp_size_rb) */
+  uint64_t grid_offset;         /* cf_t offset of grid port 0: [port][14][grid_nof_prb*12] */
+  uint64_t tb_offset;           /* byte offset of the transport block inside `tb_out` */
+} miphy_pusch_pdu;
+
+int miphy_pusch_process_batch(miphy_ctx* ctx, const miphy_pusch_pdu* pdus /* host */, uint32_t n, const float* grid /* device cf_t */,
+                              int8_t* harq_softbits, uint8_t* harq_msgs, uint8_t* harq_crc_ok, uint8_t* tb_out /* device */,
+                              miphy_pusch_result* results /* device, n */, float* scalars_out /* device, n x 20 */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * PDSCH encoder (whole transport blocks)  --  replaces srsran::pdsch_encoder::encode
  *   include/srsran/phy/upper/channel_processors/pdsch_encoder.h, lib/phy/upper/channel_processors/pdsch_encoder_impl.cpp:28-65
  *   (segment_tx: TB CRC16/24A, CB CRC24B, zero padding, fillers -> LDPC encode -> rate match into the codeword),

@@ -455,6 +455,7 @@ static void test_pusch_processor(std::shared_ptr<miphy::context> c)
   auto mod   = create_pdsch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg)->create();
   auto dmrs  = create_dmrs_pdsch_processor_factory_sw(prg)->create();
   auto p_ref = make_processor(c, false), p_hip = make_processor(c, true);
+  auto p_fused = std::make_shared<miphy::pusch_processor_factory_hip>(c, 6, true)->create(); // one device pass per PDU
   struct tc {
     modulation_scheme mod;
     unsigned          nprb, rb_start, tbs;
@@ -527,10 +528,20 @@ static void test_pusch_processor(std::shared_ptr<miphy::context> c)
     rx_softbuffer_identifier id;
     id.rnti = 1, id.harq_ack_id = 0;
     auto sb1 = pool1->reserve_softbuffer(slot_point(1, 7), id, nof_cbs), sb2 = pool2->reserve_softbuffer(slot_point(1, 7), id, nof_cbs);
-    std::vector<uint8_t> o1(tb.size(), 0), o2(tb.size(), 0);
-    notifier_spy         n1, n2;
+    auto                 pool3 = create_rx_softbuffer_pool(pc);
+    auto                 sb3   = pool3->reserve_softbuffer(slot_point(1, 7), id, nof_cbs);
+    std::vector<uint8_t> o1(tb.size(), 0), o2(tb.size(), 0), o3(tb.size(), 0);
+    notifier_spy         n1, n2, n3;
     p_ref->process(o1, sb1.get(), n1, *grid, pdu);
     p_hip->process(o2, sb2.get(), n2, *grid, pdu);
+    p_fused->process(o3, sb3.get(), n3, *grid, pdu);
+    CHECK(n3.got_sch && n3.got_csi && !n3.got_uci && n3.sch.data.tb_crc_ok && o3 == tb, "pusch_processor (fused): transport block / CRC (nprb %u)", t.nprb);
+    CHECK(n3.sch.data.nof_codeblocks_total == n1.sch.data.nof_codeblocks_total, "pusch_processor (fused): codeblock count mismatch");
+    CHECK(std::abs(n1.csi.epre_dB - n3.csi.epre_dB) < 1e-3F && std::abs(n1.csi.rsrp_dB - n3.csi.rsrp_dB) < 1e-3F &&
+              std::abs(n1.csi.sinr_dB - n3.csi.sinr_dB) < 1e-2F &&
+              std::abs(n1.csi.time_alignment.to_seconds() - n3.csi.time_alignment.to_seconds()) < 1.1 / (4096 * 30e3),
+          "pusch_processor (fused): CSI differs: epre %g/%g rsrp %g/%g sinr %g/%g", n1.csi.epre_dB, n3.csi.epre_dB, n1.csi.rsrp_dB, n3.csi.rsrp_dB,
+          n1.csi.sinr_dB, n3.csi.sinr_dB);
     CHECK(n1.got_sch && n2.got_sch && n1.got_csi && n2.got_csi && !n1.got_uci && !n2.got_uci, "pusch_processor: notifications differ");
     CHECK(n1.sch.data.tb_crc_ok && n2.sch.data.tb_crc_ok, "pusch_processor: TB CRC ref %d hip %d (nprb %u)", (int)n1.sch.data.tb_crc_ok,
           (int)n2.sch.data.tb_crc_ok, t.nprb);

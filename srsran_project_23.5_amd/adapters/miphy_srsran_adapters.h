@@ -621,6 +621,146 @@ private:
   std::vector<srsran::cf_t> host, ce_host;
 };
 
+// ---------------------------------------------------------------------------------------------------------------- PUSCH processor
+/// srsran::pusch_processor over miphy_pusch_process_batch (pusch_processor.h:158-162): estimation, demodulation and decoding in one
+/// device pass for PDUs that carry a codeword and no UCI; the resource grid goes to the device once, the transport block, the
+/// HARQ buffer of the rx_softbuffer and the channel state information come back.
+class pusch_processor_hip : public srsran::pusch_processor
+{
+public:
+  pusch_processor_hip(std::shared_ptr<context> c, unsigned nof_iterations, bool early_stop) :
+    c(std::move(c)), dec_nof_iterations(nof_iterations), dec_enable_early_stop(early_stop)
+  {
+  }
+  void process(srsran::span<uint8_t>                    data,
+               srsran::rx_softbuffer&                   softbuffer,
+               srsran::pusch_processor_result_notifier& notifier,
+               const srsran::resource_grid_reader&      grid,
+               const pdu_t&                             pdu) override
+  {
+    if (pdu.uci.nof_harq_ack != 0 || pdu.uci.nof_csi_part1 != 0 || pdu.uci.nof_csi_part2 != 0 || !pdu.codeword.has_value()) {
+      srsran::report_fatal_error("pusch_processor_hip: UCI on PUSCH / PDUs without codeword are not supported.");
+    }
+    srsran_assert(pdu.dmrs == srsran::dmrs_type::TYPE1 && pdu.nof_cdm_groups_without_data == 2 && pdu.nof_tx_layers == 1,
+                  "Only DM-RS type 1, two CDM groups without data and one layer are supported.");
+    const srsran::bounded_bitset<srsran::MAX_RB> rb_mask = pdu.freq_alloc.get_prb_mask(pdu.bwp_start_rb, pdu.bwp_size_rb);
+    const unsigned nprb = rb_mask.size(), nsc = nprb * 12, nports = pdu.rx_ports.size();
+    miphy_pusch_pdu p = {};
+    p.numerology = pdu.slot.numerology(), p.slot_in_frame = pdu.slot.slot_index(), p.rnti = pdu.rnti, p.n_id = pdu.n_id;
+    p.dmrs_scrambling_id = pdu.scrambling_id, p.Nref = pdu.tbs_lbrm_bytes * 8, p.tb_bytes = data.size(), p.harq_cb_index = 0;
+    p.n_scid = pdu.n_scid, p.mod = srsran::get_bits_per_symbol(pdu.mcs_descr.modulation), p.nof_rx_ports = nports;
+    p.start_symbol = pdu.start_symbol_index, p.nof_symbols = pdu.nof_symbols;
+    p.bg = bg_id(pdu.codeword.value().ldpc_base_graph), p.rv = pdu.codeword.value().rv, p.new_data = pdu.codeword.value().new_data;
+    p.use_early_stop = dec_enable_early_stop, p.nof_ldpc_iterations = dec_nof_iterations, p.grid_nof_prb = nprb;
+    for (unsigned i = 0; i != nports; ++i) {
+      p.rx_ports[i] = i; // the staging grid is ordered by rx_ports
+    }
+    for (unsigned l = 0; l != 14 && l != pdu.dmrs_symbol_mask.size(); ++l) {
+      if (pdu.dmrs_symbol_mask.test(l)) {
+        p.dmrs_symbols_mask |= static_cast<uint16_t>(1U << l);
+      }
+    }
+    rb_mask.for_each(0, nprb, [&p](unsigned r) { p.rb_mask[r >> 6] |= 1ULL << (r & 63); });
+    miphy_sch_segmentation sg;
+    context::check(miphy_sch_segmentation_info(data.size(), p.bg, &sg), "segmentation");
+    srsran_assert(sg.nof_cbs == softbuffer.get_nof_codeblocks(), "Wrong number of codeblocks.");
+    const size_t CBS = 66 * 384, MSG = 1056;
+    host.resize(static_cast<size_t>(nports) * 14 * nsc);
+    for (unsigned i = 0; i != nports; ++i) {
+      for (unsigned l = 0; l != 14; ++l) {
+        grid.get(srsran::span<srsran::cf_t>(host.data() + (static_cast<size_t>(i) * 14 + l) * nsc, nsc), pdu.rx_ports[i], l, 0);
+      }
+    }
+    auto*    d_g    = static_cast<float*>(c->buf(0, host.size() * sizeof(srsran::cf_t)));
+    auto*    d_soft = static_cast<int8_t*>(c->buf(1, sg.nof_cbs * CBS));
+    auto*    d_msg  = static_cast<uint8_t*>(c->buf(2, sg.nof_cbs * MSG));
+    auto*    d_misc = static_cast<uint8_t*>(c->buf(3, 64 + 64 + 128 + data.size() + 64));
+    uint8_t* d_crc  = d_misc;
+    auto*    d_res  = reinterpret_cast<miphy_pusch_result*>(d_misc + 64);
+    auto*    d_sc   = reinterpret_cast<float*>(d_misc + 128);
+    uint8_t* d_tb   = d_misc + 256;
+    srsran::span<bool>   crcs = softbuffer.get_codeblocks_crc();
+    std::vector<uint8_t> crc_h(sg.nof_cbs);
+    for (unsigned i = 0; i != sg.nof_cbs; ++i) {
+      crc_h[i] = crcs[i] ? 1 : 0;
+      auto sb  = softbuffer.get_codeblock_soft_bits(i, sg.N);
+      c->h2d(d_soft + i * CBS, sb.data(), sg.N);
+      auto mb = softbuffer.get_codeblock_data_bits(i, sg.K);
+      c->h2d(d_msg + i * MSG, mb.get_buffer().data(), (sg.K + 7) / 8);
+    }
+    c->h2d(d_crc, crc_h.data(), sg.nof_cbs);
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    c->h2d(d_tb, data.data(), data.size());
+    context::check(miphy_pusch_process_batch(c->ctx, &p, 1, d_g, d_soft, d_msg, d_crc, d_tb, d_res, d_sc, c->stream), "pusch_process");
+    miphy_pusch_result r;
+    float              sc[20];
+    c->d2h(&r, d_res, sizeof(r));
+    c->d2h(sc, d_sc, sizeof(sc));
+    c->d2h(crc_h.data(), d_crc, sg.nof_cbs);
+    c->d2h(data.data(), d_tb, data.size());
+    for (unsigned i = 0; i != sg.nof_cbs; ++i) {
+      auto sb = softbuffer.get_codeblock_soft_bits(i, sg.N);
+      c->d2h(sb.data(), d_soft + i * CBS, sg.N);
+      auto mb = softbuffer.get_codeblock_data_bits(i, sg.K);
+      c->d2h(mb.get_buffer().data(), d_msg + i * MSG, (sg.K + 7) / 8);
+    }
+    c->sync();
+    for (unsigned i = 0; i != sg.nof_cbs; ++i) {
+      crcs[i] = crc_h[i] != 0;
+    }
+    // channel_estimate::get_channel_state_information (channel_estimation.h:211-232): linear averages over the receive ports, then dB
+    srsran::channel_state_information csi = {};
+    float                             epre = 0, rsrp = 0, snr = 0;
+    double                            ta   = 0;
+    for (unsigned i = 0; i != nports; ++i) {
+      rsrp += sc[5 * i + 0], epre += sc[5 * i + 1], snr += sc[5 * i + 3], ta += sc[5 * i + 4];
+    }
+    csi.epre_dB        = srsran::convert_power_to_dB(epre / static_cast<float>(nports));
+    csi.rsrp_dB        = srsran::convert_power_to_dB(rsrp / static_cast<float>(nports));
+    csi.sinr_dB        = srsran::convert_power_to_dB(snr / static_cast<float>(nports));
+    csi.time_alignment = srsran::phy_time_unit::from_seconds(ta / nports);
+    notifier.on_csi(csi);
+    srsran::pusch_processor_result_data result;
+    result.data.tb_crc_ok            = r.tb_crc_ok != 0;
+    result.data.nof_codeblocks_total = r.nof_codeblocks_total;
+    result.data.ldpc_decoder_stats.reset();
+    if (r.nof_decoded > 0) {
+      result.data.ldpc_decoder_stats.update(r.iters_min);
+      for (unsigned i = 1; i + 1 < r.nof_decoded; ++i) {
+        result.data.ldpc_decoder_stats.update(static_cast<unsigned>(r.iters_mean + 0.5F));
+      }
+      if (r.nof_decoded > 1) {
+        result.data.ldpc_decoder_stats.update(r.iters_max);
+      }
+    }
+    notifier.on_sch(result);
+  }
+
+private:
+  std::shared_ptr<context>  c;
+  unsigned                  dec_nof_iterations;
+  bool                      dec_enable_early_stop;
+  std::vector<srsran::cf_t> host;
+};
+
+/// Replaces create_pusch_processor_factory_sw(config) (channel_processor_factories.h): only the decoder settings of the
+/// configuration are needed, the sub-block factories are not.
+class pusch_processor_factory_hip : public srsran::pusch_processor_factory
+{
+public:
+  pusch_processor_factory_hip(std::shared_ptr<context> c, unsigned nof_iterations, bool early_stop) :
+    c(std::move(c)), nof_iterations(nof_iterations), early_stop(early_stop)
+  {
+  }
+  std::unique_ptr<srsran::pusch_processor> create() override { return std::make_unique<pusch_processor_hip>(c, nof_iterations, early_stop); }
+  std::unique_ptr<srsran::pusch_pdu_validator> create_validator() override { return nullptr; }
+
+private:
+  std::shared_ptr<context> c;
+  unsigned                 nof_iterations;
+  bool                     early_stop;
+};
+
 // ---------------------------------------------------------------------------------------------------------------- PDSCH modulator / DM-RS
 /// srsran::pdsch_modulator over miphy_pdsch_modulate_batch (pdsch_modulator.h:98). One codeword on one layer, contiguous
 /// allocation -- the configurations the 23.5 software modulator handles correctly.

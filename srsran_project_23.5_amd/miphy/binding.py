@@ -60,6 +60,7 @@ def lib():
         l.miphy_dmrs_pdsch_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         l.miphy_pdsch_mod_nof_re.argtypes = [C.c_void_p]
         l.miphy_pdsch_mod_nof_re.restype = C.c_uint32
+        l.miphy_pusch_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 8
         l.miphy_pusch_demod_nof_llr.argtypes = [C.c_void_p]
         l.miphy_pusch_demod_nof_llr.restype = C.c_uint32
         _lib = l
@@ -140,6 +141,16 @@ def pdsch_mod_nof_re(job):
     """Data REs of one PdschModJob record (host computation in the library)."""
     a = np.ascontiguousarray(np.asarray(job, dtype=PdschModJob).reshape(1))
     return int(lib().miphy_pdsch_mod_nof_re(a.ctypes.data_as(C.c_void_p)))
+
+
+# Mirrors miphy_pusch_pdu.
+PuschPdu = np.dtype([("numerology", np.uint32), ("slot_in_frame", np.uint32), ("rnti", np.uint32), ("n_id", np.uint32),
+                     ("dmrs_scrambling_id", np.uint32), ("Nref", np.uint32), ("tb_bytes", np.uint32), ("harq_cb_index", np.uint32),
+                     ("n_scid", np.uint8), ("mod", np.uint8), ("nof_rx_ports", np.uint8), ("start_symbol", np.uint8), ("nof_symbols", np.uint8),
+                     ("bg", np.uint8), ("rv", np.uint8), ("new_data", np.uint8), ("rx_ports", np.uint8, 4), ("use_early_stop", np.uint8),
+                     ("reserved0", np.uint8), ("nof_ldpc_iterations", np.uint16), ("dmrs_symbols_mask", np.uint16), ("grid_nof_prb", np.uint16),
+                     ("pad", np.uint32), ("rb_mask", np.uint64, 5), ("grid_offset", np.uint64), ("tb_offset", np.uint64)], align=True)
+assert PuschPdu.itemsize == 112 and PuschPdu.fields["rb_mask"][1] == 56, PuschPdu.itemsize
 
 
 class PolarCode(C.Structure):
@@ -331,6 +342,13 @@ class Context:
         tbs = np.ascontiguousarray(tbs)
         check(lib().miphy_pusch_decode_batch(self.h, C.c_void_p(tbs.ctypes.data), tbs.size, _dptr(llrs), _dptr(harq_softbits),
                                              _dptr(harq_msgs), _dptr(harq_crc_ok), _dptr(tb_out), _dptr(results), _stream_ptr(stream)))
+
+    def pusch_process_batch(self, pdus, grid, harq_softbits, harq_msgs, harq_crc_ok, tb_out, results, scalars, stream=None):
+        """pdus: numpy PuschPdu array (host). results: torch uint8 tensor of n * PuschResult.itemsize bytes; scalars: float32 n x 20."""
+        assert isinstance(pdus, np.ndarray) and pdus.dtype == PuschPdu
+        pdus = np.ascontiguousarray(pdus)
+        check(lib().miphy_pusch_process_batch(self.h, C.c_void_p(pdus.ctypes.data), pdus.size, _dptr(grid), _dptr(harq_softbits), _dptr(harq_msgs),
+                                              _dptr(harq_crc_ok), _dptr(tb_out), _dptr(results), _dptr(scalars), _stream_ptr(stream)))
 
     def pdsch_encode_batch(self, tbs, tb_in, codeword_out, stream=None):
         assert isinstance(tbs, np.ndarray) and tbs.dtype == PdschTbDesc
