@@ -105,13 +105,15 @@ __device__ __forceinline__ void dft8(cplx* a)
 
 // One Stockham pass of radix R over the N-point buffer `x` (LDS). n = current sub-transform length, s = stride (product of
 // the radices already applied). tw = exp(-2 pi i j / N) table in global memory. All threads of the block must call.
-template <int R, bool INV>
+// WIDE: the block has at least N / 8 threads (one radix-8 butterfly per thread); otherwise at least N / 16. The register
+// arrays are sized for the case, which decides how many transforms a CU holds.
+template <int R, bool INV, bool WIDE>
 __device__ __forceinline__ void fft_pass(cplx* x, int N, int n, int s, const cplx* __restrict__ tw, int tid, int nt)
 {
   const int m  = n / R;
   const int nb = N / R; // butterflies
-  // Butterflies per thread: the launcher guarantees N <= 16 * blockDim, i.e. nb <= MAXB * nt.
-  constexpr int MAXB = (R == 8) ? 2 : (R == 4) ? 4 : (R == 2) ? 8 : 6;
+  // Butterflies per thread: nb <= MAXB * nt.
+  constexpr int MAXB = ((R == 8) ? 2 : (R == 4) ? 4 : (R == 2) ? 8 : 6) / (WIDE ? 2 : 1);
   cplx          a[MAXB][R];
   cplx          w1s[MAXB];
   int           ps[MAXB], qs[MAXB];
@@ -165,28 +167,36 @@ __device__ __forceinline__ void fft_pass(cplx* x, int N, int n, int s, const cpl
 }
 
 // Full transform of the N points in LDS buffer x (natural order in, natural order out).
-template <bool INV>
-__device__ __forceinline__ void fft_lds(cplx* x, int N, const cplx* __restrict__ tw, int tid, int nt)
+template <bool INV, bool WIDE>
+__device__ __forceinline__ void fft_lds_w(cplx* x, int N, const cplx* __restrict__ tw, int tid, int nt)
 {
   int n = N, s = 1;
   while (n % 8 == 0) {
-    fft_pass<8, INV>(x, N, n, s, tw, tid, nt);
+    fft_pass<8, INV, WIDE>(x, N, n, s, tw, tid, nt);
     n /= 8;
     s *= 8;
   }
   while (n % 4 == 0) {
-    fft_pass<4, INV>(x, N, n, s, tw, tid, nt);
+    fft_pass<4, INV, WIDE>(x, N, n, s, tw, tid, nt);
     n /= 4;
     s *= 4;
   }
   while (n % 2 == 0) {
-    fft_pass<2, INV>(x, N, n, s, tw, tid, nt);
+    fft_pass<2, INV, WIDE>(x, N, n, s, tw, tid, nt);
     n /= 2;
     s *= 2;
   }
   while (n % 3 == 0) {
-    fft_pass<3, INV>(x, N, n, s, tw, tid, nt);
+    fft_pass<3, INV, WIDE>(x, N, n, s, tw, tid, nt);
     n /= 3;
     s *= 3;
   }
+}
+template <bool INV>
+__device__ __forceinline__ void fft_lds(cplx* x, int N, const cplx* __restrict__ tw, int tid, int nt)
+{
+  if (N <= 8 * nt)
+    fft_lds_w<INV, true>(x, N, tw, tid, nt);
+  else
+    fft_lds_w<INV, false>(x, N, tw, tid, nt);
 }

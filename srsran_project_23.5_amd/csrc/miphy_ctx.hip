@@ -131,6 +131,8 @@ extern "C" int miphy_create(int device, miphy_ctx** out)
   if (!c)
     return MIPHY_ENOMEM;
   c->device   = device;
+  c->num_cus  = 256;
+  (void)hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device);
   c->ext      = new miphy_ctx_ext();
   c->h_tables = (miphy_graph_tables*)malloc(sizeof(miphy_graph_tables));
   build_tables(c->h_tables);

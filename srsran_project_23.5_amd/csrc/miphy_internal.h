@@ -40,6 +40,7 @@ struct miphy_ctx {
   void*                h_desc_staging; // pinned
   void*                d_work;         // scratch workspace for the transport-block level entry points (grown on demand)
   size_t               work_bytes;
+  int                  num_cus; // compute units of the device (persistent-kernel grid sizing)
 };
 
 void miphy_set_error(const char* fmt, ...);

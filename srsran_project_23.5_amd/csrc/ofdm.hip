@@ -4,6 +4,7 @@
 // Behaviour contract: lib/phy/lower/modulation/ofdm_demodulator_impl.cpp:93-138, ofdm_modulator_impl.cpp:55-99,
 // include/srsran/phy/lower/modulation/phase_compensation_lut.h:49-96, include/srsran/ran/cyclic_prefix.h:96-107.
 #include "fft_device.h"
+#include <algorithm>
 #include <cstdlib>
 #include "miphy_ext.h"
 #include <cmath>
@@ -126,53 +127,76 @@ bool four_step_factors(uint32_t N, uint32_t& N1, uint32_t& N2)
   }
 }
 
-__global__ void __launch_bounds__(512) ofdm_demod_kernel(const miphy_ofdm_job* __restrict__ jobs,
-                                                         const ofdm_plan_dev* __restrict__ plan,
-                                                         const cplx* __restrict__ tw,
-                                                         const cplx* __restrict__ ramp,
-                                                         const float2* __restrict__ samples,
-                                                         float2* __restrict__ grid)
+// Each workgroup loops over (slot, symbol) pairs with stride gridDim.x; the launcher starts as many workgroups as the chip
+// holds at once. (Keeping the next symbol's samples in flight in registers while transforming the current one was measured:
+// the 16 extra registers cost a resident workgroup per CU and the time stayed the same, so the loads are plain.)
+template <bool WIDE>
+__device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict__ jobs,
+                                                const ofdm_plan_dev* __restrict__ plan,
+                                                const cplx* __restrict__ tw,
+                                                const cplx* __restrict__ ramp,
+                                                const float2* __restrict__ samples,
+                                                float2* __restrict__ grid,
+                                                int total)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  cplx*                x   = reinterpret_cast<cplx*>(smem);
-  const miphy_ofdm_job job = jobs[blockIdx.y];
-  const int            l   = blockIdx.x;
-  const int            N = plan->N, rg = plan->rg;
-  const int            sym = (int)job.slot_index * 14 + l;
-  // FFT window: starts `window_offset` samples before the end of the cyclic prefix (demodulator_impl.cpp:115).
-  const float2* src = samples + job.samples_offset + plan->sym_off[sym] + plan->cp_len[sym] - plan->window_offset;
-  if ((((uintptr_t)src) & 15) == 0) { // 16-byte loads: two samples per lane
-    const float4* src4 = reinterpret_cast<const float4*>(src);
-    for (int i = threadIdx.x; i < N / 2; i += blockDim.x) {
-      const float4 v     = src4[i];
-      x[fpad(2 * i)]     = {v.x, v.y};
-      x[fpad(2 * i + 1)] = {v.z, v.w};
+  cplx*     x = reinterpret_cast<cplx*>(smem);
+  const int N = plan->N, rg = plan->rg, half = rg / 2;
+  const int nt = blockDim.x;
+  for (int idx = blockIdx.x; idx < total; idx += gridDim.x) {
+    const miphy_ofdm_job& job = jobs[idx / 14];
+    const int             l   = idx % 14;
+    const int             sym = (int)job.slot_index * 14 + l;
+    // FFT window: starts `window_offset` samples before the end of the cyclic prefix (demodulator_impl.cpp:115).
+    const float2* src = samples + job.samples_offset + plan->sym_off[sym] + plan->cp_len[sym] - plan->window_offset;
+    if ((((uintptr_t)src) & 15) == 0) { // 16-byte loads: two samples per lane
+      const float4* src4 = reinterpret_cast<const float4*>(src);
+      for (int i = threadIdx.x; i < N / 2; i += nt) {
+        const float4 v     = src4[i];
+        x[fpad(2 * i)]     = {v.x, v.y};
+        x[fpad(2 * i + 1)] = {v.z, v.w};
+      }
+    } else {
+      for (int i = threadIdx.x; i < N; i += nt) {
+        float2 v   = src[i];
+        x[fpad(i)] = {v.x, v.y};
+      }
     }
-  } else {
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-      float2 v   = src[i];
-      x[fpad(i)] = {v.x, v.y};
+    __syncthreads();
+    fft_lds_w<false, WIDE>(x, N, tw, threadIdx.x, nt);
+    const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
+    float2*    dst  = grid + job.grid_offset + (size_t)l * rg;
+    for (int k = threadIdx.x; k < rg; k += nt) {
+      const int bin = (k < half) ? N - half + k : k - half; // demodulator_impl.cpp:131-137
+      cplx      v   = cmul(x[fpad(bin)], coef);              // sc_prod(dft_output, phase * scale)
+      if (ramp)
+        v = cmul(v, ramp[bin]);                              // window-offset phase ramp (:60-76,127-129)
+      dst[k] = make_float2(v.x, v.y);
     }
-  }
-  __syncthreads();
-  fft_lds<false>(x, N, tw, threadIdx.x, blockDim.x);
-  const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
-  float2*    dst  = grid + job.grid_offset + (size_t)l * rg;
-  const int  half = rg / 2;
-  for (int k = threadIdx.x; k < rg; k += blockDim.x) {
-    const int bin = (k < half) ? N - half + k : k - half; // demodulator_impl.cpp:131-137
-    cplx      v   = cmul(x[fpad(bin)], coef);              // sc_prod(dft_output, phase * scale)
-    if (ramp)
-      v = cmul(v, ramp[bin]);                              // window-offset phase ramp (:60-76,127-129)
-    dst[k] = make_float2(v.x, v.y);
+    __syncthreads(); // x is rewritten by the next symbol
   }
 }
 
-__global__ void __launch_bounds__(512) ofdm_mod_kernel(const miphy_ofdm_job* __restrict__ jobs,
-                                                       const ofdm_plan_dev* __restrict__ plan,
-                                                       const cplx* __restrict__ tw,
-                                                       const float2* __restrict__ grid,
-                                                       float2* __restrict__ samples)
+// One radix-8 butterfly per thread: 64 registers, so that four 4096-point transforms (LDS-bound) are resident per CU.
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8)))
+ofdm_demod_wide_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const cplx* __restrict__ ramp,
+                       const float2* __restrict__ samples, float2* __restrict__ grid, int total)
+{
+  ofdm_demod_body<true>(jobs, plan, tw, ramp, samples, grid, total);
+}
+__global__ void __launch_bounds__(512)
+ofdm_demod_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const cplx* __restrict__ ramp,
+                  const float2* __restrict__ samples, float2* __restrict__ grid, int total)
+{
+  ofdm_demod_body<false>(jobs, plan, tw, ramp, samples, grid, total);
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void ofdm_mod_body(const miphy_ofdm_job* __restrict__ jobs,
+                                              const ofdm_plan_dev* __restrict__ plan,
+                                              const cplx* __restrict__ tw,
+                                              const float2* __restrict__ grid,
+                                              float2* __restrict__ samples)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cplx*                x   = reinterpret_cast<cplx*>(smem);
@@ -202,13 +226,26 @@ __global__ void __launch_bounds__(512) ofdm_mod_kernel(const miphy_ofdm_job* __r
     x[fpad(i)] = v;
   }
   __syncthreads();
-  fft_lds<true>(x, N, tw, threadIdx.x, blockDim.x);
+  fft_lds_w<true, WIDE>(x, N, tw, threadIdx.x, blockDim.x);
   const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
   for (int i = threadIdx.x; i < N + cp; i += blockDim.x) {
     const int j = (i < cp) ? N - cp + i : i - cp; // cyclic prefix = copy of the tail (:98)
     cplx      v = cmul(x[fpad(j)], coef);
     dst[i]      = make_float2(v.x, v.y);
   }
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8)))
+ofdm_mod_wide_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const float2* __restrict__ grid,
+                     float2* __restrict__ samples)
+{
+  ofdm_mod_body<true>(jobs, plan, tw, grid, samples);
+}
+__global__ void __launch_bounds__(512)
+ofdm_mod_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const float2* __restrict__ grid,
+                float2* __restrict__ samples)
+{
+  ofdm_mod_body<false>(jobs, plan, tw, grid, samples);
 }
 
 bool size_supported(uint32_t N)
@@ -438,8 +475,20 @@ extern "C" int miphy_ofdm_demodulate_slots(miphy_ctx*               ctx,
   const void* d_jobs = nullptr;
   if ((rc = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_ofdm_job) * (size_t)n, s, &d_jobs)))
     return rc;
-  hipLaunchKernelGGL(ofdm_demod_kernel, dim3(14, n), dim3(threads_for(cfg->dft_size)), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan,
-                     (const cplx*)tw, (const cplx*)ramp, (const float2*)samples, (float2*)grid);
+  const int    nt    = threads_for(cfg->dft_size);
+  const bool   wide  = cfg->dft_size <= 8u * (uint32_t)nt;
+  const int    total = 14 * (int)n;
+  const size_t lds   = fft_lds_bytes(cfg->dft_size);
+  // As many workgroups as the chip holds at once (LDS-bound), each looping over its share of the symbols.
+  static const char* env_wg = getenv("MIPHY_OFDM_WG_PER_CU");
+  const int          per_cu = env_wg ? atoi(env_wg) : (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / (lds + 512)));
+  const int          nwg    = std::min(total, ctx->num_cus * per_cu);
+  if (wide)
+    hipLaunchKernelGGL(ofdm_demod_wide_kernel, dim3(nwg), dim3(nt), lds, s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw, (const cplx*)ramp,
+                       (const float2*)samples, (float2*)grid, total);
+  else
+    hipLaunchKernelGGL(ofdm_demod_kernel, dim3(nwg), dim3(nt), lds, s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw, (const cplx*)ramp,
+                       (const float2*)samples, (float2*)grid, total);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }
@@ -472,8 +521,13 @@ extern "C" int miphy_ofdm_modulate_slots(miphy_ctx*               ctx,
   const void* d_jobs = nullptr;
   if ((rc = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_ofdm_job) * (size_t)n, s, &d_jobs)))
     return rc;
-  hipLaunchKernelGGL(ofdm_mod_kernel, dim3(14, n), dim3(threads_for(cfg->dft_size)), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan,
-                     (const cplx*)tw, (const float2*)grid, (float2*)samples);
+  const int nt = threads_for(cfg->dft_size);
+  if (cfg->dft_size <= 8u * (uint32_t)nt)
+    hipLaunchKernelGGL(ofdm_mod_wide_kernel, dim3(14, n), dim3(nt), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
+                       (const float2*)grid, (float2*)samples);
+  else
+    hipLaunchKernelGGL(ofdm_mod_kernel, dim3(14, n), dim3(nt), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
+                       (const float2*)grid, (float2*)samples);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }
