@@ -547,6 +547,62 @@ int miphy_polar_decode_list_batch(miphy_ctx* ctx, const miphy_polar_code* code, 
                                   uint8_t* msg_out /* device, n x K */, uint8_t* crc_ok_out /* device, n */,
                                   int32_t* metric_out /* device, n; may be NULL */, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Device-resident HARQ softbuffer pool  --  replaces srsran::rx_softbuffer_pool / rx_softbuffer
+ *   include/srsran/phy/upper/rx_softbuffer_pool.h:31-96, include/srsran/phy/upper/rx_softbuffer.h:42-72,
+ *   lib/phy/upper/rx_softbuffer_pool_impl.cpp:27-69, lib/phy/upper/rx_softbuffer_impl.h:33-258
+ * The pool owns the three HARQ arrays miphy_pusch_decode_batch / miphy_pusch_process_batch work on (soft bits, decoded
+ * messages, codeblock CRC flags, see above) and hands out softbuffers keyed by (rnti, harq process) with the reference's
+ * reservation rules and state machine:
+ *   reserve:  the first softbuffer whose last identifier equals (rnti, harq_id) -- in any state -- else the first available
+ *             one; fails (buffer = -1, like an invalid unique_rx_softbuffer) when that softbuffer is locked or the pool-wide
+ *             codeblock budget cannot cover nof_codeblocks. A reservation with the same number of codeblocks keeps the
+ *             softbuffer (and its contents); a different number returns its codeblocks to the budget first.
+ *   lock / unlock / release: reserved -> locked -> reserved | released; a released softbuffer can be reserved again and is
+ *             freed by the next run_slot.
+ *   run_slot: frees released softbuffers and reserved ones whose expiry slot (reservation slot + expire_timeout_slots,
+ *             modulo nof_slots_wrap, compared like slot_point) is <= slot.
+ * The pool never touches the contents. Every softbuffer owns a fixed extent of max_codeblocks_per_buffer codeblock slots
+ * (first_cb = buffer * max_codeblocks_per_buffer: the `harq_cb_index` of the transport-block descriptors), so reservations
+ * never fragment; max_nof_codeblocks is enforced as a budget exactly like the reference's codeblock pool. Device memory:
+ * max_softbuffers * max_codeblocks_per_buffer * (66*384 + 1056 + 1) bytes. Thread safe (one mutex, like the reference).
+ * ctx == NULL creates a bookkeeping-only pool without device arrays (miphy_harq_pool_arrays then fails). */
+typedef struct miphy_harq_pool miphy_harq_pool;
+
+typedef struct {
+  uint32_t max_softbuffers;           /* rx_softbuffer_pool_config::max_softbuffers */
+  uint32_t max_nof_codeblocks;        /* rx_softbuffer_pool_config::max_nof_codeblocks (budget over all softbuffers) */
+  uint32_t expire_timeout_slots;      /* rx_softbuffer_pool_config::expire_timeout_slots */
+  uint32_t nof_slots_wrap;            /* period of the slot counter: 10240 << numerology (slot_point.h:122) */
+  uint32_t max_codeblocks_per_buffer; /* extent of one softbuffer; 0 = 52 (MAX_NOF_SEGMENTS, codeblock_metadata.h:88) */
+} miphy_harq_pool_config;
+
+enum { MIPHY_HARQ_AVAILABLE = 0, MIPHY_HARQ_RESERVED = 1, MIPHY_HARQ_LOCKED = 2, MIPHY_HARQ_RELEASED = 3 };
+
+typedef struct {
+  uint32_t state; /* MIPHY_HARQ_* */
+  uint32_t rnti;
+  uint32_t harq_id;
+  uint32_t nof_codeblocks;
+  uint32_t first_cb;
+  uint32_t expire_slot;
+} miphy_harq_buffer_info;
+
+int  miphy_harq_pool_create(miphy_ctx* ctx, const miphy_harq_pool_config* cfg, miphy_harq_pool** out);
+void miphy_harq_pool_destroy(miphy_harq_pool* pool);
+/* *buffer = softbuffer index or -1 (no softbuffer: the caller drops the transmission, as the reference does). */
+int miphy_harq_pool_reserve(miphy_harq_pool* pool, uint32_t slot, uint32_t rnti, uint32_t harq_id, uint32_t nof_codeblocks,
+                            int32_t* buffer, uint32_t* first_cb);
+int miphy_harq_pool_lock(miphy_harq_pool* pool, int32_t buffer);    /* MIPHY_EINVAL unless reserved (reference: assertion) */
+int miphy_harq_pool_unlock(miphy_harq_pool* pool, int32_t buffer);  /* locked -> reserved, otherwise no effect */
+int miphy_harq_pool_release(miphy_harq_pool* pool, int32_t buffer); /* MIPHY_EINVAL unless reserved or locked */
+int miphy_harq_pool_run_slot(miphy_harq_pool* pool, uint32_t slot);
+int miphy_harq_pool_info(miphy_harq_pool* pool, int32_t buffer, miphy_harq_buffer_info* out);
+/* Remaining codeblock budget. */
+int miphy_harq_pool_free_codeblocks(miphy_harq_pool* pool, uint32_t* out);
+/* The device arrays to pass as harq_softbits / harq_msgs / harq_crc_ok. */
+int miphy_harq_pool_arrays(miphy_harq_pool* pool, int8_t** softbits, uint8_t** msgs, uint8_t** crc_ok);
+
 #ifdef __cplusplus
 }
 #endif

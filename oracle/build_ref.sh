@@ -48,7 +48,7 @@ $CXX $BASE -O1 $HERE/gen_polar_tables.cpp $OUT/libsrsran_ref.a -lpthread -o $OUT
 # Drop-in test: reference objects vs the "hip" adapters, same stimuli (runs on the GPU box only).
 REPO=$(cd "$HERE/.." && pwd)
 if [ -f "$REPO/srsran_project_23.5_amd/libmiphy.so" ]; then
-  $CXX $BASE -O1 -I$REPO/include -I$REPO/srsran_project_23.5_amd/adapters -I/opt/rocm/include $HERE/dropin_test.cpp $OUT/libsrsran_ref.a \
+  $CXX $BASE -O1 -g -rdynamic -I$REPO/include -I$REPO/srsran_project_23.5_amd/adapters -I/opt/rocm/include $HERE/dropin_test.cpp $OUT/libsrsran_ref.a \
     -L$REPO/srsran_project_23.5_amd -lmiphy -L/opt/rocm/lib -lamdhip64 -lpthread \
     -Wl,-rpath,'$ORIGIN/../../srsran_project_23.5_amd' -Wl,-rpath,/opt/rocm/lib -o $OUT/dropin_test
 fi

@@ -13,8 +13,12 @@
 #include "srsran/phy/upper/sequence_generators/sequence_generator_factories.h"
 #include "srsran/phy/upper/unique_rx_softbuffer.h"
 #include <cmath>
+#include <csignal>
+#include <execinfo.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <random>
 
 using namespace srsran;
@@ -660,12 +664,157 @@ static void test_pdcch(std::shared_ptr<miphy::context> c)
   printf("pdcch_encoder done, failures so far %d\n", failures);
 }
 
+static void test_softbuffer_pool(std::shared_ptr<miphy::context> c)
+{
+  // (a) Reservation life cycle through the rx_softbuffer_pool interface: the same random caller on the reference pool and
+  // on the device pool (a handle = one scope holding a unique_rx_softbuffer).
+  {
+    rx_softbuffer_pool_config pc;
+    pc.max_codeblock_size = ldpc::MAX_CODEBLOCK_SIZE, pc.max_softbuffers = 4, pc.max_nof_codeblocks = 20, pc.expire_timeout_slots = 8;
+    auto                                pool_ref = create_rx_softbuffer_pool(pc);
+    auto                                pool_hip = miphy::create_rx_softbuffer_pool_hip(c, pc);
+    std::map<int, unique_rx_softbuffer> held_ref, held_hip;
+    std::uniform_int_distribution<int>  op(0, 9), hd(0, 5), ue(0, 2), hq(0, 1), ncb(1, 7), adv(1, 5);
+    unsigned                            slot = 20400, valid = 0, invalid = 0;
+    for (unsigned i = 0; i != 4000; ++i) {
+      int o = op(rgen), h = hd(rgen);
+      if (o < 4) {
+        rx_softbuffer_identifier id;
+        id.rnti = 0x4600 * ue(rgen), id.harq_ack_id = hq(rgen);
+        unsigned n = ncb(rgen);
+        held_ref.erase(h), held_hip.erase(h);
+        unique_rx_softbuffer a = pool_ref->reserve_softbuffer(slot_point(1, slot), id, n), b = pool_hip->reserve_softbuffer(slot_point(1, slot), id, n);
+        CHECK(a.is_valid() == b.is_valid(), "softbuffer pool: op %u validity %d vs %d", i, (int)a.is_valid(), (int)b.is_valid());
+        if (a.is_valid() && b.is_valid()) {
+          CHECK(a.get().get_nof_codeblocks() == b.get().get_nof_codeblocks(), "softbuffer pool: op %u nof_codeblocks", i);
+          ++valid;
+          held_ref.emplace(h, std::move(a)), held_hip.emplace(h, std::move(b));
+        } else {
+          ++invalid;
+        }
+      } else if (o < 6) {
+        held_ref.erase(h), held_hip.erase(h);
+      } else if (o < 8) {
+        auto a = held_ref.find(h);
+        auto b = held_hip.find(h);
+        if (a != held_ref.end() && b != held_hip.end()) {
+          a->second.release(), b->second.release();
+          held_ref.erase(a), held_hip.erase(b);
+        }
+      } else {
+        slot = (slot + adv(rgen)) % 20480;
+        pool_ref->run_slot(slot_point(1, slot)), pool_hip->run_slot(slot_point(1, slot));
+      }
+    }
+    CHECK(valid > 200 && invalid > 200, "softbuffer pool trace not representative (%u valid, %u invalid)", valid, invalid);
+  }
+  // (b) HARQ over four transmissions: reference decoder + reference pool, HIP decoder + device pool (state never leaves the
+  // device), and reference decoder + device pool (a CPU block on the host view of the device softbuffer).
+  auto                                   crcf = create_crc_calculator_factory_sw("auto");
+  pdsch_encoder_factory_sw_configuration ec;
+  ec.encoder_factory      = create_ldpc_encoder_factory_sw("avx2");
+  ec.rate_matcher_factory = create_ldpc_rate_matcher_factory_sw();
+  ec.segmenter_factory    = create_ldpc_segmenter_tx_factory_sw(crcf);
+  auto                                   enc = create_pdsch_encoder_factory_sw(ec)->create();
+  pusch_decoder_factory_sw_configuration dc;
+  dc.crc_factory       = crcf;
+  dc.decoder_factory   = create_ldpc_decoder_factory_sw("avx2");
+  dc.dematcher_factory = create_ldpc_rate_dematcher_factory_sw("avx2");
+  dc.segmenter_factory = create_ldpc_segmenter_rx_factory_sw();
+  auto dec_factory = create_pusch_decoder_factory_sw(dc); // takes the sub-factories out of dc
+  auto dec_ref = dec_factory->create(), dec_ref2 = dec_factory->create();
+  auto dec_hip = miphy::create_pusch_decoder_factory_hip(c)->create();
+  rx_softbuffer_pool_config pc;
+  pc.max_codeblock_size = ldpc::MAX_CODEBLOCK_SIZE, pc.max_softbuffers = 4, pc.max_nof_codeblocks = 128, pc.expire_timeout_slots = 100;
+  auto pool_ref = create_rx_softbuffer_pool(pc);
+  auto pool_hip = miphy::create_rx_softbuffer_pool_hip(c, pc), pool_mix = miphy::create_rx_softbuffer_pool_hip(c, pc);
+  struct tc {
+    ldpc_base_graph_type bg;
+    modulation_scheme    mod;
+    unsigned             nprb, tbs, rnti;
+    float                sigma;
+  };
+  std::uniform_int_distribution<int> byte(0, 255);
+  unsigned                           recovered = 0, retransmissions = 0;
+  for (const tc& t : {tc{ldpc_base_graph_type::BG1, modulation_scheme::QAM16, 106, 42016, 0x4601, 0.66F}, tc{ldpc_base_graph_type::BG2, modulation_scheme::QPSK, 106, 3848, 0x4602, 1.35F},
+                      tc{ldpc_base_graph_type::BG1, modulation_scheme::QAM64, 106, 83976, 0x4601, 0.62F}}) {
+    unsigned             nsym = t.nprb * 156, G = nsym * get_bits_per_symbol(t.mod);
+    std::vector<uint8_t> tb(t.tbs / 8);
+    for (auto& b : tb) {
+      b = byte(rgen);
+    }
+    unsigned               nof_cbs = ldpc::compute_nof_codeblocks(units::bits(t.tbs), t.bg);
+    miphy_sch_segmentation sg;
+    miphy_sch_segmentation_info(tb.size(), t.bg == ldpc_base_graph_type::BG1 ? 1 : 2, &sg);
+    rx_softbuffer_identifier id;
+    id.rnti = t.rnti, id.harq_ack_id = 3;
+    unsigned rvs[4] = {0, 2, 3, 1};
+    for (unsigned tx = 0; tx != 4; ++tx) {
+      segmenter_config sc;
+      sc.base_graph = t.bg, sc.rv = rvs[tx], sc.mod = t.mod, sc.Nref = 0, sc.nof_layers = 1, sc.nof_ch_symbols = nsym;
+      std::vector<uint8_t> cw(G);
+      enc->encode(cw, tb, sc);
+      auto                         llr = noisy(cw, t.sigma);
+      pusch_decoder::configuration cfg;
+      cfg.segmenter_cfg = sc, cfg.nof_ldpc_iterations = 6, cfg.use_early_stop = true, cfg.new_data = (tx == 0);
+      slot_point           slot(1, 40 + 8 * tx);
+      std::vector<uint8_t> o1(tb.size(), 0), o2(tb.size(), 0), o3(tb.size(), 0);
+      pusch_decoder_result r1, r2, r3;
+      {
+        auto sb1 = pool_ref->reserve_softbuffer(slot, id, nof_cbs), sb2 = pool_hip->reserve_softbuffer(slot, id, nof_cbs), sb3 = pool_mix->reserve_softbuffer(slot, id, nof_cbs);
+        CHECK(sb1.is_valid() && sb2.is_valid() && sb3.is_valid(), "softbuffer reservation failed");
+        dec_ref->decode(o1, r1, &sb1.get(), llr, cfg);
+        dec_hip->decode(o2, r2, &sb2.get(), llr, cfg);
+        dec_ref2->decode(o3, r3, &sb3.get(), llr, cfg);
+        CHECK(r1.tb_crc_ok == r2.tb_crc_ok && r1.tb_crc_ok == r3.tb_crc_ok, "HARQ pool: tb_crc_ok tbs %u tx %u: %d %d %d", t.tbs, tx, (int)r1.tb_crc_ok, (int)r2.tb_crc_ok,
+              (int)r3.tb_crc_ok);
+        if (r1.tb_crc_ok) {
+          CHECK(o1 == tb && o2 == tb && o3 == tb, "HARQ pool: TB mismatch tbs %u tx %u", t.tbs, tx);
+        }
+        // the softbuffer contents after the transmission: combined soft bits and codeblock CRC flags
+        span<bool> c1 = sb1.get().get_codeblocks_crc(), c2 = sb2.get().get_codeblocks_crc(), c3 = sb3.get().get_codeblocks_crc();
+        unsigned   soft_diff = 0, crc_diff = 0;
+        for (unsigned i = 0; i != nof_cbs; ++i) {
+          auto s1 = sb1.get().get_codeblock_soft_bits(i, sg.N), s2 = sb2.get().get_codeblock_soft_bits(i, sg.N), s3 = sb3.get().get_codeblock_soft_bits(i, sg.N);
+          crc_diff += (c1[i] != c2[i]) + (c1[i] != c3[i]);
+          soft_diff += !std::equal(s1.begin(), s1.end(), s2.begin()) + !std::equal(s1.begin(), s1.end(), s3.begin());
+        }
+        CHECK(crc_diff == 0 && soft_diff == 0, "HARQ pool: softbuffer contents tbs %u tx %u: %u crc flags, %u codeblocks differ", t.tbs, tx, crc_diff, soft_diff);
+        if (r1.tb_crc_ok) {
+          sb1.release(), sb2.release(), sb3.release();
+        }
+      }
+      retransmissions += tx != 0;
+      if (r1.tb_crc_ok) {
+        recovered += tx != 0;
+        break;
+      }
+    }
+    pool_ref->run_slot(slot_point(1, 100)), pool_hip->run_slot(slot_point(1, 100)), pool_mix->run_slot(slot_point(1, 100));
+  }
+  CHECK(retransmissions >= 3 && recovered >= 2, "HARQ pool: the cases should need retransmissions and recover (%u retransmissions, %u recovered)", retransmissions, recovered);
+  printf("rx_softbuffer_pool (device-resident HARQ) done, failures so far %d\n", failures);
+}
+
+static void on_fault(int sig)
+{
+  void* frames[64];
+  int   n = backtrace(frames, 64);
+  dprintf(2, "dropin_test: signal %d\n", sig);
+  backtrace_symbols_fd(frames, n, 2);
+  _exit(128 + sig);
+}
+
 int main()
 {
+  setvbuf(stdout, nullptr, _IOLBF, 0);
+  signal(SIGSEGV, on_fault);
+  signal(SIGABRT, on_fault);
   auto c = std::make_shared<miphy::context>(0);
   test_ldpc(c);
   test_rate_matching(c);
   test_sch(c);
+  test_softbuffer_pool(c);
   test_ofdm_and_estimator(c);
   test_dft(c);
   test_pdcch(c);

@@ -253,3 +253,10 @@ for i, (type2, nports, ref_pt, syms, nprb) in enumerate([(0, 4, 0, (2, 3), 24), 
     d["dd_rb_%d" % i], d["dd_sm_%d" % i] = rb, sm
     d["dd_meta_%d" % i] = np.array([slot, ref_pt, type2, scr, nscid, amp, nports], dtype=np.float64)
 save("pdsch_mod", **d)
+
+# ---------------------------------------------------------------------- rx_softbuffer_pool reservation traces
+d = {"n": np.array(4)}
+for i, (ms, mc, ex) in enumerate([(4, 20, 8), (2, 9, 3), (6, 14, 30), (3, 100, 0)]):
+    ops = O.pool_trace(500 + i, 3000)
+    d["cfg_%d" % i], d["ops_%d" % i], d["res_%d" % i] = np.array([ms, mc, ex]), ops.astype(np.int32), O.r_pool_run(ops, ms, mc, ex).astype(np.int32)
+save("harq_pool", **d)

@@ -24,6 +24,7 @@
 #include "lib/phy/generic_functions/dft_processor_generic_impl.h"
 #include <chrono>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -995,6 +996,85 @@ int ref_pbch_encode(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, un
   }
   enc->encode(span<uint8_t>(out, pbch_encoder::E), msg);
   return 0;
+}
+
+// ---------------------------------------------------------------- rx_softbuffer_pool (reservation state machine)
+// The unique_rx_softbuffer a reservation returns is kept under the caller's handle: reserve = reserve + lock, drop = the
+// destructor (unlock), release = unique_rx_softbuffer::release. Returns the ordinal of the softbuffer object (order of first
+// appearance) or -1 for an invalid softbuffer.
+struct ref_pool_t {
+  std::unique_ptr<rx_softbuffer_pool>         pool;
+  std::map<int, unique_rx_softbuffer>         held;
+  std::vector<const void*>                    seen;
+  unsigned                                    numerology;
+};
+
+void* ref_pool_create(unsigned max_codeblock_size, unsigned max_softbuffers, unsigned max_nof_codeblocks, unsigned expire_timeout_slots, unsigned numerology)
+{
+  rx_softbuffer_pool_config cfg;
+  cfg.max_codeblock_size   = max_codeblock_size;
+  cfg.max_softbuffers      = max_softbuffers;
+  cfg.max_nof_codeblocks   = max_nof_codeblocks;
+  cfg.expire_timeout_slots = expire_timeout_slots;
+  auto* p                  = new ref_pool_t;
+  p->pool                  = create_rx_softbuffer_pool(cfg);
+  p->numerology            = numerology;
+  return p;
+}
+
+void ref_pool_destroy(void* h)
+{
+  auto* p = static_cast<ref_pool_t*>(h);
+  p->held.clear();
+  delete p;
+}
+
+int ref_pool_reserve(void* h, unsigned slot_count, unsigned rnti, unsigned harq_id, unsigned nof_codeblocks, int handle, unsigned* nof_codeblocks_out)
+{
+  auto* p = static_cast<ref_pool_t*>(h);
+  p->held.erase(handle);
+  rx_softbuffer_identifier id;
+  id.rnti        = static_cast<uint16_t>(rnti);
+  id.harq_ack_id = static_cast<uint8_t>(harq_id);
+  unique_rx_softbuffer u = p->pool->reserve_softbuffer(slot_point(p->numerology, slot_count), id, nof_codeblocks);
+  if (!u.is_valid()) {
+    return -1;
+  }
+  const void* addr     = &u.get();
+  *nof_codeblocks_out  = u.get().get_nof_codeblocks();
+  int ordinal          = -1;
+  for (size_t i = 0; i != p->seen.size(); ++i) {
+    if (p->seen[i] == addr) {
+      ordinal = static_cast<int>(i);
+    }
+  }
+  if (ordinal < 0) {
+    ordinal = static_cast<int>(p->seen.size());
+    p->seen.push_back(addr);
+  }
+  p->held.emplace(handle, std::move(u));
+  return ordinal;
+}
+
+void ref_pool_drop(void* h, int handle)
+{
+  static_cast<ref_pool_t*>(h)->held.erase(handle);
+}
+
+void ref_pool_release(void* h, int handle)
+{
+  auto* p  = static_cast<ref_pool_t*>(h);
+  auto  it = p->held.find(handle);
+  if (it != p->held.end()) {
+    it->second.release();
+    p->held.erase(it);
+  }
+}
+
+void ref_pool_run_slot(void* h, unsigned slot_count)
+{
+  auto* p = static_cast<ref_pool_t*>(h);
+  p->pool->run_slot(slot_point(p->numerology, slot_count));
 }
 
 } // extern "C"

@@ -21,6 +21,8 @@
 #include "srsran/phy/upper/channel_estimation.h"
 #include "srsran/phy/upper/channel_processors/channel_processor_factories.h"
 #include "srsran/phy/upper/rx_softbuffer.h"
+#include "srsran/phy/upper/rx_softbuffer_pool.h"
+#include "srsran/phy/upper/unique_rx_softbuffer.h"
 #include "srsran/phy/upper/signal_processors/signal_processor_factories.h"
 #include "srsran/support/error_handling.h"
 #include <algorithm>
@@ -29,6 +31,7 @@
 #include <cstring>
 #include <hip/hip_runtime_api.h>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 namespace miphy {
@@ -269,9 +272,223 @@ private:
   std::shared_ptr<context> c;
 };
 
-/// srsran::pusch_decoder over miphy_pusch_decode_batch (pusch_decoder.h:74-78). The HARQ state stays in the reference's
-/// rx_softbuffer: it is uploaded before and downloaded after the call (a device-resident pool keyed by the softbuffer is
-/// the obvious next step for a real deployment; the C ABI already works on device-resident state).
+// ---------------------------------------------------------------------------------------------------------------- HARQ softbuffer pool
+/// A softbuffer of the device-resident pool (miphy_harq_pool). pusch_decoder_hip and pusch_processor_hip recognise it and work
+/// on the device arrays in place: no HARQ state crosses PCIe. The host accessors of srsran::rx_softbuffer still work, so that
+/// a CPU block can be handed the same softbuffer: they download the codeblock into a host mirror, and everything handed out
+/// is written back to the device before the next device use and when the softbuffer is unlocked or released.
+class rx_softbuffer_hip : public srsran::unique_rx_softbuffer::softbuffer
+{
+public:
+  static constexpr size_t CBS = 66 * 384, MSG = 1056;
+
+  rx_softbuffer_hip(std::shared_ptr<context> c, miphy_harq_pool* pool, int32_t index) : c(std::move(c)), pool(pool), index(index)
+  {
+    context::check(miphy_harq_pool_arrays(pool, &d_soft, &d_msgs, &d_crc), "harq_pool_arrays");
+  }
+  unsigned get_nof_codeblocks() const override { return info().nof_codeblocks; }
+  void     reset_codeblocks_crc() override
+  {
+    const miphy_harq_buffer_info i = info();
+    crc_out                        = false;
+    context::hip(hipMemsetAsync(d_crc + i.first_cb, 0, i.nof_codeblocks, c->stream), "memset");
+    c->sync();
+  }
+  srsran::span<bool> get_codeblocks_crc() override
+  {
+    const miphy_harq_buffer_info i = info();
+    if (!crc_out) {
+      crc_bytes.resize(i.nof_codeblocks);
+      c->d2h(crc_bytes.data(), d_crc + i.first_cb, i.nof_codeblocks);
+      c->sync();
+      crc_mirror.reset(new bool[i.nof_codeblocks + 1]);
+      for (unsigned k = 0; k != i.nof_codeblocks; ++k) {
+        crc_mirror[k] = crc_bytes[k] != 0;
+      }
+      crc_out = true;
+    }
+    return srsran::span<bool>(crc_mirror.get(), i.nof_codeblocks);
+  }
+  srsran::span<srsran::log_likelihood_ratio> get_codeblock_soft_bits(unsigned codeblock_id, unsigned codeblock_size) override
+  {
+    const miphy_harq_buffer_info i = info();
+    srsran_assert(codeblock_id < i.nof_codeblocks, "Codeblock index ({}) is out of range ({}).", codeblock_id, i.nof_codeblocks);
+    srsran_assert(codeblock_size <= CBS, "Codeblock size {} exceeds maximum size {}.", codeblock_size, CBS);
+    mirror& m = mirror_of(codeblock_id);
+    if (!m.soft_out) {
+      m.soft.resize(CBS);
+      c->d2h(m.soft.data(), d_soft + (i.first_cb + codeblock_id) * CBS, CBS);
+      c->sync();
+      m.soft_out = true;
+    }
+    return srsran::span<srsran::log_likelihood_ratio>(m.soft).first(codeblock_size);
+  }
+  srsran::bit_buffer get_codeblock_data_bits(unsigned codeblock_id, unsigned data_size) override
+  {
+    const miphy_harq_buffer_info i = info();
+    srsran_assert(codeblock_id < i.nof_codeblocks, "Codeblock index ({}) is out of range ({}).", codeblock_id, i.nof_codeblocks);
+    srsran_assert(data_size <= MSG * 8, "Codeblock data size {} exceeds maximum size {}.", data_size, MSG * 8);
+    mirror& m = mirror_of(codeblock_id);
+    if (!m.msg_out) {
+      m.msg.resize(MSG * 8);
+      c->d2h(m.msg.get_buffer().data(), d_msgs + (i.first_cb + codeblock_id) * MSG, MSG);
+      c->sync();
+      m.msg_out = true;
+    }
+    return m.msg.first(data_size);
+  }
+  void lock() override { context::check(miphy_harq_pool_lock(pool, index), "harq_pool_lock"); }
+  void unlock() override
+  {
+    flush();
+    context::check(miphy_harq_pool_unlock(pool, index), "harq_pool_unlock");
+  }
+  void release() override
+  {
+    flush();
+    context::check(miphy_harq_pool_release(pool, index), "harq_pool_release");
+  }
+
+  /// Writes back whatever the host accessors handed out since the last flush (a CPU block may have modified it).
+  void flush()
+  {
+    const miphy_harq_buffer_info i    = info();
+    bool                         any  = false;
+    for (size_t k = 0; k != mirrors.size(); ++k) {
+      if (!mirrors[k]) {
+        continue;
+      }
+      mirror& m = *mirrors[k];
+      if (m.soft_out && k < i.nof_codeblocks) {
+        c->h2d(d_soft + (i.first_cb + k) * CBS, m.soft.data(), CBS);
+        any = true;
+      }
+      if (m.msg_out && k < i.nof_codeblocks) {
+        c->h2d(d_msgs + (i.first_cb + k) * MSG, m.msg.get_buffer().data(), MSG);
+        any = true;
+      }
+      m.soft_out = m.msg_out = false;
+    }
+    if (crc_out) {
+      for (size_t k = 0; k != crc_bytes.size(); ++k) {
+        crc_bytes[k] = crc_mirror[k] ? 1 : 0;
+      }
+      c->h2d(d_crc + i.first_cb, crc_bytes.data(), std::min<size_t>(crc_bytes.size(), i.nof_codeblocks));
+      any     = true;
+      crc_out = false;
+    }
+    if (any) {
+      c->sync();
+    }
+  }
+  uint32_t first_cb() const { return info().first_cb; }
+  int8_t*  softbits() const { return d_soft; }
+  uint8_t* msgs() const { return d_msgs; }
+  uint8_t* crc_ok() const { return d_crc; }
+
+private:
+  struct mirror {
+    std::vector<srsran::log_likelihood_ratio> soft;
+    srsran::dynamic_bit_buffer                msg;
+    bool                                      soft_out = false, msg_out = false;
+  };
+  miphy_harq_buffer_info info() const
+  {
+    miphy_harq_buffer_info i;
+    context::check(miphy_harq_pool_info(pool, index, &i), "harq_pool_info");
+    return i;
+  }
+  // The views handed out must stay valid while other codeblocks are visited: every mirror is its own allocation.
+  mirror& mirror_of(unsigned cb)
+  {
+    if (mirrors.size() <= cb) {
+      mirrors.resize(cb + 1);
+    }
+    if (!mirrors[cb]) {
+      mirrors[cb] = std::make_unique<mirror>();
+    }
+    return *mirrors[cb];
+  }
+
+  std::shared_ptr<context> c;
+  miphy_harq_pool*         pool;
+  int32_t                  index;
+  int8_t*                  d_soft = nullptr;
+  uint8_t *                d_msgs = nullptr, *d_crc = nullptr;
+  std::vector<std::unique_ptr<mirror>> mirrors;
+  std::vector<uint8_t>     crc_bytes;
+  std::unique_ptr<bool[]>  crc_mirror;
+  bool                     crc_out = false;
+};
+
+/// srsran::rx_softbuffer_pool over miphy_harq_pool (rx_softbuffer_pool.h:52-80): same reservation rules and life cycle as
+/// create_rx_softbuffer_pool(config), with the codeblocks in device memory. max_codeblock_size is fixed by the device
+/// layout (66 * 384 soft bits per codeblock). The slot period needs the numerology, which the reference's configuration does
+/// not carry: it is taken from the first slot_point the pool sees unless given here.
+class rx_softbuffer_pool_hip : public srsran::rx_softbuffer_pool
+{
+public:
+  rx_softbuffer_pool_hip(std::shared_ptr<context> c, const srsran::rx_softbuffer_pool_config& config) : c(std::move(c)), config(config)
+  {
+    srsran_assert(config.max_codeblock_size <= rx_softbuffer_hip::CBS, "Codeblocks of the device pool hold {} soft bits.", rx_softbuffer_hip::CBS);
+  }
+  ~rx_softbuffer_pool_hip() override
+  {
+    buffers.clear();
+    miphy_harq_pool_destroy(pool);
+  }
+  srsran::unique_rx_softbuffer
+  reserve_softbuffer(const srsran::slot_point& slot, const srsran::rx_softbuffer_identifier& id, unsigned nof_codeblocks) override
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    create(slot);
+    int32_t  b     = -1;
+    uint32_t first = 0;
+    context::check(miphy_harq_pool_reserve(pool, slot.to_uint(), id.rnti, id.harq_ack_id, nof_codeblocks, &b, &first), "harq_pool_reserve");
+    if (b < 0) {
+      return srsran::unique_rx_softbuffer();
+    }
+    return srsran::unique_rx_softbuffer(*buffers[b]); // locks, like the reference
+  }
+  void run_slot(const srsran::slot_point& slot) override
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    create(slot);
+    context::check(miphy_harq_pool_run_slot(pool, slot.to_uint()), "harq_pool_run_slot");
+  }
+
+private:
+  void create(const srsran::slot_point& slot)
+  {
+    if (pool != nullptr) {
+      return;
+    }
+    miphy_harq_pool_config cfg = {};
+    cfg.max_softbuffers = config.max_softbuffers, cfg.max_nof_codeblocks = config.max_nof_codeblocks;
+    cfg.expire_timeout_slots = config.expire_timeout_slots, cfg.nof_slots_wrap = slot.nof_slots_per_system_frame();
+    cfg.max_codeblocks_per_buffer = srsran::MAX_NOF_SEGMENTS;
+    context::check(miphy_harq_pool_create(c->ctx, &cfg, &pool), "harq_pool_create");
+    for (unsigned i = 0; i != config.max_softbuffers; ++i) {
+      buffers.emplace_back(std::make_unique<rx_softbuffer_hip>(c, pool, static_cast<int32_t>(i)));
+    }
+  }
+
+  std::shared_ptr<context>                        c;
+  srsran::rx_softbuffer_pool_config               config;
+  std::mutex                                      mutex;
+  miphy_harq_pool*                                pool = nullptr;
+  std::vector<std::unique_ptr<rx_softbuffer_hip>> buffers;
+};
+
+/// Replaces srsran::create_rx_softbuffer_pool(config).
+inline std::unique_ptr<srsran::rx_softbuffer_pool> create_rx_softbuffer_pool_hip(std::shared_ptr<context> c, const srsran::rx_softbuffer_pool_config& config)
+{
+  return std::make_unique<rx_softbuffer_pool_hip>(std::move(c), config);
+}
+
+/// srsran::pusch_decoder over miphy_pusch_decode_batch (pusch_decoder.h:74-78). With a softbuffer of rx_softbuffer_pool_hip
+/// the HARQ state is used in place in device memory; with any other rx_softbuffer (the reference's CPU pool) it is uploaded
+/// before and downloaded after the call.
 class pusch_decoder_hip : public srsran::pusch_decoder
 {
 public:
@@ -286,23 +503,31 @@ public:
     context::check(miphy_sch_segmentation_info(transport_block.size(), bg_id(cfg.segmenter_cfg.base_graph), &sg), "segmentation");
     srsran_assert(sg.nof_cbs == soft_codeword->get_nof_codeblocks(), "Wrong number of codeblocks.");
     const size_t CBS = 66 * 384, MSG = 1056;
+    auto*        resident = dynamic_cast<rx_softbuffer_hip*>(soft_codeword);
     auto*        d_llr  = static_cast<int8_t*>(c->buf(0, llrs.size()));
-    auto*        d_soft = static_cast<int8_t*>(c->buf(1, sg.nof_cbs * CBS));
-    auto*        d_msg  = static_cast<uint8_t*>(c->buf(2, sg.nof_cbs * MSG));
     auto*        d_misc = static_cast<uint8_t*>(c->buf(3, 64 + sizeof(miphy_pusch_result) + transport_block.size() + 64));
-    uint8_t*     d_crc  = d_misc;
     auto*        d_res  = reinterpret_cast<miphy_pusch_result*>(d_misc + 64);
     uint8_t*     d_tb   = d_misc + 64 + 64;
-    srsran::span<bool>   crcs = soft_codeword->get_codeblocks_crc();
+    int8_t*      d_soft = nullptr;
+    uint8_t *    d_msg = nullptr, *d_crc = nullptr;
     std::vector<uint8_t> crc_h(sg.nof_cbs);
-    for (unsigned i = 0; i != sg.nof_cbs; ++i) {
-      crc_h[i] = crcs[i] ? 1 : 0;
-      auto sb  = soft_codeword->get_codeblock_soft_bits(i, sg.N);
-      c->h2d(d_soft + i * CBS, sb.data(), sg.N);
-      auto mb = soft_codeword->get_codeblock_data_bits(i, sg.K);
-      c->h2d(d_msg + i * MSG, mb.get_buffer().data(), (sg.K + 7) / 8);
+    if (resident != nullptr) {
+      resident->flush();
+      d_soft = resident->softbits(), d_msg = resident->msgs(), d_crc = resident->crc_ok();
+    } else {
+      d_soft = static_cast<int8_t*>(c->buf(1, sg.nof_cbs * CBS));
+      d_msg  = static_cast<uint8_t*>(c->buf(2, sg.nof_cbs * MSG));
+      d_crc  = d_misc;
+      srsran::span<bool> crcs = soft_codeword->get_codeblocks_crc();
+      for (unsigned i = 0; i != sg.nof_cbs; ++i) {
+        crc_h[i] = crcs[i] ? 1 : 0;
+        auto sb  = soft_codeword->get_codeblock_soft_bits(i, sg.N);
+        c->h2d(d_soft + i * CBS, sb.data(), sg.N);
+        auto mb = soft_codeword->get_codeblock_data_bits(i, sg.K);
+        c->h2d(d_msg + i * MSG, mb.get_buffer().data(), (sg.K + 7) / 8);
+      }
+      c->h2d(d_crc, crc_h.data(), sg.nof_cbs);
     }
-    c->h2d(d_crc, crc_h.data(), sg.nof_cbs);
     c->h2d(d_llr, llrs.data(), llrs.size());
     c->h2d(d_tb, transport_block.data(), transport_block.size());
     miphy_pusch_tb_desc d = {};
@@ -316,20 +541,26 @@ public:
     d.Nref                = cfg.segmenter_cfg.Nref;
     d.nof_ch_symbols      = cfg.segmenter_cfg.nof_ch_symbols;
     d.tb_bytes            = transport_block.size();
+    d.harq_cb_index       = resident != nullptr ? resident->first_cb() : 0;
     context::check(miphy_pusch_decode_batch(c->ctx, &d, 1, d_llr, d_soft, d_msg, d_crc, d_tb, d_res, c->stream), "pusch_decode");
     miphy_pusch_result r;
     c->d2h(&r, d_res, sizeof(r));
-    c->d2h(crc_h.data(), d_crc, sg.nof_cbs);
     c->d2h(transport_block.data(), d_tb, transport_block.size());
-    for (unsigned i = 0; i != sg.nof_cbs; ++i) {
-      auto sb = soft_codeword->get_codeblock_soft_bits(i, sg.N);
-      c->d2h(sb.data(), d_soft + i * CBS, sg.N);
-      auto mb = soft_codeword->get_codeblock_data_bits(i, sg.K);
-      c->d2h(mb.get_buffer().data(), d_msg + i * MSG, (sg.K + 7) / 8);
+    if (resident == nullptr) {
+      c->d2h(crc_h.data(), d_crc, sg.nof_cbs);
+      for (unsigned i = 0; i != sg.nof_cbs; ++i) {
+        auto sb = soft_codeword->get_codeblock_soft_bits(i, sg.N);
+        c->d2h(sb.data(), d_soft + i * CBS, sg.N);
+        auto mb = soft_codeword->get_codeblock_data_bits(i, sg.K);
+        c->d2h(mb.get_buffer().data(), d_msg + i * MSG, (sg.K + 7) / 8);
+      }
     }
     c->sync();
-    for (unsigned i = 0; i != sg.nof_cbs; ++i) {
-      crcs[i] = crc_h[i] != 0;
+    if (resident == nullptr) {
+      srsran::span<bool> crcs = soft_codeword->get_codeblocks_crc();
+      for (unsigned i = 0; i != sg.nof_cbs; ++i) {
+        crcs[i] = crc_h[i] != 0;
+      }
     }
     stats.tb_crc_ok            = r.tb_crc_ok != 0;
     stats.nof_codeblocks_total = r.nof_codeblocks_total;
@@ -671,24 +902,33 @@ public:
         grid.get(srsran::span<srsran::cf_t>(host.data() + (static_cast<size_t>(i) * 14 + l) * nsc, nsc), pdu.rx_ports[i], l, 0);
       }
     }
+    auto*    resident = dynamic_cast<rx_softbuffer_hip*>(&softbuffer);
     auto*    d_g    = static_cast<float*>(c->buf(0, host.size() * sizeof(srsran::cf_t)));
-    auto*    d_soft = static_cast<int8_t*>(c->buf(1, sg.nof_cbs * CBS));
-    auto*    d_msg  = static_cast<uint8_t*>(c->buf(2, sg.nof_cbs * MSG));
     auto*    d_misc = static_cast<uint8_t*>(c->buf(3, 64 + 64 + 128 + data.size() + 64));
-    uint8_t* d_crc  = d_misc;
     auto*    d_res  = reinterpret_cast<miphy_pusch_result*>(d_misc + 64);
     auto*    d_sc   = reinterpret_cast<float*>(d_misc + 128);
     uint8_t* d_tb   = d_misc + 256;
-    srsran::span<bool>   crcs = softbuffer.get_codeblocks_crc();
+    int8_t*  d_soft = nullptr;
+    uint8_t *d_msg = nullptr, *d_crc = nullptr;
     std::vector<uint8_t> crc_h(sg.nof_cbs);
-    for (unsigned i = 0; i != sg.nof_cbs; ++i) {
-      crc_h[i] = crcs[i] ? 1 : 0;
-      auto sb  = softbuffer.get_codeblock_soft_bits(i, sg.N);
-      c->h2d(d_soft + i * CBS, sb.data(), sg.N);
-      auto mb = softbuffer.get_codeblock_data_bits(i, sg.K);
-      c->h2d(d_msg + i * MSG, mb.get_buffer().data(), (sg.K + 7) / 8);
+    if (resident != nullptr) { // softbuffer of rx_softbuffer_pool_hip: the HARQ state is used in place
+      resident->flush();
+      d_soft = resident->softbits(), d_msg = resident->msgs(), d_crc = resident->crc_ok();
+      p.harq_cb_index = resident->first_cb();
+    } else {
+      d_soft = static_cast<int8_t*>(c->buf(1, sg.nof_cbs * CBS));
+      d_msg  = static_cast<uint8_t*>(c->buf(2, sg.nof_cbs * MSG));
+      d_crc  = d_misc;
+      srsran::span<bool> crcs = softbuffer.get_codeblocks_crc();
+      for (unsigned i = 0; i != sg.nof_cbs; ++i) {
+        crc_h[i] = crcs[i] ? 1 : 0;
+        auto sb  = softbuffer.get_codeblock_soft_bits(i, sg.N);
+        c->h2d(d_soft + i * CBS, sb.data(), sg.N);
+        auto mb = softbuffer.get_codeblock_data_bits(i, sg.K);
+        c->h2d(d_msg + i * MSG, mb.get_buffer().data(), (sg.K + 7) / 8);
+      }
+      c->h2d(d_crc, crc_h.data(), sg.nof_cbs);
     }
-    c->h2d(d_crc, crc_h.data(), sg.nof_cbs);
     c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
     c->h2d(d_tb, data.data(), data.size());
     context::check(miphy_pusch_process_batch(c->ctx, &p, 1, d_g, d_soft, d_msg, d_crc, d_tb, d_res, d_sc, c->stream), "pusch_process");
@@ -696,17 +936,22 @@ public:
     float              sc[20];
     c->d2h(&r, d_res, sizeof(r));
     c->d2h(sc, d_sc, sizeof(sc));
-    c->d2h(crc_h.data(), d_crc, sg.nof_cbs);
     c->d2h(data.data(), d_tb, data.size());
-    for (unsigned i = 0; i != sg.nof_cbs; ++i) {
-      auto sb = softbuffer.get_codeblock_soft_bits(i, sg.N);
-      c->d2h(sb.data(), d_soft + i * CBS, sg.N);
-      auto mb = softbuffer.get_codeblock_data_bits(i, sg.K);
-      c->d2h(mb.get_buffer().data(), d_msg + i * MSG, (sg.K + 7) / 8);
+    if (resident == nullptr) {
+      c->d2h(crc_h.data(), d_crc, sg.nof_cbs);
+      for (unsigned i = 0; i != sg.nof_cbs; ++i) {
+        auto sb = softbuffer.get_codeblock_soft_bits(i, sg.N);
+        c->d2h(sb.data(), d_soft + i * CBS, sg.N);
+        auto mb = softbuffer.get_codeblock_data_bits(i, sg.K);
+        c->d2h(mb.get_buffer().data(), d_msg + i * MSG, (sg.K + 7) / 8);
+      }
     }
     c->sync();
-    for (unsigned i = 0; i != sg.nof_cbs; ++i) {
-      crcs[i] = crc_h[i] != 0;
+    if (resident == nullptr) {
+      srsran::span<bool> crcs = softbuffer.get_codeblocks_crc();
+      for (unsigned i = 0; i != sg.nof_cbs; ++i) {
+        crcs[i] = crc_h[i] != 0;
+      }
     }
     // channel_estimate::get_channel_state_information (channel_estimation.h:211-232): linear averages over the receive ports, then dB
     srsran::channel_state_information csi = {};

@@ -62,6 +62,16 @@ def lib():
         l.miphy_pdsch_mod_nof_re.restype = C.c_uint32
         l.miphy_pusch_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 8
         l.miphy_pusch_demod_nof_llr.argtypes = [C.c_void_p]
+        l.miphy_harq_pool_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        l.miphy_harq_pool_destroy.argtypes = [C.c_void_p]
+        l.miphy_harq_pool_destroy.restype = None
+        l.miphy_harq_pool_reserve.argtypes = [C.c_void_p] + [C.c_uint32] * 4 + [C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+        for name in ("miphy_harq_pool_lock", "miphy_harq_pool_unlock", "miphy_harq_pool_release"):
+            getattr(l, name).argtypes = [C.c_void_p, C.c_int32]
+        l.miphy_harq_pool_run_slot.argtypes = [C.c_void_p, C.c_uint32]
+        l.miphy_harq_pool_info.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        l.miphy_harq_pool_free_codeblocks.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        l.miphy_harq_pool_arrays.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 3
         l.miphy_pusch_demod_nof_llr.restype = C.c_uint32
         _lib = l
     return _lib
@@ -365,3 +375,89 @@ class Context:
         check(lib().miphy_polar_decode_list_batch(self.h, C.byref(code), list_size, crc_mode, n, _dptr(llr),
                                                   _dptr(rnti) if rnti is not None else None, _dptr(msg_out), _dptr(crc_ok_out),
                                                   _dptr(metric_out) if metric_out is not None else None, _stream_ptr(stream)))
+
+
+# ---------------------------------------------------------------------- HARQ softbuffer pool
+class HarqPoolConfig(C.Structure):
+    """Mirrors miphy_harq_pool_config (rx_softbuffer_pool_config + the slot period + the extent of one softbuffer)."""
+    _fields_ = [("max_softbuffers", C.c_uint32), ("max_nof_codeblocks", C.c_uint32), ("expire_timeout_slots", C.c_uint32),
+                ("nof_slots_wrap", C.c_uint32), ("max_codeblocks_per_buffer", C.c_uint32)]
+
+
+class HarqBufferInfo(C.Structure):
+    _fields_ = [("state", C.c_uint32), ("rnti", C.c_uint32), ("harq_id", C.c_uint32), ("nof_codeblocks", C.c_uint32),
+                ("first_cb", C.c_uint32), ("expire_slot", C.c_uint32)]
+
+
+HARQ_AVAILABLE, HARQ_RESERVED, HARQ_LOCKED, HARQ_RELEASED = 0, 1, 2, 3
+
+
+class HarqPool:
+    """miphy_harq_pool: the reference's rx_softbuffer_pool over device-resident HARQ arrays. ctx=None gives a
+    bookkeeping-only pool (reservation state machine without device memory; used by the host-logic tests)."""
+
+    def __init__(self, ctx, max_softbuffers, max_nof_codeblocks, expire_timeout_slots, numerology=1, max_codeblocks_per_buffer=0):
+        self.cfg = HarqPoolConfig(max_softbuffers, max_nof_codeblocks, expire_timeout_slots, 10240 << numerology, max_codeblocks_per_buffer)
+        self.ctx = ctx  # keeps the context alive
+        h = C.c_void_p()
+        check(lib().miphy_harq_pool_create(ctx.h if ctx is not None else None, C.byref(self.cfg), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().miphy_harq_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reserve(self, slot, rnti, harq_id, nof_codeblocks):
+        """-> (softbuffer index or -1, first codeblock slot = harq_cb_index of the transport-block descriptor)."""
+        b, f = C.c_int32(), C.c_uint32()
+        check(lib().miphy_harq_pool_reserve(self.h, slot, rnti, harq_id, nof_codeblocks, C.byref(b), C.byref(f)))
+        return b.value, f.value
+
+    def lock(self, buffer):
+        check(lib().miphy_harq_pool_lock(self.h, buffer))
+
+    def unlock(self, buffer):
+        check(lib().miphy_harq_pool_unlock(self.h, buffer))
+
+    def release(self, buffer):
+        check(lib().miphy_harq_pool_release(self.h, buffer))
+
+    def run_slot(self, slot):
+        check(lib().miphy_harq_pool_run_slot(self.h, slot))
+
+    def info(self, buffer):
+        out = HarqBufferInfo()
+        check(lib().miphy_harq_pool_info(self.h, buffer, C.byref(out)))
+        return out
+
+    def free_codeblocks(self):
+        out = C.c_uint32()
+        check(lib().miphy_harq_pool_free_codeblocks(self.h, C.byref(out)))
+        return out.value
+
+    def arrays(self):
+        """Device arrays as torch uint8 / int8 views: (softbits [ncb, 66*384] int8, msgs [ncb, 1056] uint8, crc_ok [ncb] uint8)."""
+        import torch
+        ptrs = [C.c_void_p() for _ in range(3)]
+        check(lib().miphy_harq_pool_arrays(self.h, *[C.byref(p) for p in ptrs]))
+        ncb = self.cfg.max_softbuffers * (self.cfg.max_codeblocks_per_buffer or 52)
+        dev = torch.device("cuda", self.ctx.device)
+
+        def view(ptr, nbytes, dtype):
+            class _Holder:  # __cuda_array_interface__ view over memory the pool owns
+                pass
+            hld = _Holder()
+            hld.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr.value, False), "version": 2}
+            t = torch.as_tensor(hld, device=dev)
+            return t.view(dtype)
+        soft = view(ptrs[0], ncb * HARQ_CB_STRIDE, torch.int8).view(ncb, HARQ_CB_STRIDE)
+        msgs = view(ptrs[1], ncb * HARQ_MSG_STRIDE, torch.uint8).view(ncb, HARQ_MSG_STRIDE)
+        crc = view(ptrs[2], ncb, torch.uint8)
+        return soft, msgs, crc

@@ -585,3 +585,45 @@ def pdsch_nof_re(prb_list, start, nof, dmrs_mask, type2, cdm, bwp_start, bwp_siz
                     ex = ex or (bool(pm[rb]) and bool((rm >> k) & 1) and bool((sm >> sy) & 1))
                 n += 0 if ex else 1
     return n
+
+
+# ---------------------------------------------------------------------- rx_softbuffer_pool traces
+POOL_RESERVE, POOL_DROP, POOL_RELEASE, POOL_RUN_SLOT = 0, 1, 2, 3
+
+
+def pool_trace(seed, n_ops, nof_handles=6, nof_rnti=3, nof_harq=2, max_cbs=7, start_slot=20400, period=20480):
+    """Random caller behaviour against a softbuffer pool: columns (op, slot, rnti, harq_id, nof_codeblocks, handle). A handle is
+    one scope holding a unique_rx_softbuffer. Slots advance and wrap around the system-frame period."""
+    rng = np.random.default_rng(seed)
+    ops = np.zeros((n_ops, 6), np.int64)
+    slot = start_slot
+    for i in range(n_ops):
+        op = int(rng.choice([POOL_RESERVE, POOL_DROP, POOL_RELEASE, POOL_RUN_SLOT], p=[0.4, 0.25, 0.15, 0.2]))
+        if op == POOL_RUN_SLOT:
+            slot = (slot + int(rng.integers(1, 6))) % period
+        ops[i] = (op, slot, 0x4600 * int(rng.integers(0, nof_rnti)), int(rng.integers(0, nof_harq)), int(rng.integers(1, max_cbs + 1)),
+                  int(rng.integers(0, nof_handles)))
+    return ops
+
+
+def r_pool_run(ops, max_softbuffers, max_nof_codeblocks, expire_timeout_slots, numerology=1):
+    """The reference pool driven by a trace -> per op (softbuffer ordinal or -1, nof_codeblocks) for reservations, (0, 0) otherwise."""
+    L = ref()
+    L.ref_pool_create.restype = vp
+    h = vp(L.ref_pool_create(66 * 384, max_softbuffers, max_nof_codeblocks, expire_timeout_slots, numerology))
+    out = np.zeros((len(ops), 2), np.int64)
+    try:
+        for i, (op, slot, rnti, harq, ncb, hd) in enumerate(ops.tolist()):
+            if op == POOL_RESERVE:
+                n = C.c_uint(0)
+                o = L.ref_pool_reserve(h, slot, rnti, harq, ncb, hd, C.byref(n))
+                out[i] = (o, n.value if o >= 0 else 0)
+            elif op == POOL_DROP:
+                L.ref_pool_drop(h, hd)
+            elif op == POOL_RELEASE:
+                L.ref_pool_release(h, hd)
+            else:
+                L.ref_pool_run_slot(h, slot)
+    finally:
+        L.ref_pool_destroy(h)
+    return out
