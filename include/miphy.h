@@ -514,6 +514,49 @@ int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs /* h
                              uint8_t* codeword_out /* device */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * PDSCH processor (whole PDUs)  --  replaces srsran::pdsch_processor::process
+ *   include/srsran/phy/upper/channel_processors/pdsch_processor.h:64-165, lib/phy/upper/channel_processors/pdsch_processor_impl.cpp:110-305
+ * Transport block -> resource grid in one call: the number of data REs of the allocation (reserved patterns and the DM-RS
+ * pattern of the bandwidth part excluded, pdsch_processor_impl.cpp:198-220), pdsch_encoder (Nref = 8 * tbs_lbrm_bytes),
+ * pdsch_modulator with scaling 10^(-ratio_pdsch_data_to_sss_dB / 20) and dmrs_pdsch_processor with amplitude
+ * 10^(-ratio_pdsch_dmrs_to_sss_dB / 20) on the same port. The codewords stay on the device. Same restrictions as the
+ * reference (pdsch_processor_impl.cpp:143-196): DM-RS type 1, one codeword on one layer, contiguous allocation. */
+typedef struct {
+  uint32_t slot_in_frame;              /* pdu.slot.slot_index() */
+  uint32_t rnti;
+  uint32_t n_id;                       /* data scrambling identity */
+  uint32_t dmrs_scrambling_id;
+  uint32_t tbs_lbrm_bytes;             /* 1 .. 66*384/8 */
+  uint32_t tb_bytes;
+  float    ratio_pdsch_dmrs_to_sss_dB;
+  float    ratio_pdsch_data_to_sss_dB;
+  uint8_t  bg;                         /* 1 or 2 */
+  uint8_t  rv;
+  uint8_t  mod;                        /* bits per symbol */
+  uint8_t  port;                       /* grid port of the layer */
+  uint8_t  start_symbol;
+  uint8_t  nof_symbols;
+  uint8_t  nof_cdm_groups_without_data;
+  uint8_t  n_scid;
+  uint8_t  ref_point_prb0;             /* 1: DM-RS reference point is the first PRB of the BWP (pdu_t::PRB0), 0: CRB0 */
+  uint8_t  nof_reserved;               /* 0..4 */
+  uint16_t dmrs_symbols_mask;
+  uint16_t grid_nof_prb;
+  uint16_t bwp_start_rb;
+  uint16_t bwp_size_rb;
+  uint16_t pad;
+  uint64_t rb_mask[5];                 /* allocated PRBs, grid numbering */
+  miphy_re_pattern reserved[4];
+  uint64_t tb_offset;                  /* byte offset of the packed transport block inside `tb_in` */
+  uint64_t grid_offset;                /* cf_t offset of grid port 0: [port][14][grid_nof_prb*12] */
+} miphy_pdsch_pdu;
+
+/* Data REs of the allocation (pdsch_processor_impl::compute_nof_data_re); 0 on an invalid PDU. Host function. */
+uint32_t miphy_pdsch_pdu_nof_re(const miphy_pdsch_pdu* pdu);
+int miphy_pdsch_process_batch(miphy_ctx* ctx, const miphy_pdsch_pdu* pdus /* host */, uint32_t n, const uint8_t* tb_in /* device */,
+                              float* grid /* device cf_t; only the mapped REs are written */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * PBCH encoder  --  replaces srsran::pbch_encoder::encode
  *   include/srsran/phy/upper/channel_processors/pbch_encoder.h:53-80, lib/phy/upper/channel_processors/pbch_encoder_impl.cpp:41-190
  * (payload interleaving G(j) with SFN / half-frame / SSB-index bits, Gold-sequence scrambling, CRC24C, CRC interleaver,

@@ -640,6 +640,81 @@ static void test_pdsch_modulator_and_dmrs(std::shared_ptr<miphy::context> c)
   printf("pdsch_modulator + dmrs_pdsch_processor done, failures so far %d\n", failures);
 }
 
+// pdsch_processor: the reference processor (software encoder + modulator + DM-RS) vs pdsch_processor_hip, identical grids.
+static void test_pdsch_processor(std::shared_ptr<miphy::context> c)
+{
+  auto                                   crcf = create_crc_calculator_factory_sw("auto");
+  auto                                   prg  = create_pseudo_random_generator_sw_factory();
+  pdsch_encoder_factory_sw_configuration ec;
+  ec.encoder_factory      = create_ldpc_encoder_factory_sw("avx2");
+  ec.rate_matcher_factory = create_ldpc_rate_matcher_factory_sw();
+  ec.segmenter_factory    = create_ldpc_segmenter_tx_factory_sw(crcf);
+  auto p_ref = create_pdsch_processor_factory_sw(create_pdsch_encoder_factory_sw(ec), create_pdsch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg),
+                                                 create_dmrs_pdsch_processor_factory_sw(prg))
+                   ->create();
+  auto p_hip = std::make_shared<miphy::pdsch_processor_factory_hip>(c)->create();
+  struct tc {
+    ldpc_base_graph_type bg;
+    modulation_scheme    mod;
+    unsigned             tbs, rv, bwp_start, bwp_size, rb_start, rb_count, cdm, start, nof;
+    bool                 prb0, with_reserved;
+    float                dmrs_db, data_db;
+  };
+  std::uniform_int_distribution<int> byte(0, 255);
+  for (const tc& t : {tc{ldpc_base_graph_type::BG1, modulation_scheme::QAM256, 319784, 0, 0, 273, 0, 273, 2, 0, 14, false, false, 0.0F, 0.0F},
+                      tc{ldpc_base_graph_type::BG1, modulation_scheme::QAM64, 83976, 2, 10, 120, 6, 100, 1, 1, 13, true, true, -3.0F, 1.5F},
+                      tc{ldpc_base_graph_type::BG2, modulation_scheme::QPSK, 3848, 3, 4, 40, 2, 30, 2, 2, 12, true, true, 3.0F, -2.0F},
+                      tc{ldpc_base_graph_type::BG2, modulation_scheme::QAM16, 320, 1, 0, 25, 20, 3, 2, 0, 14, false, false, 0.0F, 0.0F}}) {
+    const unsigned grid_rb = t.bwp_start + t.bwp_size, nsc = grid_rb * 12;
+    auto           g1 = create_resource_grid(2, 14, nsc), g2 = create_resource_grid(2, 14, nsc);
+    g1->set_all_zero();
+    g2->set_all_zero();
+    pdsch_processor::pdu_t pdu;
+    pdu.slot = slot_point(1, 7), pdu.rnti = 0x4601, pdu.bwp_size_rb = t.bwp_size, pdu.bwp_start_rb = t.bwp_start, pdu.cp = cyclic_prefix::NORMAL;
+    pdu.codewords.push_back(pdsch_processor::codeword_description{t.mod, static_cast<uint8_t>(t.rv)});
+    pdu.n_id = 321;
+    pdu.ports.push_back(1);
+    pdu.ref_point = t.prb0 ? pdsch_processor::pdu_t::PRB0 : pdsch_processor::pdu_t::CRB0;
+    symbol_slot_mask dm(14);
+    dm.set(2);
+    dm.set(11);
+    pdu.dmrs_symbol_mask = dm, pdu.dmrs = dmrs_type::TYPE1, pdu.scrambling_id = 4321, pdu.n_scid = true;
+    pdu.nof_cdm_groups_without_data = t.cdm;
+    pdu.freq_alloc                  = rb_allocation::make_type1(t.rb_start, t.rb_count);
+    pdu.start_symbol_index = t.start, pdu.nof_symbols = t.nof, pdu.ldpc_base_graph = t.bg, pdu.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8;
+    if (t.with_reserved) {
+      re_prb_mask rm;
+      rm.set(0);
+      rm.set(5);
+      symbol_slot_mask sm(14);
+      sm.set(4);
+      sm.set(8);
+      pdu.reserved.merge(re_pattern(t.bwp_start + t.rb_start, t.bwp_start + t.rb_start + t.rb_count, 3, rm, sm));
+    }
+    pdu.ratio_pdsch_dmrs_to_sss_dB = t.dmrs_db, pdu.ratio_pdsch_data_to_sss_dB = t.data_db;
+    std::vector<uint8_t> tb(t.tbs / 8);
+    for (auto& b : tb) {
+      b = byte(rgen);
+    }
+    static_vector<span<const uint8_t>, pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS> data;
+    data.emplace_back(tb);
+    p_ref->process(*g1, data, pdu);
+    p_hip->process(*g2, data, pdu);
+    std::vector<cf_t> a(nsc), b(nsc);
+    unsigned          bad = 0, nonzero = 0;
+    for (unsigned p = 0; p != 2; ++p) {
+      for (unsigned l = 0; l != 14; ++l) {
+        g1->get(a, p, l, 0);
+        g2->get(b, p, l, 0);
+        bad += std::memcmp(a.data(), b.data(), nsc * sizeof(cf_t)) != 0;
+        nonzero += std::any_of(a.begin(), a.end(), [](cf_t v) { return v != cf_t(0, 0); });
+      }
+    }
+    CHECK(bad == 0 && nonzero == t.nof, "pdsch_processor: %u (port, symbol) rows differ, %u rows written (tbs %u)", bad, nonzero, t.tbs);
+  }
+  printf("pdsch_processor done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -821,6 +896,7 @@ int main()
   test_pusch_demodulator(c);
   test_pusch_processor(c);
   test_pdsch_modulator_and_dmrs(c);
+  test_pdsch_processor(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);
     return 1;

@@ -1007,6 +1007,82 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------------------------- PDSCH modulator / DM-RS
+/// The reserved-RE list only exposes per-symbol masks (re_pattern_list::get_exclusion_mask): turn them back into at most four
+/// (PRB set, RE mask, symbol set) rectangles for the C ABI. Returns their number.
+inline uint8_t reserved_rectangles(const srsran::re_pattern_list& reserved, unsigned nprb, miphy_re_pattern* out)
+{
+  if (reserved.get_nof_entries() == 0) {
+    return 0;
+  }
+  const unsigned nsc = nprb * 12;
+  struct rect {
+    uint16_t                re;
+    std::array<uint64_t, 5> prbs;
+    uint16_t                symbols;
+  };
+  std::vector<rect> rects;
+  for (unsigned l = 0; l != 14; ++l) {
+    srsran::bounded_bitset<srsran::MAX_RB * srsran::NRE> msk(nsc);
+    msk.fill(0, nsc, true);
+    reserved.get_exclusion_mask(msk, l);
+    std::vector<rect> here;
+    for (unsigned r = 0; r != nprb; ++r) {
+      uint16_t v = 0;
+      for (unsigned k = 0; k != 12; ++k) {
+        v |= static_cast<uint16_t>(msk.test(r * 12 + k) ? 0U : (1U << k));
+      }
+      if (v == 0) {
+        continue;
+      }
+      auto it = std::find_if(here.begin(), here.end(), [v](const rect& x) { return x.re == v; });
+      if (it == here.end()) {
+        here.push_back(rect{v, {}, static_cast<uint16_t>(1U << l)});
+        it = here.end() - 1;
+      }
+      it->prbs[r >> 6] |= 1ULL << (r & 63);
+    }
+    for (const rect& h : here) {
+      auto it = std::find_if(rects.begin(), rects.end(), [&h](const rect& x) { return x.re == h.re && x.prbs == h.prbs; });
+      if (it == rects.end()) {
+        rects.push_back(h);
+      } else {
+        it->symbols |= h.symbols;
+      }
+    }
+  }
+  if (rects.size() > 4) {
+    srsran::report_fatal_error("The reserved RE patterns need {} rectangles, at most 4 are supported by the HIP path.", rects.size());
+  }
+  uint8_t n = 0;
+  for (const rect& x : rects) {
+    miphy_re_pattern& o = out[n++];
+    std::copy(x.prbs.begin(), x.prbs.end(), o.prb_mask);
+    o.re_mask = x.re, o.symbols = x.symbols;
+  }
+  return n;
+}
+
+/// Writes the REs a kernel produced into a resource grid: `host` is one port of a staging grid [14][nsc] that was filled with
+/// NaN before the kernel ran, so that everything that is not NaN was written.
+inline void put_written_res(srsran::resource_grid_writer& grid, unsigned port, unsigned nsc, const srsran::cf_t* host)
+{
+  std::unique_ptr<bool[]>   mask(new bool[nsc]);
+  std::vector<srsran::cf_t> vals;
+  for (unsigned l = 0; l != 14; ++l) {
+    vals.clear();
+    for (unsigned k = 0; k != nsc; ++k) {
+      const srsran::cf_t v = host[static_cast<size_t>(l) * nsc + k];
+      mask[k]              = !std::isnan(v.real());
+      if (mask[k]) {
+        vals.push_back(v);
+      }
+    }
+    if (!vals.empty()) {
+      grid.put(port, l, 0, srsran::span<const bool>(mask.get(), nsc), vals);
+    }
+  }
+}
+
 /// srsran::pdsch_modulator over miphy_pdsch_modulate_batch (pdsch_modulator.h:98). One codeword on one layer, contiguous
 /// allocation -- the configurations the 23.5 software modulator handles correctly.
 class pdsch_modulator_hip : public srsran::pdsch_modulator
@@ -1033,52 +1109,7 @@ public:
       }
     }
     prb.for_each(0, nprb, [&j](unsigned r) { j.rb_mask[r >> 6] |= 1ULL << (r & 63); });
-    // The reserved-RE list only exposes per-symbol masks: turn them back into (PRB set, RE mask, symbol set) rectangles.
-    if (config.reserved.get_nof_entries() != 0) {
-      struct rect {
-        uint16_t                 re;
-        std::array<uint64_t, 5>  prbs;
-        uint16_t                 symbols;
-      };
-      std::vector<rect> rects;
-      for (unsigned l = 0; l != 14; ++l) {
-        srsran::bounded_bitset<srsran::MAX_RB * srsran::NRE> msk(nsc);
-        msk.fill(0, nsc, true);
-        config.reserved.get_exclusion_mask(msk, l);
-        std::vector<rect> here;
-        for (unsigned r = 0; r != nprb; ++r) {
-          uint16_t v = 0;
-          for (unsigned k = 0; k != 12; ++k) {
-            v |= static_cast<uint16_t>(msk.test(r * 12 + k) ? 0U : (1U << k));
-          }
-          if (v == 0) {
-            continue;
-          }
-          auto it = std::find_if(here.begin(), here.end(), [v](const rect& x) { return x.re == v; });
-          if (it == here.end()) {
-            here.push_back(rect{v, {}, static_cast<uint16_t>(1U << l)});
-            it = here.end() - 1;
-          }
-          it->prbs[r >> 6] |= 1ULL << (r & 63);
-        }
-        for (const rect& h : here) {
-          auto it = std::find_if(rects.begin(), rects.end(), [&h](const rect& x) { return x.re == h.re && x.prbs == h.prbs; });
-          if (it == rects.end()) {
-            rects.push_back(h);
-          } else {
-            it->symbols |= h.symbols;
-          }
-        }
-      }
-      if (rects.size() > 4) {
-        srsran::report_fatal_error("pdsch_modulator_hip: the reserved RE patterns need {} rectangles, at most 4 are supported.", rects.size());
-      }
-      for (const rect& x : rects) {
-        miphy_re_pattern& o = j.reserved[j.nof_reserved++];
-        std::copy(x.prbs.begin(), x.prbs.end(), o.prb_mask);
-        o.re_mask = x.re, o.symbols = x.symbols;
-      }
-    }
+    j.nof_reserved = reserved_rectangles(config.reserved, nprb, j.reserved);
     const srsran::bit_buffer& cw = codewords[0];
     j.nof_bits                   = cw.size();
     bits.resize(cw.size());
@@ -1093,32 +1124,10 @@ public:
     context::check(miphy_pdsch_modulate_batch(c->ctx, &j, 0, 1, d_cw, d_g, c->stream), "pdsch_modulate");
     c->d2h(host.data(), d_g, host.size() * sizeof(srsran::cf_t));
     c->sync();
-    put_written(grid, config.ports[0], nsc);
+    put_written_res(grid, config.ports[0], nsc, host.data());
   }
 
 private:
-  void put_written(srsran::resource_grid_writer& grid, unsigned port, unsigned nsc)
-  {
-    std::vector<bool>         mask(nsc);
-    std::vector<srsran::cf_t> vals;
-    for (unsigned l = 0; l != 14; ++l) {
-      vals.clear();
-      bool any = false;
-      for (unsigned k = 0; k != nsc; ++k) {
-        const srsran::cf_t v = host[static_cast<size_t>(l) * nsc + k];
-        mask[k]              = !std::isnan(v.real());
-        if (mask[k]) {
-          vals.push_back(v);
-          any = true;
-        }
-      }
-      if (any) {
-        std::unique_ptr<bool[]> m(new bool[nsc]);
-        std::copy(mask.begin(), mask.end(), m.get());
-        grid.put(port, l, 0, srsran::span<const bool>(m.get(), nsc), vals);
-      }
-    }
-  }
   std::shared_ptr<context>  c;
   std::vector<uint8_t>      bits;
   std::vector<srsran::cf_t> host;
@@ -1173,6 +1182,66 @@ public:
 private:
   std::shared_ptr<context>  c;
   std::vector<srsran::cf_t> host;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- PDSCH processor
+/// srsran::pdsch_processor over miphy_pdsch_process_batch (pdsch_processor.h:164-166): encoding, modulation and DM-RS generation
+/// in one device pass; the transport block goes up, the written resource elements come back.
+class pdsch_processor_hip : public srsran::pdsch_processor
+{
+public:
+  explicit pdsch_processor_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void process(srsran::resource_grid_writer&                                                        grid,
+               srsran::static_vector<srsran::span<const uint8_t>, srsran::pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS> data,
+               const pdu_t&                                                                         pdu) override
+  {
+    srsran_assert(pdu.ports.size() == 1 && pdu.codewords.size() == 1 && data.size() == 1, "Only one layer / one codeword is supported.");
+    srsran_assert(pdu.dmrs == srsran::dmrs_type::TYPE1, "Only DM-RS Type 1 is currently supported.");
+    srsran_assert(pdu.freq_alloc.is_contiguous(), "Only contiguous allocation is currently supported.");
+    const srsran::bounded_bitset<srsran::MAX_RB> prb  = pdu.freq_alloc.get_prb_mask(pdu.bwp_start_rb, pdu.bwp_size_rb);
+    const unsigned                               nprb = prb.size(), nsc = nprb * 12;
+    miphy_pdsch_pdu p = {};
+    p.slot_in_frame = pdu.slot.slot_index(), p.rnti = pdu.rnti, p.n_id = pdu.n_id, p.dmrs_scrambling_id = pdu.scrambling_id;
+    p.tbs_lbrm_bytes = pdu.tbs_lbrm_bytes, p.tb_bytes = data[0].size();
+    p.ratio_pdsch_dmrs_to_sss_dB = pdu.ratio_pdsch_dmrs_to_sss_dB, p.ratio_pdsch_data_to_sss_dB = pdu.ratio_pdsch_data_to_sss_dB;
+    p.bg = bg_id(pdu.ldpc_base_graph), p.rv = pdu.codewords[0].rv, p.mod = srsran::get_bits_per_symbol(pdu.codewords[0].modulation);
+    p.port = 0; // the staging grid has a single port
+    p.start_symbol = pdu.start_symbol_index, p.nof_symbols = pdu.nof_symbols, p.nof_cdm_groups_without_data = pdu.nof_cdm_groups_without_data;
+    p.n_scid = pdu.n_scid ? 1 : 0, p.ref_point_prb0 = (pdu.ref_point == pdu_t::PRB0) ? 1 : 0;
+    p.grid_nof_prb = nprb, p.bwp_start_rb = pdu.bwp_start_rb, p.bwp_size_rb = pdu.bwp_size_rb;
+    for (unsigned l = 0; l != 14 && l != pdu.dmrs_symbol_mask.size(); ++l) {
+      if (pdu.dmrs_symbol_mask.test(l)) {
+        p.dmrs_symbols_mask |= static_cast<uint16_t>(1U << l);
+      }
+    }
+    prb.for_each(0, nprb, [&p](unsigned r) { p.rb_mask[r >> 6] |= 1ULL << (r & 63); });
+    p.nof_reserved = reserved_rectangles(pdu.reserved, nprb, p.reserved);
+    host.assign(static_cast<size_t>(14) * nsc, srsran::cf_t(NAN, NAN)); // NaN marks "not written by the kernels"
+    auto* d_tb = static_cast<uint8_t*>(c->buf(0, data[0].size() + 16));
+    auto* d_g  = static_cast<float*>(c->buf(1, host.size() * sizeof(srsran::cf_t)));
+    c->h2d(d_tb, data[0].data(), data[0].size());
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    context::check(miphy_pdsch_process_batch(c->ctx, &p, 1, d_tb, d_g, c->stream), "pdsch_process");
+    c->d2h(host.data(), d_g, host.size() * sizeof(srsran::cf_t));
+    c->sync();
+    put_written_res(grid, pdu.ports[0], nsc, host.data());
+  }
+
+private:
+  std::shared_ptr<context>  c;
+  std::vector<srsran::cf_t> host;
+};
+
+/// Replaces create_pdsch_processor_factory_sw(encoder, modulator, dmrs) (channel_processor_factories.h:153-156).
+class pdsch_processor_factory_hip : public srsran::pdsch_processor_factory
+{
+public:
+  explicit pdsch_processor_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  std::unique_ptr<srsran::pdsch_processor>     create() override { return std::make_unique<pdsch_processor_hip>(c); }
+  std::unique_ptr<srsran::pdsch_pdu_validator> create_validator() override { return nullptr; }
+
+private:
+  std::shared_ptr<context> c;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- PDCCH

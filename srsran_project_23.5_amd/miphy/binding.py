@@ -62,6 +62,9 @@ def lib():
         l.miphy_pdsch_mod_nof_re.restype = C.c_uint32
         l.miphy_pusch_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 8
         l.miphy_pusch_demod_nof_llr.argtypes = [C.c_void_p]
+        l.miphy_pdsch_pdu_nof_re.argtypes = [C.c_void_p]
+        l.miphy_pdsch_pdu_nof_re.restype = C.c_uint32
+        l.miphy_pdsch_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_harq_pool_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         l.miphy_harq_pool_destroy.argtypes = [C.c_void_p]
         l.miphy_harq_pool_destroy.restype = None
@@ -151,6 +154,23 @@ def pdsch_mod_nof_re(job):
     """Data REs of one PdschModJob record (host computation in the library)."""
     a = np.ascontiguousarray(np.asarray(job, dtype=PdschModJob).reshape(1))
     return int(lib().miphy_pdsch_mod_nof_re(a.ctypes.data_as(C.c_void_p)))
+
+
+# Mirrors miphy_pdsch_pdu.
+PdschPdu = np.dtype([("slot_in_frame", np.uint32), ("rnti", np.uint32), ("n_id", np.uint32), ("dmrs_scrambling_id", np.uint32),
+                     ("tbs_lbrm_bytes", np.uint32), ("tb_bytes", np.uint32), ("ratio_pdsch_dmrs_to_sss_dB", np.float32),
+                     ("ratio_pdsch_data_to_sss_dB", np.float32), ("bg", np.uint8), ("rv", np.uint8), ("mod", np.uint8), ("port", np.uint8),
+                     ("start_symbol", np.uint8), ("nof_symbols", np.uint8), ("nof_cdm_groups_without_data", np.uint8), ("n_scid", np.uint8),
+                     ("ref_point_prb0", np.uint8), ("nof_reserved", np.uint8), ("dmrs_symbols_mask", np.uint16), ("grid_nof_prb", np.uint16),
+                     ("bwp_start_rb", np.uint16), ("bwp_size_rb", np.uint16), ("pad", np.uint16), ("rb_mask", np.uint64, 5),
+                     ("reserved", RePattern, 4), ("tb_offset", np.uint64), ("grid_offset", np.uint64)], align=True)
+assert PdschPdu.itemsize == 304 and PdschPdu.fields["rb_mask"][1] == 56, PdschPdu.itemsize
+
+
+def pdsch_pdu_nof_re(pdu):
+    """Data REs of one PdschPdu record (pdsch_processor_impl::compute_nof_data_re; host computation in the library)."""
+    a = np.ascontiguousarray(np.asarray(pdu, dtype=PdschPdu).reshape(1))
+    return int(lib().miphy_pdsch_pdu_nof_re(a.ctypes.data_as(C.c_void_p)))
 
 
 # Mirrors miphy_pusch_pdu.
@@ -320,6 +340,12 @@ class Context:
     def dmrs_pdsch_map_batch(self, jobs, grid, stream=None):
         jobs, n, ptr, on_dev = self._descs(jobs, DmrsPdschJob)
         check(lib().miphy_dmrs_pdsch_map_batch(self.h, ptr, on_dev, n, _dptr(grid), _stream_ptr(stream)))
+
+    def pdsch_process_batch(self, pdus, tb_in, grid, stream=None):
+        """pdsch_processor::process for a batch of PDUs (host descriptors): transport blocks -> REs of the resource grid."""
+        assert isinstance(pdus, np.ndarray) and pdus.dtype == PdschPdu
+        pdus = np.ascontiguousarray(pdus)
+        check(lib().miphy_pdsch_process_batch(self.h, C.c_void_p(pdus.ctypes.data), pdus.size, _dptr(tb_in), _dptr(grid), _stream_ptr(stream)))
 
     # ------------------------------------------------------------------ PUSCH demodulator (equalise + soft-demap + descramble)
     def pusch_demodulate_batch(self, jobs, grid, ce, scalars, llr, stream=None):
