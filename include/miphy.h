@@ -591,6 +591,37 @@ int miphy_polar_decode_list_batch(miphy_ctx* ctx, const miphy_polar_code* code, 
                                   int32_t* metric_out /* device, n; may be NULL */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Open Fronthaul block-floating-point IQ (de)compression  --  replaces srsran::ofh::iq_decompressor::decompress and
+ * srsran::ofh::iq_compressor::compress for compression_type::BFP (U-plane payloads to / from the resource grid
+ * in device memory)
+ *   include/srsran/ofh/compression/iq_decompressor.h:35-52, iq_compressor.h:35-52, compressed_prb.h:36-80,
+ *   lib/ofh/compression/iq_compression_bfp_impl.cpp:28-143, iq_compression_bfp_avx2.cpp:31-132, compressed_prb.cpp:31-79,
+ *   quantizer.h:34-100, lib/srsvec/conversion.cpp:61-130
+ * A job is one U-plane section: `nof_prb` consecutive PRB records [udCompParam][24 x data_width bits, big endian]
+ * (1 + 3 * data_width bytes each, the bytes ofh_uplane_message_builder_impl.cpp:145-152 puts on the wire) and the nof_prb * 12
+ * subcarriers of one (port, symbol) row of a resource grid they belong to.
+ * Decompression: sample = sign_extend(bits) * 2^(udCompParam & 15) / 32767. `simd_arithmetic` != 0 reproduces the reference's
+ * production classes ("avx2" / "avx512": data_width 9 multiplies by the rounded reciprocal 1 / (32767 / 2^e)), 0 its generic
+ * class (a division for every width); both bit for bit. (For 9-bit samples and exponents 0..7 the two forms give the same
+ * single-precision value, tests/test_oracle_golden.py checks that exhaustively; the switch only matters for exponents a
+ * compliant RU does not send.)
+ * Compression (data_width 8..16; the reference's packing asserts below that): quantisation to 16 bits with
+ * scale 32767 * iq_scaling through srsvec::convert_round exactly (round to nearest even with saturation for the first
+ * floor(24 * nof_prb / 16) * 16 values of the job, round-half-away with a wrapping conversion for the rest), exponent from the
+ * largest magnitude of the PRB, arithmetic shift, packing. */
+typedef struct {
+  uint64_t payload_offset; /* byte offset of the first PRB record */
+  uint64_t grid_offset;    /* cf_t offset of the first subcarrier */
+  uint32_t nof_prb;        /* 1..275 */
+  uint32_t data_width;     /* 1..16 (compression: 8..16) */
+} miphy_ofh_bfp_job;
+
+int miphy_ofh_bfp_decompress_batch(miphy_ctx* ctx, const miphy_ofh_bfp_job* jobs, int jobs_on_device, uint32_t n, const uint8_t* payload /* device */,
+                                   float* grid /* device cf_t */, int simd_arithmetic, void* stream);
+int miphy_ofh_bfp_compress_batch(miphy_ctx* ctx, const miphy_ofh_bfp_job* jobs, int jobs_on_device, uint32_t n, const float* grid /* device cf_t */,
+                                 float iq_scaling, uint8_t* payload /* device */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Device-resident HARQ softbuffer pool  --  replaces srsran::rx_softbuffer_pool / rx_softbuffer
  *   include/srsran/phy/upper/rx_softbuffer_pool.h:31-96, include/srsran/phy/upper/rx_softbuffer.h:42-72,
  *   lib/phy/upper/rx_softbuffer_pool_impl.cpp:27-69, lib/phy/upper/rx_softbuffer_impl.h:33-258

@@ -22,7 +22,7 @@ CXX=${CXX:-g++}
 BASE="-std=c++14 -O3 -fPIC -fno-strict-aliasing -w -mavx -mavx2 -mfma -msse4.1 -mpclmul \
  -DHAVE_SSE -DHAVE_AVX -DHAVE_AVX2 -DHAVE_FMA \
  -I$R/include -I$R/external/fmt/include -I$R/external -I$R"
-SRCS=$(find $R/lib/phy $R/lib/srsvec $R/lib/srslog $R/lib/support $R/lib/ran -name '*.cpp' \
+SRCS=$(find $R/lib/phy $R/lib/srsvec $R/lib/srslog $R/lib/support $R/lib/ran $R/lib/ofh/compression -name '*.cpp' \
   | grep -v -E 'neon|fftw|generic_functions_factories\.cpp|config_yaml\.cpp|/version/version\.cpp|build_info\.cpp' | sort)
 SRCS="$SRCS $R/lib/scheduler/support/tbs_calculator.cpp $R/external/fmt/src/format.cc $R/external/fmt/src/os.cc"
 compile_one() {
@@ -30,6 +30,7 @@ compile_one() {
   o=$OBJ/$(echo "${src#$R/}" | tr '/' '_' | sed 's/\.[a-z]*$/.o/')
   extra=""
   case "$src" in
+    *ofh/compression/*avx512*) extra="-mavx512f -mavx512bw -mavx512vl -mavx512dq -mavx512cd" ;; # lib/ofh/compression/CMakeLists.txt:37-40
     *avx512*) extra="-mavx512f -mavx512bw" ;;
   esac
   if [ ! -f "$o" ] || [ "$src" -nt "$o" ]; then

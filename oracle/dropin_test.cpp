@@ -6,6 +6,7 @@
 // Built here (needs /root/reference), executed on the GPU box by tests/test_dropin_gpu.py.
 #include "lib/phy/generic_functions/dft_processor_generic_impl.h"
 #include "miphy_srsran_adapters.h"
+#include "srsran/ofh/compression/compression_factory.h"
 #include "srsran/phy/support/support_factories.h"
 #include "srsran/phy/upper/channel_modulation/channel_modulation_factories.h"
 #include "srsran/phy/upper/equalization/equalization_factories.h"
@@ -715,6 +716,47 @@ static void test_pdsch_processor(std::shared_ptr<miphy::context> c)
   printf("pdsch_processor done, failures so far %d\n", failures);
 }
 
+// Open Fronthaul BFP: the reference's production (de)compressor vs the HIP adapter, identical compressed PRBs and samples.
+static void test_ofh_bfp(std::shared_ptr<miphy::context> c)
+{
+  std::normal_distribution<float>    gauss(0.0F, 1.0F);
+  std::uniform_real_distribution<float> expo(-3.5F, 0.1F);
+  for (unsigned w : {9U, 14U, 16U, 8U, 12U}) {
+    for (unsigned nprb : {273U, 106U, 51U, 3U, 1U}) {
+      for (float scaling : {1.0F, 0.6F}) {
+        auto cmp_ref = ofh::create_iq_compressor(ofh::compression_type::BFP, scaling, "avx2");
+        auto dec_ref = ofh::create_iq_decompressor(ofh::compression_type::BFP, "avx2");
+        auto cmp_hip = miphy::create_iq_compressor_bfp_hip(c, scaling);
+        auto dec_hip = miphy::create_iq_decompressor_bfp_hip(c);
+        std::vector<cf_t> x(nprb * 12);
+        for (unsigned p = 0; p != nprb; ++p) {
+          float a = std::pow(10.0F, expo(rgen));
+          for (unsigned k = 0; k != 12; ++k) {
+            x[p * 12 + k] = cf_t(a * gauss(rgen), a * gauss(rgen));
+          }
+        }
+        ofh::ru_compression_params params;
+        params.type = ofh::compression_type::BFP, params.data_width = w;
+        std::vector<ofh::compressed_prb> p1(nprb), p2(nprb);
+        cmp_ref->compress(p1, x, params);
+        cmp_hip->compress(p2, x, params);
+        unsigned bad = 0;
+        for (unsigned p = 0; p != nprb; ++p) {
+          bad += p1[p].get_compression_param() != p2[p].get_compression_param();
+          span<const uint8_t> a = p1[p].get_packed_data(), b = p2[p].get_packed_data();
+          bad += a.size() != b.size() || !std::equal(a.begin(), a.end(), b.begin());
+        }
+        CHECK(bad == 0, "ofh bfp compress: width %u, %u PRBs: %u differences", w, nprb, bad);
+        std::vector<cf_t> y1(nprb * 12), y2(nprb * 12);
+        dec_ref->decompress(y1, p1, params);
+        dec_hip->decompress(y2, p1, params);
+        CHECK(std::memcmp(y1.data(), y2.data(), y1.size() * sizeof(cf_t)) == 0, "ofh bfp decompress: width %u, %u PRBs differ", w, nprb);
+      }
+    }
+  }
+  printf("ofh iq (de)compression BFP done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -897,6 +939,7 @@ int main()
   test_pusch_processor(c);
   test_pdsch_modulator_and_dmrs(c);
   test_pdsch_processor(c);
+  test_ofh_bfp(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);
     return 1;

@@ -1862,3 +1862,99 @@ int orc_dmrs_pdsch_map(unsigned slot_in_frame, unsigned reference_point_k_rb, in
   free(c);
   return 0;
 }
+
+/* ================================================================================================ Open Fronthaul BFP compression
+ * lib/ofh/compression/iq_compression_bfp_impl.cpp, compressed_prb.cpp, quantizer.h; include/srsran/ofh/compression/compression_params.h
+ * (Q_BIT_WIDTH = MAX_IQ_WIDTH = 16). */
+static unsigned ofh_extract_bits(const uint8_t* data, unsigned pos, unsigned length) /* compressed_prb::extract_bits (:63-79), MSB first */
+{
+  unsigned v = 0;
+  for (unsigned i = 0; i < length; ++i, ++pos)
+    v = (v << 1) | ((data[pos >> 3] >> (7 - (pos & 7))) & 1u);
+  return v;
+}
+
+void orc_ofh_bfp_decompress(const uint8_t* payload, unsigned nof_prb, unsigned w, int simd_arithmetic, float* out)
+{
+  const float gain = 32767.0f; /* quantizer(16): (1 << 15) - 1 */
+  for (unsigned p = 0; p < nof_prb; ++p) {
+    const uint8_t* rec      = payload + (size_t)p * (1 + 3 * w);
+    const unsigned exponent = rec[0];
+    const int16_t  scaler   = (int16_t)(1 << exponent);
+    for (unsigned i = 0; i < 24; ++i) {
+      /* quantizer::sign_extend (quantizer.h:88-92) */
+      int16_t v = (int16_t)ofh_extract_bits(rec + 1, i * w, w);
+      v         = (int16_t)((int16_t)(v << (16 - w)) >> (16 - w));
+      float f;
+      if (simd_arithmetic && w == 9) { /* quantizer::to_float(span) -> srsvec::convert(int16 -> float) */
+        const float scale = gain / scaler;
+        const float g     = 1.0f / scale;
+        f                 = (float)v * g;
+      } else { /* quantizer::to_float(int) (quantizer.h:70) */
+        f = (float)((int)v * (int)scaler) / gain;
+      }
+      out[(size_t)p * 24 + i] = f;
+    }
+  }
+}
+
+static unsigned ofh_determine_exponent(unsigned x, unsigned w) /* iq_compression_bfp_impl::determine_exponent (:28-41), x < 65536 */
+{
+  const unsigned max_shift = 16 - w;
+  unsigned       lz        = max_shift;
+  if (x > 0 && max_shift > 0) {
+    unsigned clz16 = 0;
+    while (!((x << clz16) & 0x8000u))
+      ++clz16;
+    lz = clz16 - 1;
+  }
+  const int raw = (int)(max_shift < lz ? max_shift : lz);
+  const int e   = (int)(16 - w) - raw;
+  return e > 0 ? (unsigned)e : 0;
+}
+
+void orc_ofh_bfp_compress(const float* in, unsigned nof_prb, unsigned w, float iq_scaling, uint8_t* payload)
+{
+  const float    scale = 32767.0f * iq_scaling; /* quantizer::to_fixed_point(span): gain * in_scale */
+  const unsigned len = 24 * nof_prb, simd_len = (len / 16) * 16;
+  int16_t*       q = (int16_t*)malloc(sizeof(int16_t) * (len ? len : 1));
+  for (unsigned i = 0; i < len; ++i) {
+    const float a = in[i] * scale;
+    if (i < simd_len) { /* _mm256_round_ps(nearest) + cvtps_epi32 + packs_epi32 */
+      const float r = rintf(a);
+      long        v;
+      if (!(r > -2147483904.0f && r < 2147483648.0f))
+        v = -2147483647L - 1; /* cvtps_epi32 integer indefinite (also NaN) */
+      else
+        v = (long)r;
+      q[i] = (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+    } else { /* static_cast<int16_t>(std::round(a)): what x86-64 makes of it -- cvttss2si to 32 bits (integer indefinite when out
+                of range), then the low 16 bits, so out-of-range values wrap here while they saturate in the SIMD part */
+      const float r = roundf(a);
+      const long  v = (r > -2147483904.0f && r < 2147483648.0f) ? (long)r : -2147483647L - 1;
+      q[i]          = (int16_t)(uint16_t)((unsigned long)v & 0xffffu);
+    }
+  }
+  for (unsigned p = 0; p < nof_prb; ++p) {
+    const int16_t* x  = q + p * 24;
+    int            mx = x[0], mn = x[0];
+    for (unsigned i = 1; i < 24; ++i) {
+      mx = x[i] > mx ? x[i] : mx;
+      mn = x[i] < mn ? x[i] : mn;
+    }
+    const int      a = abs(mx), b = abs(mn) - 1;
+    const unsigned max_abs  = (unsigned)(a > b ? a : b);
+    const unsigned exponent = ofh_determine_exponent(max_abs & 0xffffu, w);
+    uint8_t*       rec      = payload + (size_t)p * (1 + 3 * w);
+    memset(rec, 0, 1 + 3 * w);
+    rec[0] = (uint8_t)exponent;
+    for (unsigned i = 0; i < 24; ++i) { /* compressed_prb::pack_compressed_data (:31-61): the low w bits of each sample, MSB first */
+      const unsigned v = (unsigned)(uint16_t)(int16_t)(x[i] >> exponent);
+      for (unsigned b2 = 0; b2 < w; ++b2) {
+        const unsigned pos = i * w + b2;
+        rec[1 + (pos >> 3)] |= (uint8_t)(((v >> (w - 1 - b2)) & 1u) << (7 - (pos & 7)));
+      }
+    }
+  }
+  free(q);
+}

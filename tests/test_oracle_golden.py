@@ -190,3 +190,23 @@ def test_pdsch_modulator_and_dmrs():
         g = np.zeros_like(ref)
         O.o_dmrs_pdsch_map(int(slot), int(ref_pt), int(type2), int(scr), int(nscid), float(amp), d["dd_sm_%d" % i], d["dd_rb_%d" % i], list(range(int(nports))), g)
         assert np.array_equal(g.view(np.uint32), ref.view(np.uint32)), i
+
+
+def test_ofh_bfp():
+    """Open Fronthaul BFP: oracle against payloads / samples recorded from the reference's avx2 and generic classes."""
+    g = np.load(os.path.join(GOLD, "ofh_bfp.npz"))
+    for i, (w, nprb) in enumerate(g["cases"].tolist()):
+        pl = g["dec_payload_%d" % i]
+        assert np.array_equal(O.o_ofh_bfp_decompress(pl, nprb, w, True).view(np.uint32), g["dec_simd_%d" % i].view(np.uint32)), (w, nprb)
+        assert np.array_equal(O.o_ofh_bfp_decompress(pl, nprb, w, False).view(np.uint32), g["dec_generic_%d" % i].view(np.uint32)), (w, nprb)
+        if w >= 8:
+            for sc in (1.0, 0.37):
+                assert np.array_equal(O.o_ofh_bfp_compress(g["cmp_in_%d" % i], nprb, w, sc), g["cmp_out_%d_%d" % (i, int(sc * 100))]), (w, nprb, sc)
+    # The product form of the SIMD classes and the division of the generic class give the same single-precision value for every
+    # 9-bit sample and exponent 0..7 (checked exhaustively below), so the recorded outputs of the two classes coincide.
+    for i in range(len(g["cases"])):
+        assert np.array_equal(g["dec_simd_%d" % i].view(np.uint32), g["dec_generic_%d" % i].view(np.uint32))
+    x = np.arange(-256, 256, dtype=np.int32)
+    for e in range(8):
+        r = np.float32(1.0) / (np.float32(32767.0) / np.float32(1 << e))
+        assert np.array_equal((x.astype(np.float32) * r).view(np.uint32), ((x << e).astype(np.float32) / np.float32(32767.0)).view(np.uint32))
