@@ -13,6 +13,7 @@
 #include "srsran/phy/upper/rx_softbuffer_pool.h"
 #include "srsran/phy/upper/sequence_generators/sequence_generator_factories.h"
 #include "srsran/phy/upper/unique_rx_softbuffer.h"
+#include "srsran/phy/upper/upper_phy_rx_results_notifier.h"
 #include <cmath>
 #include <csignal>
 #include <execinfo.h>
@@ -423,7 +424,7 @@ struct notifier_spy : public pusch_processor_result_notifier {
 };
 } // namespace
 
-static std::unique_ptr<pusch_processor> make_processor(std::shared_ptr<miphy::context> c, bool hip)
+static std::unique_ptr<pusch_processor> make_processor(std::shared_ptr<miphy::context> c, bool hip, unsigned nof_rx_ports = 1)
 {
   auto prg  = create_pseudo_random_generator_sw_factory();
   auto crcf = create_crc_calculator_factory_sw("auto");
@@ -443,7 +444,7 @@ static std::unique_ptr<pusch_processor> make_processor(std::shared_ptr<miphy::co
   pc.decoder_factory     = hip ? miphy::create_pusch_decoder_factory_hip(c) : create_pusch_decoder_factory_sw(dc);
   pc.uci_dec_factory     = create_uci_decoder_factory_sw(uc);
   pc.ch_estimate_dimensions.nof_prb = MAX_RB, pc.ch_estimate_dimensions.nof_symbols = MAX_NSYMB_PER_SLOT;
-  pc.ch_estimate_dimensions.nof_rx_ports = 1, pc.ch_estimate_dimensions.nof_tx_layers = 1;
+  pc.ch_estimate_dimensions.nof_rx_ports = nof_rx_ports, pc.ch_estimate_dimensions.nof_tx_layers = 1;
   pc.dec_nof_iterations = 6, pc.dec_enable_early_stop = true;
   return create_pusch_processor_factory_sw(pc)->create();
 }
@@ -757,6 +758,206 @@ static void test_ofh_bfp(std::shared_ptr<miphy::context> c)
   printf("ofh iq (de)compression BFP done, failures so far %d\n", failures);
 }
 
+// uplink_processor: the PUSCH PDUs of a slot in one device submission (uplink_processor_hip + rx_softbuffer_pool_hip) against
+// the reference chain the gNB runs per PDU (uplink_processor_impl::process_pusch: software pusch_processor + rx_softbuffer_pool),
+// three UEs on a two-port grid, retransmissions in later slots.
+namespace {
+struct recorded_result {
+  unsigned                  rnti, harq_id;
+  bool                      crc_ok;
+  unsigned                  nof_codeblocks;
+  std::vector<uint8_t>      payload;
+  channel_state_information csi;
+};
+class results_recorder : public upper_phy_rx_results_notifier
+{
+public:
+  void on_new_prach_results(const ul_prach_results& /**/) override {}
+  void on_new_pusch_results_control(const ul_pusch_results_control& /**/) override {}
+  void on_new_pucch_results(const ul_pucch_results& /**/) override {}
+  void on_new_pusch_results_data(const ul_pusch_results_data& r) override
+  {
+    results.push_back(recorded_result{static_cast<unsigned>(r.rnti), r.harq_id, r.decoder_result.tb_crc_ok, r.decoder_result.nof_codeblocks_total,
+                                      std::vector<uint8_t>(r.payload.begin(), r.payload.end()), r.csi});
+  }
+  std::vector<recorded_result> results;
+};
+// uplink_processor_impl.cpp:41-105 / :155-172
+class ref_adaptor : public pusch_processor_result_notifier
+{
+public:
+  ref_adaptor(upper_phy_rx_results_notifier& n, const uplink_processor::pusch_pdu& pdu, span<const uint8_t> payload) : n(n), pdu(pdu), payload(payload) {}
+  void on_csi(const channel_state_information& v) override { csi = v; }
+  void on_uci(const pusch_processor_result_control& /**/) override {}
+  void on_sch(const pusch_processor_result_data& sch) override
+  {
+    ul_pusch_results_data out;
+    out.rnti = to_rnti(pdu.pdu.rnti), out.slot = pdu.pdu.slot, out.csi = csi, out.harq_id = pdu.harq_id, out.decoder_result = sch.data;
+    out.payload = sch.data.tb_crc_ok ? payload : span<const uint8_t>();
+    n.on_new_pusch_results_data(out);
+    ok = sch.data.tb_crc_ok;
+  }
+  bool ok = false;
+
+private:
+  upper_phy_rx_results_notifier&     n;
+  const uplink_processor::pusch_pdu& pdu;
+  span<const uint8_t>                payload;
+  channel_state_information          csi = {};
+};
+} // namespace
+
+static void test_uplink_processor(std::shared_ptr<miphy::context> c)
+{
+  const unsigned grid_rb = 106, nsc = grid_rb * 12, nof_ports = 2;
+  auto           crcf = create_crc_calculator_factory_sw("auto");
+  auto           prg  = create_pseudo_random_generator_sw_factory();
+  pdsch_encoder_factory_sw_configuration ec;
+  ec.encoder_factory      = create_ldpc_encoder_factory_sw("avx2");
+  ec.rate_matcher_factory = create_ldpc_rate_matcher_factory_sw();
+  ec.segmenter_factory    = create_ldpc_segmenter_tx_factory_sw(crcf);
+  auto tx = create_pdsch_processor_factory_sw(create_pdsch_encoder_factory_sw(ec), create_pdsch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg),
+                                              create_dmrs_pdsch_processor_factory_sw(prg))
+                ->create();
+  auto                      p_ref = make_processor(c, false, nof_ports);
+  rx_softbuffer_pool_config pc;
+  pc.max_codeblock_size = ldpc::MAX_CODEBLOCK_SIZE, pc.max_softbuffers = 8, pc.max_nof_codeblocks = 64, pc.expire_timeout_slots = 100;
+  auto                        pool_ref = create_rx_softbuffer_pool(pc);
+  auto                        pool_hip = miphy::create_rx_softbuffer_pool_hip(c, pc);
+  miphy::uplink_processor_hip ul_hip(c, nullptr, nullptr, nof_ports, grid_rb, 6, true);
+  struct ue {
+    unsigned          rnti, harq, rb_start, nprb, tbs;
+    modulation_scheme mod;
+    float             backoff_db; // transmit power below the other UEs
+    std::vector<uint8_t> tb;
+    unsigned             tx   = 0;
+    bool                 done = false;
+  };
+  std::vector<ue> ues = {{0x4601, 1, 0, 60, 42016, modulation_scheme::QAM64, 0.0F, {}}, {0x4602, 0, 60, 30, 3848, modulation_scheme::QPSK, 0.0F, {}},
+                         {0x4603, 5, 90, 16, 3848, modulation_scheme::QAM16, 10.0F, {}}};
+  std::uniform_int_distribution<int> byte(0, 255);
+  for (ue& u : ues) {
+    u.tb.resize(u.tbs / 8);
+    for (auto& b : u.tb) {
+      b = byte(rgen);
+    }
+  }
+  const unsigned   rvs[4] = {0, 2, 3, 1};
+  symbol_slot_mask dm(14);
+  dm.set(2);
+  unsigned compared = 0, failed_first = 0, recovered = 0;
+  for (unsigned round = 0; round != 4; ++round) {
+    slot_point slot(1, 20 + 8 * round);
+    // transmit side: every pending UE into one grid, then two receive ports with different gains and noise
+    auto txg = create_resource_grid(1, 14, nsc), rxg = create_resource_grid(nof_ports, 14, nsc);
+    txg->set_all_zero();
+    std::vector<uplink_processor::pusch_pdu> pdus;
+    for (ue& u : ues) {
+      if (u.done) {
+        continue;
+      }
+      ldpc_base_graph_type bg = (u.tbs > 3824) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+      pdsch_processor::pdu_t t;
+      t.slot = slot, t.rnti = u.rnti, t.bwp_size_rb = grid_rb, t.bwp_start_rb = 0, t.cp = cyclic_prefix::NORMAL;
+      t.codewords.push_back(pdsch_processor::codeword_description{u.mod, static_cast<uint8_t>(rvs[u.tx])});
+      t.n_id = 100 + u.harq;
+      t.ports.push_back(0);
+      t.ref_point = pdsch_processor::pdu_t::CRB0, t.dmrs_symbol_mask = dm, t.dmrs = dmrs_type::TYPE1, t.scrambling_id = 500 + u.harq, t.n_scid = false;
+      t.nof_cdm_groups_without_data = 2, t.freq_alloc = rb_allocation::make_type1(u.rb_start, u.nprb), t.start_symbol_index = 0, t.nof_symbols = 14;
+      t.ldpc_base_graph = bg, t.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8;
+      const float fade_db = (u.rnti == 0x4603 && u.tx == 0) ? 14.0F : 0.0F; // the first transmission of this UE is lost in a fade
+      t.ratio_pdsch_data_to_sss_dB = u.backoff_db + fade_db, t.ratio_pdsch_dmrs_to_sss_dB = u.backoff_db + fade_db - 3.0F; // DM-RS 3 dB above the data
+      static_vector<span<const uint8_t>, pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS> data;
+      data.emplace_back(u.tb);
+      tx->process(*txg, data, t);
+      uplink_processor::pusch_pdu up;
+      up.harq_id = u.harq, up.tb_size = u.tb.size();
+      pusch_processor::pdu_t& pdu = up.pdu;
+      pdu.slot = slot, pdu.rnti = u.rnti, pdu.bwp_size_rb = grid_rb, pdu.bwp_start_rb = 0, pdu.cp = cyclic_prefix::NORMAL;
+      pdu.mcs_descr.modulation = u.mod, pdu.mcs_descr.target_code_rate = 0.5F;
+      pdu.codeword.emplace();
+      pdu.codeword.value().rv = rvs[u.tx], pdu.codeword.value().ldpc_base_graph = bg, pdu.codeword.value().new_data = (u.tx == 0);
+      pdu.uci = {};
+      pdu.uci.alpha_scaling = 1.0F, pdu.uci.beta_offset_harq_ack = 20.0F, pdu.uci.beta_offset_csi_part1 = 6.25F, pdu.uci.beta_offset_csi_part2 = 6.25F;
+      pdu.n_id = 100 + u.harq, pdu.nof_tx_layers = 1;
+      pdu.rx_ports.push_back(0);
+      pdu.rx_ports.push_back(1);
+      pdu.dmrs_symbol_mask = dm, pdu.dmrs = dmrs_type::TYPE1, pdu.scrambling_id = 500 + u.harq, pdu.n_scid = false, pdu.nof_cdm_groups_without_data = 2;
+      pdu.freq_alloc = rb_allocation::make_type1(u.rb_start, u.nprb);
+      pdu.start_symbol_index = 0, pdu.nof_symbols = 14, pdu.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8;
+      pdus.push_back(up);
+    }
+    if (pdus.empty()) {
+      break;
+    }
+    std::normal_distribution<float> noise(0.F, 0.08F * 0.7071F);
+    const cf_t                      gain[2] = {cf_t(1.0F, 0.0F), cf_t(0.45F, 0.55F)};
+    std::vector<cf_t>               row(nsc), out(nsc);
+    for (unsigned l = 0; l != 14; ++l) {
+      txg->get(row, 0, l, 0);
+      for (unsigned p = 0; p != nof_ports; ++p) {
+        for (unsigned k = 0; k != nsc; ++k) {
+          out[k] = gain[p] * row[k] + cf_t(noise(rgen), noise(rgen));
+        }
+        rxg->put(p, l, 0, out);
+      }
+    }
+    // reference: what upper_phy_rx_symbol_handler_impl::process_pusch + uplink_processor_impl::process_pusch do per PDU
+    results_recorder                  rec_ref, rec_hip;
+    std::vector<std::vector<uint8_t>> pay_ref(pdus.size()), pay_hip(pdus.size());
+    for (size_t i = 0; i != pdus.size(); ++i) {
+      const auto&              pdu = pdus[i];
+      rx_softbuffer_identifier id;
+      id.rnti = pdu.pdu.rnti, id.harq_ack_id = pdu.harq_id;
+      unsigned ncb = ldpc::compute_nof_codeblocks(units::bytes(pdu.tb_size).to_bits(), pdu.pdu.codeword->ldpc_base_graph);
+      pay_ref[i].assign(pdu.tb_size, 0), pay_hip[i].assign(pdu.tb_size, 0);
+      unique_rx_softbuffer b1 = pool_ref->reserve_softbuffer(slot, id, ncb);
+      CHECK(b1.is_valid(), "uplink_processor: reference softbuffer");
+      ref_adaptor ad(rec_ref, pdu, pay_ref[i]);
+      p_ref->process(pay_ref[i], b1.get(), ad, *rxg, pdu.pdu);
+      if (ad.ok) {
+        b1.release();
+      }
+      unique_rx_softbuffer b2 = pool_hip->reserve_softbuffer(slot, id, ncb);
+      CHECK(b2.is_valid(), "uplink_processor: device softbuffer");
+      ul_hip.process_pusch(pay_hip[i], std::move(b2), rec_hip, *rxg, pdu);
+    }
+    CHECK(rec_hip.results.empty(), "uplink_processor_hip must queue until flush()");
+    ul_hip.flush();
+    CHECK(rec_ref.results.size() == pdus.size() && rec_hip.results.size() == pdus.size(), "uplink_processor: %zu / %zu results for %zu PDUs", rec_ref.results.size(),
+          rec_hip.results.size(), pdus.size());
+    for (size_t i = 0; i != pdus.size() && i < rec_hip.results.size() && i < rec_ref.results.size(); ++i) {
+      const recorded_result &a = rec_ref.results[i], &b = rec_hip.results[i];
+      CHECK(a.rnti == b.rnti && a.harq_id == b.harq_id && a.crc_ok == b.crc_ok && a.nof_codeblocks == b.nof_codeblocks && a.payload == b.payload,
+            "uplink_processor: round %u PDU %zu: rnti %x/%x crc %d/%d payload %zu/%zu bytes", round, i, a.rnti, b.rnti, (int)a.crc_ok, (int)b.crc_ok, a.payload.size(),
+            b.payload.size());
+      CHECK(std::abs(a.csi.epre_dB - b.csi.epre_dB) < 1e-3F && std::abs(a.csi.rsrp_dB - b.csi.rsrp_dB) < 1e-3F && std::abs(a.csi.sinr_dB - b.csi.sinr_dB) < 2e-2F,
+            "uplink_processor: round %u PDU %zu CSI: epre %g/%g rsrp %g/%g sinr %g/%g", round, i, a.csi.epre_dB, b.csi.epre_dB, a.csi.rsrp_dB, b.csi.rsrp_dB,
+            a.csi.sinr_dB, b.csi.sinr_dB);
+      ++compared;
+      for (ue& u : ues) {
+        if (u.rnti == a.rnti) {
+          if (a.crc_ok) {
+            CHECK(a.payload == u.tb, "uplink_processor: wrong transport block for rnti %x", a.rnti);
+            u.done = true;
+            recovered += u.tx > 0;
+          } else {
+            failed_first += u.tx == 0;
+            ++u.tx;
+          }
+        }
+      }
+    }
+    pool_ref->run_slot(slot), pool_hip->run_slot(slot);
+  }
+  CHECK(compared >= 4 && failed_first >= 1 && recovered >= 1, "uplink_processor: scenario not exercised (%u compared, %u failed first, %u recovered)", compared, failed_first,
+        recovered);
+  for (const ue& u : ues) {
+    CHECK(u.done, "uplink_processor: rnti %x never decoded", u.rnti);
+  }
+  printf("uplink_processor (slot batch, device HARQ pool) done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -937,6 +1138,7 @@ int main()
   test_pdcch(c);
   test_pusch_demodulator(c);
   test_pusch_processor(c);
+  test_uplink_processor(c);
   test_pdsch_modulator_and_dmrs(c);
   test_pdsch_processor(c);
   test_ofh_bfp(c);

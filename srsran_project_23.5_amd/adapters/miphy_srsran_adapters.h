@@ -25,6 +25,8 @@
 #include "srsran/phy/upper/rx_softbuffer.h"
 #include "srsran/phy/upper/rx_softbuffer_pool.h"
 #include "srsran/phy/upper/unique_rx_softbuffer.h"
+#include "srsran/phy/upper/uplink_processor.h"
+#include "srsran/phy/upper/upper_phy_rx_results_notifier.h"
 #include "srsran/phy/upper/signal_processors/signal_processor_factories.h"
 #include "srsran/support/error_handling.h"
 #include <algorithm>
@@ -1006,6 +1008,261 @@ private:
   std::shared_ptr<context> c;
   unsigned                 nof_iterations;
   bool                     early_stop;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- uplink processor
+/// srsran::uplink_processor (uplink_processor.h:52-98, lib/phy/upper/uplink_processor_impl.cpp:143-214) that batches the PUSCH
+/// PDUs of a slot into one device submission: process_pusch() only queues the PDU, flush() uploads the resource grid once,
+/// runs miphy_pusch_process_batch over all queued PDUs and then notifies the results in the order the PDUs were queued, with
+/// the notifications of uplink_processor_impl (channel state information, decoder result, payload view only when the CRC
+/// passed, softbuffer released when the CRC passed). PRACH detection and PUCCH processing are delegated to the CPU blocks given
+/// at construction. The softbuffers must come from rx_softbuffer_pool_hip (HARQ state resident on the device); a PDU with any
+/// other softbuffer is processed at once through the per-PDU path.
+///
+/// The interface has no end-of-slot call: the caller invokes flush() after its loop over the PDUs of the slot
+/// (upper_phy_rx_symbol_handler_impl.cpp:97-107); a PDU of another slot, a full queue and the destructor flush as well.
+class uplink_processor_hip : public srsran::uplink_processor
+{
+public:
+  uplink_processor_hip(std::shared_ptr<context>                 c,
+                       std::unique_ptr<srsran::prach_detector>  prach,
+                       std::unique_ptr<srsran::pucch_processor> pucch,
+                       unsigned                                 grid_nof_ports,
+                       unsigned                                 grid_nof_prb,
+                       unsigned                                 dec_nof_iterations,
+                       bool                                     dec_enable_early_stop,
+                       unsigned                                 max_batch = 64) :
+    c(std::move(c)),
+    prach(std::move(prach)),
+    pucch(std::move(pucch)),
+    single(this->c, dec_nof_iterations, dec_enable_early_stop),
+    nports(grid_nof_ports),
+    nprb(grid_nof_prb),
+    nof_iterations(dec_nof_iterations),
+    early_stop(dec_enable_early_stop),
+    max_batch(max_batch)
+  {
+  }
+  ~uplink_processor_hip() override { flush(); }
+
+  void process_prach(srsran::upper_phy_rx_results_notifier& notifier, const srsran::prach_buffer& buffer, const srsran::prach_buffer_context& context) override
+  {
+    srsran_assert(prach, "A PRACH detector is required.");
+    srsran::ul_prach_results r;
+    r.context = context;
+    srsran::prach_detector::configuration cfg;
+    cfg.root_sequence_index = context.root_sequence_index, cfg.format = context.format, cfg.restricted_set = context.restricted_set;
+    cfg.zero_correlation_zone = context.zero_correlation_zone, cfg.start_preamble_index = context.start_preamble_index;
+    cfg.nof_preamble_indices = context.nof_preamble_indices, cfg.ra_scs = srsran::to_ra_subcarrier_spacing(context.pusch_scs);
+    r.result = prach->detect(buffer, cfg);
+    notifier.on_new_prach_results(r);
+  }
+
+  void process_pucch(srsran::upper_phy_rx_results_notifier& notifier, const srsran::resource_grid_reader& grid, const pucch_pdu& pdu) override
+  {
+    srsran_assert(pucch, "A PUCCH processor is required.");
+    srsran::ul_pucch_results r;
+    r.context = pdu.context;
+    switch (pdu.context.format) {
+      case srsran::pucch_format::FORMAT_0:
+        r.processor_result = pucch->process(grid, pdu.format0);
+        break;
+      case srsran::pucch_format::FORMAT_1:
+        r.processor_result = pucch->process(grid, pdu.format1);
+        break;
+      case srsran::pucch_format::FORMAT_2:
+        r.processor_result = pucch->process(grid, pdu.format2);
+        break;
+      case srsran::pucch_format::FORMAT_3:
+        r.processor_result = pucch->process(grid, pdu.format3);
+        break;
+      default:
+        r.processor_result = pucch->process(grid, pdu.format4);
+        break;
+    }
+    notifier.on_new_pucch_results(r);
+  }
+
+  void process_pusch(srsran::span<uint8_t>                  data,
+                     srsran::unique_rx_softbuffer           softbuffer,
+                     srsran::upper_phy_rx_results_notifier& notifier,
+                     const srsran::resource_grid_reader&    grid,
+                     const pusch_pdu&                       pdu) override
+  {
+    auto* resident = dynamic_cast<rx_softbuffer_hip*>(&softbuffer.get());
+    if (resident == nullptr) { // not a device softbuffer: per-PDU path, like uplink_processor_impl::process_pusch
+      notifier_adaptor n(notifier, pdu, data);
+      single.process(data, softbuffer.get(), n, grid, pdu.pdu);
+      if (n.tb_crc_ok) {
+        softbuffer.release();
+      }
+      return;
+    }
+    if (!queue.empty() && (queue.front().pdu.pdu.slot != pdu.pdu.slot || queue_grid != &grid || queue.size() >= max_batch)) {
+      flush();
+    }
+    queue_grid = &grid;
+    queue.emplace_back(entry{data, std::move(softbuffer), resident, &notifier, pdu});
+  }
+
+  /// Submits the queued PUSCH PDUs as one batch and delivers their results.
+  void flush()
+  {
+    if (queue.empty()) {
+      return;
+    }
+    const unsigned n = queue.size(), nsc = nprb * 12;
+    host.resize(static_cast<size_t>(nports) * 14 * nsc);
+    for (unsigned p = 0; p != nports; ++p) {
+      for (unsigned l = 0; l != 14; ++l) {
+        queue_grid->get(srsran::span<srsran::cf_t>(host.data() + (static_cast<size_t>(p) * 14 + l) * nsc, nsc), p, l, 0);
+      }
+    }
+    std::vector<miphy_pusch_pdu> pdus(n);
+    size_t                       tb_bytes = 0;
+    int8_t*                      d_soft   = queue.front().resident->softbits();
+    uint8_t *                    d_msg = queue.front().resident->msgs(), *d_crc = queue.front().resident->crc_ok();
+    for (unsigned i = 0; i != n; ++i) {
+      entry&                                  e   = queue[i];
+      const srsran::pusch_processor::pdu_t&   pdu = e.pdu.pdu;
+      srsran_assert(e.resident->softbits() == d_soft, "All softbuffers of a batch must belong to the same device pool.");
+      srsran_assert(pdu.uci.nof_harq_ack == 0 && pdu.uci.nof_csi_part1 == 0 && pdu.uci.nof_csi_part2 == 0 && pdu.codeword.has_value(),
+                    "UCI on PUSCH / PDUs without codeword are not supported.");
+      srsran_assert(pdu.dmrs == srsran::dmrs_type::TYPE1 && pdu.nof_cdm_groups_without_data == 2 && pdu.nof_tx_layers == 1,
+                    "Only DM-RS type 1, two CDM groups without data and one layer are supported.");
+      const srsran::bounded_bitset<srsran::MAX_RB> rb_mask = pdu.freq_alloc.get_prb_mask(pdu.bwp_start_rb, pdu.bwp_size_rb);
+      srsran_assert(rb_mask.size() <= nprb, "The allocation exceeds the resource grid.");
+      e.resident->flush();
+      miphy_pusch_pdu& p = pdus[i];
+      p                  = {};
+      p.numerology = pdu.slot.numerology(), p.slot_in_frame = pdu.slot.slot_index(), p.rnti = pdu.rnti, p.n_id = pdu.n_id;
+      p.dmrs_scrambling_id = pdu.scrambling_id, p.Nref = pdu.tbs_lbrm_bytes * 8, p.tb_bytes = e.data.size();
+      p.harq_cb_index = e.resident->first_cb();
+      p.n_scid = pdu.n_scid, p.mod = srsran::get_bits_per_symbol(pdu.mcs_descr.modulation), p.nof_rx_ports = pdu.rx_ports.size();
+      p.start_symbol = pdu.start_symbol_index, p.nof_symbols = pdu.nof_symbols;
+      p.bg = bg_id(pdu.codeword.value().ldpc_base_graph), p.rv = pdu.codeword.value().rv, p.new_data = pdu.codeword.value().new_data;
+      p.use_early_stop = early_stop, p.nof_ldpc_iterations = nof_iterations, p.grid_nof_prb = nprb;
+      for (unsigned k = 0; k != pdu.rx_ports.size(); ++k) {
+        srsran_assert(pdu.rx_ports[k] < nports, "Receive port outside the resource grid.");
+        p.rx_ports[k] = pdu.rx_ports[k];
+      }
+      for (unsigned l = 0; l != 14 && l != pdu.dmrs_symbol_mask.size(); ++l) {
+        if (pdu.dmrs_symbol_mask.test(l)) {
+          p.dmrs_symbols_mask |= static_cast<uint16_t>(1U << l);
+        }
+      }
+      rb_mask.for_each(0, rb_mask.size(), [&p](unsigned r) { p.rb_mask[r >> 6] |= 1ULL << (r & 63); });
+      p.grid_offset = 0, p.tb_offset = tb_bytes;
+      tb_bytes += (e.data.size() + 15) & ~static_cast<size_t>(15);
+    }
+    auto*    d_g    = static_cast<float*>(c->buf(0, host.size() * sizeof(srsran::cf_t)));
+    auto*    d_tb   = static_cast<uint8_t*>(c->buf(1, tb_bytes + 16));
+    auto*    d_misc = static_cast<uint8_t*>(c->buf(2, static_cast<size_t>(n) * (sizeof(miphy_pusch_result) + 80) + 64));
+    auto*    d_res  = reinterpret_cast<miphy_pusch_result*>(d_misc);
+    auto*    d_sc   = reinterpret_cast<float*>(d_misc + ((static_cast<size_t>(n) * sizeof(miphy_pusch_result) + 63) & ~static_cast<size_t>(63)));
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    context::check(miphy_pusch_process_batch(c->ctx, pdus.data(), n, d_g, d_soft, d_msg, d_crc, d_tb, d_res, d_sc, c->stream), "pusch_process");
+    std::vector<miphy_pusch_result> res(n);
+    std::vector<float>              sc(static_cast<size_t>(n) * 20);
+    tbs.resize(tb_bytes);
+    c->d2h(res.data(), d_res, n * sizeof(miphy_pusch_result));
+    c->d2h(sc.data(), d_sc, sc.size() * sizeof(float));
+    c->d2h(tbs.data(), d_tb, tb_bytes);
+    c->sync();
+    for (unsigned i = 0; i != n; ++i) {
+      entry&                      e = queue[i];
+      const miphy_pusch_result&   r = res[i];
+      srsran::ul_pusch_results_data out;
+      out.rnti = srsran::to_rnti(e.pdu.pdu.rnti), out.slot = e.pdu.pdu.slot, out.harq_id = e.pdu.harq_id;
+      out.csi = csi_of(&sc[static_cast<size_t>(i) * 20], e.pdu.pdu.rx_ports.size());
+      fill_decoder_result(out.decoder_result, r);
+      if (r.tb_crc_ok != 0) {
+        std::memcpy(e.data.data(), &tbs[pdus[i].tb_offset], e.data.size());
+        out.payload = e.data;
+      }
+      e.notifier->on_new_pusch_results_data(out);
+      if (r.tb_crc_ok != 0) {
+        e.softbuffer.release();
+      }
+    }
+    queue.clear(); // the remaining unique_rx_softbuffers unlock here
+  }
+
+  /// channel_estimate::get_channel_state_information (channel_estimation.h:211-232) from the estimator scalars of a PDU.
+  static srsran::channel_state_information csi_of(const float* sc, unsigned nof_ports)
+  {
+    srsran::channel_state_information csi = {};
+    float                             epre = 0, rsrp = 0, snr = 0;
+    double                            ta   = 0;
+    for (unsigned i = 0; i != nof_ports; ++i) {
+      rsrp += sc[5 * i + 0], epre += sc[5 * i + 1], snr += sc[5 * i + 3], ta += sc[5 * i + 4];
+    }
+    csi.epre_dB        = srsran::convert_power_to_dB(epre / static_cast<float>(nof_ports));
+    csi.rsrp_dB        = srsran::convert_power_to_dB(rsrp / static_cast<float>(nof_ports));
+    csi.sinr_dB        = srsran::convert_power_to_dB(snr / static_cast<float>(nof_ports));
+    csi.time_alignment = srsran::phy_time_unit::from_seconds(ta / nof_ports);
+    return csi;
+  }
+  static void fill_decoder_result(srsran::pusch_decoder_result& out, const miphy_pusch_result& r)
+  {
+    out.tb_crc_ok            = r.tb_crc_ok != 0;
+    out.nof_codeblocks_total = r.nof_codeblocks_total;
+    out.ldpc_decoder_stats.reset();
+    if (r.nof_decoded > 0) {
+      out.ldpc_decoder_stats.update(r.iters_min);
+      for (unsigned i = 1; i + 1 < r.nof_decoded; ++i) {
+        out.ldpc_decoder_stats.update(static_cast<unsigned>(r.iters_mean + 0.5F));
+      }
+      if (r.nof_decoded > 1) {
+        out.ldpc_decoder_stats.update(r.iters_max);
+      }
+    }
+  }
+
+private:
+  /// pusch_processor_result_notifier_adaptor of uplink_processor_impl.cpp:41-105 for the per-PDU path.
+  class notifier_adaptor : public srsran::pusch_processor_result_notifier
+  {
+  public:
+    notifier_adaptor(srsran::upper_phy_rx_results_notifier& n, const pusch_pdu& pdu, srsran::span<const uint8_t> payload) : n(n), pdu(pdu), payload(payload) {}
+    void on_csi(const srsran::channel_state_information& v) override { csi = v; }
+    void on_uci(const srsran::pusch_processor_result_control& /**/) override {}
+    void on_sch(const srsran::pusch_processor_result_data& sch) override
+    {
+      srsran::ul_pusch_results_data out;
+      out.rnti = srsran::to_rnti(pdu.pdu.rnti), out.slot = pdu.pdu.slot, out.csi = csi, out.harq_id = pdu.harq_id;
+      out.decoder_result = sch.data;
+      out.payload        = sch.data.tb_crc_ok ? payload : srsran::span<const uint8_t>();
+      n.on_new_pusch_results_data(out);
+      tb_crc_ok = sch.data.tb_crc_ok;
+    }
+    bool tb_crc_ok = false;
+
+  private:
+    srsran::upper_phy_rx_results_notifier& n;
+    const pusch_pdu&                       pdu;
+    srsran::span<const uint8_t>            payload;
+    srsran::channel_state_information      csi = {};
+  };
+  struct entry {
+    srsran::span<uint8_t>                  data;
+    srsran::unique_rx_softbuffer           softbuffer;
+    rx_softbuffer_hip*                     resident;
+    srsran::upper_phy_rx_results_notifier* notifier;
+    pusch_pdu                              pdu;
+  };
+
+  std::shared_ptr<context>                 c;
+  std::unique_ptr<srsran::prach_detector>  prach;
+  std::unique_ptr<srsran::pucch_processor> pucch;
+  pusch_processor_hip                      single;
+  unsigned                                 nports, nprb, nof_iterations;
+  bool                                     early_stop;
+  unsigned                                 max_batch;
+  std::vector<entry>                       queue;
+  const srsran::resource_grid_reader*      queue_grid = nullptr;
+  std::vector<srsran::cf_t>                host;
+  std::vector<uint8_t>                     tbs;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- PDSCH modulator / DM-RS
