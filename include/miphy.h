@@ -591,35 +591,42 @@ int miphy_polar_decode_list_batch(miphy_ctx* ctx, const miphy_polar_code* code, 
                                   int32_t* metric_out /* device, n; may be NULL */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Open Fronthaul block-floating-point IQ (de)compression  --  replaces srsran::ofh::iq_decompressor::decompress and
- * srsran::ofh::iq_compressor::compress for compression_type::BFP (U-plane payloads to / from the resource grid
- * in device memory)
- *   include/srsran/ofh/compression/iq_decompressor.h:35-52, iq_compressor.h:35-52, compressed_prb.h:36-80,
- *   lib/ofh/compression/iq_compression_bfp_impl.cpp:28-143, iq_compression_bfp_avx2.cpp:31-132, compressed_prb.cpp:31-79,
- *   quantizer.h:34-100, lib/srsvec/conversion.cpp:61-130
- * A job is one U-plane section: `nof_prb` consecutive PRB records [udCompParam][24 x data_width bits, big endian]
- * (1 + 3 * data_width bytes each, the bytes ofh_uplane_message_builder_impl.cpp:145-152 puts on the wire) and the nof_prb * 12
- * subcarriers of one (port, symbol) row of a resource grid they belong to.
- * Decompression: sample = sign_extend(bits) * 2^(udCompParam & 15) / 32767. `simd_arithmetic` != 0 reproduces the reference's
- * production classes ("avx2" / "avx512": data_width 9 multiplies by the rounded reciprocal 1 / (32767 / 2^e)), 0 its generic
- * class (a division for every width); both bit for bit. (For 9-bit samples and exponents 0..7 the two forms give the same
- * single-precision value, tests/test_oracle_golden.py checks that exhaustively; the switch only matters for exponents a
- * compliant RU does not send.)
- * Compression (data_width 8..16; the reference's packing asserts below that): quantisation to 16 bits with
- * scale 32767 * iq_scaling through srsvec::convert_round exactly (round to nearest even with saturation for the first
- * floor(24 * nof_prb / 16) * 16 values of the job, round-half-away with a wrapping conversion for the rest), exponent from the
- * largest magnitude of the PRB, arithmetic shift, packing. */
+ * Open Fronthaul IQ (de)compression  --  replaces srsran::ofh::iq_decompressor::decompress and
+ * srsran::ofh::iq_compressor::compress for the two methods the reference implements, compression_type::none (fixed point)
+ * and compression_type::BFP (block floating point) (U-plane payloads to / from the resource grid in device memory)
+ *   include/srsran/ofh/compression/iq_decompressor.h:35-52, iq_compressor.h:35-52, compressed_prb.h:36-80, compression_params.h:38-53,
+ *   lib/ofh/compression/iq_compression_bfp_impl.cpp:28-143, iq_compression_bfp_avx2.cpp:31-132, iq_compression_none_impl.cpp:29-69,
+ *   compressed_prb.cpp:31-79, quantizer.h:34-100, lib/srsvec/conversion.cpp:61-130
+ * A job is one U-plane section: `nof_prb` consecutive PRB records as ofh_uplane_message_builder_impl.cpp:145-152 puts them on the
+ * wire -- BFP: [udCompParam][24 x data_width bits, big endian] (1 + 3 * data_width bytes), none: the 3 * data_width bytes of
+ * samples only -- and the nof_prb * 12 subcarriers of one (port, symbol) row of a resource grid they belong to.
+ * Decompression: BFP sample = sign_extend(bits) * 2^(udCompParam & 15) / 32767; none sample = sign_extend(bits) / (2^(w-1) - 1).
+ * `simd_arithmetic` != 0 reproduces the reference's production BFP classes ("avx2" / "avx512": data_width 9 multiplies by the
+ * rounded reciprocal 1 / (32767 / 2^e)), 0 its generic class (a division for every width); both bit for bit. (For 9-bit samples
+ * and exponents 0..7 the two forms give the same single-precision value, tests/test_oracle_golden.py checks that exhaustively;
+ * the switch only matters for exponents a compliant RU does not send.)
+ * Compression (data_width 8..16; the reference's packing asserts below that): quantisation through srsvec::convert_round exactly
+ * (round to nearest even with saturation for the SIMD part of the converted span, round-half-away with a wrapping conversion for
+ * its tail: BFP converts the whole job with scale 32767 * iq_scaling and 16-bit range, so the tail is the last 24 * nof_prb mod 16
+ * values; none converts PRB by PRB with scale (2^(w-1) - 1) * iq_scaling, so the tail is the last 8 values of every PRB), then for
+ * BFP the exponent from the largest magnitude of the PRB and an arithmetic shift, then packing of the low data_width bits. */
+enum { MIPHY_OFH_COMPRESSION_NONE = 0, MIPHY_OFH_COMPRESSION_BFP = 1 }; /* values of srsran::ofh::compression_type */
+
 typedef struct {
   uint64_t payload_offset; /* byte offset of the first PRB record */
   uint64_t grid_offset;    /* cf_t offset of the first subcarrier */
   uint32_t nof_prb;        /* 1..275 */
-  uint32_t data_width;     /* 1..16 (compression: 8..16) */
-} miphy_ofh_bfp_job;
+  uint16_t data_width;     /* 1..16 (compression: 8..16) */
+  uint16_t compression;    /* MIPHY_OFH_COMPRESSION_*; other methods -> MIPHY_EUNSUPP (the reference aborts on them) */
+} miphy_ofh_iq_job;
 
-int miphy_ofh_bfp_decompress_batch(miphy_ctx* ctx, const miphy_ofh_bfp_job* jobs, int jobs_on_device, uint32_t n, const uint8_t* payload /* device */,
-                                   float* grid /* device cf_t */, int simd_arithmetic, void* stream);
-int miphy_ofh_bfp_compress_batch(miphy_ctx* ctx, const miphy_ofh_bfp_job* jobs, int jobs_on_device, uint32_t n, const float* grid /* device cf_t */,
-                                 float iq_scaling, uint8_t* payload /* device */, void* stream);
+/* Bytes of one PRB record: 3 * data_width, plus the udCompParam byte for BFP. Host function. */
+uint32_t miphy_ofh_iq_record_bytes(uint32_t compression, uint32_t data_width);
+
+int miphy_ofh_iq_decompress_batch(miphy_ctx* ctx, const miphy_ofh_iq_job* jobs, int jobs_on_device, uint32_t n, const uint8_t* payload /* device */,
+                                  float* grid /* device cf_t */, int simd_arithmetic, void* stream);
+int miphy_ofh_iq_compress_batch(miphy_ctx* ctx, const miphy_ofh_iq_job* jobs, int jobs_on_device, uint32_t n, const float* grid /* device cf_t */,
+                                float iq_scaling, uint8_t* payload /* device */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Device-resident HARQ softbuffer pool  --  replaces srsran::rx_softbuffer_pool / rx_softbuffer

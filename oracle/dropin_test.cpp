@@ -717,18 +717,20 @@ static void test_pdsch_processor(std::shared_ptr<miphy::context> c)
   printf("pdsch_processor done, failures so far %d\n", failures);
 }
 
-// Open Fronthaul BFP: the reference's production (de)compressor vs the HIP adapter, identical compressed PRBs and samples.
-static void test_ofh_bfp(std::shared_ptr<miphy::context> c)
+// Open Fronthaul IQ compression (BFP and uncompressed): the reference's production (de)compressors vs the HIP adapter, identical
+// compressed PRBs and samples.
+static void test_ofh_iq(std::shared_ptr<miphy::context> c)
 {
   std::normal_distribution<float>    gauss(0.0F, 1.0F);
   std::uniform_real_distribution<float> expo(-3.5F, 0.1F);
+  for (ofh::compression_type type : {ofh::compression_type::BFP, ofh::compression_type::none})
   for (unsigned w : {9U, 14U, 16U, 8U, 12U}) {
     for (unsigned nprb : {273U, 106U, 51U, 3U, 1U}) {
       for (float scaling : {1.0F, 0.6F}) {
-        auto cmp_ref = ofh::create_iq_compressor(ofh::compression_type::BFP, scaling, "avx2");
-        auto dec_ref = ofh::create_iq_decompressor(ofh::compression_type::BFP, "avx2");
-        auto cmp_hip = miphy::create_iq_compressor_bfp_hip(c, scaling);
-        auto dec_hip = miphy::create_iq_decompressor_bfp_hip(c);
+        auto cmp_ref = ofh::create_iq_compressor(type, scaling, "avx2");
+        auto dec_ref = ofh::create_iq_decompressor(type, "avx2");
+        auto cmp_hip = miphy::create_iq_compressor_hip(c, scaling);
+        auto dec_hip = miphy::create_iq_decompressor_hip(c);
         std::vector<cf_t> x(nprb * 12);
         for (unsigned p = 0; p != nprb; ++p) {
           float a = std::pow(10.0F, expo(rgen));
@@ -737,13 +739,13 @@ static void test_ofh_bfp(std::shared_ptr<miphy::context> c)
           }
         }
         ofh::ru_compression_params params;
-        params.type = ofh::compression_type::BFP, params.data_width = w;
+        params.type = type, params.data_width = w;
         std::vector<ofh::compressed_prb> p1(nprb), p2(nprb);
         cmp_ref->compress(p1, x, params);
         cmp_hip->compress(p2, x, params);
         unsigned bad = 0;
         for (unsigned p = 0; p != nprb; ++p) {
-          bad += p1[p].get_compression_param() != p2[p].get_compression_param();
+          bad += type == ofh::compression_type::BFP && p1[p].get_compression_param() != p2[p].get_compression_param();
           span<const uint8_t> a = p1[p].get_packed_data(), b = p2[p].get_packed_data();
           bad += a.size() != b.size() || !std::equal(a.begin(), a.end(), b.begin());
         }
@@ -755,7 +757,7 @@ static void test_ofh_bfp(std::shared_ptr<miphy::context> c)
       }
     }
   }
-  printf("ofh iq (de)compression BFP done, failures so far %d\n", failures);
+  printf("ofh iq (de)compression (BFP, none) done, failures so far %d\n", failures);
 }
 
 // uplink_processor: the PUSCH PDUs of a slot in one device submission (uplink_processor_hip + rx_softbuffer_pool_hip) against
@@ -1141,7 +1143,7 @@ int main()
   test_uplink_processor(c);
   test_pdsch_modulator_and_dmrs(c);
   test_pdsch_processor(c);
-  test_ofh_bfp(c);
+  test_ofh_iq(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);
     return 1;

@@ -261,22 +261,25 @@ for i, (ms, mc, ex) in enumerate([(4, 20, 8), (2, 9, 3), (6, 14, 30), (3, 100, 0
     d["cfg_%d" % i], d["ops_%d" % i], d["res_%d" % i] = np.array([ms, mc, ex]), ops.astype(np.int32), O.r_pool_run(ops, ms, mc, ex).astype(np.int32)
 save("harq_pool", **d)
 
-# ---------------------------------------------------------------------- Open Fronthaul BFP (de)compression
+# ---------------------------------------------------------------------- Open Fronthaul IQ (de)compression: BFP and uncompressed
 d = {}
-cases = [(9, 273), (9, 51), (14, 106), (12, 7), (16, 25), (8, 2), (4, 5), (1, 3)]
+cases = [(1, 9, 273), (1, 9, 51), (1, 14, 106), (1, 12, 7), (1, 16, 25), (1, 8, 2), (1, 4, 5), (1, 1, 3), (0, 16, 273), (0, 9, 106), (0, 12, 3),
+         (0, 8, 1), (0, 5, 4)]
 d["cases"] = np.array(cases)
-for i, (w, nprb) in enumerate(cases):
-    pl = rng.integers(0, 256, O.ofh_payload_bytes(nprb, w), dtype=np.uint8)
-    pl[::1 + 3 * w] = rng.integers(0, 16 - w + 1, nprb)
+for i, (comp, w, nprb) in enumerate(cases):
+    pl = rng.integers(0, 256, O.ofh_payload_bytes(nprb, w, comp), dtype=np.uint8)
+    if comp == O.OFH_BFP:
+        pl[::1 + 3 * w] = rng.integers(0, 16 - w + 1, nprb)
     d["dec_payload_%d" % i] = pl
-    d["dec_simd_%d" % i] = O.r_ofh_bfp_decompress(pl, nprb, w, "avx2")
-    d["dec_generic_%d" % i] = O.r_ofh_bfp_decompress(pl, nprb, w, "generic")
+    d["dec_simd_%d" % i] = O.r_ofh_iq_decompress(pl, nprb, w, "avx2", comp)
+    d["dec_generic_%d" % i] = O.r_ofh_iq_decompress(pl, nprb, w, "generic", comp)
     if w >= 8:
         x = ((rng.standard_normal(nprb * 12) + 1j * rng.standard_normal(nprb * 12)) * 10 ** rng.uniform(-3, 0.2, nprb).repeat(12)).astype(np.complex64)
         xr = x.view(np.float32)
-        xr[::11] = np.round(xr[::11] * 32767 * 2) / 2 / 32767  # exact .5 ties after scaling
+        g = 32767 if comp == O.OFH_BFP else (1 << (w - 1)) - 1
+        xr[::11] = np.round(xr[::11] * g * 2) / 2 / g  # exact .5 ties after scaling
         d["cmp_in_%d" % i] = x
         for sc in (1.0, 0.37):
-            d["cmp_out_%d_%d" % (i, int(sc * 100))] = O.r_ofh_bfp_compress(x, nprb, w, sc, "avx2")
-            assert np.array_equal(d["cmp_out_%d_%d" % (i, int(sc * 100))], O.r_ofh_bfp_compress(x, nprb, w, sc, "generic"))
-save("ofh_bfp", **d)
+            d["cmp_out_%d_%d" % (i, int(sc * 100))] = O.r_ofh_iq_compress(x, nprb, w, sc, "avx2", comp)
+            assert np.array_equal(d["cmp_out_%d_%d" % (i, int(sc * 100))], O.r_ofh_iq_compress(x, nprb, w, sc, "generic", comp))
+save("ofh_iq", **d)

@@ -1874,19 +1874,21 @@ static unsigned ofh_extract_bits(const uint8_t* data, unsigned pos, unsigned len
   return v;
 }
 
-void orc_ofh_bfp_decompress(const uint8_t* payload, unsigned nof_prb, unsigned w, int simd_arithmetic, float* out)
+void orc_ofh_iq_decompress(int compression, const uint8_t* payload, unsigned nof_prb, unsigned w, int simd_arithmetic, float* out)
 {
-  const float gain = 32767.0f; /* quantizer(16): (1 << 15) - 1 */
+  const int      bfp  = compression == 1;
+  const unsigned hdr  = bfp ? 1u : 0u;
+  const float    gain = bfp ? 32767.0f : (float)(1 << (w - 1)) - 1.0f; /* quantizer(bit_width): (1 << (bit_width - 1)) - 1 */
   for (unsigned p = 0; p < nof_prb; ++p) {
-    const uint8_t* rec      = payload + (size_t)p * (1 + 3 * w);
-    const unsigned exponent = rec[0];
+    const uint8_t* rec      = payload + (size_t)p * (hdr + 3 * w);
+    const unsigned exponent = bfp ? rec[0] : 0;
     const int16_t  scaler   = (int16_t)(1 << exponent);
     for (unsigned i = 0; i < 24; ++i) {
       /* quantizer::sign_extend (quantizer.h:88-92) */
-      int16_t v = (int16_t)ofh_extract_bits(rec + 1, i * w, w);
+      int16_t v = (int16_t)ofh_extract_bits(rec + hdr, i * w, w);
       v         = (int16_t)((int16_t)(v << (16 - w)) >> (16 - w));
       float f;
-      if (simd_arithmetic && w == 9) { /* quantizer::to_float(span) -> srsvec::convert(int16 -> float) */
+      if (bfp && simd_arithmetic && w == 9) { /* quantizer::to_float(span) -> srsvec::convert(int16 -> float) */
         const float scale = gain / scaler;
         const float g     = 1.0f / scale;
         f                 = (float)v * g;
@@ -1913,14 +1915,18 @@ static unsigned ofh_determine_exponent(unsigned x, unsigned w) /* iq_compression
   return e > 0 ? (unsigned)e : 0;
 }
 
-void orc_ofh_bfp_compress(const float* in, unsigned nof_prb, unsigned w, float iq_scaling, uint8_t* payload)
+void orc_ofh_iq_compress(int compression, const float* in, unsigned nof_prb, unsigned w, float iq_scaling, uint8_t* payload)
 {
-  const float    scale = 32767.0f * iq_scaling; /* quantizer::to_fixed_point(span): gain * in_scale */
-  const unsigned len = 24 * nof_prb, simd_len = (len / 16) * 16;
-  int16_t*       q = (int16_t*)malloc(sizeof(int16_t) * (len ? len : 1));
+  const int      bfp   = compression == 1;
+  const unsigned hdr   = bfp ? 1u : 0u;
+  const float    scale = (bfp ? 32767.0f : (float)(1 << (w - 1)) - 1.0f) * iq_scaling; /* quantizer::to_fixed_point(span): gain * in_scale */
+  const unsigned len   = 24 * nof_prb;
+  int16_t*       q     = (int16_t*)malloc(sizeof(int16_t) * (len ? len : 1));
   for (unsigned i = 0; i < len; ++i) {
-    const float a = in[i] * scale;
-    if (i < simd_len) { /* _mm256_round_ps(nearest) + cvtps_epi32 + packs_epi32 */
+    /* srsvec::convert_round over the whole call (BFP) or over one PRB at a time (none): SIMD part, then scalar tail */
+    const unsigned pos = bfp ? i : i % 24, span_len = bfp ? len : 24, simd_len = (span_len / 16) * 16;
+    const float    a   = in[i] * scale;
+    if (pos < simd_len) { /* _mm256_round_ps(nearest) + cvtps_epi32 + packs_epi32 */
       const float r = rintf(a);
       long        v;
       if (!(r > -2147483904.0f && r < 2147483648.0f))
@@ -1936,23 +1942,27 @@ void orc_ofh_bfp_compress(const float* in, unsigned nof_prb, unsigned w, float i
     }
   }
   for (unsigned p = 0; p < nof_prb; ++p) {
-    const int16_t* x  = q + p * 24;
-    int            mx = x[0], mn = x[0];
-    for (unsigned i = 1; i < 24; ++i) {
-      mx = x[i] > mx ? x[i] : mx;
-      mn = x[i] < mn ? x[i] : mn;
+    const int16_t* x        = q + p * 24;
+    unsigned       exponent = 0;
+    if (bfp) {
+      int mx = x[0], mn = x[0];
+      for (unsigned i = 1; i < 24; ++i) {
+        mx = x[i] > mx ? x[i] : mx;
+        mn = x[i] < mn ? x[i] : mn;
+      }
+      const int      a = abs(mx), b = abs(mn) - 1;
+      const unsigned max_abs = (unsigned)(a > b ? a : b);
+      exponent               = ofh_determine_exponent(max_abs & 0xffffu, w);
     }
-    const int      a = abs(mx), b = abs(mn) - 1;
-    const unsigned max_abs  = (unsigned)(a > b ? a : b);
-    const unsigned exponent = ofh_determine_exponent(max_abs & 0xffffu, w);
-    uint8_t*       rec      = payload + (size_t)p * (1 + 3 * w);
-    memset(rec, 0, 1 + 3 * w);
-    rec[0] = (uint8_t)exponent;
+    uint8_t* rec = payload + (size_t)p * (hdr + 3 * w);
+    memset(rec, 0, hdr + 3 * w);
+    if (bfp)
+      rec[0] = (uint8_t)exponent;
     for (unsigned i = 0; i < 24; ++i) { /* compressed_prb::pack_compressed_data (:31-61): the low w bits of each sample, MSB first */
       const unsigned v = (unsigned)(uint16_t)(int16_t)(x[i] >> exponent);
       for (unsigned b2 = 0; b2 < w; ++b2) {
         const unsigned pos = i * w + b2;
-        rec[1 + (pos >> 3)] |= (uint8_t)(((v >> (w - 1 - b2)) & 1u) << (7 - (pos & 7)));
+        rec[hdr + (pos >> 3)] |= (uint8_t)(((v >> (w - 1 - b2)) & 1u) << (7 - (pos & 7)));
       }
     }
   }

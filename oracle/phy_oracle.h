@@ -164,16 +164,18 @@ int orc_pdsch_modulate(unsigned rnti, unsigned n_id, float scaling, unsigned nof
 int orc_dmrs_pdsch_map(unsigned slot_in_frame, unsigned reference_point_k_rb, int type2, unsigned scrambling_id, int n_scid, float amplitude,
                        const uint8_t* symbols_mask, const uint8_t* rb_mask, unsigned nof_prb_grid, unsigned nof_ports, const uint8_t* ports, float* grid);
 
-/* ------------------------------------------------------------------------------------------------ Open Fronthaul BFP
- * payload: per PRB [udCompParam][24 x data_width bits, big endian] = 1 + 3*data_width bytes (the U-plane section payload,
- * ofh_uplane_message_builder_impl.cpp:145-152). simd_arithmetic: the production AVX2 / AVX-512 classes (data_width 9 multiplies by
- * the rounded reciprocal 1 / (32767 / 2^e), iq_compression_bfp_avx2.cpp:92-132, srsvec/conversion.cpp:101-130); 0: the generic
- * class (division by 32767, iq_compression_bfp_impl.cpp:100-121). */
-void orc_ofh_bfp_decompress(const uint8_t* payload, unsigned nof_prb, unsigned data_width, int simd_arithmetic, float* out /* cf_t, nof_prb*12 */);
-/* iq_compression_bfp_impl::compress (:47-98): quantisation through srsvec::convert_round (round to nearest even with int16
- * saturation on the first floor(24*nof_prb/16)*16 values, std::round and a wrapping cast on the rest, conversion.cpp:61-99),
- * exponent, shift, pack. data_width 8..16 (narrower widths trip an assertion in the reference's packing, bit_buffer::insert). */
-void orc_ofh_bfp_compress(const float* in /* cf_t, nof_prb*12 */, unsigned nof_prb, unsigned data_width, float iq_scaling, uint8_t* payload);
+/* ------------------------------------------------------------------------------------------------ Open Fronthaul IQ
+ * compression: 0 = none (fixed point, iq_compression_none_impl.cpp:29-69), 1 = BFP (iq_compression_bfp_impl.cpp:28-143).
+ * payload: per PRB, BFP [udCompParam][24 x data_width bits, big endian] = 1 + 3*data_width bytes, none the 3*data_width bytes only
+ * (the U-plane section payload, ofh_uplane_message_builder_impl.cpp:145-152). simd_arithmetic: the production AVX2 / AVX-512 BFP
+ * classes (data_width 9 multiplies by the rounded reciprocal 1 / (32767 / 2^e), iq_compression_bfp_avx2.cpp:92-132,
+ * srsvec/conversion.cpp:101-130); 0: the generic class (division by 32767, iq_compression_bfp_impl.cpp:100-121). */
+void orc_ofh_iq_decompress(int compression, const uint8_t* payload, unsigned nof_prb, unsigned data_width, int simd_arithmetic, float* out /* cf_t, nof_prb*12 */);
+/* iq_compression_bfp_impl::compress (:47-98) / iq_compression_none_impl::compress (:29-51): quantisation through
+ * srsvec::convert_round (round to nearest even with int16 saturation on the SIMD part of each converted span, std::round and a
+ * wrapping cast on its tail, conversion.cpp:61-99; BFP converts the whole call at once, none PRB by PRB), [exponent, shift,] pack.
+ * data_width 8..16 (narrower widths trip an assertion in the reference's packing, bit_buffer::insert). */
+void orc_ofh_iq_compress(int compression, const float* in /* cf_t, nof_prb*12 */, unsigned nof_prb, unsigned data_width, float iq_scaling, uint8_t* payload);
 
 #ifdef __cplusplus
 }

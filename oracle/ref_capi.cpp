@@ -1079,40 +1079,46 @@ void ref_pool_run_slot(void* h, unsigned slot_count)
 }
 
 // ---------------------------------------------------------------- Open Fronthaul BFP (de)compression
-// payload: per PRB [udCompParam][3 * data_width bytes], the layout ofh_uplane_message_builder_impl.cpp:145-152 serialises.
-int ref_ofh_bfp_decompress(const char* impl, const uint8_t* payload, unsigned nof_prb, unsigned data_width, float* out)
+// payload: per PRB [udCompParam (BFP only)][3 * data_width bytes], the layout ofh_uplane_message_builder_impl.cpp:145-152 serialises.
+int ref_ofh_iq_decompress(int compression, const char* impl, const uint8_t* payload, unsigned nof_prb, unsigned data_width, float* out)
 {
-  auto                             dec = ofh::create_iq_decompressor(ofh::compression_type::BFP, impl);
+  const ofh::compression_type      type = compression == 1 ? ofh::compression_type::BFP : ofh::compression_type::none;
+  const unsigned                   hdr  = compression == 1 ? 1 : 0;
+  auto                             dec  = ofh::create_iq_decompressor(type, impl);
   std::vector<ofh::compressed_prb> prbs(nof_prb);
   for (unsigned p = 0; p != nof_prb; ++p) {
-    const uint8_t* rec = payload + static_cast<size_t>(p) * (1 + 3 * data_width);
-    prbs[p].set_compression_param(rec[0]);
-    std::memcpy(prbs[p].get_buffer().data(), rec + 1, 3 * data_width);
+    const uint8_t* rec = payload + static_cast<size_t>(p) * (hdr + 3 * data_width);
+    prbs[p].set_compression_param(hdr ? rec[0] : 0);
+    std::memcpy(prbs[p].get_buffer().data(), rec + hdr, 3 * data_width);
     prbs[p].set_stored_size(3 * data_width);
   }
   ofh::ru_compression_params params;
-  params.type       = ofh::compression_type::BFP;
+  params.type       = type;
   params.data_width = data_width;
   dec->decompress(span<cf_t>(reinterpret_cast<cf_t*>(out), nof_prb * 12), prbs, params);
   return 0;
 }
 
-int ref_ofh_bfp_compress(const char* impl, const float* in, unsigned nof_prb, unsigned data_width, float iq_scaling, uint8_t* payload)
+int ref_ofh_iq_compress(int compression, const char* impl, const float* in, unsigned nof_prb, unsigned data_width, float iq_scaling, uint8_t* payload)
 {
-  auto                             enc = ofh::create_iq_compressor(ofh::compression_type::BFP, iq_scaling, impl);
+  const ofh::compression_type      type = compression == 1 ? ofh::compression_type::BFP : ofh::compression_type::none;
+  const unsigned                   hdr  = compression == 1 ? 1 : 0;
+  auto                             enc  = ofh::create_iq_compressor(type, iq_scaling, impl);
   std::vector<ofh::compressed_prb> prbs(nof_prb);
   ofh::ru_compression_params       params;
-  params.type       = ofh::compression_type::BFP;
+  params.type       = type;
   params.data_width = data_width;
   enc->compress(prbs, span<const cf_t>(reinterpret_cast<const cf_t*>(in), nof_prb * 12), params);
   for (unsigned p = 0; p != nof_prb; ++p) {
-    uint8_t* rec = payload + static_cast<size_t>(p) * (1 + 3 * data_width);
-    rec[0]       = prbs[p].get_compression_param();
+    uint8_t* rec = payload + static_cast<size_t>(p) * (hdr + 3 * data_width);
+    if (hdr) {
+      rec[0] = prbs[p].get_compression_param();
+    }
     span<const uint8_t> d = prbs[p].get_packed_data();
     if (d.size() != 3 * data_width) {
       return -1;
     }
-    std::memcpy(rec + 1, d.data(), d.size());
+    std::memcpy(rec + hdr, d.data(), d.size());
   }
   return 0;
 }

@@ -1503,19 +1503,20 @@ private:
   std::shared_ptr<context> c;
 };
 
-// ---------------------------------------------------------------------------------------------------------------- Open Fronthaul BFP
-/// srsran::ofh::iq_decompressor / iq_compressor for compression_type::BFP over miphy_ofh_bfp_*_batch
-/// (iq_decompressor.h:49-50, iq_compressor.h:49-50). The compressed_prb objects are laid out as the U-plane section payload
-/// ([udCompParam][packed IQ] per PRB) on the way to and from the device.
-class iq_compression_bfp_hip : public srsran::ofh::iq_compressor, public srsran::ofh::iq_decompressor
+// ---------------------------------------------------------------------------------------------------------------- Open Fronthaul IQ compression
+/// srsran::ofh::iq_decompressor / iq_compressor for compression_type::BFP and compression_type::none over miphy_ofh_iq_*_batch
+/// (iq_decompressor.h:49-50, iq_compressor.h:49-50): what iq_{de}compressor_selector dispatches to for the two methods the reference
+/// implements. The compressed_prb objects are laid out as the U-plane section payload ([udCompParam][packed IQ] per PRB for BFP,
+/// the packed IQ alone for the uncompressed format) on the way to and from the device.
+class iq_compression_hip : public srsran::ofh::iq_compressor, public srsran::ofh::iq_decompressor
 {
 public:
-  explicit iq_compression_bfp_hip(std::shared_ptr<context> c, float iq_scaling = 1.0F) : c(std::move(c)), iq_scaling(iq_scaling) {}
+  explicit iq_compression_hip(std::shared_ptr<context> c, float iq_scaling = 1.0F) : c(std::move(c)), iq_scaling(iq_scaling) {}
   void compress(srsran::span<srsran::ofh::compressed_prb> output, srsran::span<const srsran::cf_t> input, const srsran::ofh::ru_compression_params& params) override
   {
-    srsran_assert(params.type == srsran::ofh::compression_type::BFP, "Only BFP is supported.");
     srsran_assert(input.size() == output.size() * 12, "Wrong number of input samples.");
-    const unsigned w = params.data_width, rec = 1 + 3 * w, nprb = output.size();
+    const uint16_t comp = method(params);
+    const unsigned w = params.data_width, hdr = comp == MIPHY_OFH_COMPRESSION_BFP ? 1 : 0, rec = hdr + 3 * w, nprb = output.size();
     if (nprb == 0) {
       return;
     }
@@ -1523,58 +1524,71 @@ public:
     auto* d_p = static_cast<uint8_t*>(c->buf(1, static_cast<size_t>(nprb) * rec));
     bytes.resize(static_cast<size_t>(nprb) * rec);
     c->h2d(d_x, input.data(), input.size() * sizeof(srsran::cf_t));
-    // one job per 275 PRBs; the quantiser's SIMD / scalar split is defined over the whole span, which the last job carries
-    std::vector<miphy_ofh_bfp_job> jobs;
     srsran_assert(nprb <= 275, "At most 275 PRBs per call.");
-    jobs.push_back(miphy_ofh_bfp_job{0, 0, nprb, w});
-    context::check(miphy_ofh_bfp_compress_batch(c->ctx, jobs.data(), 0, jobs.size(), d_x, iq_scaling, d_p, c->stream), "ofh_bfp_compress");
+    miphy_ofh_iq_job job{0, 0, nprb, static_cast<uint16_t>(w), comp};
+    context::check(miphy_ofh_iq_compress_batch(c->ctx, &job, 0, 1, d_x, iq_scaling, d_p, c->stream), "ofh_iq_compress");
     c->d2h(bytes.data(), d_p, bytes.size());
     c->sync();
     for (unsigned p = 0; p != nprb; ++p) {
-      output[p].set_compression_param(bytes[static_cast<size_t>(p) * rec]);
-      std::memcpy(output[p].get_buffer().data(), &bytes[static_cast<size_t>(p) * rec + 1], 3 * w);
+      if (hdr != 0) {
+        output[p].set_compression_param(bytes[static_cast<size_t>(p) * rec]);
+      }
+      std::memcpy(output[p].get_buffer().data(), &bytes[static_cast<size_t>(p) * rec + hdr], 3 * w);
       output[p].set_stored_size(3 * w);
     }
   }
   void decompress(srsran::span<srsran::cf_t> output, srsran::span<const srsran::ofh::compressed_prb> input, const srsran::ofh::ru_compression_params& params) override
   {
-    srsran_assert(params.type == srsran::ofh::compression_type::BFP, "Only BFP is supported.");
     srsran_assert(output.size() == input.size() * 12, "Wrong number of output samples.");
-    const unsigned w = params.data_width, rec = 1 + 3 * w, nprb = input.size();
+    const uint16_t comp = method(params);
+    const unsigned w = params.data_width, hdr = comp == MIPHY_OFH_COMPRESSION_BFP ? 1 : 0, rec = hdr + 3 * w, nprb = input.size();
     if (nprb == 0) {
       return;
     }
     srsran_assert(nprb <= 275, "At most 275 PRBs per call.");
     bytes.resize(static_cast<size_t>(nprb) * rec);
     for (unsigned p = 0; p != nprb; ++p) {
-      bytes[static_cast<size_t>(p) * rec] = input[p].get_compression_param();
+      if (hdr != 0) {
+        bytes[static_cast<size_t>(p) * rec] = input[p].get_compression_param();
+      }
       // get_packed_data() depends on set_stored_size(), which the U-plane decoder does not call: take the bytes themselves
-      std::memcpy(&bytes[static_cast<size_t>(p) * rec + 1], const_cast<srsran::ofh::compressed_prb&>(input[p]).get_buffer().data(), 3 * w);
+      std::memcpy(&bytes[static_cast<size_t>(p) * rec + hdr], const_cast<srsran::ofh::compressed_prb&>(input[p]).get_buffer().data(), 3 * w);
     }
     auto* d_p = static_cast<uint8_t*>(c->buf(0, bytes.size()));
     auto* d_x = static_cast<float*>(c->buf(1, output.size() * sizeof(srsran::cf_t)));
     c->h2d(d_p, bytes.data(), bytes.size());
-    miphy_ofh_bfp_job job{0, 0, nprb, w};
-    context::check(miphy_ofh_bfp_decompress_batch(c->ctx, &job, 0, 1, d_p, d_x, 1, c->stream), "ofh_bfp_decompress");
+    miphy_ofh_iq_job job{0, 0, nprb, static_cast<uint16_t>(w), comp};
+    context::check(miphy_ofh_iq_decompress_batch(c->ctx, &job, 0, 1, d_p, d_x, 1, c->stream), "ofh_iq_decompress");
     c->d2h(output.data(), d_x, output.size() * sizeof(srsran::cf_t));
     c->sync();
   }
 
 private:
+  static uint16_t method(const srsran::ofh::ru_compression_params& params)
+  {
+    if (params.type == srsran::ofh::compression_type::BFP) {
+      return MIPHY_OFH_COMPRESSION_BFP;
+    }
+    if (params.type == srsran::ofh::compression_type::none) {
+      return MIPHY_OFH_COMPRESSION_NONE;
+    }
+    srsran::report_fatal_error("Compression of {} type is not implemented", srsran::ofh::to_string(params.type));
+  }
+
   std::shared_ptr<context> c;
   float                    iq_scaling;
   std::vector<uint8_t>     bytes;
 };
 
-/// Replace create_iq_compressor(compression_type::BFP, iq_scaling, impl) and create_iq_decompressor(compression_type::BFP, impl)
-/// (compression_factory.h:36-45).
-inline std::unique_ptr<srsran::ofh::iq_compressor> create_iq_compressor_bfp_hip(std::shared_ptr<context> c, float iq_scaling = 1.0F)
+/// Replace create_iq_compressor(type, iq_scaling, impl) and create_iq_decompressor(type, impl) for type = none | BFP, or the
+/// selectors built from them (compression_factory.h:36-50).
+inline std::unique_ptr<srsran::ofh::iq_compressor> create_iq_compressor_hip(std::shared_ptr<context> c, float iq_scaling = 1.0F)
 {
-  return std::make_unique<iq_compression_bfp_hip>(std::move(c), iq_scaling);
+  return std::make_unique<iq_compression_hip>(std::move(c), iq_scaling);
 }
-inline std::unique_ptr<srsran::ofh::iq_decompressor> create_iq_decompressor_bfp_hip(std::shared_ptr<context> c)
+inline std::unique_ptr<srsran::ofh::iq_decompressor> create_iq_decompressor_hip(std::shared_ptr<context> c)
 {
-  return std::make_unique<iq_compression_bfp_hip>(std::move(c));
+  return std::make_unique<iq_compression_hip>(std::move(c));
 }
 
 // ---------------------------------------------------------------------------------------------------------------- PDCCH

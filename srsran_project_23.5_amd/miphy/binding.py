@@ -65,8 +65,8 @@ def lib():
         l.miphy_pdsch_pdu_nof_re.argtypes = [C.c_void_p]
         l.miphy_pdsch_pdu_nof_re.restype = C.c_uint32
         l.miphy_pdsch_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-        l.miphy_ofh_bfp_decompress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-        l.miphy_ofh_bfp_compress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+        l.miphy_ofh_iq_decompress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        l.miphy_ofh_iq_compress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         l.miphy_harq_pool_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         l.miphy_harq_pool_destroy.argtypes = [C.c_void_p]
         l.miphy_harq_pool_destroy.restype = None
@@ -158,9 +158,11 @@ def pdsch_mod_nof_re(job):
     return int(lib().miphy_pdsch_mod_nof_re(a.ctypes.data_as(C.c_void_p)))
 
 
-# Mirrors miphy_ofh_bfp_job.
-OfhBfpJob = np.dtype([("payload_offset", np.uint64), ("grid_offset", np.uint64), ("nof_prb", np.uint32), ("data_width", np.uint32)], align=True)
-assert OfhBfpJob.itemsize == 24
+# Mirrors miphy_ofh_iq_job.
+OfhIqJob = np.dtype([("payload_offset", np.uint64), ("grid_offset", np.uint64), ("nof_prb", np.uint32), ("data_width", np.uint16),
+                     ("compression", np.uint16)], align=True)
+OFH_COMPRESSION_NONE, OFH_COMPRESSION_BFP = 0, 1  # srsran::ofh::compression_type
+assert OfhIqJob.itemsize == 24
 
 # Mirrors miphy_pdsch_pdu.
 PdschPdu = np.dtype([("slot_in_frame", np.uint32), ("rnti", np.uint32), ("n_id", np.uint32), ("dmrs_scrambling_id", np.uint32),
@@ -353,14 +355,14 @@ class Context:
         pdus = np.ascontiguousarray(pdus)
         check(lib().miphy_pdsch_process_batch(self.h, C.c_void_p(pdus.ctypes.data), pdus.size, _dptr(tb_in), _dptr(grid), _stream_ptr(stream)))
 
-    # ------------------------------------------------------------------ Open Fronthaul BFP (U-plane payloads <-> grid rows)
-    def ofh_bfp_decompress_batch(self, jobs, payload, grid, simd_arithmetic=True, stream=None):
-        jobs, n, ptr, on_dev = self._descs(jobs, OfhBfpJob)
-        check(lib().miphy_ofh_bfp_decompress_batch(self.h, ptr, on_dev, n, _dptr(payload), _dptr(grid), int(simd_arithmetic), _stream_ptr(stream)))
+    # ------------------------------------------------------------------ Open Fronthaul IQ (de)compression (U-plane payloads <-> grid rows)
+    def ofh_iq_decompress_batch(self, jobs, payload, grid, simd_arithmetic=True, stream=None):
+        jobs, n, ptr, on_dev = self._descs(jobs, OfhIqJob)
+        check(lib().miphy_ofh_iq_decompress_batch(self.h, ptr, on_dev, n, _dptr(payload), _dptr(grid), int(simd_arithmetic), _stream_ptr(stream)))
 
-    def ofh_bfp_compress_batch(self, jobs, grid, payload, iq_scaling=1.0, stream=None):
-        jobs, n, ptr, on_dev = self._descs(jobs, OfhBfpJob)
-        check(lib().miphy_ofh_bfp_compress_batch(self.h, ptr, on_dev, n, _dptr(grid), float(iq_scaling), _dptr(payload), _stream_ptr(stream)))
+    def ofh_iq_compress_batch(self, jobs, grid, payload, iq_scaling=1.0, stream=None):
+        jobs, n, ptr, on_dev = self._descs(jobs, OfhIqJob)
+        check(lib().miphy_ofh_iq_compress_batch(self.h, ptr, on_dev, n, _dptr(grid), float(iq_scaling), _dptr(payload), _stream_ptr(stream)))
 
     # ------------------------------------------------------------------ PUSCH demodulator (equalise + soft-demap + descramble)
     def pusch_demodulate_batch(self, jobs, grid, ce, scalars, llr, stream=None):

@@ -629,36 +629,39 @@ def r_pool_run(ops, max_softbuffers, max_nof_codeblocks, expire_timeout_slots, n
     return out
 
 
-# ---------------------------------------------------------------------- Open Fronthaul BFP
-def ofh_payload_bytes(nof_prb, w):
-    return nof_prb * (1 + 3 * w)
+# ---------------------------------------------------------------------- Open Fronthaul IQ (de)compression
+OFH_NONE, OFH_BFP = 0, 1  # srsran::ofh::compression_type
 
 
-def o_ofh_bfp_decompress(payload, nof_prb, w, simd=True):
+def ofh_payload_bytes(nof_prb, w, comp=OFH_BFP):
+    return nof_prb * ((1 if comp == OFH_BFP else 0) + 3 * w)
+
+
+def o_ofh_iq_decompress(payload, nof_prb, w, simd=True, comp=OFH_BFP):
     payload = np.ascontiguousarray(payload, dtype=np.uint8)
-    assert payload.size >= ofh_payload_bytes(nof_prb, w)
+    assert payload.size >= ofh_payload_bytes(nof_prb, w, comp)
     out = np.zeros(nof_prb * 12, dtype=np.complex64)
-    oracle().orc_ofh_bfp_decompress(_p(payload), C.c_uint(nof_prb), C.c_uint(w), int(simd), _p(out))
+    oracle().orc_ofh_iq_decompress(int(comp), _p(payload), C.c_uint(nof_prb), C.c_uint(w), int(simd), _p(out))
     return out
 
 
-def o_ofh_bfp_compress(x, nof_prb, w, iq_scaling=1.0):
+def o_ofh_iq_compress(x, nof_prb, w, iq_scaling=1.0, comp=OFH_BFP):
     x = np.ascontiguousarray(x, dtype=np.complex64)
     assert x.size == nof_prb * 12
-    payload = np.zeros(ofh_payload_bytes(nof_prb, w), dtype=np.uint8)
-    oracle().orc_ofh_bfp_compress(_p(x), C.c_uint(nof_prb), C.c_uint(w), C.c_float(iq_scaling), _p(payload))
+    payload = np.zeros(ofh_payload_bytes(nof_prb, w, comp), dtype=np.uint8)
+    oracle().orc_ofh_iq_compress(int(comp), _p(x), C.c_uint(nof_prb), C.c_uint(w), C.c_float(iq_scaling), _p(payload))
     return payload
 
 
-def r_ofh_bfp_decompress(payload, nof_prb, w, impl="avx2"):
+def r_ofh_iq_decompress(payload, nof_prb, w, impl="avx2", comp=OFH_BFP):
     payload = np.ascontiguousarray(payload, dtype=np.uint8)
     out = np.zeros(nof_prb * 12, dtype=np.complex64)
-    assert ref().ref_ofh_bfp_decompress(impl.encode(), _p(payload), C.c_uint(nof_prb), C.c_uint(w), _p(out)) == 0
+    assert ref().ref_ofh_iq_decompress(int(comp), impl.encode(), _p(payload), C.c_uint(nof_prb), C.c_uint(w), _p(out)) == 0
     return out
 
 
-def r_ofh_bfp_compress(x, nof_prb, w, iq_scaling=1.0, impl="avx2"):
+def r_ofh_iq_compress(x, nof_prb, w, iq_scaling=1.0, impl="avx2", comp=OFH_BFP):
     x = np.ascontiguousarray(x, dtype=np.complex64)
-    payload = np.zeros(ofh_payload_bytes(nof_prb, w), dtype=np.uint8)
-    assert ref().ref_ofh_bfp_compress(impl.encode(), _p(x), C.c_uint(nof_prb), C.c_uint(w), C.c_float(iq_scaling), _p(payload)) == 0
+    payload = np.zeros(ofh_payload_bytes(nof_prb, w, comp), dtype=np.uint8)
+    assert ref().ref_ofh_iq_compress(int(comp), impl.encode(), _p(x), C.c_uint(nof_prb), C.c_uint(w), C.c_float(iq_scaling), _p(payload)) == 0
     return payload

@@ -192,16 +192,17 @@ def test_pdsch_modulator_and_dmrs():
         assert np.array_equal(g.view(np.uint32), ref.view(np.uint32)), i
 
 
-def test_ofh_bfp():
-    """Open Fronthaul BFP: oracle against payloads / samples recorded from the reference's avx2 and generic classes."""
-    g = np.load(os.path.join(GOLD, "ofh_bfp.npz"))
-    for i, (w, nprb) in enumerate(g["cases"].tolist()):
+def test_ofh_iq_compression():
+    """Open Fronthaul IQ formats (BFP and uncompressed): oracle against payloads / samples recorded from the reference's avx2 and
+    generic classes."""
+    g = np.load(os.path.join(GOLD, "ofh_iq.npz"))
+    for i, (comp, w, nprb) in enumerate(g["cases"].tolist()):
         pl = g["dec_payload_%d" % i]
-        assert np.array_equal(O.o_ofh_bfp_decompress(pl, nprb, w, True).view(np.uint32), g["dec_simd_%d" % i].view(np.uint32)), (w, nprb)
-        assert np.array_equal(O.o_ofh_bfp_decompress(pl, nprb, w, False).view(np.uint32), g["dec_generic_%d" % i].view(np.uint32)), (w, nprb)
+        assert np.array_equal(O.o_ofh_iq_decompress(pl, nprb, w, True, comp).view(np.uint32), g["dec_simd_%d" % i].view(np.uint32)), (comp, w, nprb)
+        assert np.array_equal(O.o_ofh_iq_decompress(pl, nprb, w, False, comp).view(np.uint32), g["dec_generic_%d" % i].view(np.uint32)), (comp, w, nprb)
         if w >= 8:
             for sc in (1.0, 0.37):
-                assert np.array_equal(O.o_ofh_bfp_compress(g["cmp_in_%d" % i], nprb, w, sc), g["cmp_out_%d_%d" % (i, int(sc * 100))]), (w, nprb, sc)
+                assert np.array_equal(O.o_ofh_iq_compress(g["cmp_in_%d" % i], nprb, w, sc, comp), g["cmp_out_%d_%d" % (i, int(sc * 100))]), (comp, w, nprb, sc)
     # The product form of the SIMD classes and the division of the generic class give the same single-precision value for every
     # 9-bit sample and exponent 0..7 (checked exhaustively below), so the recorded outputs of the two classes coincide.
     for i in range(len(g["cases"])):

@@ -237,29 +237,33 @@ def test_pdsch_modulator_and_dmrs():
         assert np.array_equal(g.view(np.uint32), ref.view(np.uint32))
 
 
-def test_ofh_bfp_compression():
-    """Every data width, odd and even PRB counts (the SIMD / scalar split of the quantiser), ties, clipping and overflow inputs,
-    against the reference's generic, avx2 and avx512 classes."""
+def test_ofh_iq_compression():
+    """Both formats, every data width, odd and even PRB counts (the SIMD / scalar split of the quantiser), ties, clipping and
+    overflow inputs, against the reference's generic, avx2 and avx512 classes."""
     rng = np.random.default_rng(77)
-    for w in range(1, 17):
-        for nprb in (1, 2, 3, 17, 273):
-            pl = rng.integers(0, 256, O.ofh_payload_bytes(nprb, w), dtype=np.uint8)
-            pl[::1 + 3 * w] = rng.integers(0, 16 - w + 1, nprb)
-            for impl, simd in (("avx2", True), ("avx512", True), ("generic", False)):
-                assert np.array_equal(O.o_ofh_bfp_decompress(pl, nprb, w, simd).view(np.uint32), O.r_ofh_bfp_decompress(pl, nprb, w, impl).view(np.uint32)), (w, nprb, impl)
-    for t in range(600):
-        w, nprb = int(rng.integers(8, 17)), int(rng.integers(1, 8))
-        x = ((rng.standard_normal(nprb * 12) + 1j * rng.standard_normal(nprb * 12)) * 10 ** rng.uniform(-4, 0.5)).astype(np.complex64)
-        if t % 7 == 0:
-            x = (np.round(x.view(np.float32) * 32767 * 2) / 2 / 32767).astype(np.float32).view(np.complex64)
-        if t % 50 == 0:
-            x.view(np.float32)[::5] = 1e12
-        sc = float(rng.choice([1.0, 0.5, 0.37]))
-        a = O.o_ofh_bfp_compress(x, nprb, w, sc)
-        for impl in ("generic", "avx2", "avx512"):
-            assert np.array_equal(a, O.r_ofh_bfp_compress(x, nprb, w, sc, impl)), (t, w, nprb, sc, impl)
-        # decompress(compress(x)) is x to within the quantisation step of the block
-        if np.max(np.abs(x.view(np.float32))) * sc < 1.0:
-            y = O.o_ofh_bfp_decompress(a, nprb, w, True)
-            step = 2.0 ** a[::1 + 3 * w].astype(np.float64).repeat(24) / 32767
-            assert np.all(np.abs(y.view(np.float32) - x.view(np.float32) * np.float32(sc)) <= step * 1.001 + 1e-7), (t, w)
+    for comp in (O.OFH_BFP, O.OFH_NONE):
+        for w in range(1, 17):
+            for nprb in (1, 2, 3, 17, 273):
+                pl = rng.integers(0, 256, O.ofh_payload_bytes(nprb, w, comp), dtype=np.uint8)
+                if comp == O.OFH_BFP:
+                    pl[::1 + 3 * w] = rng.integers(0, 16 - w + 1, nprb)
+                for impl, simd in (("avx2", True), ("avx512", True), ("generic", False)):
+                    assert np.array_equal(O.o_ofh_iq_decompress(pl, nprb, w, simd, comp).view(np.uint32),
+                                          O.r_ofh_iq_decompress(pl, nprb, w, impl, comp).view(np.uint32)), (comp, w, nprb, impl)
+        for t in range(400):
+            w, nprb = int(rng.integers(8, 17)), int(rng.integers(1, 8))
+            gain = 32767 if comp == O.OFH_BFP else (1 << (w - 1)) - 1
+            x = ((rng.standard_normal(nprb * 12) + 1j * rng.standard_normal(nprb * 12)) * 10 ** rng.uniform(-4, 0.5)).astype(np.complex64)
+            if t % 7 == 0:
+                x = (np.round(x.view(np.float32) * gain * 2) / 2 / gain).astype(np.float32).view(np.complex64)
+            if t % 50 == 0:
+                x.view(np.float32)[::5] = 1e12
+            sc = float(rng.choice([1.0, 0.5, 0.37]))
+            a = O.o_ofh_iq_compress(x, nprb, w, sc, comp)
+            for impl in ("generic", "avx2", "avx512"):
+                assert np.array_equal(a, O.r_ofh_iq_compress(x, nprb, w, sc, impl, comp)), (comp, t, w, nprb, sc, impl)
+            # decompress(compress(x)) is x to within the quantisation step of the block
+            if np.max(np.abs(x.view(np.float32))) * sc < 1.0:
+                y = O.o_ofh_iq_decompress(a, nprb, w, True, comp)
+                step = (2.0 ** a[::1 + 3 * w].astype(np.float64).repeat(24) / 32767) if comp == O.OFH_BFP else np.full(nprb * 24, 1.0 / gain)
+                assert np.all(np.abs(y.view(np.float32) - x.view(np.float32) * np.float32(sc)) <= step * 1.001 + 1e-7), (comp, t, w)

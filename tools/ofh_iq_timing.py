@@ -1,5 +1,5 @@
-"""Times the Open Fronthaul BFP kernels on the benchmark's grid volume (256 slots x 14 symbols x 273 PRB, 9-bit samples) and
-prints the algorithmic bytes per second against the HBM peak. usage (GPU box): python tools/ofh_bfp_timing.py"""
+"""Times the Open Fronthaul IQ (de)compression kernels (BFP) on the benchmark's grid volume (256 slots x 14 symbols x 273 PRB, 9-bit samples) and
+prints the algorithmic bytes per second against the HBM peak. usage (GPU box): python tools/ofh_iq_timing.py"""
 import os
 import sys
 
@@ -17,15 +17,15 @@ def main():
     slots, nprb, w = 256, 273, 9
     n = slots * 14
     rec = nprb * (1 + 3 * w)
-    jobs = np.zeros(n, dtype=miphy.OfhBfpJob)
+    jobs = np.zeros(n, dtype=miphy.OfhIqJob)
     for i in range(n):
-        jobs[i] = (i * rec, i * nprb * 12, nprb, w)
+        jobs[i] = (i * rec, i * nprb * 12, nprb, w, miphy.OFH_COMPRESSION_BFP)
     jd = torch.from_numpy(jobs.view(np.uint8).copy()).cuda()
     x = torch.view_as_complex((torch.randn(n * nprb * 12, 2, device="cuda") * 0.1).clamp(-0.99, 0.99).contiguous())
     p = torch.zeros(n * rec, dtype=torch.uint8, device="cuda")
     y = torch.zeros_like(x)
     algo = n * rec + x.numel() * 8
-    for name, fn in (("compress", lambda: ctx.ofh_bfp_compress_batch(jd, x, p)), ("decompress", lambda: ctx.ofh_bfp_decompress_batch(jd, p, y))):
+    for name, fn in (("compress", lambda: ctx.ofh_iq_compress_batch(jd, x, p)), ("decompress", lambda: ctx.ofh_iq_decompress_batch(jd, p, y))):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
