@@ -960,6 +960,115 @@ static void test_uplink_processor(std::shared_ptr<miphy::context> c)
   printf("uplink_processor (slot batch, device HARQ pool) done, failures so far %d\n", failures);
 }
 
+// downlink_processor: the PDSCH PDUs of a slot in one device submission at finish_processing_pdus() against the reference
+// pdsch_processor applied PDU by PDU on a zeroed grid (what downlink_processor_single_executor_impl does for PDSCH).
+namespace {
+class gateway_spy : public upper_phy_rg_gateway
+{
+public:
+  void send(const resource_grid_context& context, const resource_grid_reader& grid) override
+  {
+    ++count;
+    slot = context.slot, sector = context.sector, sent = &grid;
+  }
+  unsigned                    count = 0, sector = 0;
+  slot_point                  slot;
+  const resource_grid_reader* sent = nullptr;
+};
+} // namespace
+
+static void test_downlink_processor(std::shared_ptr<miphy::context> c)
+{
+  const unsigned grid_rb = 106, nsc = grid_rb * 12, nof_ports = 2;
+  auto           crcf = create_crc_calculator_factory_sw("auto");
+  auto           prg  = create_pseudo_random_generator_sw_factory();
+  pdsch_encoder_factory_sw_configuration ec;
+  ec.encoder_factory      = create_ldpc_encoder_factory_sw("avx2");
+  ec.rate_matcher_factory = create_ldpc_rate_matcher_factory_sw();
+  ec.segmenter_factory    = create_ldpc_segmenter_tx_factory_sw(crcf);
+  auto p_ref = create_pdsch_processor_factory_sw(create_pdsch_encoder_factory_sw(ec), create_pdsch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg),
+                                                 create_dmrs_pdsch_processor_factory_sw(prg))
+                   ->create();
+  gateway_spy                   gw;
+  miphy::downlink_processor_hip dl(c, gw, nullptr, nullptr, nullptr, nof_ports, grid_rb);
+  struct ue {
+    unsigned          rnti, port, rb_start, nprb, tbs, rv;
+    modulation_scheme mod;
+    bool              with_reserved;
+  };
+  const std::vector<ue> ues = {{0x4601, 0, 0, 60, 42016, 0, modulation_scheme::QAM64, false}, {0x4602, 1, 10, 30, 3848, 2, modulation_scheme::QPSK, true},
+                               {0x4603, 0, 60, 46, 83976, 0, modulation_scheme::QAM256, true}, {0x4604, 1, 60, 4, 320, 1, modulation_scheme::QAM16, false}};
+  std::uniform_int_distribution<int> byte(0, 255);
+  for (unsigned round = 0; round != 2; ++round) {
+    auto g1 = create_resource_grid(nof_ports, 14, nsc), g2 = create_resource_grid(nof_ports, 14, nsc);
+    g1->set_all_zero();
+    // garbage in the HIP grid: configure_resource_grid must zero it
+    std::vector<cf_t> junk(nsc, cf_t(3.0F, -4.0F));
+    for (unsigned p = 0; p != nof_ports; ++p) {
+      for (unsigned l = 0; l != 14; ++l) {
+        g2->put(p, l, 0, junk);
+      }
+    }
+    resource_grid_context ctx;
+    ctx.slot = slot_point(1, 11 + round), ctx.sector = 3;
+    CHECK(!dl.is_reserved(), "downlink_processor: reserved before configuration");
+    dl.configure_resource_grid(ctx, *g2);
+    CHECK(dl.is_reserved(), "downlink_processor: not reserved after configuration");
+    std::vector<std::vector<uint8_t>> tbs;
+    tbs.reserve(ues.size());
+    symbol_slot_mask dm(14);
+    dm.set(2);
+    dm.set(11);
+    for (const ue& u : ues) {
+      pdsch_processor::pdu_t pdu;
+      pdu.slot = ctx.slot, pdu.rnti = u.rnti, pdu.bwp_size_rb = grid_rb, pdu.bwp_start_rb = 0, pdu.cp = cyclic_prefix::NORMAL;
+      pdu.codewords.push_back(pdsch_processor::codeword_description{u.mod, static_cast<uint8_t>(u.rv)});
+      pdu.n_id = 40 + u.port;
+      pdu.ports.push_back(u.port);
+      pdu.ref_point = pdsch_processor::pdu_t::CRB0, pdu.dmrs_symbol_mask = dm, pdu.dmrs = dmrs_type::TYPE1, pdu.scrambling_id = 700 + round, pdu.n_scid = (u.port != 0);
+      pdu.nof_cdm_groups_without_data = 2, pdu.freq_alloc = rb_allocation::make_type1(u.rb_start, u.nprb), pdu.start_symbol_index = 1, pdu.nof_symbols = 13;
+      pdu.ldpc_base_graph = (u.tbs > 3824) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2, pdu.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8;
+      pdu.ratio_pdsch_dmrs_to_sss_dB = -3.0F, pdu.ratio_pdsch_data_to_sss_dB = 0.5F * u.port;
+      if (u.with_reserved) {
+        re_prb_mask rm;
+        rm.set(3);
+        rm.set(9);
+        symbol_slot_mask sm(14);
+        sm.set(5);
+        sm.set(6);
+        pdu.reserved.merge(re_pattern(u.rb_start, u.rb_start + u.nprb, 2, rm, sm));
+      }
+      tbs.emplace_back(u.tbs / 8);
+      for (auto& b : tbs.back()) {
+        b = byte(rgen);
+      }
+      static_vector<span<const uint8_t>, pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS> data;
+      data.emplace_back(tbs.back());
+      p_ref->process(*g1, data, pdu);
+      dl.process_pdsch(data, pdu);
+    }
+    CHECK(gw.count == round, "downlink_processor: grid sent before finish_processing_pdus()");
+    dl.finish_processing_pdus();
+    CHECK(gw.count == round + 1 && gw.sent == g2.get() && gw.slot == ctx.slot && gw.sector == 3, "downlink_processor: gateway call (count %u)", gw.count);
+    CHECK(!dl.is_reserved(), "downlink_processor: still reserved after the grid was sent");
+    std::vector<cf_t> a(nsc), b(nsc);
+    unsigned          bad = 0;
+    for (unsigned p = 0; p != nof_ports; ++p) {
+      for (unsigned l = 0; l != 14; ++l) {
+        g1->get(a, p, l, 0);
+        g2->get(b, p, l, 0);
+        bad += std::memcmp(a.data(), b.data(), nsc * sizeof(cf_t)) != 0;
+      }
+    }
+    CHECK(bad == 0, "downlink_processor: round %u: %u (port, symbol) rows differ", round, bad);
+  }
+  // without a configured grid nothing is processed and nothing is sent
+  static_vector<span<const uint8_t>, pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS> none;
+  dl.finish_processing_pdus();
+  CHECK(gw.count == 2, "downlink_processor: sent without a grid");
+  printf("downlink_processor (slot batch) done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -1143,6 +1252,7 @@ int main()
   test_uplink_processor(c);
   test_pdsch_modulator_and_dmrs(c);
   test_pdsch_processor(c);
+  test_downlink_processor(c);
   test_ofh_iq(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);

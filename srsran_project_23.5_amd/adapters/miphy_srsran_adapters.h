@@ -21,7 +21,11 @@
 #include "srsran/phy/support/resource_grid.h"
 #include "srsran/phy/upper/channel_coding/channel_coding_factories.h"
 #include "srsran/phy/upper/channel_estimation.h"
+#include "srsran/phy/support/resource_grid_context.h"
 #include "srsran/phy/upper/channel_processors/channel_processor_factories.h"
+#include "srsran/phy/upper/downlink_processor.h"
+#include "srsran/phy/upper/resource_grid_mapper.h"
+#include "srsran/phy/upper/upper_phy_rg_gateway.h"
 #include "srsran/phy/upper/rx_softbuffer.h"
 #include "srsran/phy/upper/rx_softbuffer_pool.h"
 #include "srsran/phy/upper/unique_rx_softbuffer.h"
@@ -1501,6 +1505,150 @@ public:
 
 private:
   std::shared_ptr<context> c;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- downlink processor
+/// srsran::downlink_processor (downlink_processor.h:45-111, lib/phy/upper/downlink_processor_single_executor_impl.cpp:54-199) that
+/// batches the PDSCH PDUs of a slot: process_pdsch() queues, finish_processing_pdus() -- the reference's own end-of-slot call --
+/// runs miphy_pdsch_process_batch over all of them (transport blocks up once, written REs down once), puts the REs into the grid
+/// and sends it through the gateway. PDCCH, SSB and CSI-RS go to the CPU processors given at construction, at once. Same
+/// observable behaviour as the reference processor with a synchronous executor: nothing happens without a configured grid, the
+/// grid is zeroed on configuration and sent exactly once, after finish_processing_pdus().
+class downlink_processor_hip : public srsran::downlink_processor
+{
+public:
+  downlink_processor_hip(std::shared_ptr<context>                      c,
+                         srsran::upper_phy_rg_gateway&                 gateway,
+                         std::unique_ptr<srsran::pdcch_processor>      pdcch,
+                         std::unique_ptr<srsran::ssb_processor>        ssb,
+                         std::unique_ptr<srsran::nzp_csi_rs_generator> csi_rs,
+                         unsigned                                      grid_nof_ports,
+                         unsigned                                      grid_nof_prb) :
+    c(std::move(c)), gateway(gateway), pdcch(std::move(pdcch)), ssb(std::move(ssb)), csi_rs(std::move(csi_rs)), nports(grid_nof_ports), nprb(grid_nof_prb)
+  {
+  }
+
+  void process_pdcch(const srsran::pdcch_processor::pdu_t& pdu) override
+  {
+    if (grid == nullptr) {
+      return;
+    }
+    srsran_assert(pdcch, "A PDCCH processor is required.");
+    srsran::resource_grid_mapper mapper(*grid);
+    pdcch->process(mapper, pdu);
+  }
+  void process_ssb(const srsran::ssb_processor::pdu_t& pdu) override
+  {
+    if (grid == nullptr) {
+      return;
+    }
+    srsran_assert(ssb, "An SSB processor is required.");
+    ssb->process(*grid, pdu);
+  }
+  void process_nzp_csi_rs(const srsran::nzp_csi_rs_generator::config_t& config) override
+  {
+    if (grid == nullptr) {
+      return;
+    }
+    srsran_assert(csi_rs, "A CSI-RS generator is required.");
+    csi_rs->map(*grid, config);
+  }
+  void process_pdsch(const srsran::static_vector<srsran::span<const uint8_t>, srsran::pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS>& data,
+                     const srsran::pdsch_processor::pdu_t&                                                                        pdu) override
+  {
+    if (grid == nullptr) {
+      return;
+    }
+    srsran_assert(pdu.ports.size() == 1 && pdu.codewords.size() == 1 && data.size() == 1, "Only one layer / one codeword is supported.");
+    srsran_assert(pdu.dmrs == srsran::dmrs_type::TYPE1, "Only DM-RS Type 1 is currently supported.");
+    srsran_assert(pdu.freq_alloc.is_contiguous(), "Only contiguous allocation is currently supported.");
+    srsran_assert(pdu.ports[0] < nports, "Transmit port outside the resource grid.");
+    queue.push_back(entry{data[0], pdu});
+  }
+  void configure_resource_grid(const srsran::resource_grid_context& context, srsran::resource_grid& grid_) override
+  {
+    srsran_assert(queue.empty(), "Reusing downlink processor that it is still processing PDUs.");
+    rg_context = context;
+    grid       = &grid_;
+    grid->set_all_zero();
+  }
+  void finish_processing_pdus() override
+  {
+    if (grid == nullptr) {
+      return;
+    }
+    run_pdsch_batch();
+    gateway.send(rg_context, *grid);
+    grid = nullptr;
+  }
+  bool is_reserved() const override { return grid != nullptr; }
+
+private:
+  void run_pdsch_batch()
+  {
+    if (queue.empty()) {
+      return;
+    }
+    const unsigned               n = queue.size(), nsc = nprb * 12;
+    std::vector<miphy_pdsch_pdu> pdus(n);
+    size_t                       tb_bytes = 0;
+    for (unsigned i = 0; i != n; ++i) {
+      const srsran::pdsch_processor::pdu_t&        pdu = queue[i].pdu;
+      const srsran::bounded_bitset<srsran::MAX_RB> prb = pdu.freq_alloc.get_prb_mask(pdu.bwp_start_rb, pdu.bwp_size_rb);
+      srsran_assert(prb.size() <= nprb, "The allocation exceeds the resource grid.");
+      miphy_pdsch_pdu& p = pdus[i];
+      p                  = {};
+      p.slot_in_frame = pdu.slot.slot_index(), p.rnti = pdu.rnti, p.n_id = pdu.n_id, p.dmrs_scrambling_id = pdu.scrambling_id;
+      p.tbs_lbrm_bytes = pdu.tbs_lbrm_bytes, p.tb_bytes = queue[i].data.size();
+      p.ratio_pdsch_dmrs_to_sss_dB = pdu.ratio_pdsch_dmrs_to_sss_dB, p.ratio_pdsch_data_to_sss_dB = pdu.ratio_pdsch_data_to_sss_dB;
+      p.bg = bg_id(pdu.ldpc_base_graph), p.rv = pdu.codewords[0].rv, p.mod = srsran::get_bits_per_symbol(pdu.codewords[0].modulation);
+      p.port = pdu.ports[0];
+      p.start_symbol = pdu.start_symbol_index, p.nof_symbols = pdu.nof_symbols, p.nof_cdm_groups_without_data = pdu.nof_cdm_groups_without_data;
+      p.n_scid = pdu.n_scid ? 1 : 0, p.ref_point_prb0 = (pdu.ref_point == srsran::pdsch_processor::pdu_t::PRB0) ? 1 : 0;
+      p.grid_nof_prb = nprb, p.bwp_start_rb = pdu.bwp_start_rb, p.bwp_size_rb = pdu.bwp_size_rb;
+      for (unsigned l = 0; l != 14 && l != pdu.dmrs_symbol_mask.size(); ++l) {
+        if (pdu.dmrs_symbol_mask.test(l)) {
+          p.dmrs_symbols_mask |= static_cast<uint16_t>(1U << l);
+        }
+      }
+      prb.for_each(0, prb.size(), [&p](unsigned r) { p.rb_mask[r >> 6] |= 1ULL << (r & 63); });
+      p.nof_reserved = reserved_rectangles(pdu.reserved, prb.size(), p.reserved);
+      p.tb_offset = tb_bytes, p.grid_offset = 0;
+      tb_bytes += (queue[i].data.size() + 15) & ~static_cast<size_t>(15);
+    }
+    tbs.assign(tb_bytes + 16, 0);
+    for (unsigned i = 0; i != n; ++i) {
+      std::memcpy(&tbs[pdus[i].tb_offset], queue[i].data.data(), queue[i].data.size());
+    }
+    host.assign(static_cast<size_t>(nports) * 14 * nsc, srsran::cf_t(NAN, NAN)); // NaN marks "not written by the kernels"
+    auto* d_tb = static_cast<uint8_t*>(c->buf(0, tbs.size()));
+    auto* d_g  = static_cast<float*>(c->buf(1, host.size() * sizeof(srsran::cf_t)));
+    c->h2d(d_tb, tbs.data(), tbs.size());
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    context::check(miphy_pdsch_process_batch(c->ctx, pdus.data(), n, d_tb, d_g, c->stream), "pdsch_process");
+    c->d2h(host.data(), d_g, host.size() * sizeof(srsran::cf_t));
+    c->sync();
+    for (unsigned p = 0; p != nports; ++p) {
+      put_written_res(*grid, p, nsc, host.data() + static_cast<size_t>(p) * 14 * nsc);
+    }
+    queue.clear();
+  }
+
+  struct entry {
+    srsran::span<const uint8_t>    data;
+    srsran::pdsch_processor::pdu_t pdu;
+  };
+  std::shared_ptr<context>                      c;
+  srsran::upper_phy_rg_gateway&                 gateway;
+  std::unique_ptr<srsran::pdcch_processor>      pdcch;
+  std::unique_ptr<srsran::ssb_processor>        ssb;
+  std::unique_ptr<srsran::nzp_csi_rs_generator> csi_rs;
+  unsigned                                      nports, nprb;
+  srsran::resource_grid_context                 rg_context = {};
+  srsran::resource_grid*                        grid       = nullptr;
+  std::vector<entry>                            queue;
+  std::vector<uint8_t>                          tbs;
+  std::vector<srsran::cf_t>                     host;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- Open Fronthaul IQ compression
