@@ -200,3 +200,48 @@ __device__ __forceinline__ void fft_lds(cplx* x, int N, const cplx* __restrict__
   else
     fft_lds_w<INV, false>(x, N, tw, tid, nt);
 }
+
+// N = 4096 = 8^4 on 512 threads (the 100 MHz / 30 kHz symbol): one radix-8 butterfly per thread and pass with every stride a
+// compile-time constant, so that the padded LDS addresses of a pass are one base plus immediates (reads: fpad(t) + 576 k; writes:
+// 9 t + k, then fpad(q) + 9 S p + (9 S / 8) k). Same butterflies, twiddles and order of operations as fft_lds: identical results.
+template <bool INV, int S>
+__device__ __forceinline__ void fft4096_pass(cplx* x, const cplx* __restrict__ tw, int t)
+{
+  constexpr int M = 512 / S; // sub-transform length / 8
+  const int     p = t / S, q = t % S;
+  cplx          w1 = {1.f, 0.f};
+  if (M > 1)
+    w1 = tw[p * S];
+  const cplx* xr = x + fpad(t);
+  cplx        a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    a[k] = xr[576 * k];
+  __syncthreads();
+  dft8<INV>(a);
+  if (M > 1) {
+    w1     = cconj_if<INV>(w1);
+    cplx w = w1;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      a[k] = cmul(a[k], w);
+      if (k + 1 < 8)
+        w = cmul(w, w1);
+    }
+  }
+  constexpr int WS = (S == 1) ? 1 : 9 * S / 8;
+  cplx*         xw = x + ((S == 1) ? 9 * t : fpad(q) + 9 * S * p);
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    xw[k * WS] = a[k];
+  __syncthreads();
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft4096_lds(cplx* x, const cplx* __restrict__ tw, int t)
+{
+  fft4096_pass<INV, 1>(x, tw, t);
+  fft4096_pass<INV, 8>(x, tw, t);
+  fft4096_pass<INV, 64>(x, tw, t);
+  fft4096_pass<INV, 512>(x, tw, t);
+}

@@ -130,7 +130,7 @@ bool four_step_factors(uint32_t N, uint32_t& N1, uint32_t& N2)
 // Each workgroup loops over (slot, symbol) pairs with stride gridDim.x; the launcher starts as many workgroups as the chip
 // holds at once. (Keeping the next symbol's samples in flight in registers while transforming the current one was measured:
 // the 16 extra registers cost a resident workgroup per CU and the time stayed the same, so the loads are plain.)
-template <bool WIDE>
+template <bool WIDE, int NCT>
 __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict__ jobs,
                                                 const ofdm_plan_dev* __restrict__ plan,
                                                 const cplx* __restrict__ tw,
@@ -140,10 +140,10 @@ __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict
                                                 int total)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  cplx*     x = reinterpret_cast<cplx*>(smem);
-  const int N = plan->N, rg = plan->rg, half = rg / 2;
-  const int nt = blockDim.x;
-  for (int idx = blockIdx.x; idx < total; idx += gridDim.x) {
+  cplx*     x  = reinterpret_cast<cplx*>(smem);
+  const int N  = NCT != 0 ? NCT : plan->N, rg = plan->rg, half = rg / 2;
+  const int nt = NCT != 0 ? NCT / 8 : (int)blockDim.x;
+  auto symbol = [&](int idx) {
     const miphy_ofdm_job& job = jobs[idx / 14];
     const int             l   = idx % 14;
     const int             sym = (int)job.slot_index * 14 + l;
@@ -163,7 +163,10 @@ __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict
       }
     }
     __syncthreads();
-    fft_lds_w<false, WIDE>(x, N, tw, threadIdx.x, nt);
+    if (NCT == 4096)
+      fft4096_lds<false>(x, tw, threadIdx.x);
+    else
+      fft_lds_w<false, WIDE>(x, N, tw, threadIdx.x, nt);
     const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
     float2*    dst  = grid + job.grid_offset + (size_t)l * rg;
     for (int k = threadIdx.x; k < rg; k += nt) {
@@ -173,6 +176,15 @@ __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict
         v = cmul(v, ramp[bin]);                              // window-offset phase ramp (:60-76,127-129)
       dst[k] = make_float2(v.x, v.y);
     }
+  };
+  if (NCT != 0) { // one symbol per workgroup, straight-line code: inside a loop over symbols the compiler keeps the addresses
+                  // of all four passes live across iterations and spills (252-308 bytes of scratch per lane were measured)
+    if ((int)blockIdx.x < total)
+      symbol(blockIdx.x);
+    return;
+  }
+  for (int idx = blockIdx.x; idx < total; idx += gridDim.x) {
+    symbol(idx);
     __syncthreads(); // x is rewritten by the next symbol
   }
 }
@@ -182,16 +194,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))
 ofdm_demod_wide_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const cplx* __restrict__ ramp,
                        const float2* __restrict__ samples, float2* __restrict__ grid, int total)
 {
-  ofdm_demod_body<true>(jobs, plan, tw, ramp, samples, grid, total);
+  ofdm_demod_body<true, 0>(jobs, plan, tw, ramp, samples, grid, total);
+}
+// The 4096-point symbol of the 100 MHz / 30 kHz carrier on 512 threads: compile-time strides (fft4096_lds).
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8)))
+ofdm_demod_4096_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const cplx* __restrict__ ramp,
+                       const float2* __restrict__ samples, float2* __restrict__ grid, int total)
+{
+  ofdm_demod_body<true, 4096>(jobs, plan, tw, ramp, samples, grid, total);
 }
 __global__ void __launch_bounds__(512)
 ofdm_demod_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const cplx* __restrict__ ramp,
                   const float2* __restrict__ samples, float2* __restrict__ grid, int total)
 {
-  ofdm_demod_body<false>(jobs, plan, tw, ramp, samples, grid, total);
+  ofdm_demod_body<false, 0>(jobs, plan, tw, ramp, samples, grid, total);
 }
 
-template <bool WIDE>
+template <bool WIDE, int NCT>
 __device__ __forceinline__ void ofdm_mod_body(const miphy_ofdm_job* __restrict__ jobs,
                                               const ofdm_plan_dev* __restrict__ plan,
                                               const cplx* __restrict__ tw,
@@ -226,7 +245,10 @@ __device__ __forceinline__ void ofdm_mod_body(const miphy_ofdm_job* __restrict__
     x[fpad(i)] = v;
   }
   __syncthreads();
-  fft_lds_w<true, WIDE>(x, N, tw, threadIdx.x, blockDim.x);
+  if (NCT == 4096)
+    fft4096_lds<true>(x, tw, threadIdx.x);
+  else
+    fft_lds_w<true, WIDE>(x, N, tw, threadIdx.x, blockDim.x);
   const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
   for (int i = threadIdx.x; i < N + cp; i += blockDim.x) {
     const int j = (i < cp) ? N - cp + i : i - cp; // cyclic prefix = copy of the tail (:98)
@@ -239,13 +261,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))
 ofdm_mod_wide_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const float2* __restrict__ grid,
                      float2* __restrict__ samples)
 {
-  ofdm_mod_body<true>(jobs, plan, tw, grid, samples);
+  ofdm_mod_body<true, 0>(jobs, plan, tw, grid, samples);
+}
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8)))
+ofdm_mod_4096_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const float2* __restrict__ grid,
+                     float2* __restrict__ samples)
+{
+  ofdm_mod_body<true, 4096>(jobs, plan, tw, grid, samples);
 }
 __global__ void __launch_bounds__(512)
 ofdm_mod_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const float2* __restrict__ grid,
                 float2* __restrict__ samples)
 {
-  ofdm_mod_body<false>(jobs, plan, tw, grid, samples);
+  ofdm_mod_body<false, 0>(jobs, plan, tw, grid, samples);
 }
 
 bool size_supported(uint32_t N)
@@ -483,7 +511,10 @@ extern "C" int miphy_ofdm_demodulate_slots(miphy_ctx*               ctx,
   static const char* env_wg = getenv("MIPHY_OFDM_WG_PER_CU");
   const int          per_cu = env_wg ? atoi(env_wg) : (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / (lds + 512)));
   const int          nwg    = std::min(total, ctx->num_cus * per_cu);
-  if (wide)
+  if (wide && cfg->dft_size == 4096 && nt == 512)
+    hipLaunchKernelGGL(ofdm_demod_4096_kernel, dim3(total), dim3(nt), lds, s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw, (const cplx*)ramp,
+                       (const float2*)samples, (float2*)grid, total);
+  else if (wide)
     hipLaunchKernelGGL(ofdm_demod_wide_kernel, dim3(nwg), dim3(nt), lds, s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw, (const cplx*)ramp,
                        (const float2*)samples, (float2*)grid, total);
   else
@@ -522,7 +553,10 @@ extern "C" int miphy_ofdm_modulate_slots(miphy_ctx*               ctx,
   if ((rc = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_ofdm_job) * (size_t)n, s, &d_jobs)))
     return rc;
   const int nt = threads_for(cfg->dft_size);
-  if (cfg->dft_size <= 8u * (uint32_t)nt)
+  if (cfg->dft_size == 4096 && nt == 512)
+    hipLaunchKernelGGL(ofdm_mod_4096_kernel, dim3(14, n), dim3(nt), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
+                       (const float2*)grid, (float2*)samples);
+  else if (cfg->dft_size <= 8u * (uint32_t)nt)
     hipLaunchKernelGGL(ofdm_mod_wide_kernel, dim3(14, n), dim3(nt), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
                        (const float2*)grid, (float2*)samples);
   else
