@@ -64,11 +64,14 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid)
   if ((tid & 63) == 0)
     red[tid >> 6] = v;
   __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+  float r = red[0];
+  for (unsigned w = 1; w < blockDim.x / 64; ++w)
+    r += red[w];
+  return r;
 }
 
 
-__global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job* __restrict__ jobs,
+__global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job* __restrict__ jobs,
                                                     const gold_jump* __restrict__ gj,
                                                     const cplx* __restrict__ tw,
                                                     const float2* __restrict__ grid,
@@ -197,7 +200,10 @@ __global__ void __launch_bounds__(256) chest_kernel(const miphy_pusch_chest_job*
   for (int i = tid; i < np; i += nt)
     fbuf[fpad(prb_of[i / 6] * 12 + 2 * (i % 6) + delta)] = lse[i];
   __syncthreads();
-  fft_lds<true>(fbuf, CE_DFT, tw, tid, nt);
+  if (nt == 512)
+    fft4096_lds<true>(fbuf, tw, tid); // CE_DFT = 4096 on 512 threads: compile-time strides
+  else
+    fft_lds<true>(fbuf, CE_DFT, tw, tid, nt);
   // arg-max of |.|^2 over the first / last HALF_CP taps (first occurrence wins, like std::max_element)
   float best = -1.f;
   int   bidx = 0x7fffffff;
@@ -340,7 +346,9 @@ extern "C" int miphy_dmrs_pusch_estimate_batch(miphy_ctx*                   ctx,
   static const char* genv = getenv("MIPHY_CHEST_GROUPS");
   int                ngrp = genv ? atoi(genv) : 1; // measured: splitting does not pay once the per-workgroup prologue is parallel
   ngrp                    = ngrp < 1 ? 1 : (ngrp > 14 ? 14 : ngrp);
-  hipLaunchKernelGGL(chest_kernel, dim3(n, 4 * max_layers, ngrp), dim3(256), lds, s, (const miphy_pusch_chest_job*)d_jobs,
+  static const char* tenv = getenv("MIPHY_CHEST_THREADS");
+  const int          cthreads = (tenv && atoi(tenv) == 256) ? 256 : 512;
+  hipLaunchKernelGGL(chest_kernel, dim3(n, 4 * max_layers, ngrp), dim3(cthreads), lds, s, (const miphy_pusch_chest_job*)d_jobs,
                      (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw,
                      (const float2*)grid, (float2*)ce, scalars);
   MIPHY_HIP_CHECK(hipGetLastError());
