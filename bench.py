@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--slots", type=int, default=256, help="slots per GPU per step")
+    ap.add_argument("--slots", type=int, default=1024, help="slots per GPU per step (1024 slots = 38 912 codeblocks = exactly 38 rounds of the 1024 codeblocks the chip holds at once)")
     ap.add_argument("--max-iter", type=int, default=6)
     ap.add_argument("--early-stop", type=int, default=0)
     ap.add_argument("--snr-db", type=float, default=33.0, help="per-RE SNR of the synthesised slots")
