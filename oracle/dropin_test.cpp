@@ -1069,6 +1069,98 @@ static void test_downlink_processor(std::shared_ptr<miphy::context> c)
   printf("downlink_processor (slot batch) done, failures so far %d\n", failures);
 }
 
+// Block error behaviour at moderate SNR: many random slots through the all-software processor and through the fused HIP processor,
+// verdict by verdict. (The LLRs of the two differ by at most one quantisation step in a few per cent of the positions -- the
+// reference equaliser uses an approximate reciprocal -- so a borderline block may flip; more than that would be a defect.)
+static void test_pusch_processor_bler(std::shared_ptr<miphy::context> c)
+{
+  auto                                   crcf = create_crc_calculator_factory_sw("auto");
+  auto                                   prg  = create_pseudo_random_generator_sw_factory();
+  pdsch_encoder_factory_sw_configuration ec;
+  ec.encoder_factory      = create_ldpc_encoder_factory_sw("avx2");
+  ec.rate_matcher_factory = create_ldpc_rate_matcher_factory_sw();
+  ec.segmenter_factory    = create_ldpc_segmenter_tx_factory_sw(crcf);
+  auto tx = create_pdsch_processor_factory_sw(create_pdsch_encoder_factory_sw(ec), create_pdsch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg),
+                                              create_dmrs_pdsch_processor_factory_sw(prg))
+                ->create();
+  auto p_ref   = make_processor(c, false);
+  auto p_fused = std::make_shared<miphy::pusch_processor_factory_hip>(c, 6, true)->create();
+  struct tc {
+    modulation_scheme mod;
+    unsigned          nprb, tbs;
+    float             snr_db;
+  };
+  std::uniform_int_distribution<int> byte(0, 255);
+  for (const tc& t : {tc{modulation_scheme::QAM16, 52, 20496, 18.0F}, tc{modulation_scheme::QAM16, 52, 20496, 16.5F}, tc{modulation_scheme::QAM64, 106, 83976, 25.0F},
+                      tc{modulation_scheme::QPSK, 25, 3848, 9.0F}}) {
+    const unsigned nsc = t.nprb * 12, nslots = 40;
+    unsigned       fail_ref = 0, fail_hip = 0, differ = 0;
+    for (unsigned n = 0; n != nslots; ++n) {
+      ldpc_base_graph_type bg = (t.tbs > 3824) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+      std::vector<uint8_t> tb(t.tbs / 8);
+      for (auto& b : tb) {
+        b = byte(rgen);
+      }
+      slot_point       slot(1, n % 20);
+      symbol_slot_mask dm(14);
+      dm.set(2);
+      auto grid = create_resource_grid(1, 14, nsc);
+      grid->set_all_zero();
+      pdsch_processor::pdu_t d;
+      d.slot = slot, d.rnti = 0x4601, d.bwp_size_rb = t.nprb, d.bwp_start_rb = 0, d.cp = cyclic_prefix::NORMAL;
+      d.codewords.push_back(pdsch_processor::codeword_description{t.mod, 0});
+      d.n_id = 935;
+      d.ports.push_back(0);
+      d.ref_point = pdsch_processor::pdu_t::CRB0, d.dmrs_symbol_mask = dm, d.dmrs = dmrs_type::TYPE1, d.scrambling_id = 42, d.n_scid = false;
+      d.nof_cdm_groups_without_data = 2, d.freq_alloc = rb_allocation::make_type1(0, t.nprb), d.start_symbol_index = 0, d.nof_symbols = 14;
+      d.ldpc_base_graph = bg, d.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8, d.ratio_pdsch_data_to_sss_dB = 0.0F, d.ratio_pdsch_dmrs_to_sss_dB = -3.0F;
+      static_vector<span<const uint8_t>, pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS> data;
+      data.emplace_back(tb);
+      tx->process(*grid, data, d);
+      std::normal_distribution<float> noise(0.F, std::pow(10.0F, -t.snr_db / 20.0F) * 0.7071F);
+      std::vector<cf_t>               row(nsc);
+      for (unsigned l = 0; l != 14; ++l) {
+        grid->get(row, 0, l, 0);
+        for (auto& v : row) {
+          v += cf_t(noise(rgen), noise(rgen));
+        }
+        grid->put(0, l, 0, row);
+      }
+      pusch_processor::pdu_t pdu;
+      pdu.slot = slot, pdu.rnti = 0x4601, pdu.bwp_size_rb = t.nprb, pdu.bwp_start_rb = 0, pdu.cp = cyclic_prefix::NORMAL;
+      pdu.mcs_descr.modulation = t.mod, pdu.mcs_descr.target_code_rate = 0.5F;
+      pdu.codeword.emplace();
+      pdu.codeword.value().rv = 0, pdu.codeword.value().ldpc_base_graph = bg, pdu.codeword.value().new_data = true;
+      pdu.uci = {};
+      pdu.uci.alpha_scaling = 1.0F, pdu.uci.beta_offset_harq_ack = 20.0F, pdu.uci.beta_offset_csi_part1 = 6.25F, pdu.uci.beta_offset_csi_part2 = 6.25F;
+      pdu.n_id = 935, pdu.nof_tx_layers = 1;
+      pdu.rx_ports.push_back(0);
+      pdu.dmrs_symbol_mask = dm, pdu.dmrs = dmrs_type::TYPE1, pdu.scrambling_id = 42, pdu.n_scid = false, pdu.nof_cdm_groups_without_data = 2;
+      pdu.freq_alloc = rb_allocation::make_type1(0, t.nprb);
+      pdu.start_symbol_index = 0, pdu.nof_symbols = 14, pdu.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8;
+      unsigned                  nof_cbs = ldpc::compute_nof_codeblocks(units::bits(t.tbs), bg);
+      rx_softbuffer_pool_config pc;
+      pc.max_codeblock_size = ldpc::MAX_CODEBLOCK_SIZE, pc.max_softbuffers = 1, pc.max_nof_codeblocks = 64, pc.expire_timeout_slots = 10;
+      auto                     pool1 = create_rx_softbuffer_pool(pc), pool2 = create_rx_softbuffer_pool(pc);
+      rx_softbuffer_identifier id;
+      id.rnti = 1, id.harq_ack_id = 0;
+      auto                 sb1 = pool1->reserve_softbuffer(slot, id, nof_cbs), sb2 = pool2->reserve_softbuffer(slot, id, nof_cbs);
+      std::vector<uint8_t> o1(tb.size(), 0), o2(tb.size(), 0);
+      notifier_spy         n1, n2;
+      p_ref->process(o1, sb1.get(), n1, *grid, pdu);
+      p_fused->process(o2, sb2.get(), n2, *grid, pdu);
+      fail_ref += !n1.sch.data.tb_crc_ok, fail_hip += !n2.sch.data.tb_crc_ok, differ += n1.sch.data.tb_crc_ok != n2.sch.data.tb_crc_ok;
+      if (n2.sch.data.tb_crc_ok) {
+        CHECK(o2 == tb, "pusch_processor BLER: wrong transport block with CRC ok");
+      }
+    }
+    printf("  %u PRB %u bits at %.1f dB: block errors reference %u / %u, HIP %u / %u, verdicts differing %u\n", t.nprb, t.tbs, t.snr_db, fail_ref, nslots, fail_hip,
+           nslots, differ);
+    CHECK(differ <= 2, "pusch_processor BLER: %u of %u verdicts differ (%u PRB, %.1f dB)", differ, nslots, t.nprb, t.snr_db);
+  }
+  printf("pusch_processor block-error comparison done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -1250,6 +1342,7 @@ int main()
   test_pusch_demodulator(c);
   test_pusch_processor(c);
   test_uplink_processor(c);
+  test_pusch_processor_bler(c);
   test_pdsch_modulator_and_dmrs(c);
   test_pdsch_processor(c);
   test_downlink_processor(c);

@@ -116,7 +116,7 @@ def test_pbch_encoder_batch(ctx):
         assert np.array_equal(out[i], exp), i
 
 
-@pytest.mark.parametrize("A,AL,sigma", [(12, 1, 1.1), (40, 1, 0.9), (40, 2, 1.25), (70, 4, 1.6), (128, 8, 1.5), (57, 16, 2.6)])
+@pytest.mark.parametrize("A,AL,sigma", [(12, 1, 1.1), (40, 1, 0.9), (40, 2, 1.25), (70, 4, 1.6), (128, 8, 1.5), (57, 16, 3.0)])
 def test_scl_list_decoder_pdcch(ctx, A, AL, sigma):
     """SCL (L = 1, 2, 4, 8; plain and CRC-aided) against the oracle's restatement, bit for bit incl. metric and CRC verdict
     (BASELINE configs[3]: PDCCH aggregation levels 1-16). There is no reference counterpart for L > 1; properties checked on
@@ -133,7 +133,9 @@ def test_scl_list_decoder_pdcch(ctx, A, AL, sigma):
     for i in range(nb):
         tx = o_pdcch_encode(pays[i], int(rntis[i]), E)
         y = (1.0 - 2.0 * tx) + sigma * rng.standard_normal(E)
-        llrs[i] = np.round(np.clip(4 * y, -20, 20) / 20 * 120)
+        # channel LLR 2 y / sigma^2 on the reference's int8 scale (range 20 -> 120): with a fixed gain instead, the repetition
+        # combining of the high aggregation levels saturates every soft bit and no decoder has soft information left
+        llrs[i] = np.round(np.clip(2 * y / sigma ** 2, -20, 20) / 20 * 120)
     l_d = torch.from_numpy(llrs.reshape(-1)).cuda()
     r_d = torch.from_numpy(rntis.view(np.int16)).cuda()
     n_ca8 = n_ssc = 0
@@ -159,8 +161,8 @@ def test_scl_list_decoder_pdcch(ctx, A, AL, sigma):
         c = np.zeros(K, np.uint8)
         oracle().orc_polar_interleave(m.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), C.c_uint(K), 1)
         n_ssc += int(np.array_equal(c[:A], pays[i]))
-    # statistical, not a theorem (int8 saturation / +-inf LLRs after repetition can favour the SSC rate-1 shortcut): allow 10 %
-    assert n_ca8 >= n_ssc - max(2, nb // 10), (n_ca8, n_ssc)
+    # at these operating points the list decoder recovers 1.4-3 times as many blocks as the reference-style SSC decoder
+    assert n_ca8 >= n_ssc + 5, (n_ca8, n_ssc)
 
 
 def test_scl_pbch_and_uplink_codes(ctx):
