@@ -39,7 +39,7 @@ def _build_slot(ctx, miphy, torch, nprb, mod, tbs_bits, slot, rnti, n_id, scr, s
 def test_process_batch_recovers_transport_blocks_and_matches_the_separate_calls(ctx):
     import torch
     import miphy
-    cases = [(273, 8, 319784, 33.0), (106, 6, 83976, 26.0), (52, 4, 20496, 18.0), (25, 2, 3848, 14.0)]
+    cases = [(273, 8, 319784, 33.0), (106, 6, 83976, 26.0), (52, 4, 20496, 21.0), (25, 2, 3848, 16.0)]  # SNRs with margin: the reference chain loses 12 % of the 16QAM blocks at 18 dB
     pdus = np.zeros(len(cases), dtype=miphy.PuschPdu)
     grids, tbs, goff, tboff, cboff = [], [], 0, 0, 0
     for i, (nprb, mod, tbs_bits, snr) in enumerate(cases):
