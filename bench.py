@@ -366,14 +366,14 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
     # VALU-issue roofline of the decoder (it is not an HBM kernel): wave64 VALU instructions per launch from the SQ counters of the
-    # same workload (profiles/r01_pmc_sq_v4_all_kernels.csv, SQ_INSTS_VALU; scales with the codeblocks) over the launch time, against
+    # same workload (profiles/r01_pmc_sq_v8_all_kernels.csv, SQ_INSTS_VALU of a 38 912-codeblock launch; scales with the codeblocks) over the launch time, against
     # 1024 SIMDs x (2.4 GHz / 4 cycles per wave64 instruction).
     valu = None
     try:
         import csv
-        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_sq_v4_all_kernels.csv"))):
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_sq_v8_all_kernels.csv"))):
             if r["kernel"] == "ldpc_decode_pk_kernel" and r["counter"] == "SQ_INSTS_VALU":
-                per_cb = float(r["mean_per_dispatch"]) / 9728.0
+                per_cb = float(r["mean_per_dispatch"]) / 38912.0
                 ach = per_cb * S * C / (kernel_ms["ldpc_decode"] * 1e-3) / 1e9
                 valu = {"kernel": "ldpc_decode", "bound": "valu_issue", "achieved": ach, "peak": 1024 * 2.4 / 4, "unit": "G wave-instr/s",
                         "frac": ach / (1024 * 2.4 / 4), "valu_wave_instructions_per_codeblock": per_cb}
