@@ -21,7 +21,14 @@ __device__ __forceinline__ int fpad(int i)
 // LDS bytes needed for an N-point buffer.
 __host__ __device__ constexpr size_t fft_lds_bytes(size_t N)
 {
-  return (N + (N >> 3) + 1) * 8;
+  return (N + (N >> 3) + 16) * 8; // + the skew of fpad_skew
+}
+// Padding of the 4096-point OFDM kernels: fpad plus one element after every 512. The radix-8 reads of a pass are 512 elements
+// apart (t + 512 k); with fpad alone that is 576 elements = 18 x 256 bytes, i.e. the two addresses of a paired 64-bit read
+// (ds_read2st64_b64) fall on the same banks -- measured as LDS bank-conflict cycles 1.6 x the LDS instruction cycles.
+__device__ __forceinline__ int fpad_skew(int i)
+{
+  return i + (i >> 3) + (i >> 9);
 }
 __device__ __forceinline__ cplx cmul(cplx a, cplx b)
 {
@@ -204,10 +211,11 @@ __device__ __forceinline__ void fft_lds(cplx* x, int N, const cplx* __restrict__
 // N = 4096 = 8^4 on 512 threads (the 100 MHz / 30 kHz symbol): one radix-8 butterfly per thread and pass with every stride a
 // compile-time constant, so that the padded LDS addresses of a pass are one base plus immediates (reads: fpad(t) + 576 k; writes:
 // 9 t + k, then fpad(q) + 9 S p + (9 S / 8) k). Same butterflies, twiddles and order of operations as fft_lds: identical results.
-template <bool INV, int S>
+template <bool INV, int S, bool SKEW>
 __device__ __forceinline__ void fft4096_pass(cplx* x, const cplx* __restrict__ tw, int t)
 {
-  constexpr int M = 512 / S; // sub-transform length / 8
+  constexpr int M  = 512 / S;            // sub-transform length / 8
+  constexpr int RS = SKEW ? 577 : 576;   // read stride: fpad(_skew)(t + 512 k) = fpad(t) + RS k
   const int     p = t / S, q = t % S;
   cplx          w1 = {1.f, 0.f};
   if (M > 1)
@@ -216,7 +224,7 @@ __device__ __forceinline__ void fft4096_pass(cplx* x, const cplx* __restrict__ t
   cplx        a[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k)
-    a[k] = xr[576 * k];
+    a[k] = xr[RS * k];
   __syncthreads();
   dft8<INV>(a);
   if (M > 1) {
@@ -229,19 +237,24 @@ __device__ __forceinline__ void fft4096_pass(cplx* x, const cplx* __restrict__ t
         w = cmul(w, w1);
     }
   }
-  constexpr int WS = (S == 1) ? 1 : 9 * S / 8;
-  cplx*         xw = x + ((S == 1) ? 9 * t : fpad(q) + 9 * S * p);
+  // write index q + S (8 p + k), padded: S = 1: 9 t + k [+ t / 64]; S = 8: q + 72 p + 9 k [+ p / 8]; S = 64: fpad(q) + 576 p + 72 k
+  // [+ p]; S = 512: fpad(q) + 576 k [+ k]
+  constexpr int WS = (S == 1) ? 1 : (S == 512 ? RS : 9 * S / 8);
+  int           wb = (S == 1) ? 9 * t : fpad(q) + 9 * S * p;
+  if (SKEW)
+    wb += (S == 1) ? (t >> 6) : (S == 8 ? (p >> 3) : (S == 64 ? p : 0));
+  cplx* xw = x + wb;
 #pragma unroll
   for (int k = 0; k < 8; ++k)
     xw[k * WS] = a[k];
   __syncthreads();
 }
 
-template <bool INV>
+template <bool INV, bool SKEW = false>
 __device__ __forceinline__ void fft4096_lds(cplx* x, const cplx* __restrict__ tw, int t)
 {
-  fft4096_pass<INV, 1>(x, tw, t);
-  fft4096_pass<INV, 8>(x, tw, t);
-  fft4096_pass<INV, 64>(x, tw, t);
-  fft4096_pass<INV, 512>(x, tw, t);
+  fft4096_pass<INV, 1, SKEW>(x, tw, t);
+  fft4096_pass<INV, 8, SKEW>(x, tw, t);
+  fft4096_pass<INV, 64, SKEW>(x, tw, t);
+  fft4096_pass<INV, 512, SKEW>(x, tw, t);
 }

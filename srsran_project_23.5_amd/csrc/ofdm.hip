@@ -143,6 +143,7 @@ __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict
   cplx*     x  = reinterpret_cast<cplx*>(smem);
   const int N  = NCT != 0 ? NCT : plan->N, rg = plan->rg, half = rg / 2;
   const int nt = NCT != 0 ? NCT / 8 : (int)blockDim.x;
+  auto pad = [](int i) { return NCT == 4096 ? fpad_skew(i) : fpad(i); };
   auto symbol = [&](int idx) {
     const miphy_ofdm_job& job = jobs[idx / 14];
     const int             l   = idx % 14;
@@ -153,25 +154,25 @@ __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict
       const float4* src4 = reinterpret_cast<const float4*>(src);
       for (int i = threadIdx.x; i < N / 2; i += nt) {
         const float4 v     = src4[i];
-        x[fpad(2 * i)]     = {v.x, v.y};
-        x[fpad(2 * i + 1)] = {v.z, v.w};
+        x[pad(2 * i)]     = {v.x, v.y};
+        x[pad(2 * i + 1)] = {v.z, v.w};
       }
     } else {
       for (int i = threadIdx.x; i < N; i += nt) {
-        float2 v   = src[i];
-        x[fpad(i)] = {v.x, v.y};
+        float2 v  = src[i];
+        x[pad(i)] = {v.x, v.y};
       }
     }
     __syncthreads();
     if (NCT == 4096)
-      fft4096_lds<false>(x, tw, threadIdx.x);
+      fft4096_lds<false, true>(x, tw, threadIdx.x);
     else
       fft_lds_w<false, WIDE>(x, N, tw, threadIdx.x, nt);
     const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
     float2*    dst  = grid + job.grid_offset + (size_t)l * rg;
     for (int k = threadIdx.x; k < rg; k += nt) {
       const int bin = (k < half) ? N - half + k : k - half; // demodulator_impl.cpp:131-137
-      cplx      v   = cmul(x[fpad(bin)], coef);              // sc_prod(dft_output, phase * scale)
+      cplx      v   = cmul(x[pad(bin)], coef);               // sc_prod(dft_output, phase * scale)
       if (ramp)
         v = cmul(v, ramp[bin]);                              // window-offset phase ramp (:60-76,127-129)
       dst[k] = make_float2(v.x, v.y);
@@ -242,17 +243,17 @@ __device__ __forceinline__ void ofdm_mod_body(const miphy_ofdm_job* __restrict__
       float2 g = src[i - (N - half)];
       v        = {g.x, g.y};
     }
-    x[fpad(i)] = v;
+    x[NCT == 4096 ? fpad_skew(i) : fpad(i)] = v;
   }
   __syncthreads();
   if (NCT == 4096)
-    fft4096_lds<true>(x, tw, threadIdx.x);
+    fft4096_lds<true, true>(x, tw, threadIdx.x);
   else
     fft_lds_w<true, WIDE>(x, N, tw, threadIdx.x, blockDim.x);
   const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
   for (int i = threadIdx.x; i < N + cp; i += blockDim.x) {
     const int j = (i < cp) ? N - cp + i : i - cp; // cyclic prefix = copy of the tail (:98)
-    cplx      v = cmul(x[fpad(j)], coef);
+    cplx      v = cmul(x[NCT == 4096 ? fpad_skew(j) : fpad(j)], coef);
     dst[i]      = make_float2(v.x, v.y);
   }
 }
