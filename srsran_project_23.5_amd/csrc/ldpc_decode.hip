@@ -479,10 +479,10 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   if (use_pk)
     return miphy_ldpc_pk_launch((const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, n, pk_threads, pk_lds, llr, out_bits, iters, nodes_all, harq_slot,
                                 harq_crc_ok, s);
-  static thread_local size_t lds_set = 0;
-  if (max_lds > lds_set) {
+  // Above the default 64 KB of dynamic LDS the limit has to be raised; it is a per-device attribute of the kernel, so it is set on
+  // every such launch (a cache per thread would be wrong for a thread that drives several devices).
+  if (max_lds > 48 * 1024) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
-    lds_set = max_lds;
   }
   hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n), dim3(max_threads), max_lds, s, (const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot, harq_crc_ok);
   MIPHY_HIP_CHECK(hipGetLastError());

@@ -422,10 +422,10 @@ int miphy_ldpc_pk_launch(const miphy_ldpc_dec_desc* d_descs, const miphy_graph_t
   static const char* pad = getenv("MIPHY_LDPC_PAD_LDS"); // occupancy experiments only
   if (pad)
     lds += (size_t)atoi(pad);
-  static thread_local size_t lds_set = 0;
-  if (lds > lds_set) {
+  // Above the default 64 KB of dynamic LDS the limit has to be raised; it is a per-device attribute of the kernel, so it is set on
+  // every such launch (a cache per thread would be wrong for a thread that drives several devices).
+  if (lds > 48 * 1024) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_pk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set = lds;
   }
   hipLaunchKernelGGL(ldpc_decode_pk_kernel, dim3(n), dim3(threads), lds, s, d_descs, tab, llr, out_bits, iters, nodes_all, harq_slot, harq_crc_ok);
   MIPHY_HIP_CHECK(hipGetLastError());

@@ -155,7 +155,8 @@ extern "C" void miphy_destroy(miphy_ctx* c)
     (void)hipFree(p);
   delete c->ext;
   (void)hipFree(c->d_desc_staging);
-  (void)hipFree(c->d_work);
+  for (void* w : c->d_work)
+    (void)hipFree(w);
   (void)hipHostFree(c->h_desc_staging);
   free(c->h_tables);
   delete c;
@@ -176,19 +177,19 @@ int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t b
   return MIPHY_OK;
 }
 
-int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out)
+int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out, int which)
 {
-  if (bytes > ctx->work_bytes) {
+  if (bytes > ctx->work_bytes[which]) {
     MIPHY_HIP_CHECK(hipStreamSynchronize(s));
-    if (ctx->d_work)
-      MIPHY_HIP_CHECK(hipFree(ctx->d_work));
-    ctx->d_work     = nullptr;
-    ctx->work_bytes = 0;
-    size_t want     = bytes + bytes / 4 + (1u << 20);
-    MIPHY_HIP_CHECK(hipMalloc(&ctx->d_work, want));
-    ctx->work_bytes = want;
+    if (ctx->d_work[which])
+      MIPHY_HIP_CHECK(hipFree(ctx->d_work[which]));
+    ctx->d_work[which]     = nullptr;
+    ctx->work_bytes[which] = 0;
+    size_t want            = bytes + bytes / 4 + (1u << 20);
+    MIPHY_HIP_CHECK(hipMalloc(&ctx->d_work[which], want));
+    ctx->work_bytes[which] = want;
   }
-  *out = ctx->d_work;
+  *out = ctx->d_work[which];
   return MIPHY_OK;
 }
 

@@ -38,8 +38,8 @@ struct miphy_ctx {
   void*                d_desc_staging;
   size_t               desc_staging_bytes;
   void*                h_desc_staging; // pinned
-  void*                d_work;         // scratch workspace for the transport-block level entry points (grown on demand)
-  size_t               work_bytes;
+  void*                d_work[3];      // scratch workspaces, grown on demand: [0] the transport-block level entry points, DFT, polar;
+  size_t               work_bytes[3];  // [1] intermediate buffers of miphy_pusch_process_batch, [2] codewords of miphy_pdsch_process_batch
   int                  num_cus; // compute units of the device (persistent-kernel grid sizing)
 };
 
@@ -71,7 +71,7 @@ int miphy_ldpc_decode_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* descs, i
                              uint8_t* harq_crc_ok, void* stream);
 
 // Returns a device scratch buffer of at least `bytes` (reallocated, after a stream sync, when it has to grow).
-int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out);
+int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out, int which = 0);
 
 // Packed (two rows per lane) LDPC decoder kernel, ldpc_decode_pk.hip.
 size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all);

@@ -7,12 +7,6 @@
 #include <vector>
 
 namespace {
-struct proc_work {
-  void*  p     = nullptr;
-  size_t bytes = 0;
-};
-thread_local proc_work g_work; // codewords (one bit per byte), grown on demand, one per calling thread
-
 // pdsch_processor_impl::modulate (:256-276): the modulator configuration of a PDU.
 void mod_job_of(const miphy_pdsch_pdu& p, miphy_pdsch_mod_job& m)
 {
@@ -80,17 +74,11 @@ extern "C" int miphy_pdsch_process_batch(miphy_ctx* ctx, const miphy_pdsch_pdu* 
     d.grid_offset = p.grid_offset;
     cw_bytes += ((size_t)m.nof_bits + 15u) & ~(size_t)15u;
   }
-  if (cw_bytes + 64 > g_work.bytes) {
-    MIPHY_HIP_CHECK(hipStreamSynchronize(s));
-    if (g_work.p)
-      MIPHY_HIP_CHECK(hipFree(g_work.p));
-    g_work         = {};
-    const size_t w = cw_bytes + cw_bytes / 4 + (1u << 20);
-    MIPHY_HIP_CHECK(hipMalloc(&g_work.p, w));
-    g_work.bytes = w;
-  }
-  uint8_t* d_cw = static_cast<uint8_t*>(g_work.p);
-  int      rc;
+  void* work = nullptr; // codewords (one bit per byte) in a workspace of the context
+  int   rc   = miphy_get_workspace(ctx, cw_bytes + 64, s, &work, 2);
+  if (rc)
+    return rc;
+  uint8_t* d_cw = static_cast<uint8_t*>(work);
   if ((rc = miphy_pdsch_encode_batch(ctx, tb.data(), n, tb_in, d_cw, s)))
     return rc;
   if ((rc = miphy_pdsch_modulate_batch(ctx, mj.data(), 0, n, d_cw, grid, s)))

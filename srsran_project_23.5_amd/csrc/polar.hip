@@ -776,10 +776,10 @@ extern "C" int miphy_polar_decode_list_batch(miphy_ctx*              ctx,
     it = ctx->ext->polar_kset.emplace(key, d).first;
   }
   const size_t lds = (size_t)p->N + 2 * (size_t)list_size * 3 * p->N + 8 * 4 + 24 * 4 + 2 * p->N + 64;
-  static thread_local size_t lds_set = 0;
-  if (lds > lds_set) {
+  // Above the default 64 KB of dynamic LDS the limit has to be raised; it is a per-device attribute of the kernel, so it is set on
+  // every such launch (a cache per thread would be wrong for a thread that drives several devices).
+  if (lds > 48 * 1024) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set = lds;
   }
   hipLaunchKernelGGL(polar_scl_kernel, dim3(n), dim3(64), lds, (hipStream_t)stream, *p, (int)list_size, (int)crc_mode, llr, rnti, it->second, msg_out,
                      crc_ok_out, metric_out);

@@ -8,14 +8,6 @@
 #include <cmath>
 #include <vector>
 
-namespace {
-struct proc_work {
-  void*  p     = nullptr;
-  size_t bytes = 0;
-};
-thread_local proc_work g_work; // intermediate buffers (channel estimates, scalars, LLRs), grown on demand, one per calling thread
-} // namespace
-
 extern "C" int miphy_pusch_process_batch(miphy_ctx* ctx, const miphy_pusch_pdu* pdus, uint32_t n, const float* grid, int8_t* harq_softbits,
                                          uint8_t* harq_msgs, uint8_t* harq_crc_ok, uint8_t* tb_out, miphy_pusch_result* results, float* scalars_out,
                                          void* stream)
@@ -66,20 +58,13 @@ extern "C" int miphy_pusch_process_batch(miphy_ctx* ctx, const miphy_pusch_pdu* 
     ce_elems += (size_t)p.nof_rx_ports * nsym_ce * nsc;
     llr_bytes += (d.nof_llr + 15u) & ~15u;
   }
-  // [channel estimates cf_t | LLRs]; the estimator scalars go straight to the caller's array.
-  const size_t need = ce_elems * 8 + llr_bytes + 64;
-  if (need > g_work.bytes) {
-    MIPHY_HIP_CHECK(hipStreamSynchronize(s));
-    if (g_work.p)
-      MIPHY_HIP_CHECK(hipFree(g_work.p));
-    g_work         = {};
-    const size_t w = need + need / 4 + (1u << 20);
-    MIPHY_HIP_CHECK(hipMalloc(&g_work.p, w));
-    g_work.bytes = w;
-  }
-  float*  d_ce  = static_cast<float*>(g_work.p);
-  int8_t* d_llr = reinterpret_cast<int8_t*>(g_work.p) + ce_elems * 8;
-  int     rc;
+  // [channel estimates cf_t | LLRs] in a workspace of the context; the estimator scalars go straight to the caller's array.
+  void* work = nullptr;
+  int   rc   = miphy_get_workspace(ctx, ce_elems * 8 + llr_bytes + 64, s, &work, 1);
+  if (rc)
+    return rc;
+  float*  d_ce  = static_cast<float*>(work);
+  int8_t* d_llr = reinterpret_cast<int8_t*>(work) + ce_elems * 8;
   if ((rc = miphy_dmrs_pusch_estimate_batch(ctx, cj.data(), 0, n, grid, d_ce, scalars_out, s)))
     return rc;
   if ((rc = miphy_pusch_demodulate_batch(ctx, dj.data(), 0, n, grid, d_ce, scalars_out, d_llr, s)))
