@@ -20,7 +20,7 @@ def test_collectives_on_device_single_rank(ctx):
     port = s.getsockname()[1]
     s.close()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         dev = torch.device("cuda", 0)
         nof_units = 38
