@@ -557,6 +557,40 @@ int miphy_pdsch_process_batch(miphy_ctx* ctx, const miphy_pdsch_pdu* pdus /* hos
                               float* grid /* device cf_t; only the mapped REs are written */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * PDCCH processor (whole PDUs)  --  replaces srsran::pdcch_processor::process after the CCE-to-PRB mapping
+ *   include/srsran/phy/upper/channel_processors/pdcch_processor.h:41-152, lib/phy/upper/channel_processors/pdcch_processor_impl.cpp:65-117,
+ *   pdcch_modulator_impl.cpp:30-91, lib/phy/upper/signal_processors/dmrs_pdcch_processor_impl.cpp:30-101, dmrs_helper.h:44-96
+ * DCI payload -> resource-grid REs in one call: pdcch_encoder (CRC24C with the RNTI mask, interleaver, polar code, E = 108 x
+ * aggregation level), scrambling with c_init = (n_rnti << 16) + n_id_data, QPSK, scaling 10^(data_power_offset_dB / 20), mapping on
+ * REs {0,2,3,4,6,7,8,10,11} of the PRBs of `rb_mask` over `duration` symbols (symbol by symbol, ascending subcarrier), and the DM-RS
+ * of every symbol (c_init from slot, symbol and n_id_dmrs; three pilots per PRB on REs 1, 5, 9, sequence counted from the
+ * reference point, amplitude 10^(dmrs_power_offset_dB / 20) / sqrt(2)). rb_mask is the result of the reference's CCE-to-PRB
+ * mapping (pdcch_processor_impl::compute_rb_mask, host bookkeeping that stays with the caller). Normal cyclic prefix, one port. */
+typedef struct {
+  uint32_t slot_in_frame;         /* pdu.slot.slot_index() */
+  uint32_t rnti;                  /* dci.rnti: CRC mask */
+  uint32_t n_id_pdcch_data;
+  uint32_t n_rnti;
+  uint32_t n_id_pdcch_dmrs;
+  uint32_t reference_point_k_rb;  /* bwp_start_rb for CORESET 0, else 0 (pdcch_processor_impl.cpp:98-99) */
+  float    data_power_offset_dB;
+  float    dmrs_power_offset_dB;
+  uint16_t payload_size;          /* 12..128 bits */
+  uint8_t  aggregation_level;     /* 1, 2, 4, 8 or 16 */
+  uint8_t  start_symbol;          /* coreset.start_symbol_index */
+  uint8_t  duration;              /* 1..3 */
+  uint8_t  port;                  /* grid port */
+  uint16_t grid_nof_prb;
+  uint64_t rb_mask[5];            /* 6 x aggregation_level / duration PRBs */
+  uint64_t payload_offset;        /* byte offset of the payload bits (one per byte) inside `payloads` */
+  uint64_t grid_offset;           /* cf_t offset of grid port 0: [port][14][grid_nof_prb*12] */
+  uint64_t work_offset;           /* set by the library */
+} miphy_pdcch_pdu;
+
+int miphy_pdcch_process_batch(miphy_ctx* ctx, const miphy_pdcch_pdu* pdus /* host */, uint32_t n, const uint8_t* payloads /* device */,
+                              float* grid /* device cf_t; only the mapped REs are written */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * PBCH encoder  --  replaces srsran::pbch_encoder::encode
  *   include/srsran/phy/upper/channel_processors/pbch_encoder.h:53-80, lib/phy/upper/channel_processors/pbch_encoder_impl.cpp:41-190
  * (payload interleaving G(j) with SFN / half-frame / SSB-index bits, Gold-sequence scrambling, CRC24C, CRC interleaver,

@@ -283,3 +283,17 @@ for i, (comp, w, nprb) in enumerate(cases):
             d["cmp_out_%d_%d" % (i, int(sc * 100))] = O.r_ofh_iq_compress(x, nprb, w, sc, "avx2", comp)
             assert np.array_equal(d["cmp_out_%d_%d" % (i, int(sc * 100))], O.r_ofh_iq_compress(x, nprb, w, sc, "generic", comp))
 save("ofh_iq", **d)
+
+# ---------------------------------------------------------------------- PDCCH processor (reference grids + the PRB masks of its CCE mapping)
+d = {}
+cases = O.pdcch_cases(np.random.default_rng(2024), 24)
+d["n"] = np.array(len(cases))
+for i, (mapping, bs, bz, start, dur, fr, rbz, il, shift, cce, AL) in enumerate(cases):
+    A = int(rng.integers(12, min(129, 108 * AL - 24)))
+    pay = rng.integers(0, 2, A, dtype=np.uint8)
+    rnti, nd, ndm, nr, slot = int(rng.integers(1, 65536)), int(rng.integers(0, 65536)), int(rng.integers(0, 65536)), int(rng.integers(0, 65536)), int(rng.integers(0, 20))
+    ddb, xdb = float(rng.choice([0.0, 3.0, -1.5])), float(rng.choice([0.0, -3.0, 2.0]))
+    g, rb = O.r_pdcch_process(mapping, bs, bz, start, dur, fr, rbz, il, shift, 1, slot, rnti, ndm, nd, nr, cce, AL, ddb, xdb, pay, bs + bz)
+    d["grid_%d" % i], d["rb_%d" % i], d["pay_%d" % i] = g, rb, pay
+    d["meta_%d" % i] = np.array([slot, rnti, nd, nr, ndm, bs if mapping == 0 else 0, xdb, ddb, AL, start, dur, mapping], dtype=np.float64)
+save("pdcch_proc", **d)

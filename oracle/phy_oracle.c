@@ -1968,3 +1968,59 @@ void orc_ofh_iq_compress(int compression, const float* in, unsigned nof_prb, uns
   }
   free(q);
 }
+
+/* ================================================================================================ PDCCH processor */
+int orc_pdcch_process(unsigned slot_in_frame, unsigned rnti, unsigned n_id_data, unsigned n_rnti, unsigned n_id_dmrs, unsigned reference_point_k_rb,
+                      float data_power_offset_dB, float dmrs_power_offset_dB, const uint8_t* payload, unsigned A, unsigned aggregation_level,
+                      unsigned start_symbol, unsigned duration, const uint8_t* rb_mask, unsigned nof_prb_grid, float* grid)
+{
+  static const unsigned data_re[9] = {0, 2, 3, 4, 6, 7, 8, 10, 11};
+  const unsigned        E = 108 * aggregation_level, nsc = nof_prb_grid * 12;
+  unsigned              nprb = 0;
+  for (unsigned rb = 0; rb < nof_prb_grid; ++rb)
+    nprb += rb_mask[rb] ? 1 : 0;
+  if (nprb * 9 * duration * 2 != E)
+    return -1;
+  uint8_t* enc = (uint8_t*)malloc(E);
+  uint8_t* c   = (uint8_t*)malloc(E > 6 * nof_prb_grid ? E : 6 * nof_prb_grid);
+  float*   sym = (float*)malloc(sizeof(float) * E);
+  if (orc_pdcch_encode(payload, A, rnti, E, enc) < 0) {
+    free(enc), free(c), free(sym);
+    return -1;
+  }
+  /* pdcch_modulator_impl::scramble (:30-40), modulate (:42-56), map (:58-73) */
+  orc_gold_sequence(((n_rnti << 16) + n_id_data) % (1u << 31), 0, E, c);
+  for (unsigned i = 0; i < E; ++i)
+    enc[i] = (enc[i] ^ c[i]) & 1u;
+  orc_modulate(2, E / 2, enc, sym);
+  const float scaling = powf(10.0f, data_power_offset_dB / 20.0f); /* convert_dB_to_amplitude (math_utils.h:101-104) */
+  if (isnormal(scaling))
+    for (unsigned i = 0; i < E; ++i)
+      sym[i] = sym[i] * scaling;
+  unsigned i = 0;
+  for (unsigned sy = start_symbol; sy < start_symbol + duration; ++sy)
+    for (unsigned rb = 0; rb < nof_prb_grid; ++rb)
+      if (rb_mask[rb])
+        for (unsigned q = 0; q < 9; ++q, ++i) {
+          float* o = grid + 2 * ((size_t)sy * nsc + rb * 12 + data_re[q]);
+          o[0] = sym[2 * i], o[1] = sym[2 * i + 1];
+        }
+  /* dmrs_pdcch_processor_impl (:30-101) with dmrs_sequence_generate (dmrs_helper.h:44-96): three pilots per PRB, counted from the reference point */
+  const float amp = (float)(M_SQRT1_2 * (double)powf(10.0f, dmrs_power_offset_dB / 20.0f));
+  for (unsigned sy = start_symbol; sy < start_symbol + duration; ++sy) {
+    const unsigned long long t = ((unsigned long long)(14 * slot_in_frame + sy + 1) * (2ull * n_id_dmrs + 1)) % (1ull << 31);
+    const unsigned c_init      = (unsigned)((t * (1ull << 17) + 2ull * n_id_dmrs) % (1ull << 31));
+    orc_gold_sequence(c_init, 0, 6 * nof_prb_grid, c);
+    for (unsigned rb = reference_point_k_rb; rb < nof_prb_grid; ++rb) {
+      if (!rb_mask[rb])
+        continue;
+      for (unsigned q = 0; q < 3; ++q) {
+        const unsigned g = (rb - reference_point_k_rb) * 3 + q;
+        float*         o = grid + 2 * ((size_t)sy * nsc + rb * 12 + 1 + 4 * q);
+        o[0] = c[2 * g] ? -amp : amp, o[1] = c[2 * g + 1] ? -amp : amp;
+      }
+    }
+  }
+  free(enc), free(c), free(sym);
+  return (int)(E / 2);
+}

@@ -164,6 +164,14 @@ int orc_pdsch_modulate(unsigned rnti, unsigned n_id, float scaling, unsigned nof
 int orc_dmrs_pdsch_map(unsigned slot_in_frame, unsigned reference_point_k_rb, int type2, unsigned scrambling_id, int n_scid, float amplitude,
                        const uint8_t* symbols_mask, const uint8_t* rb_mask, unsigned nof_prb_grid, unsigned nof_ports, const uint8_t* ports, float* grid);
 
+/* ------------------------------------------------------------------------------------------------ PDCCH processor
+ * pdcch_processor_impl::process after the CCE-to-PRB mapping (pdcch_processor_impl.cpp:65-117): encoder, scrambling + QPSK + scaling +
+ * mapping (pdcch_modulator_impl.cpp:30-91), DM-RS (dmrs_pdcch_processor_impl.cpp:30-101). rb_mask: one byte per PRB of the grid.
+ * grid: one port, [14][nof_prb_grid*12] cf_t; only the mapped REs are written. Returns the number of data REs or -1. */
+int orc_pdcch_process(unsigned slot_in_frame, unsigned rnti, unsigned n_id_data, unsigned n_rnti, unsigned n_id_dmrs, unsigned reference_point_k_rb,
+                      float data_power_offset_dB, float dmrs_power_offset_dB, const uint8_t* payload, unsigned A, unsigned aggregation_level,
+                      unsigned start_symbol, unsigned duration, const uint8_t* rb_mask, unsigned nof_prb_grid, float* grid);
+
 /* ------------------------------------------------------------------------------------------------ Open Fronthaul IQ
  * compression: 0 = none (fixed point, iq_compression_none_impl.cpp:29-69), 1 = BFP (iq_compression_bfp_impl.cpp:28-143).
  * payload: per PRB, BFP [udCompParam][24 x data_width bits, big endian] = 1 + 3*data_width bytes, none the 3*data_width bytes only

@@ -10,6 +10,9 @@
 // Nothing here re-implements an algorithm.
 #include "srsran/ofh/compression/compression_factory.h"
 #include "srsran/phy/generic_functions/dft_processor.h"
+#include "srsran/phy/upper/resource_grid_mapper.h"
+#include "srsran/ran/pdcch/cce_to_prb_mapping.h"
+#include "srsran/ran/precoding/precoding_codebooks.h"
 #include "srsran/phy/upper/channel_coding/channel_coding_factories.h"
 #include "srsran/phy/upper/channel_processors/channel_processor_factories.h"
 #include "srsran/phy/upper/rx_softbuffer_pool.h"
@@ -1119,6 +1122,70 @@ int ref_ofh_iq_compress(int compression, const char* impl, const float* in, unsi
       return -1;
     }
     std::memcpy(rec + hdr, d.data(), d.size());
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- PDCCH processor
+// mapping: 0 CORESET0, 1 non-interleaved, 2 interleaved. freq_resources: one byte per group of 6 PRBs (up to 45). grid: port 0,
+// [14][nof_prb_grid*12]; rb_mask_out: the PRBs the reference's CCE-to-PRB mapping selected (what the device path takes as input).
+int ref_pdcch_process(int mapping, unsigned bwp_start, unsigned bwp_size, unsigned start_symbol, unsigned duration, const uint8_t* freq_resources,
+                      unsigned nof_freq_resources, unsigned reg_bundle_size, unsigned interleaver_size, unsigned shift_index, unsigned numerology,
+                      unsigned slot_index, unsigned rnti, unsigned n_id_dmrs, unsigned n_id_data, unsigned n_rnti, unsigned cce_index,
+                      unsigned aggregation_level, float dmrs_dB, float data_dB, const uint8_t* payload, unsigned A, unsigned nof_prb_grid, float* grid,
+                      uint8_t* rb_mask_out)
+{
+  auto prg  = create_pseudo_random_generator_sw_factory();
+  auto proc = create_pdcch_processor_factory_sw(create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw()),
+                                                create_pdcch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg),
+                                                create_dmrs_pdcch_processor_factory_sw(prg))
+                  ->create();
+  pdcch_processor::pdu_t pdu;
+  pdu.slot = slot_point(numerology, slot_index), pdu.cp = cyclic_prefix::NORMAL;
+  pdu.coreset.bwp_size_rb = bwp_size, pdu.coreset.bwp_start_rb = bwp_start, pdu.coreset.start_symbol_index = start_symbol, pdu.coreset.duration = duration;
+  pdu.coreset.frequency_resources = freq_resource_bitmap(nof_freq_resources);
+  for (unsigned i = 0; i != nof_freq_resources; ++i) {
+    if (freq_resources[i]) {
+      pdu.coreset.frequency_resources.set(i, true);
+    }
+  }
+  pdu.coreset.cce_to_reg_mapping = mapping == 0   ? pdcch_processor::cce_to_reg_mapping_type::CORESET0
+                                   : mapping == 1 ? pdcch_processor::cce_to_reg_mapping_type::NON_INTERLEAVED
+                                                  : pdcch_processor::cce_to_reg_mapping_type::INTERLEAVED;
+  pdu.coreset.reg_bundle_size = reg_bundle_size, pdu.coreset.interleaver_size = interleaver_size, pdu.coreset.shift_index = shift_index;
+  pdu.dci.rnti = rnti, pdu.dci.n_id_pdcch_dmrs = n_id_dmrs, pdu.dci.n_id_pdcch_data = n_id_data, pdu.dci.n_rnti = n_rnti, pdu.dci.cce_index = cce_index;
+  pdu.dci.aggregation_level = aggregation_level, pdu.dci.dmrs_power_offset_dB = dmrs_dB, pdu.dci.data_power_offset_dB = data_dB;
+  for (unsigned i = 0; i != A; ++i) {
+    pdu.dci.payload.push_back(payload[i]);
+  }
+  pdu.dci.precoding = make_single_port();
+  // the same CCE-to-PRB mapping the processor applies (pdcch_processor_impl::compute_rb_mask)
+  prb_index_list prbs;
+  switch (pdu.coreset.cce_to_reg_mapping) {
+    case pdcch_processor::cce_to_reg_mapping_type::CORESET0:
+      prbs = cce_to_prb_mapping_coreset0(bwp_start, bwp_size, duration, shift_index, aggregation_level, cce_index);
+      break;
+    case pdcch_processor::cce_to_reg_mapping_type::NON_INTERLEAVED:
+      prbs = cce_to_prb_mapping_non_interleaved(bwp_start, pdu.coreset.frequency_resources, duration, aggregation_level, cce_index);
+      break;
+    default:
+      prbs = cce_to_prb_mapping_interleaved(bwp_start, pdu.coreset.frequency_resources, duration, reg_bundle_size, interleaver_size, shift_index, aggregation_level,
+                                            cce_index);
+      break;
+  }
+  std::memset(rb_mask_out, 0, nof_prb_grid);
+  for (uint16_t r : prbs) {
+    if (r >= nof_prb_grid) {
+      return -1;
+    }
+    rb_mask_out[r] = 1;
+  }
+  auto g = create_resource_grid(1, 14, nof_prb_grid * 12);
+  g->set_all_zero();
+  resource_grid_mapper mapper(*g);
+  proc->process(mapper, pdu);
+  for (unsigned l = 0; l != 14; ++l) {
+    g->get(span<cf_t>(reinterpret_cast<cf_t*>(grid) + static_cast<size_t>(l) * nof_prb_grid * 12, nof_prb_grid * 12), 0, l, 0);
   }
   return 0;
 }

@@ -237,6 +237,63 @@ __global__ void __launch_bounds__(256) dmrs_pdsch_kernel(const miphy_dmrs_pdsch_
   }
 }
 
+// PDCCH: QPSK mapping of the encoded, scrambled bits and the DM-RS of one (PDU, symbol of the CORESET) per workgroup
+// (pdcch_modulator_impl.cpp:30-91, dmrs_pdcch_processor_impl.cpp:30-101).
+__global__ void __launch_bounds__(256) pdcch_map_kernel(const miphy_pdcch_pdu* __restrict__ pdus, const gold_tables* __restrict__ gt,
+                                                        const uint8_t* __restrict__ enc_base, float2* __restrict__ grid)
+{
+  __shared__ uint32_t w1[128], w2[128];
+  __shared__ uint16_t prb_of[276];
+  __shared__ uint64_t rbm[5];
+  __shared__ int      nprb_s;
+  const miphy_pdcch_pdu* __restrict__ pp = pdus + blockIdx.x;
+  const int s = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+  if (s >= pp->duration)
+    return;
+  const int sy = pp->start_symbol + s, nprb_grid = pp->grid_nof_prb, ref = pp->reference_point_k_rb;
+  if (tid < 5)
+    rbm[tid] = pp->rb_mask[tid];
+  __syncthreads();
+  build_prb_list(rbm, nprb_grid, 0, prb_of, &nprb_s, tid, nt);
+  __syncthreads();
+  const int nprb = nprb_s, R = 9 * nprb, prefix = s * R;
+  float2*   g    = grid + pp->grid_offset + ((size_t)pp->port * 14 + sy) * (nprb_grid * 12);
+  // data: scrambling slice of this symbol, c_init = (n_rnti << 16) + n_id (mod 2^31)
+  gold_long_block(*gt, ((pp->n_rnti << 16) + pp->n_id_pdcch_data) & 0x7fffffffu, 2u * (uint32_t)prefix, ((2 * R + 31) >> 5) + 1, w1, w2, w1, tid, nt);
+  const float    scaling = powf(10.0f, pp->data_power_offset_dB / 20.0f); // convert_dB_to_amplitude
+  const bool     scale   = isnormal(scaling);
+  const uint8_t* enc     = enc_base + pp->work_offset;
+  for (int idx = tid; idx < R; idx += nt) {
+    const int      i = idx / 9, q = idx - i * 9;
+    const int      k = q + (q + 2) / 3;                       // REs 0,2,3,4,6,7,8,10,11: the DM-RS sit on 1, 5, 9
+    const int      d = prefix + idx;                          // QPSK symbol index within the PDU
+    const uint32_t c0 = (w1[(2 * idx) >> 5] >> ((2 * idx) & 31)) & 1u, c1 = (w1[(2 * idx + 1) >> 5] >> ((2 * idx + 1) & 31)) & 1u;
+    const uint32_t nat = ((uint32_t)(enc[2 * d] & 1u) ^ c0) | (((uint32_t)(enc[2 * d + 1] & 1u) ^ c1) << 1);
+    float2 x = map_symbol(2, nat, (unsigned)d);
+    if (scale) {
+      x.x = x.x * scaling;
+      x.y = x.y * scaling;
+    }
+    g[prb_of[i] * 12 + k] = x;
+  }
+  __syncthreads();
+  // DM-RS of this symbol (normal cyclic prefix: 14 symbols per slot)
+  const uint64_t t      = ((uint64_t)(14u * pp->slot_in_frame + (uint32_t)sy + 1u) * (2ull * pp->n_id_pdcch_dmrs + 1ull)) % (1ull << 31);
+  const uint32_t c_init = (uint32_t)((t * (1ull << 17) + 2ull * pp->n_id_pdcch_dmrs) % (1ull << 31));
+  const int      nbits  = 2 * 3 * (nprb_grid - ref);
+  gold_long_block(*gt, c_init, 0, ((nbits + 31) >> 5) + 1, w1, w2, w1, tid, nt);
+  const float amp = (float)(0.70710678118654752440 * (double)powf(10.0f, pp->dmrs_power_offset_dB / 20.0f));
+  for (int idx = tid; idx < 3 * nprb; idx += nt) {
+    const int i = idx / 3, q = idx - 3 * i, rb = prb_of[i];
+    if (rb < ref)
+      continue; // never generated (dmrs_helper.h:58)
+    const int   gI = (rb - ref) * 3 + q;
+    const float re = ((w1[(2 * gI) >> 5] >> ((2 * gI) & 31)) & 1u) ? -amp : amp;
+    const float im = ((w1[(2 * gI + 1) >> 5] >> ((2 * gI + 1) & 31)) & 1u) ? -amp : amp;
+    g[rb * 12 + 1 + 4 * q] = make_float2(re, im);
+  }
+}
+
 uint32_t host_nof_re(const miphy_pdsch_mod_job& j)
 {
   unsigned dm = 0;
@@ -328,6 +385,54 @@ extern "C" int miphy_dmrs_pdsch_map_batch(miphy_ctx* ctx, const miphy_dmrs_pdsch
   if (rc)
     return rc;
   hipLaunchKernelGGL(dmrs_pdsch_kernel, dim3(n, 14), dim3(256), 0, s, (const miphy_dmrs_pdsch_job*)d_jobs, gt, (float2*)grid);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- PDCCH processor
+extern "C" int miphy_pdcch_process_batch(miphy_ctx* ctx, const miphy_pdcch_pdu* pdus, uint32_t n, const uint8_t* payloads, float* grid, void* stream)
+{
+  MIPHY_REQUIRE(ctx && pdus && payloads && grid, "miphy_pdcch_process_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  MIPHY_REQUIRE(n <= 65535, "pdcch_process: at most 65535 PDUs per call");
+  hipStream_t                  s = (hipStream_t)stream;
+  std::vector<miphy_pdcch_pdu> p(pdus, pdus + n);
+  size_t                       enc_bytes = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    miphy_pdcch_pdu& q  = p[i];
+    const unsigned   al = q.aggregation_level;
+    MIPHY_REQUIRE(al == 1 || al == 2 || al == 4 || al == 8 || al == 16, "pdcch_process: PDU %u: invalid aggregation level %u", i, al);
+    MIPHY_REQUIRE(q.duration >= 1 && q.duration <= 3 && q.start_symbol + q.duration <= 14, "pdcch_process: PDU %u: invalid CORESET duration", i);
+    MIPHY_REQUIRE(q.payload_size >= 12 && q.payload_size <= 128, "pdcch_process: PDU %u: payload size %u out of range (12..128)", i, (unsigned)q.payload_size);
+    MIPHY_REQUIRE(q.grid_nof_prb >= 1 && q.grid_nof_prb <= 275 && q.reference_point_k_rb < q.grid_nof_prb, "pdcch_process: PDU %u: invalid grid", i);
+    MIPHY_REQUIRE(q.rnti <= 0xffff && q.n_rnti <= 0xffff && q.n_id_pdcch_data <= 0xffff && q.n_id_pdcch_dmrs <= 0xffff, "pdcch_process: PDU %u: identifier out of range", i);
+    unsigned nprb = 0;
+    for (unsigned r = 0; r < q.grid_nof_prb; ++r)
+      nprb += (unsigned)((q.rb_mask[r >> 6] >> (r & 63)) & 1ull);
+    // E = aggregation level x 6 REG x 9 RE x 2 bits must fill the PRBs of the mask over the CORESET symbols
+    MIPHY_REQUIRE(nprb * q.duration == 6u * al, "pdcch_process: PDU %u: %u PRBs x %u symbols do not match aggregation level %u", i, nprb, (unsigned)q.duration, al);
+    q.work_offset = enc_bytes;
+    enc_bytes += (108u * al + 15u) & ~15u;
+  }
+  void* work = nullptr;
+  int   rc   = miphy_get_workspace(ctx, enc_bytes + 64, s, &work, 2);
+  if (rc)
+    return rc;
+  const void* d_pdus = nullptr;
+  if ((rc = miphy_stage_descs(ctx, p.data(), 0, sizeof(miphy_pdcch_pdu) * (size_t)n, s, &d_pdus)))
+    return rc;
+  const gold_tables* gt = nullptr;
+  if ((rc = miphy_get_gold_tables(ctx, &gt)))
+    return rc;
+  uint8_t* d_enc = static_cast<uint8_t*>(work);
+  for (uint32_t i = 0; i < n; ++i) { // a handful of PDUs per slot: one small launch each (the code depends on payload size and level)
+    const miphy_pdcch_pdu* dq = static_cast<const miphy_pdcch_pdu*>(d_pdus) + i;
+    if ((rc = miphy_pdcch_encode_batch(ctx, p[i].payload_size, 108u * p[i].aggregation_level, 1, payloads + p[i].payload_offset,
+                                       reinterpret_cast<const uint16_t*>(&dq->rnti), d_enc + p[i].work_offset, s)))
+      return rc;
+  }
+  hipLaunchKernelGGL(pdcch_map_kernel, dim3(n, 3), dim3(256), 0, s, (const miphy_pdcch_pdu*)d_pdus, gt, d_enc, (float2*)grid);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

@@ -67,6 +67,7 @@ def lib():
         l.miphy_pdsch_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_ofh_iq_decompress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         l.miphy_ofh_iq_compress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+        l.miphy_pdcch_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_harq_pool_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         l.miphy_harq_pool_destroy.argtypes = [C.c_void_p]
         l.miphy_harq_pool_destroy.restype = None
@@ -180,6 +181,14 @@ def pdsch_pdu_nof_re(pdu):
     a = np.ascontiguousarray(np.asarray(pdu, dtype=PdschPdu).reshape(1))
     return int(lib().miphy_pdsch_pdu_nof_re(a.ctypes.data_as(C.c_void_p)))
 
+
+# Mirrors miphy_pdcch_pdu.
+PdcchPdu = np.dtype([("slot_in_frame", np.uint32), ("rnti", np.uint32), ("n_id_pdcch_data", np.uint32), ("n_rnti", np.uint32), ("n_id_pdcch_dmrs", np.uint32),
+                     ("reference_point_k_rb", np.uint32), ("data_power_offset_dB", np.float32), ("dmrs_power_offset_dB", np.float32),
+                     ("payload_size", np.uint16), ("aggregation_level", np.uint8), ("start_symbol", np.uint8), ("duration", np.uint8), ("port", np.uint8),
+                     ("grid_nof_prb", np.uint16), ("rb_mask", np.uint64, 5), ("payload_offset", np.uint64), ("grid_offset", np.uint64),
+                     ("work_offset", np.uint64)], align=True)
+assert PdcchPdu.itemsize == 104 and PdcchPdu.fields["rb_mask"][1] == 40, PdcchPdu.itemsize
 
 # Mirrors miphy_pusch_pdu.
 PuschPdu = np.dtype([("numerology", np.uint32), ("slot_in_frame", np.uint32), ("rnti", np.uint32), ("n_id", np.uint32),
@@ -354,6 +363,12 @@ class Context:
         assert isinstance(pdus, np.ndarray) and pdus.dtype == PdschPdu
         pdus = np.ascontiguousarray(pdus)
         check(lib().miphy_pdsch_process_batch(self.h, C.c_void_p(pdus.ctypes.data), pdus.size, _dptr(tb_in), _dptr(grid), _stream_ptr(stream)))
+
+    def pdcch_process_batch(self, pdus, payloads, grid, stream=None):
+        """pdcch_processor::process (after the CCE-to-PRB mapping) for a batch of PDUs (host descriptors): DCI payload bits -> grid REs."""
+        assert isinstance(pdus, np.ndarray) and pdus.dtype == PdcchPdu
+        pdus = np.ascontiguousarray(pdus)
+        check(lib().miphy_pdcch_process_batch(self.h, C.c_void_p(pdus.ctypes.data), pdus.size, _dptr(payloads), _dptr(grid), _stream_ptr(stream)))
 
     # ------------------------------------------------------------------ Open Fronthaul IQ (de)compression (U-plane payloads <-> grid rows)
     def ofh_iq_decompress_batch(self, jobs, payload, grid, simd_arithmetic=True, stream=None):

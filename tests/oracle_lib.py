@@ -665,3 +665,62 @@ def r_ofh_iq_compress(x, nof_prb, w, iq_scaling=1.0, impl="avx2", comp=OFH_BFP):
     payload = np.zeros(ofh_payload_bytes(nof_prb, w, comp), dtype=np.uint8)
     assert ref().ref_ofh_iq_compress(int(comp), impl.encode(), _p(x), C.c_uint(nof_prb), C.c_uint(w), C.c_float(iq_scaling), _p(payload)) == 0
     return payload
+
+
+# ---------------------------------------------------------------------- PDCCH processor
+def o_pdcch_process(slot_in_frame, rnti, n_id_data, n_rnti, n_id_dmrs, ref_point, data_dB, dmrs_dB, payload, AL, start, duration, rb_mask, grid):
+    """grid: complex64 [14][nsc] of one port, updated in place. Returns the number of data REs."""
+    pl = np.ascontiguousarray(payload, dtype=np.uint8)
+    rb = np.ascontiguousarray(rb_mask, dtype=np.uint8)
+    assert grid.dtype == np.complex64 and grid.flags.c_contiguous and grid.shape == (14, rb.size * 12)
+    return oracle().orc_pdcch_process(C.c_uint(slot_in_frame), C.c_uint(rnti), C.c_uint(n_id_data), C.c_uint(n_rnti), C.c_uint(n_id_dmrs), C.c_uint(ref_point),
+                                      C.c_float(data_dB), C.c_float(dmrs_dB), _p(pl), C.c_uint(pl.size), C.c_uint(AL), C.c_uint(start), C.c_uint(duration), _p(rb),
+                                      C.c_uint(rb.size), _p(grid))
+
+
+def r_pdcch_process(mapping, bwp_start, bwp_size, start, duration, freq_resources, reg_bundle, interleaver, shift, numerology, slot_index, rnti, n_id_dmrs,
+                    n_id_data, n_rnti, cce_index, AL, dmrs_dB, data_dB, payload, nprb_grid):
+    """The reference processor. Returns (grid [14][nsc], rb_mask bytes [nprb_grid] from its CCE-to-PRB mapping)."""
+    fr = np.ascontiguousarray(freq_resources, dtype=np.uint8)
+    pl = np.ascontiguousarray(payload, dtype=np.uint8)
+    grid = np.zeros((14, nprb_grid * 12), dtype=np.complex64)
+    rb = np.zeros(nprb_grid, dtype=np.uint8)
+    rc = ref().ref_pdcch_process(int(mapping), C.c_uint(bwp_start), C.c_uint(bwp_size), C.c_uint(start), C.c_uint(duration), _p(fr), C.c_uint(fr.size),
+                                 C.c_uint(reg_bundle), C.c_uint(interleaver), C.c_uint(shift), C.c_uint(numerology), C.c_uint(slot_index), C.c_uint(rnti),
+                                 C.c_uint(n_id_dmrs), C.c_uint(n_id_data), C.c_uint(n_rnti), C.c_uint(cce_index), C.c_uint(AL), C.c_float(dmrs_dB),
+                                 C.c_float(data_dB), _p(pl), C.c_uint(pl.size), C.c_uint(nprb_grid), _p(grid), _p(rb))
+    assert rc == 0, rc
+    return grid, rb
+
+
+def pdcch_cases(rng, n):
+    """Random valid PDCCH configurations: (mapping, bwp_start, bwp_size, start, duration, freq_resources, reg_bundle, interleaver, shift, cce_index, AL)."""
+    out = []
+    while len(out) < n:
+        mapping = int(rng.integers(0, 3))
+        duration = int(rng.integers(1, 4))
+        AL = int(rng.choice([1, 2, 4, 8, 16]))
+        if mapping == 0:  # CORESET 0: 24, 48 or 96 PRBs at the start of the BWP, interleaved with bundle 6, interleaver 2
+            size = int(rng.choice([24, 48, 96]))
+            bwp_start, bwp_size = int(rng.integers(0, 20)), size
+            nfr = size // 6
+            fr = np.ones(nfr, np.uint8)
+            reg_bundle, interleaver, shift = 6, 2, int(rng.integers(0, 1008))
+        else:
+            nfr = int(rng.integers(2, 17))
+            fr = (rng.uniform(size=nfr) < 0.8).astype(np.uint8)
+            fr[0] = 1
+            bwp_start, bwp_size = int(rng.integers(0, 30)), nfr * 6 + int(rng.integers(0, 6))
+            reg_bundle = int(rng.choice([2, 6] if duration < 3 else [3, 6])) if mapping == 2 else 6
+            interleaver, shift = int(rng.choice([2, 3, 6])), int(rng.integers(0, 275))
+        nreg = int(fr.sum()) * 6 * duration
+        ncce = nreg // 6
+        if ncce < AL:
+            continue
+        if mapping == 2 and (nreg % (reg_bundle * interleaver)) != 0:
+            continue
+        if mapping == 0 and (nreg % (6 * 2)) != 0:
+            continue
+        cce_index = AL * int(rng.integers(0, ncce // AL))
+        out.append((mapping, bwp_start, bwp_size, int(rng.integers(0, 3)), duration, fr, reg_bundle, interleaver, shift, cce_index, AL))
+    return out

@@ -211,3 +211,17 @@ def test_ofh_iq_compression():
     for e in range(8):
         r = np.float32(1.0) / (np.float32(32767.0) / np.float32(1 << e))
         assert np.array_equal((x.astype(np.float32) * r).view(np.uint32), ((x << e).astype(np.float32) / np.float32(32767.0)).view(np.uint32))
+
+
+def test_pdcch_processor():
+    """PDCCH processor: oracle against grids recorded from the reference processor (all three CCE-to-REG mapping types)."""
+    g = np.load(os.path.join(GOLD, "pdcch_proc.npz"))
+    kinds = set()
+    for i in range(int(g["n"])):
+        slot, rnti, nd, nr, ndm, ref, xdb, ddb, AL, start, dur, mapping = g["meta_%d" % i]
+        out = np.zeros_like(g["grid_%d" % i])
+        n = O.o_pdcch_process(int(slot), int(rnti), int(nd), int(nr), int(ndm), int(ref), float(xdb), float(ddb), g["pay_%d" % i], int(AL), int(start), int(dur),
+                              g["rb_%d" % i], out)
+        assert n == 54 * int(AL) and np.array_equal(out.view(np.uint32), g["grid_%d" % i].view(np.uint32)), i
+        kinds.add(int(mapping))
+    assert kinds == {0, 1, 2}

@@ -267,3 +267,16 @@ def test_ofh_iq_compression():
                 y = O.o_ofh_iq_decompress(a, nprb, w, True, comp)
                 step = (2.0 ** a[::1 + 3 * w].astype(np.float64).repeat(24) / 32767) if comp == O.OFH_BFP else np.full(nprb * 24, 1.0 / gain)
                 assert np.all(np.abs(y.view(np.float32) - x.view(np.float32) * np.float32(sc)) <= step * 1.001 + 1e-7), (comp, t, w)
+
+
+def test_pdcch_processor():
+    rng = np.random.default_rng(91)
+    for (mapping, bs, bz, start, dur, fr, rbz, il, shift, cce, AL) in O.pdcch_cases(rng, 60):
+        A = int(rng.integers(12, min(129, 108 * AL - 24)))
+        pay = rng.integers(0, 2, A, dtype=np.uint8)
+        rnti, nd, ndm, nr, slot = int(rng.integers(1, 65536)), int(rng.integers(0, 65536)), int(rng.integers(0, 65536)), int(rng.integers(0, 65536)), int(rng.integers(0, 20))
+        ddb, xdb = float(rng.choice([0.0, 3.0, -1.5])), float(rng.choice([0.0, -3.0, 2.0]))
+        g, rb = O.r_pdcch_process(mapping, bs, bz, start, dur, fr, rbz, il, shift, 1, slot, rnti, ndm, nd, nr, cce, AL, ddb, xdb, pay, bs + bz)
+        out = np.zeros_like(g)
+        assert O.o_pdcch_process(slot, rnti, nd, nr, ndm, bs if mapping == 0 else 0, xdb, ddb, pay, AL, start, dur, rb, out) == 54 * AL
+        assert np.array_equal(out.view(np.uint32), g.view(np.uint32)), (mapping, bs, bz, dur, AL)
