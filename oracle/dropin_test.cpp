@@ -12,7 +12,9 @@
 #include "srsran/phy/upper/equalization/equalization_factories.h"
 #include "srsran/phy/upper/rx_softbuffer_pool.h"
 #include "srsran/phy/upper/sequence_generators/sequence_generator_factories.h"
+#include "srsran/phy/upper/resource_grid_mapper.h"
 #include "srsran/phy/upper/unique_rx_softbuffer.h"
+#include "srsran/ran/precoding/precoding_codebooks.h"
 #include "srsran/phy/upper/upper_phy_rx_results_notifier.h"
 #include <cmath>
 #include <csignal>
@@ -1161,6 +1163,58 @@ static void test_pusch_processor_bler(std::shared_ptr<miphy::context> c)
   printf("pusch_processor block-error comparison done, failures so far %d\n", failures);
 }
 
+// pdcch_processor: reference (software encoder + modulator + DM-RS) vs pdcch_processor_hip through a resource_grid_mapper, all three
+// CCE-to-REG mapping types; identical grids.
+static void test_pdcch_processor(std::shared_ptr<miphy::context> c)
+{
+  auto prg   = create_pseudo_random_generator_sw_factory();
+  auto p_ref = create_pdcch_processor_factory_sw(create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw()),
+                                                 create_pdcch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg),
+                                                 create_dmrs_pdcch_processor_factory_sw(prg))
+                   ->create();
+  auto p_hip = std::make_shared<miphy::pdcch_processor_factory_hip>(c)->create();
+  struct tc {
+    pdcch_processor::cce_to_reg_mapping_type map;
+    unsigned                                 bwp_start, bwp_size, start, duration, nof_fr, bundle, interleaver, shift, cce, al, A;
+    float                                    dmrs_db, data_db;
+  };
+  using M = pdcch_processor::cce_to_reg_mapping_type;
+  std::uniform_int_distribution<int> bit(0, 1);
+  for (const tc& t : {tc{M::CORESET0, 10, 48, 0, 2, 8, 6, 2, 321, 4, 4, 57, 0.0F, 0.0F}, tc{M::NON_INTERLEAVED, 0, 100, 1, 1, 16, 6, 2, 0, 8, 8, 128, 3.0F, -1.5F},
+                      tc{M::INTERLEAVED, 5, 96, 0, 3, 16, 3, 2, 77, 0, 16, 40, 0.0F, 2.0F}, tc{M::INTERLEAVED, 0, 54, 2, 2, 9, 2, 3, 5, 3, 1, 12, -3.0F, 0.0F},
+                      tc{M::NON_INTERLEAVED, 20, 30, 0, 1, 5, 6, 2, 0, 2, 2, 70, 0.0F, 0.0F}}) {
+    pdcch_processor::pdu_t pdu;
+    pdu.slot = slot_point(1, 9), pdu.cp = cyclic_prefix::NORMAL;
+    pdu.coreset.bwp_size_rb = t.bwp_size, pdu.coreset.bwp_start_rb = t.bwp_start, pdu.coreset.start_symbol_index = t.start, pdu.coreset.duration = t.duration;
+    pdu.coreset.frequency_resources = freq_resource_bitmap(t.nof_fr);
+    pdu.coreset.frequency_resources.fill(0, t.nof_fr, true);
+    pdu.coreset.cce_to_reg_mapping = t.map, pdu.coreset.reg_bundle_size = t.bundle, pdu.coreset.interleaver_size = t.interleaver, pdu.coreset.shift_index = t.shift;
+    pdu.dci.rnti = 0x4601, pdu.dci.n_id_pdcch_dmrs = 500, pdu.dci.n_id_pdcch_data = 501, pdu.dci.n_rnti = 0x4601, pdu.dci.cce_index = t.cce;
+    pdu.dci.aggregation_level = t.al, pdu.dci.dmrs_power_offset_dB = t.dmrs_db, pdu.dci.data_power_offset_dB = t.data_db;
+    for (unsigned i = 0; i != t.A; ++i) {
+      pdu.dci.payload.push_back(bit(rgen));
+    }
+    pdu.dci.precoding = make_single_port();
+    const unsigned nsc = (t.bwp_start + t.bwp_size) * 12;
+    auto           g1 = create_resource_grid(1, 14, nsc), g2 = create_resource_grid(1, 14, nsc);
+    g1->set_all_zero();
+    g2->set_all_zero();
+    resource_grid_mapper m1(*g1), m2(*g2);
+    p_ref->process(m1, pdu);
+    p_hip->process(m2, pdu);
+    std::vector<cf_t> a(nsc), b(nsc);
+    unsigned          bad = 0, written = 0;
+    for (unsigned l = 0; l != 14; ++l) {
+      g1->get(a, 0, l, 0);
+      g2->get(b, 0, l, 0);
+      bad += std::memcmp(a.data(), b.data(), nsc * sizeof(cf_t)) != 0;
+      written += std::any_of(a.begin(), a.end(), [](cf_t v) { return v != cf_t(0, 0); });
+    }
+    CHECK(bad == 0 && written == t.duration, "pdcch_processor: %u symbols differ, %u written (aggregation level %u, duration %u)", bad, written, t.al, t.duration);
+  }
+  printf("pdcch_processor done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -1339,6 +1393,7 @@ int main()
   test_ofdm_and_estimator(c);
   test_dft(c);
   test_pdcch(c);
+  test_pdcch_processor(c);
   test_pusch_demodulator(c);
   test_pusch_processor(c);
   test_uplink_processor(c);

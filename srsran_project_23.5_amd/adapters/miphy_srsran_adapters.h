@@ -26,6 +26,8 @@
 #include "srsran/phy/upper/downlink_processor.h"
 #include "srsran/phy/upper/resource_grid_mapper.h"
 #include "srsran/phy/upper/upper_phy_rg_gateway.h"
+#include "srsran/ran/pdcch/cce_to_prb_mapping.h"
+#include "srsran/ran/precoding/precoding_codebooks.h"
 #include "srsran/phy/upper/rx_softbuffer.h"
 #include "srsran/phy/upper/rx_softbuffer_pool.h"
 #include "srsran/phy/upper/unique_rx_softbuffer.h"
@@ -1502,6 +1504,94 @@ public:
   explicit pdsch_processor_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
   std::unique_ptr<srsran::pdsch_processor>     create() override { return std::make_unique<pdsch_processor_hip>(c); }
   std::unique_ptr<srsran::pdsch_pdu_validator> create_validator() override { return nullptr; }
+
+private:
+  std::shared_ptr<context> c;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- PDCCH processor
+/// srsran::pdcch_processor over miphy_pdcch_process_batch (pdcch_processor.h:151): the CCE-to-PRB mapping is the reference's own host
+/// function (pdcch_processor_impl::compute_rb_mask, lib/ran/pdcch/cce_to_prb_mapping.cpp), everything after it -- encoding, scrambling,
+/// modulation, mapping and DM-RS -- runs on the device; the written REs come back through the resource_grid_mapper's grid.
+class pdcch_processor_hip : public srsran::pdcch_processor
+{
+public:
+  explicit pdcch_processor_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void process(srsran::resource_grid_mapper& mapper, const pdu_t& pdu) override
+  {
+    const coreset_description& coreset = pdu.coreset;
+    const dci_description&     dci     = pdu.dci;
+    srsran_assert(coreset.duration > 0 && coreset.duration <= srsran::pdcch_constants::MAX_CORESET_DURATION, "Invalid CORESET duration ({})", coreset.duration);
+    srsran::prb_index_list prbs;
+    switch (coreset.cce_to_reg_mapping) {
+      case cce_to_reg_mapping_type::CORESET0:
+        prbs = srsran::cce_to_prb_mapping_coreset0(coreset.bwp_start_rb, coreset.bwp_size_rb, coreset.duration, coreset.shift_index, dci.aggregation_level, dci.cce_index);
+        break;
+      case cce_to_reg_mapping_type::NON_INTERLEAVED:
+        prbs = srsran::cce_to_prb_mapping_non_interleaved(coreset.bwp_start_rb, coreset.frequency_resources, coreset.duration, dci.aggregation_level, dci.cce_index);
+        break;
+      default:
+        prbs = srsran::cce_to_prb_mapping_interleaved(coreset.bwp_start_rb, coreset.frequency_resources, coreset.duration, coreset.reg_bundle_size, coreset.interleaver_size,
+                                                      coreset.shift_index, dci.aggregation_level, dci.cce_index);
+        break;
+    }
+    const unsigned  nprb = coreset.bwp_start_rb + coreset.bwp_size_rb, nsc = nprb * 12;
+    miphy_pdcch_pdu p    = {};
+    p.slot_in_frame = pdu.slot.slot_index(), p.rnti = dci.rnti, p.n_id_pdcch_data = dci.n_id_pdcch_data, p.n_rnti = dci.n_rnti;
+    p.n_id_pdcch_dmrs = dci.n_id_pdcch_dmrs;
+    p.reference_point_k_rb = coreset.cce_to_reg_mapping == cce_to_reg_mapping_type::CORESET0 ? coreset.bwp_start_rb : 0;
+    p.data_power_offset_dB = dci.data_power_offset_dB, p.dmrs_power_offset_dB = dci.dmrs_power_offset_dB;
+    p.payload_size = dci.payload.size(), p.aggregation_level = dci.aggregation_level, p.start_symbol = coreset.start_symbol_index;
+    p.duration = coreset.duration, p.port = 0, p.grid_nof_prb = nprb;
+    for (uint16_t r : prbs) {
+      p.rb_mask[r >> 6] |= 1ULL << (r & 63);
+    }
+    host.assign(static_cast<size_t>(14) * nsc, srsran::cf_t(NAN, NAN)); // NaN marks "not written by the kernels"
+    auto* d_pl = static_cast<uint8_t*>(c->buf(0, dci.payload.size() + 16));
+    auto* d_g  = static_cast<float*>(c->buf(1, host.size() * sizeof(srsran::cf_t)));
+    c->h2d(d_pl, dci.payload.data(), dci.payload.size());
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    context::check(miphy_pdcch_process_batch(c->ctx, &p, 1, d_pl, d_g, c->stream), "pdcch_process");
+    c->d2h(host.data(), d_g, host.size() * sizeof(srsran::cf_t));
+    c->sync();
+    // Data REs {0,2,3,4,6,7,8,10,11} and DM-RS REs {1,5,9}: every RE of the allocated PRBs over the CORESET symbols was written, so
+    // one pattern (all twelve REs) hands them to the mapper in its own order: symbol by symbol, ascending subcarrier.
+    srsran::re_pattern pattern;
+    pattern.prb_mask = srsran::bounded_bitset<srsran::MAX_RB>(nprb);
+    for (uint16_t r : prbs) {
+      pattern.prb_mask.set(r, true);
+    }
+    pattern.symbols.fill(coreset.start_symbol_index, coreset.start_symbol_index + coreset.duration);
+    pattern.re_mask = ~srsran::re_prb_mask();
+    srsran::dynamic_re_buffer res(1, prbs.size() * 12 * coreset.duration);
+    srsran::span<srsran::cf_t> out = res.get_slice(0);
+    unsigned                   n   = 0;
+    for (unsigned l = coreset.start_symbol_index; l != coreset.start_symbol_index + coreset.duration; ++l) {
+      for (unsigned r = 0; r != nprb; ++r) {
+        if (pattern.prb_mask.test(r)) {
+          for (unsigned k = 0; k != 12; ++k) {
+            out[n++] = host[static_cast<size_t>(l) * nsc + r * 12 + k];
+          }
+        }
+      }
+    }
+    srsran::re_pattern_list patterns;
+    patterns.merge(pattern);
+    mapper.map(res, patterns, srsran::make_single_port());
+  }
+
+private:
+  std::shared_ptr<context>  c;
+  std::vector<srsran::cf_t> host;
+};
+
+/// Replaces create_pdcch_processor_factory_sw(encoder, modulator, dmrs) (channel_processor_factories.h:113-116).
+class pdcch_processor_factory_hip : public srsran::pdcch_processor_factory
+{
+public:
+  explicit pdcch_processor_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  std::unique_ptr<srsran::pdcch_processor>     create() override { return std::make_unique<pdcch_processor_hip>(c); }
+  std::unique_ptr<srsran::pdcch_pdu_validator> create_validator() override { return nullptr; }
 
 private:
   std::shared_ptr<context> c;
