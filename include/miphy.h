@@ -609,6 +609,30 @@ typedef struct {
 int miphy_pbch_encode_batch(miphy_ctx* ctx, const miphy_pbch_msg* msgs /* host */, uint32_t n, uint8_t* out /* device */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * SS/PBCH block processor  --  replaces srsran::ssb_processor::process after the position look-up
+ *   include/srsran/phy/upper/channel_processors/ssb_processor.h:41-80, lib/phy/upper/channel_processors/ssb_processor_impl.cpp:30-106,
+ *   pbch_modulator_impl.cpp:28-113, lib/phy/upper/signal_processors/dmrs_pbch_processor_impl.cpp:28-100, pss_processor_impl.cpp:28-91,
+ *   sss_processor_impl.cpp:28-119
+ * One call: PBCH encoding (miphy_pbch_encode_batch), scrambling with the cell identity advanced by (ssb_idx & 7) * 864, QPSK on the
+ * 432 PBCH REs, the 144 PBCH DM-RS (c_init from ssb_idx / half frame / cell identity, +-1/sqrt(2)), PSS (127 REs, amplitude
+ * 10^(beta_pss / 20)) and SSS, written to every listed port. ssb_first_symbol / ssb_first_subcarrier are the reference's
+ * ssb_get_l_first() % 14 and ssb_get_k_first() (include/srsran/ran/ssb_mapping.h), host bookkeeping that stays with the caller. */
+typedef struct {
+  miphy_pbch_msg msg;             /* N_id = physical cell identity, ssb_idx, L_max, hrf, sfn, k_ssb, payload */
+  uint32_t ssb_first_subcarrier;
+  uint32_t ssb_first_symbol;      /* 0..10 */
+  float    beta_pss_dB;
+  uint16_t grid_nof_prb;
+  uint8_t  nof_ports;             /* 1..4 */
+  uint8_t  ports[4];
+  uint8_t  pad;
+  uint64_t grid_offset;           /* cf_t offset of grid port 0: [port][14][grid_nof_prb*12] */
+} miphy_ssb_pdu;
+
+int miphy_ssb_process_batch(miphy_ctx* ctx, const miphy_ssb_pdu* pdus /* host */, uint32_t n, float* grid /* device cf_t; only the SSB REs are written */,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Polar successive-cancellation LIST decoder (list size 1, 2, 4 or 8), optionally CRC-aided  --  no counterpart in the
  * reference (its polar_decoder is the list-size-1 SSC decoder that miphy_polar_decode_batch reproduces bit for bit); this
  * is the SCL-8 path BASELINE.json's north_star / configs[3] ask for. Same rate-dematcher and LLR algebra as the reference;

@@ -297,3 +297,17 @@ for i, (mapping, bs, bz, start, dur, fr, rbz, il, shift, cce, AL) in enumerate(c
     d["grid_%d" % i], d["rb_%d" % i], d["pay_%d" % i] = g, rb, pay
     d["meta_%d" % i] = np.array([slot, rnti, nd, nr, ndm, bs if mapping == 0 else 0, xdb, ddb, AL, start, dur, mapping], dtype=np.float64)
 save("pdcch_proc", **d)
+
+# ---------------------------------------------------------------------- SS/PBCH block processor (reference grids + the positions it derived)
+d = {}
+cases = O.ssb_cases(np.random.default_rng(77), 16)
+k = 0
+for (mu, sfn, slot, N_id, beta, ssb_idx, L_max, scs, kssb, off, case) in cases:
+    pay = rng.integers(0, 2, 32, dtype=np.uint8)
+    rc, g, l0, k0 = O.r_ssb_process(mu, sfn, slot, N_id, beta, ssb_idx, L_max, scs, kssb, off, case, pay, 106)
+    assert rc == 0
+    d["grid_%d" % k], d["pay_%d" % k] = g, pay
+    d["meta_%d" % k] = np.array([N_id, ssb_idx, L_max, 1 if slot >= (5 << mu) else 0, sfn, kssb, k0, l0, beta, case], dtype=np.float64)
+    k += 1
+d["n"] = np.array(k)
+save("ssb_proc", **d)

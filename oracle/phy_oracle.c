@@ -2024,3 +2024,64 @@ int orc_pdcch_process(unsigned slot_in_frame, unsigned rnti, unsigned n_id_data,
   free(enc), free(c), free(sym);
   return (int)(E / 2);
 }
+
+/* ================================================================================================ SS/PBCH block processor */
+int orc_ssb_process(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, unsigned sfn, unsigned k_ssb, const uint8_t* payload, unsigned k0, unsigned l0,
+                    float beta_pss_dB, unsigned nof_prb_grid, float* grid)
+{
+  const unsigned nsc = nof_prb_grid * 12, v = N_id % 4;
+  uint8_t        enc[864], c[864];
+  float          sym[864];
+  if (k0 + 240 > nsc || l0 + 4 > 14)
+    return -1;
+  orc_pbch_encode(N_id, ssb_idx, L_max, hrf, sfn, k_ssb, payload, enc);
+  /* pbch_modulator_impl::scramble (:28-38), modulate (:40-48), map (:50-94) */
+  orc_gold_sequence(N_id, (ssb_idx & 7u) * 864u, 864, c);
+  for (unsigned i = 0; i < 864; ++i)
+    enc[i] = (enc[i] ^ c[i]) & 1u;
+  orc_modulate(2, 432, enc, sym);
+  unsigned cnt = 0;
+  for (unsigned part = 0; part < 4; ++part) { /* symbol 1, symbol 2 lower, symbol 2 upper, symbol 3 */
+    const unsigned l = l0 + (part == 0 ? 1 : (part == 3 ? 3 : 2)), ka = (part == 2) ? 192 : 0, kb = (part == 1) ? 48 : 240;
+    for (unsigned k = ka; k < kb; ++k)
+      if (k % 4 != v) {
+        float* o = grid + 2 * ((size_t)l * nsc + k0 + k);
+        o[0] = sym[2 * cnt], o[1] = sym[2 * cnt + 1];
+        ++cnt;
+      }
+  }
+  /* dmrs_pbch_processor_impl::c_init (:28-39), generation, mapping */
+  unsigned i_ssb = (ssb_idx & 3u) + 4u * (hrf ? 1u : 0u);
+  if (L_max == 8 || L_max == 64)
+    i_ssb = ssb_idx & 7u;
+  const unsigned c_init = (((i_ssb + 1u) * ((N_id / 4u) + 1u)) << 11) + ((i_ssb + 1u) << 6) + (N_id % 4u);
+  orc_gold_sequence(c_init, 0, 288, c);
+  const float a = (float)M_SQRT1_2;
+  cnt           = 0;
+  for (unsigned part = 0; part < 4; ++part) {
+    const unsigned l = l0 + (part == 0 ? 1 : (part == 3 ? 3 : 2)), ka = (part == 2) ? 192 : 0, kb = (part == 1) ? 48 : 240;
+    for (unsigned k = ka + v; k < kb; k += 4) {
+      float* o = grid + 2 * ((size_t)l * nsc + k0 + k);
+      o[0] = c[2 * cnt] ? -a : a, o[1] = c[2 * cnt + 1] ? -a : a;
+      ++cnt;
+    }
+  }
+  /* pss_processor_impl (:28-68) and sss_processor_impl (:28-103): m-sequences, cyclic shifts, products */
+  uint8_t xp[134] = {0, 1, 1, 0, 1, 1, 1}, x0[134] = {1}, x1[134] = {1};
+  for (unsigned i = 0; i < 127; ++i) {
+    xp[i + 7] = (uint8_t)((xp[i + 4] + xp[i]) % 2);
+    x0[i + 7] = (uint8_t)((x0[i + 4] + x0[i]) % 2);
+    x1[i + 7] = (uint8_t)((x1[i + 1] + x1[i]) % 2);
+  }
+  const unsigned nid1 = N_id / 3, nid2 = N_id % 3, m = (43 * nid2) % 127, m0 = 15 * (nid1 / 112) + 5 * nid2, m1 = nid1 % 112;
+  const float    amp = powf(10.0f, beta_pss_dB / 20.0f);
+  for (unsigned n = 0; n < 127; ++n) {
+    const float dp = 1.0f - 2.0f * (float)xp[(n + m) % 127];
+    float*      o  = grid + 2 * ((size_t)l0 * nsc + k0 + 56 + n);
+    o[0] = dp * amp, o[1] = 0.0f * amp;
+    const float ar = (1.0f - 2.0f * (float)x0[(n + m0) % 127]) * 1.0f, ai = 0.0f * 1.0f, br = 1.0f - 2.0f * (float)x1[(n + m1) % 127], bi = 0.0f;
+    o    = grid + 2 * ((size_t)(l0 + 2) * nsc + k0 + 56 + n);
+    o[0] = ar * br - ai * bi, o[1] = ar * bi + ai * br;
+  }
+  return 0;
+}

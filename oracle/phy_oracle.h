@@ -172,6 +172,12 @@ int orc_pdcch_process(unsigned slot_in_frame, unsigned rnti, unsigned n_id_data,
                       float data_power_offset_dB, float dmrs_power_offset_dB, const uint8_t* payload, unsigned A, unsigned aggregation_level,
                       unsigned start_symbol, unsigned duration, const uint8_t* rb_mask, unsigned nof_prb_grid, float* grid);
 
+/* ------------------------------------------------------------------------------------------------ SS/PBCH block processor
+ * ssb_processor_impl::process (ssb_processor_impl.cpp:30-106) after the position look-up: PBCH encoder, pbch_modulator (:28-113),
+ * dmrs_pbch_processor (:28-100), pss_processor (:28-91), sss_processor (:28-119). grid: one port, [14][nof_prb_grid*12] cf_t. */
+int orc_ssb_process(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, unsigned sfn, unsigned k_ssb, const uint8_t* payload, unsigned ssb_first_subcarrier,
+                    unsigned ssb_first_symbol, float beta_pss_dB, unsigned nof_prb_grid, float* grid);
+
 /* ------------------------------------------------------------------------------------------------ Open Fronthaul IQ
  * compression: 0 = none (fixed point, iq_compression_none_impl.cpp:29-69), 1 = BFP (iq_compression_bfp_impl.cpp:28-143).
  * payload: per PRB, BFP [udCompParam][24 x data_width bits, big endian] = 1 + 3*data_width bytes, none the 3*data_width bytes only

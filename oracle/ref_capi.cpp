@@ -12,6 +12,7 @@
 #include "srsran/phy/generic_functions/dft_processor.h"
 #include "srsran/phy/upper/resource_grid_mapper.h"
 #include "srsran/ran/pdcch/cce_to_prb_mapping.h"
+#include "srsran/ran/ssb_mapping.h"
 #include "srsran/ran/precoding/precoding_codebooks.h"
 #include "srsran/phy/upper/channel_coding/channel_coding_factories.h"
 #include "srsran/phy/upper/channel_processors/channel_processor_factories.h"
@@ -1184,6 +1185,48 @@ int ref_pdcch_process(int mapping, unsigned bwp_start, unsigned bwp_size, unsign
   g->set_all_zero();
   resource_grid_mapper mapper(*g);
   proc->process(mapper, pdu);
+  for (unsigned l = 0; l != 14; ++l) {
+    g->get(span<cf_t>(reinterpret_cast<cf_t*>(grid) + static_cast<size_t>(l) * nof_prb_grid * 12, nof_prb_grid * 12), 0, l, 0);
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- SS/PBCH block processor
+// pattern_case 0..4 = A..E; returns the first symbol (in the slot) and first subcarrier the reference derived (ssb_mapping.h), which are
+// the inputs of the device path. grid: port 0, [14][nof_prb_grid*12].
+int ref_ssb_process(unsigned numerology, unsigned sfn, unsigned slot_in_frame, unsigned N_id, float beta_pss, unsigned ssb_idx, unsigned L_max,
+                    unsigned common_scs_khz, unsigned subcarrier_offset, unsigned offset_to_pointA, int pattern_case, const uint8_t* payload,
+                    unsigned nof_prb_grid, float* grid, unsigned* l_start_out, unsigned* k_start_out)
+{
+  ssb_processor_factory_sw_configuration cfg;
+  auto                                   prg = create_pseudo_random_generator_sw_factory();
+  cfg.encoder_factory   = create_pbch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), prg, create_polar_factory_sw());
+  cfg.modulator_factory = create_pbch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg);
+  cfg.dmrs_factory      = create_dmrs_pbch_processor_factory_sw(prg);
+  cfg.pss_factory       = create_pss_processor_factory_sw();
+  cfg.sss_factory       = create_sss_processor_factory_sw();
+  auto proc             = create_ssb_processor_factory_sw(cfg)->create();
+  ssb_processor::pdu_t pdu;
+  pdu.slot = slot_point(numerology, sfn, slot_in_frame), pdu.phys_cell_id = N_id, pdu.beta_pss = beta_pss, pdu.ssb_idx = ssb_idx, pdu.L_max = L_max;
+  pdu.common_scs        = common_scs_khz == 15 ? subcarrier_spacing::kHz15 : (common_scs_khz == 30 ? subcarrier_spacing::kHz30 : subcarrier_spacing::kHz60);
+  pdu.subcarrier_offset = subcarrier_offset, pdu.offset_to_pointA = offset_to_pointA;
+  pdu.pattern_case      = static_cast<ssb_pattern_case>(pattern_case);
+  for (unsigned i = 0; i != 32; ++i) {
+    pdu.bch_payload[i] = payload[i];
+  }
+  pdu.ports.push_back(0);
+  const unsigned l_in_burst = ssb_get_l_first(pdu.pattern_case, ssb_idx);
+  if (l_in_burst / 14 != pdu.slot.hrf_slot_index()) {
+    return -2; // the slot does not carry this block
+  }
+  *l_start_out = l_in_burst % 14;
+  *k_start_out = ssb_get_k_first(to_frequency_range(pdu.pattern_case), to_subcarrier_spacing(pdu.pattern_case), pdu.common_scs, pdu.offset_to_pointA, pdu.subcarrier_offset);
+  if (*k_start_out + 240 > nof_prb_grid * 12) {
+    return -1;
+  }
+  auto g = create_resource_grid(1, 14, nof_prb_grid * 12);
+  g->set_all_zero();
+  proc->process(*g, pdu);
   for (unsigned l = 0; l != 14; ++l) {
     g->get(span<cf_t>(reinterpret_cast<cf_t*>(grid) + static_cast<size_t>(l) * nof_prb_grid * 12, nof_prb_grid * 12), 0, l, 0);
   }

@@ -294,6 +294,92 @@ __global__ void __launch_bounds__(256) pdcch_map_kernel(const miphy_pdcch_pdu* _
   }
 }
 
+// SS/PBCH block: PBCH symbols, PBCH DM-RS, PSS and SSS of one block per workgroup (pbch_modulator_impl.cpp:28-113,
+// dmrs_pbch_processor_impl.cpp:28-100, pss_processor_impl.cpp:28-91, sss_processor_impl.cpp:28-119).
+__global__ void __launch_bounds__(256) ssb_map_kernel(const miphy_ssb_pdu* __restrict__ pdus, const gold_tables* __restrict__ gt,
+                                                      const uint8_t* __restrict__ enc_base, float2* __restrict__ grid)
+{
+#pragma clang fp contract(off)
+  __shared__ uint32_t w1[64], w2[64];
+  __shared__ uint8_t  xp[134], x0[134], x1[134]; // m-sequences of PSS / SSS
+  const miphy_ssb_pdu* __restrict__ pp = pdus + blockIdx.x;
+  const int      tid = threadIdx.x, nt = blockDim.x;
+  const unsigned N_id = pp->msg.N_id, ssb_idx = pp->msg.ssb_idx, v = N_id % 4;
+  const unsigned l0 = pp->ssb_first_symbol, k0 = pp->ssb_first_subcarrier, nsc = pp->grid_nof_prb * 12u;
+  if (tid < 3) {
+    uint8_t* x = tid == 0 ? xp : (tid == 1 ? x0 : x1);
+    for (int i = 0; i < 7; ++i)
+      x[i] = 0;
+    if (tid == 0)
+      x[6] = 1, x[5] = 1, x[4] = 1, x[3] = 0, x[2] = 1, x[1] = 1, x[0] = 0; // pss_processor_impl.cpp:32-38
+    else
+      x[0] = 1;                                                             // sss_processor_impl.cpp:30-37, 51-58
+    for (int i = 0; i < 127; ++i)
+      x[i + 7] = (uint8_t)((x[i + (tid == 2 ? 1 : 4)] + x[i]) & 1u);
+  }
+  // PBCH: scrambling sequence of the cell, advanced by (ssb_idx & 7) * 864 (pbch_modulator_impl.cpp:28-38)
+  gold_long_block(*gt, N_id, (ssb_idx & 7u) * 864u, 28, w1, w2, w1, tid, nt);
+  const uint8_t* enc = enc_base + (size_t)blockIdx.x * 864u;
+  // position of the idx-th PBCH symbol / DM-RS: symbol 1 (240 subcarriers), symbol 2 lower (48) and upper (48) part, symbol 3 (240)
+  auto place = [&](int idx, int per4, unsigned& l, unsigned& k) { // per4 = 3 data REs or 1 DM-RS per group of four subcarriers
+    const int n1 = 60 * per4, n2 = 12 * per4;
+    int       g, r, base, ls;
+    if (idx < n1)
+      ls = 1, base = 0, g = idx / per4, r = idx - g * per4;
+    else if (idx < n1 + n2)
+      ls = 2, base = 0, g = (idx - n1) / per4, r = (idx - n1) - g * per4;
+    else if (idx < n1 + 2 * n2)
+      ls = 2, base = 192, g = (idx - n1 - n2) / per4, r = (idx - n1 - n2) - g * per4;
+    else
+      ls = 3, base = 0, g = (idx - n1 - 2 * n2) / per4, r = (idx - n1 - 2 * n2) - g * per4;
+    const int pos = per4 == 1 ? (int)v : r + (r >= (int)v ? 1 : 0); // DM-RS on k % 4 == v, data on the other three
+    l = l0 + ls, k = k0 + base + 4 * g + pos;
+  };
+  for (int idx = tid; idx < 432; idx += nt) {
+    const uint32_t c0  = (w1[(2 * idx) >> 5] >> ((2 * idx) & 31)) & 1u, c1 = (w1[(2 * idx + 1) >> 5] >> ((2 * idx + 1) & 31)) & 1u;
+    const uint32_t nat = ((uint32_t)(enc[2 * idx] & 1u) ^ c0) | (((uint32_t)(enc[2 * idx + 1] & 1u) ^ c1) << 1);
+    const float2   x   = map_symbol(2, nat, (unsigned)idx);
+    unsigned       l, k;
+    place(idx, 3, l, k);
+    for (int p = 0; p < pp->nof_ports; ++p)
+      grid[pp->grid_offset + ((size_t)pp->ports[p] * 14 + l) * nsc + k] = x;
+  }
+  __syncthreads();
+  // DM-RS for PBCH (dmrs_pbch_processor_impl.cpp:28-47)
+  uint32_t i_ssb = (ssb_idx & 3u) + 4u * (pp->msg.hrf ? 1u : 0u);
+  if (pp->msg.L_max == 8 || pp->msg.L_max == 64)
+    i_ssb = ssb_idx & 7u;
+  const uint32_t c_init = (((i_ssb + 1u) * ((N_id / 4u) + 1u)) << 11) + ((i_ssb + 1u) << 6) + (N_id % 4u);
+  gold_long_block(*gt, c_init, 0, 10, w1, w2, w1, tid, nt);
+  const float a = (float)0.70710678118654752440; // prg->generate(sequence, M_SQRT1_2)
+  for (int idx = tid; idx < 144; idx += nt) {
+    const float re = ((w1[(2 * idx) >> 5] >> ((2 * idx) & 31)) & 1u) ? -a : a;
+    const float im = ((w1[(2 * idx + 1) >> 5] >> ((2 * idx + 1) & 31)) & 1u) ? -a : a;
+    unsigned    l, k;
+    place(idx, 1, l, k);
+    for (int p = 0; p < pp->nof_ports; ++p)
+      grid[pp->grid_offset + ((size_t)pp->ports[p] * 14 + l) * nsc + k] = make_float2(re, im);
+  }
+  // PSS (symbol 0) and SSS (symbol 2), subcarriers 56..182 of the block
+  const unsigned nid1 = N_id / 3u, nid2 = N_id % 3u;
+  const unsigned m = (43u * nid2) % 127u, m0 = 15u * (nid1 / 112u) + 5u * nid2, m1 = nid1 % 112u;
+  const float    amp_pss = powf(10.0f, pp->beta_pss_dB / 20.0f); // convert_dB_to_amplitude(beta_pss)
+  for (int n = tid; n < 127; n += nt) {
+    const float dp = 1.0f - 2.0f * (float)xp[(n + m) % 127u];
+    // srsvec::sc_prod(cf_t, float): both components are multiplied
+    const float2 pss = make_float2(dp * amp_pss, 0.0f * amp_pss);
+    const float  d0v = 1.0f - 2.0f * (float)x0[(n + m0) % 127u], d1v = 1.0f - 2.0f * (float)x1[(n + m1) % 127u];
+    // sc_prod by amplitude 1, then the complex product with d1 (real-valued factors: the imaginary part is a signed zero)
+    const float ar = d0v * 1.0f, ai = 0.0f * 1.0f, br = d1v, bi = 0.0f;
+    const float2 sss = make_float2(ar * br - ai * bi, ar * bi + ai * br);
+    for (int p = 0; p < pp->nof_ports; ++p) {
+      float2* g = grid + pp->grid_offset + (size_t)pp->ports[p] * 14 * nsc + k0 + 56 + n;
+      g[(size_t)(l0 + 0) * nsc] = pss;
+      g[(size_t)(l0 + 2) * nsc] = sss;
+    }
+  }
+}
+
 uint32_t host_nof_re(const miphy_pdsch_mod_job& j)
 {
   unsigned dm = 0;
@@ -433,6 +519,42 @@ extern "C" int miphy_pdcch_process_batch(miphy_ctx* ctx, const miphy_pdcch_pdu* 
       return rc;
   }
   hipLaunchKernelGGL(pdcch_map_kernel, dim3(n, 3), dim3(256), 0, s, (const miphy_pdcch_pdu*)d_pdus, gt, d_enc, (float2*)grid);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- SS/PBCH block processor
+extern "C" int miphy_ssb_process_batch(miphy_ctx* ctx, const miphy_ssb_pdu* pdus, uint32_t n, float* grid, void* stream)
+{
+  MIPHY_REQUIRE(ctx && pdus && grid, "miphy_ssb_process_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  MIPHY_REQUIRE(n <= 65535, "ssb_process: at most 65535 blocks per call");
+  hipStream_t                 s = (hipStream_t)stream;
+  std::vector<miphy_pbch_msg> msgs(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const miphy_ssb_pdu& q = pdus[i];
+    MIPHY_REQUIRE(q.msg.N_id < 1008, "ssb_process: block %u: invalid physical cell identity %u", i, q.msg.N_id);
+    MIPHY_REQUIRE(q.msg.L_max == 4 || q.msg.L_max == 8 || q.msg.L_max == 64, "ssb_process: block %u: invalid L_max %u", i, q.msg.L_max);
+    MIPHY_REQUIRE(q.nof_ports >= 1 && q.nof_ports <= 4, "ssb_process: block %u: invalid number of ports", i);
+    MIPHY_REQUIRE(q.grid_nof_prb >= 20 && q.grid_nof_prb <= 275 && q.ssb_first_subcarrier + 240u <= q.grid_nof_prb * 12u, "ssb_process: block %u: the block does not fit the grid",
+                  i);
+    MIPHY_REQUIRE(q.ssb_first_symbol + 4u <= 14u, "ssb_process: block %u: the block does not fit the slot", i);
+    msgs[i] = q.msg;
+  }
+  void* work = nullptr; // encoded PBCH bits, 864 per block
+  int   rc   = miphy_get_workspace(ctx, (size_t)n * 864 + 64, s, &work, 2);
+  if (rc)
+    return rc;
+  if ((rc = miphy_pbch_encode_batch(ctx, msgs.data(), n, static_cast<uint8_t*>(work), s)))
+    return rc;
+  const void* d_pdus = nullptr;
+  if ((rc = miphy_stage_descs(ctx, pdus, 0, sizeof(miphy_ssb_pdu) * (size_t)n, s, &d_pdus)))
+    return rc;
+  const gold_tables* gt = nullptr;
+  if ((rc = miphy_get_gold_tables(ctx, &gt)))
+    return rc;
+  hipLaunchKernelGGL(ssb_map_kernel, dim3(n), dim3(256), 0, s, (const miphy_ssb_pdu*)d_pdus, gt, static_cast<const uint8_t*>(work), (float2*)grid);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

@@ -68,6 +68,7 @@ def lib():
         l.miphy_ofh_iq_decompress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         l.miphy_ofh_iq_compress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         l.miphy_pdcch_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_ssb_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         l.miphy_harq_pool_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         l.miphy_harq_pool_destroy.argtypes = [C.c_void_p]
         l.miphy_harq_pool_destroy.restype = None
@@ -243,6 +244,10 @@ def sch_segmentation(tb_bytes, bg):
 PbchMsg = np.dtype([("N_id", np.uint32), ("ssb_idx", np.uint32), ("L_max", np.uint32), ("hrf", np.uint32), ("sfn", np.uint32),
                     ("k_ssb", np.uint32), ("payload", np.uint8, 32)], align=True)
 assert PbchMsg.itemsize == 56
+# Mirrors miphy_ssb_pdu.
+SsbPdu = np.dtype([("msg", PbchMsg), ("ssb_first_subcarrier", np.uint32), ("ssb_first_symbol", np.uint32), ("beta_pss_dB", np.float32),
+                   ("grid_nof_prb", np.uint16), ("nof_ports", np.uint8), ("ports", np.uint8, 4), ("pad", np.uint8), ("grid_offset", np.uint64)], align=True)
+assert SsbPdu.itemsize == 88 and SsbPdu.fields["grid_offset"][1] == 80, SsbPdu.itemsize
 
 
 # Mirrors miphy_crc_desc.
@@ -363,6 +368,12 @@ class Context:
         assert isinstance(pdus, np.ndarray) and pdus.dtype == PdschPdu
         pdus = np.ascontiguousarray(pdus)
         check(lib().miphy_pdsch_process_batch(self.h, C.c_void_p(pdus.ctypes.data), pdus.size, _dptr(tb_in), _dptr(grid), _stream_ptr(stream)))
+
+    def ssb_process_batch(self, pdus, grid, stream=None):
+        """ssb_processor::process (after the position look-up) for a batch of SS/PBCH blocks (host descriptors)."""
+        assert isinstance(pdus, np.ndarray) and pdus.dtype == SsbPdu
+        pdus = np.ascontiguousarray(pdus)
+        check(lib().miphy_ssb_process_batch(self.h, C.c_void_p(pdus.ctypes.data), pdus.size, _dptr(grid), _stream_ptr(stream)))
 
     def pdcch_process_batch(self, pdus, payloads, grid, stream=None):
         """pdcch_processor::process (after the CCE-to-PRB mapping) for a batch of PDUs (host descriptors): DCI payload bits -> grid REs."""

@@ -724,3 +724,40 @@ def pdcch_cases(rng, n):
         cce_index = AL * int(rng.integers(0, ncce // AL))
         out.append((mapping, bwp_start, bwp_size, int(rng.integers(0, 3)), duration, fr, reg_bundle, interleaver, shift, cce_index, AL))
     return out
+
+
+# ---------------------------------------------------------------------- SS/PBCH block processor
+def o_ssb_process(N_id, ssb_idx, L_max, hrf, sfn, k_ssb, payload, k0, l0, beta_pss_dB, nprb_grid, grid):
+    pl = np.ascontiguousarray(payload, dtype=np.uint8)
+    assert pl.size == 32 and grid.dtype == np.complex64 and grid.shape == (14, nprb_grid * 12) and grid.flags.c_contiguous
+    return oracle().orc_ssb_process(C.c_uint(N_id), C.c_uint(ssb_idx), C.c_uint(L_max), int(hrf), C.c_uint(sfn), C.c_uint(k_ssb), _p(pl), C.c_uint(k0), C.c_uint(l0),
+                                    C.c_float(beta_pss_dB), C.c_uint(nprb_grid), _p(grid))
+
+
+def r_ssb_process(numerology, sfn, slot_in_frame, N_id, beta_pss, ssb_idx, L_max, common_scs_khz, subcarrier_offset, offset_to_pointA, pattern_case, payload,
+                  nprb_grid):
+    """The reference SSB processor. Returns (rc, grid [14][nsc], l_start, k_start); rc -2 when the slot does not carry the block."""
+    pl = np.ascontiguousarray(payload, dtype=np.uint8)
+    grid = np.zeros((14, nprb_grid * 12), dtype=np.complex64)
+    l0, k0 = C.c_uint(0), C.c_uint(0)
+    rc = ref().ref_ssb_process(C.c_uint(numerology), C.c_uint(sfn), C.c_uint(slot_in_frame), C.c_uint(N_id), C.c_float(beta_pss), C.c_uint(ssb_idx), C.c_uint(L_max),
+                               C.c_uint(common_scs_khz), C.c_uint(subcarrier_offset), C.c_uint(offset_to_pointA), int(pattern_case), _p(pl), C.c_uint(nprb_grid),
+                               _p(grid), C.byref(l0), C.byref(k0))
+    return rc, grid, l0.value, k0.value
+
+
+def ssb_cases(rng, n):
+    """Random valid SS/PBCH configurations (FR1 pattern cases A, B, C): (numerology, sfn, slot, N_id, beta, ssb_idx, L_max, scs, k_ssb, offset, case)."""
+    out = []
+    first = {0: [2, 8, 16, 22, 30, 36, 44, 50], 1: [4, 8, 16, 20, 32, 36, 44, 48], 2: [2, 8, 16, 22, 30, 36, 44, 50]}  # TS 38.213 4.1, L_max <= 8
+    while len(out) < n:
+        case = int(rng.integers(0, 3))
+        mu = 0 if case == 0 else 1
+        L_max = int(rng.choice([4, 8]))
+        ssb_idx = int(rng.integers(0, L_max))
+        slot_hrf = first[case][ssb_idx] // 14
+        hrf = int(rng.integers(0, 2))
+        slots_per_hrf = 5 << mu
+        out.append((mu, int(rng.integers(0, 1024)), hrf * slots_per_hrf + slot_hrf, int(rng.integers(0, 1008)), float(rng.choice([0.0, 3.0, -3.0])), ssb_idx, L_max,
+                    15 if mu == 0 else 30, int(rng.integers(0, 12 if mu == 0 else 24)) & ~(0 if mu == 0 else 1), int(rng.integers(0, 40)) * (1 if mu == 0 else 2), case))
+    return out

@@ -225,3 +225,13 @@ def test_pdcch_processor():
         assert n == 54 * int(AL) and np.array_equal(out.view(np.uint32), g["grid_%d" % i].view(np.uint32)), i
         kinds.add(int(mapping))
     assert kinds == {0, 1, 2}
+
+
+def test_ssb_processor():
+    """SS/PBCH block: oracle against grids recorded from the reference processor (PBCH, its DM-RS, PSS, SSS; bit patterns incl. signed zeros)."""
+    g = np.load(os.path.join(GOLD, "ssb_proc.npz"))
+    for i in range(int(g["n"])):
+        N_id, ssb_idx, L_max, hrf, sfn, kssb, k0, l0, beta, case = g["meta_%d" % i]
+        out = np.zeros_like(g["grid_%d" % i])
+        assert O.o_ssb_process(int(N_id), int(ssb_idx), int(L_max), int(hrf), int(sfn), int(kssb), g["pay_%d" % i], int(k0), int(l0), float(beta), 106, out) == 0
+        assert np.array_equal(out.view(np.uint32), g["grid_%d" % i].view(np.uint32)), i

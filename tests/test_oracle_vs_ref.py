@@ -280,3 +280,17 @@ def test_pdcch_processor():
         out = np.zeros_like(g)
         assert O.o_pdcch_process(slot, rnti, nd, nr, ndm, bs if mapping == 0 else 0, xdb, ddb, pay, AL, start, dur, rb, out) == 54 * AL
         assert np.array_equal(out.view(np.uint32), g.view(np.uint32)), (mapping, bs, bz, dur, AL)
+
+
+def test_ssb_processor():
+    rng = np.random.default_rng(92)
+    n = 0
+    for (mu, sfn, slot, N_id, beta, ssb_idx, L_max, scs, kssb, off, case) in O.ssb_cases(rng, 80):
+        pay = rng.integers(0, 2, 32, dtype=np.uint8)
+        rc, g, l0, k0 = O.r_ssb_process(mu, sfn, slot, N_id, beta, ssb_idx, L_max, scs, kssb, off, case, pay, 106)
+        assert rc == 0
+        out = np.zeros_like(g)
+        assert O.o_ssb_process(N_id, ssb_idx, L_max, 1 if slot >= (5 << mu) else 0, sfn, kssb, pay, k0, l0, beta, 106, out) == 0
+        assert np.array_equal(out.view(np.uint32), g.view(np.uint32)), (case, N_id, ssb_idx, L_max)
+        n += 1
+    assert n == 80
