@@ -1215,6 +1215,56 @@ static void test_pdcch_processor(std::shared_ptr<miphy::context> c)
   printf("pdcch_processor done, failures so far %d\n", failures);
 }
 
+// ssb_processor: the reference (software PBCH encoder / modulator, DM-RS, PSS, SSS) vs ssb_processor_hip; identical grids on every port.
+static void test_ssb_processor(std::shared_ptr<miphy::context> c)
+{
+  ssb_processor_factory_sw_configuration cfg;
+  auto                                   prg = create_pseudo_random_generator_sw_factory();
+  cfg.encoder_factory   = create_pbch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), prg, create_polar_factory_sw());
+  cfg.modulator_factory = create_pbch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg);
+  cfg.dmrs_factory      = create_dmrs_pbch_processor_factory_sw(prg);
+  cfg.pss_factory       = create_pss_processor_factory_sw();
+  cfg.sss_factory       = create_sss_processor_factory_sw();
+  auto p_ref            = create_ssb_processor_factory_sw(cfg)->create();
+  auto p_hip            = std::make_shared<miphy::ssb_processor_factory_hip>(c)->create();
+  struct tc {
+    ssb_pattern_case   pc;
+    subcarrier_spacing scs;
+    unsigned           mu, slot, pci, ssb_idx, L_max, k_ssb, offset;
+    float              beta;
+  };
+  std::uniform_int_distribution<int> bit(0, 1);
+  for (const tc& t : {tc{ssb_pattern_case::A, subcarrier_spacing::kHz15, 0, 0, 500, 0, 4, 3, 10, 0.0F}, tc{ssb_pattern_case::C, subcarrier_spacing::kHz30, 1, 1, 1007, 2, 8, 6, 24, 3.0F},
+                      tc{ssb_pattern_case::B, subcarrier_spacing::kHz30, 1, 11, 3, 3, 4, 0, 0, -3.0F}, tc{ssb_pattern_case::C, subcarrier_spacing::kHz30, 1, 3, 65, 7, 8, 22, 60, 0.0F}}) {
+    ssb_processor::pdu_t pdu;
+    pdu.slot = slot_point(t.mu, 77, t.slot), pdu.phys_cell_id = t.pci, pdu.beta_pss = t.beta, pdu.ssb_idx = t.ssb_idx, pdu.L_max = t.L_max;
+    pdu.common_scs = t.scs, pdu.subcarrier_offset = t.k_ssb, pdu.offset_to_pointA = t.offset, pdu.pattern_case = t.pc;
+    for (auto& b : pdu.bch_payload) {
+      b = bit(rgen);
+    }
+    pdu.ports.push_back(0);
+    pdu.ports.push_back(1);
+    const unsigned nsc = 106 * 12;
+    auto           g1 = create_resource_grid(2, 14, nsc), g2 = create_resource_grid(2, 14, nsc);
+    g1->set_all_zero();
+    g2->set_all_zero();
+    p_ref->process(*g1, pdu);
+    p_hip->process(*g2, pdu);
+    std::vector<cf_t> a(nsc), b(nsc);
+    unsigned          bad = 0, written = 0;
+    for (unsigned p = 0; p != 2; ++p) {
+      for (unsigned l = 0; l != 14; ++l) {
+        g1->get(a, p, l, 0);
+        g2->get(b, p, l, 0);
+        bad += std::memcmp(a.data(), b.data(), nsc * sizeof(cf_t)) != 0;
+        written += std::any_of(a.begin(), a.end(), [](cf_t v) { return v != cf_t(0, 0); });
+      }
+    }
+    CHECK(bad == 0 && written == 8, "ssb_processor: %u (port, symbol) rows differ, %u written (pci %u, ssb_idx %u)", bad, written, t.pci, t.ssb_idx);
+  }
+  printf("ssb_processor done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -1394,6 +1444,7 @@ int main()
   test_dft(c);
   test_pdcch(c);
   test_pdcch_processor(c);
+  test_ssb_processor(c);
   test_pusch_demodulator(c);
   test_pusch_processor(c);
   test_uplink_processor(c);

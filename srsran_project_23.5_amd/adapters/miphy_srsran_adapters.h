@@ -27,6 +27,7 @@
 #include "srsran/phy/upper/resource_grid_mapper.h"
 #include "srsran/phy/upper/upper_phy_rg_gateway.h"
 #include "srsran/ran/pdcch/cce_to_prb_mapping.h"
+#include "srsran/ran/ssb_mapping.h"
 #include "srsran/ran/precoding/precoding_codebooks.h"
 #include "srsran/phy/upper/rx_softbuffer.h"
 #include "srsran/phy/upper/rx_softbuffer_pool.h"
@@ -1592,6 +1593,62 @@ public:
   explicit pdcch_processor_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
   std::unique_ptr<srsran::pdcch_processor>     create() override { return std::make_unique<pdcch_processor_hip>(c); }
   std::unique_ptr<srsran::pdcch_pdu_validator> create_validator() override { return nullptr; }
+
+private:
+  std::shared_ptr<context> c;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- SS/PBCH block processor
+/// srsran::ssb_processor over miphy_ssb_process_batch (ssb_processor.h:80): the block position is the reference's own look-up
+/// (ssb_get_l_first / ssb_get_k_first, ssb_mapping.h), everything else -- PBCH encoding and modulation, its DM-RS, PSS and SSS -- is one
+/// device pass; the 4 x 240 REs of the block come back and are put on every port of the PDU.
+class ssb_processor_hip : public srsran::ssb_processor
+{
+public:
+  explicit ssb_processor_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void process(srsran::resource_grid_writer& grid, const pdu_t& pdu) override
+  {
+    const unsigned l_in_burst = srsran::ssb_get_l_first(pdu.pattern_case, pdu.ssb_idx);
+    const unsigned l_start    = l_in_burst % srsran::get_nsymb_per_slot(srsran::cyclic_prefix::NORMAL);
+    const unsigned k_start    = srsran::ssb_get_k_first(srsran::to_frequency_range(pdu.pattern_case), srsran::to_subcarrier_spacing(pdu.pattern_case), pdu.common_scs,
+                                                     pdu.offset_to_pointA, pdu.subcarrier_offset);
+    srsran_assert((l_in_burst / srsran::get_nsymb_per_slot(srsran::cyclic_prefix::NORMAL)) == pdu.slot.hrf_slot_index(), "Invalid slot index ({}) for SSB index {}",
+                  pdu.slot.hrf_slot_index(), l_in_burst);
+    // staging grid: one port, just wide enough for the block
+    const unsigned nprb = (k_start + 240 + 11) / 12, nsc = nprb * 12;
+    miphy_ssb_pdu  p    = {};
+    p.msg.N_id = pdu.phys_cell_id, p.msg.ssb_idx = pdu.ssb_idx, p.msg.L_max = pdu.L_max, p.msg.hrf = pdu.slot.is_odd_hrf() ? 1 : 0, p.msg.sfn = pdu.slot.sfn();
+    p.msg.k_ssb = pdu.subcarrier_offset.to_uint();
+    for (unsigned i = 0; i != 32 && i != pdu.bch_payload.size(); ++i) {
+      p.msg.payload[i] = pdu.bch_payload[i];
+    }
+    p.ssb_first_subcarrier = k_start, p.ssb_first_symbol = l_start, p.beta_pss_dB = pdu.beta_pss, p.grid_nof_prb = nprb < 20 ? 20 : nprb;
+    p.nof_ports = 1, p.ports[0] = 0;
+    const unsigned nsc_g = p.grid_nof_prb * 12;
+    (void)nsc;
+    host.assign(static_cast<size_t>(14) * nsc_g, srsran::cf_t(NAN, NAN));
+    auto* d_g = static_cast<float*>(c->buf(0, host.size() * sizeof(srsran::cf_t)));
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    context::check(miphy_ssb_process_batch(c->ctx, &p, 1, d_g, c->stream), "ssb_process");
+    c->d2h(host.data(), d_g, host.size() * sizeof(srsran::cf_t));
+    c->sync();
+    for (unsigned port : pdu.ports) {
+      put_written_res(grid, port, nsc_g, host.data());
+    }
+  }
+
+private:
+  std::shared_ptr<context>  c;
+  std::vector<srsran::cf_t> host;
+};
+
+/// Replaces create_ssb_processor_factory_sw(config) (channel_processor_factories.h:293-301).
+class ssb_processor_factory_hip : public srsran::ssb_processor_factory
+{
+public:
+  explicit ssb_processor_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  std::unique_ptr<srsran::ssb_processor>     create() override { return std::make_unique<ssb_processor_hip>(c); }
+  std::unique_ptr<srsran::ssb_pdu_validator> create_validator() override { return nullptr; }
 
 private:
   std::shared_ptr<context> c;
