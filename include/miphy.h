@@ -633,6 +633,36 @@ int miphy_ssb_process_batch(miphy_ctx* ctx, const miphy_ssb_pdu* pdus /* host */
                             void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * NZP-CSI-RS generator  --  replaces srsran::nzp_csi_rs_generator::map after the pattern look-up
+ *   include/srsran/phy/upper/signal_processors/nzp_csi_rs_generator.h:37-91, lib/phy/upper/signal_processors/nzp_csi_rs_generator_impl.cpp:34-296
+ * Per port and OFDM symbol of its pattern: Gold sequence with c_init = (2^10 (14 n_slot + l + 1)(2 n_id + 1) + n_id) mod 2^31, the
+ * elements below the first occupied PRB skipped (:69-108), QPSK of amplitude `amplitude` / sqrt(2), the CDM weights w_t[l'] w_f[k']
+ * of the port's index in its CDM group (:34-57, 223-296), written to the REs of the port's pattern inside [start_rb, start_rb + nof_rb).
+ * The per-port patterns (rb_begin / rb_end / rb_stride, RE mask, symbol mask) are the output of the reference's get_csi_rs_pattern()
+ * (TS 38.211 Table 7.4.1.5.3-1 bookkeeping, include/srsran/ran/csi_rs/csi_rs_pattern.h), which stays with the caller. */
+typedef struct {
+  uint32_t slot_in_frame;
+  uint32_t scrambling_id;
+  float    amplitude;
+  uint16_t start_rb;
+  uint16_t nof_rb;
+  uint16_t rb_begin;       /* csi_rs_pattern */
+  uint16_t rb_end;
+  uint16_t rb_stride;
+  uint16_t grid_nof_prb;
+  uint8_t  mapping_row;    /* csi_rs_mapping_table_row (only row 2 changes the sequence offset) */
+  uint8_t  cdm;            /* csi_rs_cdm_type: 0 none, 1 FD-CDM2, 2 CDM4-FD2-TD2, 3 CDM8-FD2-TD4 */
+  uint8_t  freq_density;   /* csi_rs_freq_density_type: 0 0.5 even PRBs, 1 0.5 odd PRBs, 2 one, 3 three */
+  uint8_t  nof_ports;      /* 1..16 */
+  uint8_t  ports[16];      /* grid port of each CSI-RS port */
+  uint16_t re_mask[16];    /* csi_rs_pattern_port::re_mask, bit k = subcarrier k of the PRB */
+  uint16_t symbol_mask[16];
+  uint64_t grid_offset;    /* cf_t offset of grid port 0: [port][14][grid_nof_prb*12] */
+} miphy_csi_rs_job;
+
+int miphy_csi_rs_map_batch(miphy_ctx* ctx, const miphy_csi_rs_job* jobs, int jobs_on_device, uint32_t n, float* grid /* device cf_t */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Polar successive-cancellation LIST decoder (list size 1, 2, 4 or 8), optionally CRC-aided  --  no counterpart in the
  * reference (its polar_decoder is the list-size-1 SSC decoder that miphy_polar_decode_batch reproduces bit for bit); this
  * is the SCL-8 path BASELINE.json's north_star / configs[3] ask for. Same rate-dematcher and LLR algebra as the reference;

@@ -311,3 +311,14 @@ for (mu, sfn, slot, N_id, beta, ssb_idx, L_max, scs, kssb, off, case) in cases:
     k += 1
 d["n"] = np.array(k)
 save("ssb_proc", **d)
+
+# ---------------------------------------------------------------------- NZP-CSI-RS generator (reference grids + the patterns of get_csi_rs_pattern)
+d = {}
+cases = O.csi_rs_cases(np.random.default_rng(31), 24)
+for i, (row, nports, k, cdm, dens, start_rb, nof_rb, l0, slot, scr, amp) in enumerate(cases):
+    l0 = min(l0, 12)
+    g, bes, rm, sm = O.r_csi_rs_map(1, slot, start_rb, nof_rb, row, k, l0, 0, cdm, dens, scr, amp, nports, 80)
+    d["grid_%d" % i], d["rm_%d" % i], d["sm_%d" % i] = g, rm[:nports], sm[:nports]
+    d["meta_%d" % i] = np.array([slot, scr, amp, start_rb, nof_rb, bes[0], bes[1], bes[2], row, cdm, dens, nports], dtype=np.float64)
+d["n"] = np.array(len(cases))
+save("csi_rs", **d)

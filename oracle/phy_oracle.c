@@ -2085,3 +2085,88 @@ int orc_ssb_process(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, un
   }
   return 0;
 }
+
+/* ================================================================================================ NZP-CSI-RS generator */
+int orc_csi_rs_map(unsigned slot_in_frame, unsigned scrambling_id, float amplitude, unsigned start_rb, unsigned nof_rb, unsigned rb_begin, unsigned rb_end,
+                   unsigned rb_stride, unsigned mapping_row, unsigned cdm, unsigned freq_density, unsigned nof_ports, const uint8_t* ports,
+                   const uint16_t* re_mask, const uint16_t* symbol_mask, unsigned nof_prb_grid, float* grid)
+{
+  static const float w_f[2][2] = {{1.f, 1.f}, {1.f, -1.f}};
+  static const float w_t[4][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f}, {1.f, 1.f, -1.f, -1.f}, {1.f, -1.f, -1.f, 1.f}};
+  const unsigned     nsc = nof_prb_grid * 12;
+  /* get_seq_len (:131-161) */
+  unsigned seq_len = nof_rb;
+  if (freq_density <= 1) {
+    seq_len /= 2;
+    if (nof_rb % 2 != 0) {
+      if (start_rb % 2 != 0)
+        seq_len += (freq_density == 1);
+      else
+        seq_len += (freq_density == 0);
+    }
+  } else if (freq_density == 3) {
+    seq_len *= 3;
+  }
+  if (cdm != 0)
+    seq_len *= 2;
+  /* get_nof_skipped_elements (:69-108) */
+  unsigned first_prb = start_rb, adv;
+  if (freq_density == 0)
+    first_prb = start_rb + start_rb % 2;
+  else if (freq_density == 1)
+    first_prb = start_rb + (1 - start_rb % 2);
+  if (freq_density == 3)
+    adv = 3 * first_prb;
+  else if (freq_density == 2)
+    adv = (mapping_row == 2) ? first_prb : 2 * first_prb;
+  else
+    adv = (mapping_row == 2) ? first_prb / 2 : first_prb;
+  const unsigned gsize = cdm == 0 ? 1 : (cdm == 1 ? 2 : (cdm == 2 ? 4 : 8));
+  const float    amp   = (float)(M_SQRT1_2 * (double)amplitude);
+  uint8_t*       c     = (uint8_t*)malloc(2 * seq_len + 2);
+  float*         seq   = (float*)malloc(sizeof(float) * (2 * seq_len + 2));
+  for (unsigned p = 0; p < nof_ports; ++p) {
+    const unsigned cidx = p % gsize;
+    unsigned       lidx = 0;
+    for (unsigned l = 0; l < 14; ++l) {
+      if (!((symbol_mask[p] >> l) & 1u))
+        continue;
+      const unsigned long long t = (1024ull * (14 * slot_in_frame + l + 1) * (2ull * scrambling_id + 1) + scrambling_id) % (1ull << 31);
+      orc_gold_sequence((unsigned)t, 2 * adv, 2 * seq_len, c);
+      for (unsigned k = 0; k < seq_len; ++k) {
+        float re = c[2 * k] ? -amp : amp, im = c[2 * k + 1] ? -amp : amp;
+        if (cdm == 1) {
+          const float w = w_f[cidx & 1][k & 1];
+          re = w * re, im = w * im;
+        } else if (cdm >= 2) {
+          const float w = w_t[cidx >> 1][lidx] * w_f[cidx & 1][k & 1];
+          re = w * re, im = w * im;
+        }
+        seq[2 * k] = re, seq[2 * k + 1] = im;
+      }
+      ++lidx;
+      /* grid.put(port, l, start_rb * NRE, mask_csi, sequence): ascending subcarriers of the pattern inside the PRB window */
+      unsigned k = 0;
+      for (unsigned rb = rb_begin; rb < rb_end; rb += rb_stride) {
+        if (rb < start_rb || rb >= start_rb + nof_rb)
+          continue;
+        for (unsigned sc = 0; sc < 12; ++sc)
+          if ((re_mask[p] >> sc) & 1u) {
+            if (k >= seq_len) {
+              free(c), free(seq);
+              return -1;
+            }
+            float* o = grid + 2 * (((size_t)ports[p] * 14 + l) * nsc + rb * 12 + sc);
+            o[0] = seq[2 * k], o[1] = seq[2 * k + 1];
+            ++k;
+          }
+      }
+      if (k != seq_len) {
+        free(c), free(seq);
+        return -1;
+      }
+    }
+  }
+  free(c), free(seq);
+  return 0;
+}

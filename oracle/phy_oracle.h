@@ -178,6 +178,13 @@ int orc_pdcch_process(unsigned slot_in_frame, unsigned rnti, unsigned n_id_data,
 int orc_ssb_process(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, unsigned sfn, unsigned k_ssb, const uint8_t* payload, unsigned ssb_first_subcarrier,
                     unsigned ssb_first_symbol, float beta_pss_dB, unsigned nof_prb_grid, float* grid);
 
+/* ------------------------------------------------------------------------------------------------ NZP-CSI-RS generator
+ * nzp_csi_rs_generator_impl::map (nzp_csi_rs_generator_impl.cpp:163-221) with generate_sequence (:110-129), get_nof_skipped_elements (:69-108),
+ * get_seq_len (:131-161) and apply_cdm (:223-296), given the per-port patterns of get_csi_rs_pattern(). grid: [max port + 1][14][nsc] cf_t. */
+int orc_csi_rs_map(unsigned slot_in_frame, unsigned scrambling_id, float amplitude, unsigned start_rb, unsigned nof_rb, unsigned rb_begin, unsigned rb_end,
+                   unsigned rb_stride, unsigned mapping_row, unsigned cdm, unsigned freq_density, unsigned nof_ports, const uint8_t* ports,
+                   const uint16_t* re_mask, const uint16_t* symbol_mask, unsigned nof_prb_grid, float* grid);
+
 /* ------------------------------------------------------------------------------------------------ Open Fronthaul IQ
  * compression: 0 = none (fixed point, iq_compression_none_impl.cpp:29-69), 1 = BFP (iq_compression_bfp_impl.cpp:28-143).
  * payload: per PRB, BFP [udCompParam][24 x data_width bits, big endian] = 1 + 3*data_width bytes, none the 3*data_width bytes only

@@ -11,6 +11,7 @@
 #include "srsran/ofh/compression/compression_factory.h"
 #include "srsran/phy/generic_functions/dft_processor.h"
 #include "srsran/phy/upper/resource_grid_mapper.h"
+#include "srsran/ran/csi_rs/csi_rs_pattern.h"
 #include "srsran/ran/pdcch/cce_to_prb_mapping.h"
 #include "srsran/ran/ssb_mapping.h"
 #include "srsran/ran/precoding/precoding_codebooks.h"
@@ -1229,6 +1230,50 @@ int ref_ssb_process(unsigned numerology, unsigned sfn, unsigned slot_in_frame, u
   proc->process(*g, pdu);
   for (unsigned l = 0; l != 14; ++l) {
     g->get(span<cf_t>(reinterpret_cast<cf_t*>(grid) + static_cast<size_t>(l) * nof_prb_grid * 12, nof_prb_grid * 12), 0, l, 0);
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- NZP-CSI-RS generator
+// Runs the reference generator and returns the per-port patterns its get_csi_rs_pattern() produced (the inputs of the device path).
+// grid: [nof_ports][14][nof_prb_grid*12], port i of the configuration on grid port i.
+int ref_csi_rs_map(unsigned numerology, unsigned slot_index, unsigned start_rb, unsigned nof_rb, unsigned row, const unsigned* k_ref, unsigned nof_k_ref,
+                   unsigned l0, unsigned l1, unsigned cdm, unsigned density, unsigned scrambling_id, float amplitude, unsigned nof_ports, unsigned nof_prb_grid,
+                   float* grid, unsigned* rb_begin_end_stride, uint16_t* re_mask, uint16_t* symbol_mask)
+{
+  auto                           gen = create_nzp_csi_rs_generator_factory_sw(create_pseudo_random_generator_sw_factory())->create();
+  nzp_csi_rs_generator::config_t cfg;
+  cfg.slot = slot_point(numerology, slot_index), cfg.cp = cyclic_prefix::NORMAL, cfg.start_rb = start_rb, cfg.nof_rb = nof_rb, cfg.csi_rs_mapping_table_row = row;
+  for (unsigned i = 0; i != nof_k_ref; ++i) {
+    cfg.freq_allocation_ref_idx.push_back(k_ref[i]);
+  }
+  cfg.symbol_l0 = l0, cfg.symbol_l1 = l1, cfg.cdm = static_cast<csi_rs_cdm_type>(cdm), cfg.freq_density = static_cast<csi_rs_freq_density_type>(density);
+  cfg.scrambling_id = scrambling_id, cfg.amplitude = amplitude, cfg.pmi = 0;
+  for (unsigned i = 0; i != nof_ports; ++i) {
+    cfg.ports.push_back(i);
+  }
+  csi_rs_pattern_configuration pc;
+  pc.start_rb = start_rb, pc.nof_rb = nof_rb, pc.csi_rs_mapping_table_row = row, pc.freq_allocation_ref_idx = cfg.freq_allocation_ref_idx;
+  pc.symbol_l0 = l0, pc.symbol_l1 = l1, pc.cdm = cfg.cdm, pc.freq_density = cfg.freq_density, pc.nof_ports = nof_ports;
+  csi_rs_pattern pat     = get_csi_rs_pattern(pc);
+  rb_begin_end_stride[0] = pat.rb_begin, rb_begin_end_stride[1] = pat.rb_end, rb_begin_end_stride[2] = pat.rb_stride;
+  for (unsigned p = 0; p != nof_ports; ++p) {
+    uint16_t rm = 0, sm = 0;
+    for (unsigned k = 0; k != 12; ++k) {
+      rm |= static_cast<uint16_t>(pat.prb_patterns[p].re_mask.test(k) ? (1U << k) : 0U);
+    }
+    for (unsigned l = 0; l != 14; ++l) {
+      sm |= static_cast<uint16_t>(pat.prb_patterns[p].symbol_mask.test(l) ? (1U << l) : 0U);
+    }
+    re_mask[p] = rm, symbol_mask[p] = sm;
+  }
+  auto g = create_resource_grid(nof_ports, 14, nof_prb_grid * 12);
+  g->set_all_zero();
+  gen->map(*g, cfg);
+  for (unsigned p = 0; p != nof_ports; ++p) {
+    for (unsigned l = 0; l != 14; ++l) {
+      g->get(span<cf_t>(reinterpret_cast<cf_t*>(grid) + (static_cast<size_t>(p) * 14 + l) * nof_prb_grid * 12, nof_prb_grid * 12), p, l, 0);
+    }
   }
   return 0;
 }

@@ -380,6 +380,75 @@ __global__ void __launch_bounds__(256) ssb_map_kernel(const miphy_ssb_pdu* __res
   }
 }
 
+// NZP-CSI-RS: one (job, port, OFDM symbol) per workgroup (nzp_csi_rs_generator_impl.cpp:34-296).
+__global__ void __launch_bounds__(256) csi_rs_kernel(const miphy_csi_rs_job* __restrict__ jobs, const gold_tables* __restrict__ gt, float2* __restrict__ grid)
+{
+#pragma clang fp contract(off)
+  __shared__ uint32_t w1[64], w2[64];
+  const miphy_csi_rs_job* __restrict__ jp = jobs + blockIdx.x;
+  const int port = blockIdx.y, l = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+  if (port >= jp->nof_ports || !((jp->symbol_mask[port] >> l) & 1u))
+    return;
+  const unsigned start_rb = jp->start_rb, nof_rb = jp->nof_rb, dens = jp->freq_density, cdm = jp->cdm;
+  // sequence length of one symbol (:131-161) and the elements skipped below the first occupied PRB (:69-108)
+  unsigned seq_len = nof_rb, first_prb = start_rb, adv;
+  if (dens <= 1) {
+    seq_len /= 2;
+    if ((nof_rb & 1u) && (((start_rb & 1u) != 0) == (dens == 1)))
+      ++seq_len;
+    first_prb = dens == 0 ? start_rb + (start_rb & 1u) : start_rb + (1u - (start_rb & 1u));
+    adv       = jp->mapping_row == 2 ? first_prb / 2 : first_prb;
+  } else if (dens == 3) {
+    seq_len *= 3;
+    adv = 3 * first_prb;
+  } else {
+    adv = jp->mapping_row == 2 ? first_prb : 2 * first_prb;
+  }
+  if (cdm != 0)
+    seq_len *= 2;
+  const uint64_t t      = ((uint64_t)1024u * (14u * jp->slot_in_frame + (uint32_t)l + 1u) * (2ull * jp->scrambling_id + 1ull) + jp->scrambling_id) % (1ull << 31);
+  gold_long_block(*gt, (uint32_t)t, 2u * adv, ((2 * (int)seq_len + 31) >> 5) + 1, w1, w2, w1, tid, nt);
+  const float    amp   = (float)(0.70710678118654752440 * (double)jp->amplitude);
+  const unsigned gsize = cdm == 0 ? 1u : (cdm == 1 ? 2u : (cdm == 2 ? 4u : 8u));
+  const unsigned cidx  = (unsigned)port % gsize;                                  // index inside the CDM group
+  const unsigned lidx  = (unsigned)__popc(jp->symbol_mask[port] & ((1u << l) - 1u)); // l' = position of this symbol in the port's pattern
+  // w_f = {+1, (-1)^cidx}; w_t[l'] from the Hadamard rows of the tables (:34-57)
+  const float wf1 = (cidx & 1u) ? -1.0f : 1.0f;
+  float       wt  = 1.0f;
+  if (cdm >= 2) {
+    const unsigned row = cidx >> 1; // 0..1 (TD2) or 0..3 (TD4): rows {++++, +-+-, ++--, +--+}
+    const unsigned neg = row == 0 ? 0x0u : (row == 1 ? 0xau : (row == 2 ? 0xcu : 0x6u));
+    wt                 = ((neg >> lidx) & 1u) ? -1.0f : 1.0f;
+  }
+  const unsigned re_mask = jp->re_mask[port], n_re = (unsigned)__popc(re_mask);
+  const unsigned stride = jp->rb_stride ? jp->rb_stride : 1u, nsc = jp->grid_nof_prb * 12u;
+  float2*        g      = grid + jp->grid_offset + ((size_t)jp->ports[port] * 14 + l) * nsc;
+  // pattern PRBs inside [start_rb, start_rb + nof_rb), ascending; element k of the sequence goes to the k-th set RE
+  unsigned j0 = 0; // first pattern PRB index inside the window
+  if (start_rb > jp->rb_begin)
+    j0 = (start_rb - jp->rb_begin + stride - 1u) / stride;
+  for (unsigned k = tid; k < seq_len; k += nt) {
+    const unsigned j = k / n_re, r = k - j * n_re;
+    const unsigned rb = jp->rb_begin + (j0 + j) * stride;
+    if (rb >= jp->rb_end || rb >= start_rb + nof_rb)
+      continue;
+    unsigned m = re_mask; // r-th set bit
+    for (unsigned q = 0; q < r; ++q)
+      m &= m - 1u;
+    const unsigned sc = (unsigned)__ffs((int)m) - 1u;
+    float re = ((w1[(2 * k) >> 5] >> ((2 * k) & 31)) & 1u) ? -amp : amp;
+    float im = ((w1[(2 * k + 1) >> 5] >> ((2 * k + 1) & 31)) & 1u) ? -amp : amp;
+    if (cdm == 1) {
+      const float w = (k & 1u) ? wf1 : 1.0f; // table.w_f[k'] * seq
+      re = w * re, im = w * im;
+    } else if (cdm >= 2) {
+      const float w = wt * ((k & 1u) ? wf1 : 1.0f); // (w_t[l'] * w_f[k']) * seq
+      re = w * re, im = w * im;
+    }
+    g[rb * 12u + sc] = make_float2(re, im);
+  }
+}
+
 uint32_t host_nof_re(const miphy_pdsch_mod_job& j)
 {
   unsigned dm = 0;
@@ -555,6 +624,39 @@ extern "C" int miphy_ssb_process_batch(miphy_ctx* ctx, const miphy_ssb_pdu* pdus
   if ((rc = miphy_get_gold_tables(ctx, &gt)))
     return rc;
   hipLaunchKernelGGL(ssb_map_kernel, dim3(n), dim3(256), 0, s, (const miphy_ssb_pdu*)d_pdus, gt, static_cast<const uint8_t*>(work), (float2*)grid);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- NZP-CSI-RS generator
+extern "C" int miphy_csi_rs_map_batch(miphy_ctx* ctx, const miphy_csi_rs_job* jobs, int jobs_on_device, uint32_t n, float* grid, void* stream)
+{
+  MIPHY_REQUIRE(ctx && jobs && grid, "miphy_csi_rs_map_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  MIPHY_REQUIRE(n <= 65535, "csi_rs_map: at most 65535 jobs per call");
+  if (!jobs_on_device)
+    for (uint32_t i = 0; i < n; ++i) {
+      const miphy_csi_rs_job& j = jobs[i];
+      MIPHY_REQUIRE(j.nof_ports >= 1 && j.nof_ports <= 16, "csi_rs_map: job %u: invalid number of ports %u", i, (unsigned)j.nof_ports);
+      MIPHY_REQUIRE(j.cdm <= 3 && j.freq_density <= 3, "csi_rs_map: job %u: invalid CDM type or density", i);
+      MIPHY_REQUIRE(j.grid_nof_prb >= 1 && j.grid_nof_prb <= 275 && (unsigned)j.start_rb + j.nof_rb <= j.grid_nof_prb && j.rb_end <= j.grid_nof_prb && j.nof_rb >= 1,
+                    "csi_rs_map: job %u: the PRB range exceeds the grid", i);
+      MIPHY_REQUIRE(j.rb_stride >= 1 && j.rb_begin <= j.rb_end, "csi_rs_map: job %u: invalid PRB pattern", i);
+      const unsigned per_symbol = (j.freq_density == 3 ? 3u : 1u) * (j.cdm ? 2u : 1u) * j.nof_rb;
+      MIPHY_REQUIRE(per_symbol <= 1000, "csi_rs_map: job %u: sequence too long", i);
+      for (unsigned p = 0; p < j.nof_ports; ++p)
+        MIPHY_REQUIRE(j.re_mask[p] != 0 && j.re_mask[p] < (1u << 12) && j.symbol_mask[p] != 0 && j.symbol_mask[p] < (1u << 14), "csi_rs_map: job %u: port %u: invalid pattern", i, p);
+    }
+  hipStream_t s      = (hipStream_t)stream;
+  const void* d_jobs = nullptr;
+  int         rc     = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_csi_rs_job) * (size_t)n, s, &d_jobs);
+  if (rc)
+    return rc;
+  const gold_tables* gt = nullptr;
+  if ((rc = miphy_get_gold_tables(ctx, &gt)))
+    return rc;
+  hipLaunchKernelGGL(csi_rs_kernel, dim3(n, 16, 14), dim3(256), 0, s, (const miphy_csi_rs_job*)d_jobs, gt, (float2*)grid);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

@@ -69,6 +69,7 @@ def lib():
         l.miphy_ofh_iq_compress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         l.miphy_pdcch_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_ssb_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        l.miphy_csi_rs_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         l.miphy_harq_pool_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         l.miphy_harq_pool_destroy.argtypes = [C.c_void_p]
         l.miphy_harq_pool_destroy.restype = None
@@ -182,6 +183,13 @@ def pdsch_pdu_nof_re(pdu):
     a = np.ascontiguousarray(np.asarray(pdu, dtype=PdschPdu).reshape(1))
     return int(lib().miphy_pdsch_pdu_nof_re(a.ctypes.data_as(C.c_void_p)))
 
+
+# Mirrors miphy_csi_rs_job.
+CsiRsJob = np.dtype([("slot_in_frame", np.uint32), ("scrambling_id", np.uint32), ("amplitude", np.float32), ("start_rb", np.uint16), ("nof_rb", np.uint16),
+                     ("rb_begin", np.uint16), ("rb_end", np.uint16), ("rb_stride", np.uint16), ("grid_nof_prb", np.uint16), ("mapping_row", np.uint8),
+                     ("cdm", np.uint8), ("freq_density", np.uint8), ("nof_ports", np.uint8), ("ports", np.uint8, 16), ("re_mask", np.uint16, 16),
+                     ("symbol_mask", np.uint16, 16), ("grid_offset", np.uint64)], align=True)
+assert CsiRsJob.itemsize == 120 and CsiRsJob.fields["grid_offset"][1] == 112, CsiRsJob.itemsize
 
 # Mirrors miphy_pdcch_pdu.
 PdcchPdu = np.dtype([("slot_in_frame", np.uint32), ("rnti", np.uint32), ("n_id_pdcch_data", np.uint32), ("n_rnti", np.uint32), ("n_id_pdcch_dmrs", np.uint32),
@@ -368,6 +376,10 @@ class Context:
         assert isinstance(pdus, np.ndarray) and pdus.dtype == PdschPdu
         pdus = np.ascontiguousarray(pdus)
         check(lib().miphy_pdsch_process_batch(self.h, C.c_void_p(pdus.ctypes.data), pdus.size, _dptr(tb_in), _dptr(grid), _stream_ptr(stream)))
+
+    def csi_rs_map_batch(self, jobs, grid, stream=None):
+        jobs, n, ptr, on_dev = self._descs(jobs, CsiRsJob)
+        check(lib().miphy_csi_rs_map_batch(self.h, ptr, on_dev, n, _dptr(grid), _stream_ptr(stream)))
 
     def ssb_process_batch(self, pdus, grid, stream=None):
         """ssb_processor::process (after the position look-up) for a batch of SS/PBCH blocks (host descriptors)."""

@@ -761,3 +761,45 @@ def ssb_cases(rng, n):
         out.append((mu, int(rng.integers(0, 1024)), hrf * slots_per_hrf + slot_hrf, int(rng.integers(0, 1008)), float(rng.choice([0.0, 3.0, -3.0])), ssb_idx, L_max,
                     15 if mu == 0 else 30, int(rng.integers(0, 12 if mu == 0 else 24)) & ~(0 if mu == 0 else 1), int(rng.integers(0, 40)) * (1 if mu == 0 else 2), case))
     return out
+
+
+# ---------------------------------------------------------------------- NZP-CSI-RS generator
+# (row, nof_ports, nof k_ref, cdm, allowed densities [0 even, 1 odd, 2 one, 3 three], k alignment, uses l1)
+CSI_RS_ROWS = [(1, 1, 1, 0, [3], 1, 0), (2, 1, 1, 0, [0, 1, 2], 1, 0), (3, 2, 1, 1, [0, 1, 2], 2, 0), (4, 4, 1, 1, [2], 4, 0), (5, 4, 1, 1, [2], 2, 0),
+               (6, 8, 4, 1, [2], 2, 0), (7, 8, 2, 1, [2], 2, 0), (8, 8, 2, 2, [2], 2, 0)]
+
+
+def csi_rs_cases(rng, n):
+    out = []
+    for i in range(n):
+        row, nports, nk, cdm, dens, align, _ = CSI_RS_ROWS[i % len(CSI_RS_ROWS)]
+        if row == 1:
+            k = [int(rng.integers(0, 4))]
+        elif row == 4:
+            k = [int(rng.choice([0, 4, 8]))]
+        else:
+            k = sorted(int(x) for x in rng.choice(np.arange(0, 11, 2), nk, replace=False))
+        start_rb, nof_rb = int(rng.integers(0, 20)), int(rng.integers(4, 60))
+        out.append((row, nports, k, cdm, int(rng.choice(dens)), start_rb, nof_rb, int(rng.integers(0, 12)), int(rng.integers(0, 20)), int(rng.integers(0, 1024)),
+                    float(rng.choice([1.0, 0.5, 1.4125]))))
+    return out
+
+
+def r_csi_rs_map(numerology, slot_index, start_rb, nof_rb, row, k_ref, l0, l1, cdm, density, scr_id, amplitude, nof_ports, nprb_grid):
+    kr = (C.c_uint * len(k_ref))(*k_ref)
+    grid = np.zeros((nof_ports, 14, nprb_grid * 12), dtype=np.complex64)
+    bes = (C.c_uint * 3)()
+    rm, sm = np.zeros(16, np.uint16), np.zeros(16, np.uint16)
+    assert ref().ref_csi_rs_map(C.c_uint(numerology), C.c_uint(slot_index), C.c_uint(start_rb), C.c_uint(nof_rb), C.c_uint(row), kr, C.c_uint(len(k_ref)), C.c_uint(l0),
+                                C.c_uint(l1), C.c_uint(cdm), C.c_uint(density), C.c_uint(scr_id), C.c_float(amplitude), C.c_uint(nof_ports), C.c_uint(nprb_grid),
+                                _p(grid), bes, _p(rm), _p(sm)) == 0
+    return grid, (bes[0], bes[1], bes[2]), rm, sm
+
+
+def o_csi_rs_map(slot, scr_id, amplitude, start_rb, nof_rb, bes, row, cdm, density, ports, re_mask, symbol_mask, nprb_grid, grid):
+    pt = np.ascontiguousarray(ports, dtype=np.uint8)
+    rm, sm = np.ascontiguousarray(re_mask, dtype=np.uint16), np.ascontiguousarray(symbol_mask, dtype=np.uint16)
+    assert grid.dtype == np.complex64 and grid.flags.c_contiguous
+    return oracle().orc_csi_rs_map(C.c_uint(slot), C.c_uint(scr_id), C.c_float(amplitude), C.c_uint(start_rb), C.c_uint(nof_rb), C.c_uint(bes[0]), C.c_uint(bes[1]),
+                                   C.c_uint(bes[2]), C.c_uint(row), C.c_uint(cdm), C.c_uint(density), C.c_uint(pt.size), _p(pt), _p(rm), _p(sm), C.c_uint(nprb_grid),
+                                   _p(grid))

@@ -79,7 +79,7 @@ int main(void) {
          sizeof(miphy_sch_segmentation), sizeof(miphy_pusch_demod_job), sizeof(miphy_re_pattern), sizeof(miphy_pdsch_mod_job), sizeof(miphy_dmrs_pdsch_job));
   printf("%zu %zu %zu %zu\n", sizeof(miphy_pusch_pdu), sizeof(miphy_pdsch_pdu), sizeof(miphy_harq_pool_config), sizeof(miphy_harq_buffer_info));
   printf("%zu %zu\n", sizeof(miphy_ofh_iq_job), sizeof(miphy_pdcch_pdu));
-  printf("%zu\n", sizeof(miphy_ssb_pdu));
+  printf("%zu %zu\n", sizeof(miphy_ssb_pdu), sizeof(miphy_csi_rs_job));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -93,7 +93,7 @@ int main(void) {
             miphy.PuschTbDesc.itemsize, miphy.PuschResult.itemsize, miphy.PdschTbDesc.itemsize, ctypes.sizeof(miphy.binding.SchSegmentation),
             miphy.PuschDemodJob.itemsize, miphy.RePattern.itemsize, miphy.PdschModJob.itemsize, miphy.DmrsPdschJob.itemsize,
             miphy.PuschPdu.itemsize, miphy.PdschPdu.itemsize, ctypes.sizeof(miphy.HarqPoolConfig), ctypes.sizeof(miphy.HarqBufferInfo),
-            miphy.OfhIqJob.itemsize, miphy.PdcchPdu.itemsize, miphy.SsbPdu.itemsize]
+            miphy.OfhIqJob.itemsize, miphy.PdcchPdu.itemsize, miphy.SsbPdu.itemsize, miphy.CsiRsJob.itemsize]
     assert sizes == mine, (sizes, mine)
 
 

@@ -235,3 +235,17 @@ def test_ssb_processor():
         out = np.zeros_like(g["grid_%d" % i])
         assert O.o_ssb_process(int(N_id), int(ssb_idx), int(L_max), int(hrf), int(sfn), int(kssb), g["pay_%d" % i], int(k0), int(l0), float(beta), 106, out) == 0
         assert np.array_equal(out.view(np.uint32), g["grid_%d" % i].view(np.uint32)), i
+
+
+def test_nzp_csi_rs_generator():
+    """NZP-CSI-RS: oracle against grids recorded from the reference generator (mapping rows 1-8, every density and CDM type it supports)."""
+    g = np.load(os.path.join(GOLD, "csi_rs.npz"))
+    rows = set()
+    for i in range(int(g["n"])):
+        slot, scr, amp, start_rb, nof_rb, b, e, st, row, cdm, dens, nports = g["meta_%d" % i]
+        out = np.zeros_like(g["grid_%d" % i])
+        assert O.o_csi_rs_map(int(slot), int(scr), float(amp), int(start_rb), int(nof_rb), (int(b), int(e), int(st)), int(row), int(cdm), int(dens),
+                              list(range(int(nports))), g["rm_%d" % i], g["sm_%d" % i], 80, out) == 0
+        assert np.array_equal(out.view(np.uint32), g["grid_%d" % i].view(np.uint32)), i
+        rows.add(int(row))
+    assert rows == {1, 2, 3, 4, 5, 6, 7, 8}

@@ -294,3 +294,13 @@ def test_ssb_processor():
         assert np.array_equal(out.view(np.uint32), g.view(np.uint32)), (case, N_id, ssb_idx, L_max)
         n += 1
     assert n == 80
+
+
+def test_nzp_csi_rs_generator():
+    rng = np.random.default_rng(93)
+    for (row, nports, k, cdm, dens, start_rb, nof_rb, l0, slot, scr, amp) in O.csi_rs_cases(rng, 96):
+        l0 = min(l0, 12)
+        g, bes, rm, sm = O.r_csi_rs_map(1, slot, start_rb, nof_rb, row, k, l0, 0, cdm, dens, scr, amp, nports, 80)
+        out = np.zeros_like(g)
+        assert O.o_csi_rs_map(slot, scr, amp, start_rb, nof_rb, bes, row, cdm, dens, list(range(nports)), rm, sm, 80, out) == 0
+        assert np.array_equal(out.view(np.uint32), g.view(np.uint32)), (row, dens, start_rb, nof_rb)
