@@ -1265,6 +1265,54 @@ static void test_ssb_processor(std::shared_ptr<miphy::context> c)
   printf("ssb_processor done, failures so far %d\n", failures);
 }
 
+// nzp_csi_rs_generator: reference vs nzp_csi_rs_generator_hip; identical grids on every port, for the mapping rows the upper PHY uses.
+static void test_csi_rs(std::shared_ptr<miphy::context> c)
+{
+  auto g_ref = create_nzp_csi_rs_generator_factory_sw(create_pseudo_random_generator_sw_factory())->create();
+  auto g_hip = std::make_shared<miphy::nzp_csi_rs_generator_factory_hip>(c)->create();
+  struct tc {
+    unsigned                 row, nports, start_rb, nof_rb, l0;
+    std::vector<unsigned>    k;
+    csi_rs_cdm_type          cdm;
+    csi_rs_freq_density_type dens;
+    float                    amp;
+  };
+  for (const tc& t : {tc{1, 1, 0, 52, 4, {1}, csi_rs_cdm_type::no_CDM, csi_rs_freq_density_type::three, 1.0F},
+                      tc{2, 1, 3, 49, 8, {6}, csi_rs_cdm_type::no_CDM, csi_rs_freq_density_type::dot5_odd_RB, 0.5F},
+                      tc{3, 2, 10, 40, 5, {4}, csi_rs_cdm_type::fd_CDM2, csi_rs_freq_density_type::one, 1.4125F},
+                      tc{4, 4, 0, 24, 13, {8}, csi_rs_cdm_type::fd_CDM2, csi_rs_freq_density_type::one, 1.0F},
+                      tc{5, 4, 7, 33, 6, {2}, csi_rs_cdm_type::fd_CDM2, csi_rs_freq_density_type::one, 1.0F},
+                      tc{8, 8, 1, 50, 9, {0, 6}, csi_rs_cdm_type::cdm4_FD2_TD2, csi_rs_freq_density_type::one, 0.7F}}) {
+    nzp_csi_rs_generator::config_t cfg;
+    cfg.slot = slot_point(1, 13), cfg.cp = cyclic_prefix::NORMAL, cfg.start_rb = t.start_rb, cfg.nof_rb = t.nof_rb, cfg.csi_rs_mapping_table_row = t.row;
+    for (unsigned k : t.k) {
+      cfg.freq_allocation_ref_idx.push_back(k);
+    }
+    cfg.symbol_l0 = t.l0, cfg.symbol_l1 = 0, cfg.cdm = t.cdm, cfg.freq_density = t.dens, cfg.scrambling_id = 777, cfg.amplitude = t.amp, cfg.pmi = 0;
+    for (unsigned p = 0; p != t.nports; ++p) {
+      cfg.ports.push_back(t.nports - 1 - p); // a permutation of the grid ports
+    }
+    const unsigned nsc = 80 * 12;
+    auto           g1 = create_resource_grid(t.nports, 14, nsc), g2 = create_resource_grid(t.nports, 14, nsc);
+    g1->set_all_zero();
+    g2->set_all_zero();
+    g_ref->map(*g1, cfg);
+    g_hip->map(*g2, cfg);
+    std::vector<cf_t> a(nsc), b(nsc);
+    unsigned          bad = 0, written = 0;
+    for (unsigned p = 0; p != t.nports; ++p) {
+      for (unsigned l = 0; l != 14; ++l) {
+        g1->get(a, p, l, 0);
+        g2->get(b, p, l, 0);
+        bad += std::memcmp(a.data(), b.data(), nsc * sizeof(cf_t)) != 0;
+        written += std::any_of(a.begin(), a.end(), [](cf_t v) { return v != cf_t(0, 0); });
+      }
+    }
+    CHECK(bad == 0 && written >= t.nports, "nzp_csi_rs_generator: row %u: %u (port, symbol) rows differ, %u written", t.row, bad, written);
+  }
+  printf("nzp_csi_rs_generator done, failures so far %d\n", failures);
+}
+
 static void test_pdcch(std::shared_ptr<miphy::context> c)
 {
   auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
@@ -1445,6 +1493,7 @@ int main()
   test_pdcch(c);
   test_pdcch_processor(c);
   test_ssb_processor(c);
+  test_csi_rs(c);
   test_pusch_demodulator(c);
   test_pusch_processor(c);
   test_uplink_processor(c);

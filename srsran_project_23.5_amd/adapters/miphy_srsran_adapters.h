@@ -26,6 +26,7 @@
 #include "srsran/phy/upper/downlink_processor.h"
 #include "srsran/phy/upper/resource_grid_mapper.h"
 #include "srsran/phy/upper/upper_phy_rg_gateway.h"
+#include "srsran/ran/csi_rs/csi_rs_pattern.h"
 #include "srsran/ran/pdcch/cce_to_prb_mapping.h"
 #include "srsran/ran/ssb_mapping.h"
 #include "srsran/ran/precoding/precoding_codebooks.h"
@@ -34,6 +35,7 @@
 #include "srsran/phy/upper/unique_rx_softbuffer.h"
 #include "srsran/phy/upper/uplink_processor.h"
 #include "srsran/phy/upper/upper_phy_rx_results_notifier.h"
+#include "srsran/phy/upper/signal_processors/nzp_csi_rs_generator.h"
 #include "srsran/phy/upper/signal_processors/signal_processor_factories.h"
 #include "srsran/support/error_handling.h"
 #include <algorithm>
@@ -1649,6 +1651,66 @@ public:
   explicit ssb_processor_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
   std::unique_ptr<srsran::ssb_processor>     create() override { return std::make_unique<ssb_processor_hip>(c); }
   std::unique_ptr<srsran::ssb_pdu_validator> create_validator() override { return nullptr; }
+
+private:
+  std::shared_ptr<context> c;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- NZP-CSI-RS generator
+/// srsran::nzp_csi_rs_generator over miphy_csi_rs_map_batch (nzp_csi_rs_generator.h:91): the per-port patterns are the reference's own
+/// get_csi_rs_pattern() (TS 38.211 Table 7.4.1.5.3-1 bookkeeping), sequence generation, CDM weights and RE mapping run on the device.
+class nzp_csi_rs_generator_hip : public srsran::nzp_csi_rs_generator
+{
+public:
+  explicit nzp_csi_rs_generator_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void map(srsran::resource_grid_writer& grid, const config_t& config) override
+  {
+    const unsigned nof_ports = config.ports.size();
+    srsran_assert(config.pmi == 0, "Precoding is not currently supported");
+    srsran_assert(nof_ports >= 1 && nof_ports <= 16, "Invalid number of ports.");
+    srsran::csi_rs_pattern_configuration pc;
+    pc.start_rb = config.start_rb, pc.nof_rb = config.nof_rb, pc.csi_rs_mapping_table_row = config.csi_rs_mapping_table_row;
+    pc.freq_allocation_ref_idx = config.freq_allocation_ref_idx, pc.symbol_l0 = config.symbol_l0, pc.symbol_l1 = config.symbol_l1;
+    pc.cdm = config.cdm, pc.freq_density = config.freq_density, pc.nof_ports = nof_ports;
+    const srsran::csi_rs_pattern pat = srsran::get_csi_rs_pattern(pc);
+    const unsigned               nprb = config.start_rb + config.nof_rb, nsc = nprb * 12;
+    miphy_csi_rs_job             j    = {};
+    j.slot_in_frame = config.slot.slot_index(), j.scrambling_id = config.scrambling_id, j.amplitude = config.amplitude;
+    j.start_rb = config.start_rb, j.nof_rb = config.nof_rb, j.rb_begin = pat.rb_begin, j.rb_end = std::min<unsigned>(pat.rb_end, nprb), j.rb_stride = pat.rb_stride;
+    j.grid_nof_prb = nprb, j.mapping_row = config.csi_rs_mapping_table_row, j.cdm = static_cast<uint8_t>(config.cdm);
+    j.freq_density = static_cast<uint8_t>(config.freq_density), j.nof_ports = nof_ports;
+    for (unsigned p = 0; p != nof_ports; ++p) {
+      j.ports[p] = p; // staging grid indexed by CSI-RS port
+      for (unsigned k = 0; k != 12; ++k) {
+        j.re_mask[p] |= static_cast<uint16_t>(pat.prb_patterns[p].re_mask.test(k) ? (1U << k) : 0U);
+      }
+      for (unsigned l = 0; l != 14; ++l) {
+        j.symbol_mask[p] |= static_cast<uint16_t>(pat.prb_patterns[p].symbol_mask.test(l) ? (1U << l) : 0U);
+      }
+    }
+    host.assign(static_cast<size_t>(nof_ports) * 14 * nsc, srsran::cf_t(NAN, NAN)); // NaN marks "not written by the kernel"
+    auto* d_g = static_cast<float*>(c->buf(0, host.size() * sizeof(srsran::cf_t)));
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    context::check(miphy_csi_rs_map_batch(c->ctx, &j, 0, 1, d_g, c->stream), "csi_rs_map");
+    c->d2h(host.data(), d_g, host.size() * sizeof(srsran::cf_t));
+    c->sync();
+    for (unsigned p = 0; p != nof_ports; ++p) {
+      put_written_res(grid, config.ports[p], nsc, host.data() + static_cast<size_t>(p) * 14 * nsc);
+    }
+  }
+
+private:
+  std::shared_ptr<context>  c;
+  std::vector<srsran::cf_t> host;
+};
+
+/// Replaces create_nzp_csi_rs_generator_factory_sw(prg) (signal_processor_factories.h:81-82).
+class nzp_csi_rs_generator_factory_hip : public srsran::nzp_csi_rs_generator_factory
+{
+public:
+  explicit nzp_csi_rs_generator_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  std::unique_ptr<srsran::nzp_csi_rs_generator>               create() override { return std::make_unique<nzp_csi_rs_generator_hip>(c); }
+  std::unique_ptr<srsran::nzp_csi_rs_configuration_validator> create_validator() override { return nullptr; }
 
 private:
   std::shared_ptr<context> c;
