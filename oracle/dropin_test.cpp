@@ -992,7 +992,18 @@ static void test_downlink_processor(std::shared_ptr<miphy::context> c)
                                                  create_dmrs_pdsch_processor_factory_sw(prg))
                    ->create();
   gateway_spy                   gw;
-  miphy::downlink_processor_hip dl(c, gw, nullptr, nullptr, nullptr, nof_ports, grid_rb);
+  auto                          dl_owner = miphy::create_downlink_processor_hip(c, gw, nof_ports, grid_rb); // PDCCH / SSB / CSI-RS on the device too
+  srsran::downlink_processor&   dl       = *dl_owner;
+  auto prg2      = create_pseudo_random_generator_sw_factory();
+  auto pdcch_ref = create_pdcch_processor_factory_sw(create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw()),
+                                                     create_pdcch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg2), create_dmrs_pdcch_processor_factory_sw(prg2))
+                       ->create();
+  ssb_processor_factory_sw_configuration scfg;
+  scfg.encoder_factory   = create_pbch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), prg2, create_polar_factory_sw());
+  scfg.modulator_factory = create_pbch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg2);
+  scfg.dmrs_factory = create_dmrs_pbch_processor_factory_sw(prg2), scfg.pss_factory = create_pss_processor_factory_sw(), scfg.sss_factory = create_sss_processor_factory_sw();
+  auto ssb_ref = create_ssb_processor_factory_sw(scfg)->create();
+  auto csi_ref = create_nzp_csi_rs_generator_factory_sw(prg2)->create();
   struct ue {
     unsigned          rnti, port, rb_start, nprb, tbs, rv;
     modulation_scheme mod;
@@ -1048,6 +1059,32 @@ static void test_downlink_processor(std::shared_ptr<miphy::context> c)
       data.emplace_back(tbs.back());
       p_ref->process(*g1, data, pdu);
       dl.process_pdsch(data, pdu);
+    }
+    if (round == 1) { // the other PDU types of a slot, on REs the PDSCH allocations above leave free (symbol 0 and PRBs 56..59 of port 1)
+      pdcch_processor::pdu_t pc;
+      pc.slot = ctx.slot, pc.cp = cyclic_prefix::NORMAL;
+      pc.coreset.bwp_size_rb = grid_rb, pc.coreset.bwp_start_rb = 0, pc.coreset.start_symbol_index = 0, pc.coreset.duration = 1;
+      pc.coreset.frequency_resources = freq_resource_bitmap(8);
+      pc.coreset.frequency_resources.fill(0, 8, true);
+      pc.coreset.cce_to_reg_mapping = pdcch_processor::cce_to_reg_mapping_type::NON_INTERLEAVED, pc.coreset.reg_bundle_size = 6, pc.coreset.interleaver_size = 2;
+      pc.coreset.shift_index = 0;
+      pc.dci.rnti = 0x4601, pc.dci.n_id_pdcch_dmrs = 10, pc.dci.n_id_pdcch_data = 11, pc.dci.n_rnti = 0x4601, pc.dci.cce_index = 4, pc.dci.aggregation_level = 4;
+      pc.dci.dmrs_power_offset_dB = 0.0F, pc.dci.data_power_offset_dB = 0.0F;
+      for (unsigned i = 0; i != 45; ++i) {
+        pc.dci.payload.push_back(static_cast<uint8_t>(byte(rgen) & 1));
+      }
+      pc.dci.precoding = make_single_port();
+      resource_grid_mapper m1(*g1);
+      pdcch_ref->process(m1, pc);
+      dl.process_pdcch(pc);
+      nzp_csi_rs_generator::config_t cc;
+      cc.slot = ctx.slot, cc.cp = cyclic_prefix::NORMAL, cc.start_rb = 56, cc.nof_rb = 4, cc.csi_rs_mapping_table_row = 2;
+      cc.freq_allocation_ref_idx.push_back(5);
+      cc.symbol_l0 = 0, cc.symbol_l1 = 0, cc.cdm = csi_rs_cdm_type::no_CDM, cc.freq_density = csi_rs_freq_density_type::one, cc.scrambling_id = 99, cc.amplitude = 1.0F;
+      cc.pmi = 0;
+      cc.ports.push_back(1);
+      csi_ref->map(*g1, cc);
+      dl.process_nzp_csi_rs(cc);
     }
     CHECK(gw.count == round, "downlink_processor: grid sent before finish_processing_pdus()");
     dl.finish_processing_pdus();

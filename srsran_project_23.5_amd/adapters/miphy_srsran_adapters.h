@@ -1860,6 +1860,15 @@ private:
   std::vector<srsran::cf_t>                     host;
 };
 
+/// A downlink processor whose four PDU types all run on the device: PDSCH batched per slot, PDCCH / SSB / CSI-RS through the
+/// device processors above (replaces the pool entry downlink_processor_single_executor_factory::create builds, upper_phy_factories.cpp:269-300).
+inline std::unique_ptr<srsran::downlink_processor>
+create_downlink_processor_hip(std::shared_ptr<context> c, srsran::upper_phy_rg_gateway& gateway, unsigned grid_nof_ports, unsigned grid_nof_prb)
+{
+  return std::make_unique<downlink_processor_hip>(c, gateway, std::make_unique<pdcch_processor_hip>(c), std::make_unique<ssb_processor_hip>(c),
+                                                  std::make_unique<nzp_csi_rs_generator_hip>(c), grid_nof_ports, grid_nof_prb);
+}
+
 // ---------------------------------------------------------------------------------------------------------------- Open Fronthaul IQ compression
 /// srsran::ofh::iq_decompressor / iq_compressor for compression_type::BFP and compression_type::none over miphy_ofh_iq_*_batch
 /// (iq_decompressor.h:49-50, iq_compressor.h:49-50): what iq_{de}compressor_selector dispatches to for the two methods the reference
