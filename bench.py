@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: PUSCH receive hot path on synthetic 100 MHz n78 slots (273 PRB, 30 kHz SCS).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over a batch of S synthetic uplink slots per GPU: time-domain samples in, transport-block
-bits out (OFDM demodulation -> DM-RS channel estimation -> equalise / soft-demap / descramble -> rate dematch -> LDPC decode).
-The workload is BASELINE.json configs[2]: 273-PRB PUSCH, 256QAM R=948/1024, 1 layer, 38 codeblocks (BG1, Z=384) per slot,
-TBS = 319 784 information bits per slot.  The slots are synthesised once, outside the timed region, by the transmit side of the
-same library on the device (SCH encoder, PDSCH-style modulator, DM-RS mapper, OFDM modulator) plus AWGN, and are resident in HBM
-before timing starts.
+N > 1 without a launcher: this script starts `python -m torch.distributed.run --nproc-per-node N` on itself as a CHILD process
+before anything touches the GPU, one rank per GPU over RCCL (when the machine has fewer than N GPUs every rank shares cuda:0 over
+gloo and the line says `"rehearsal_shared_gpu": true`). Under a launcher (WORLD_SIZE set) it is one rank of that job.
 
-`value` = LDPC information bits / s over the whole step (all ranks).  Extra keys: `slots_per_s` (whole pipeline),
-per-kernel HIP-event times, `roofline` of the dominant kernel and `cpu_baseline` (reference AVX2 path from oracle/_ref
-when it loads, else the scalar oracle port), as the task contract asks.
+One "step" = one pass of the hot path over a batch of S synthetic uplink slots per GPU: time-domain samples in, transport blocks
+out (OFDM demodulation -> DM-RS channel estimation -> equalise / soft-demap / descramble -> rate dematch -> LDPC decode ->
+transport-block assembly + TB CRC). The workload is BASELINE.json configs[2]: 273-PRB PUSCH, 256QAM R=948/1024, 1 layer, 38
+codeblocks (BG1, Z=384) per slot, TBS = 319 784 information bits per slot. The slots are synthesised once, outside the timed
+region, by the transmit side of the same library on the device (SCH encoder, modulator, DM-RS mapper, OFDM modulator) plus AWGN,
+and are resident in HBM before timing starts.
+
+`value` = LDPC information bits / s over the whole step (all ranks). Extra keys: per-kernel HIP-event times and
+algorithmic GB/s, `roofline` of the dominant kernel, `roofline_valu` (the decoder is a VALU kernel), `cpu_baseline` (the
+reference's own receive chain on all host cores; `cpu_baseline_t1`, `cpu_baseline_decoder_only`), `pcie_inclusive`, the other
+codeblock configurations (`legs`: 16QAM R=658, BG1 Z=384 R=1/3, polar AL 1-16) and, with N > 1, `ingest_scatter` (one ingest
+GPU scatters LLR slabs over RCCL, every rank decodes, results gathered).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
@@ -27,7 +35,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "srsran_project_23.5_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+NOF_SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md constants table)
+PROFILE_ROUND = "r02"
+
+RNTI, N_ID, DMRS_SCR_ID = 0x4601, 935, 1
+DMRS_SCALING = 1.4125375  # DM-RS boosted by 3 dB with two CDM groups without data (sch_dmrs_power.h)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--slots", type=int, default=1024, help="slots per GPU per step (1024 slots = 38 912 codeblocks)")
+    ap.add_argument("--max-iter", type=int, default=6)
+    ap.add_argument("--early-stop", type=int, default=0)
+    ap.add_argument("--snr-db", type=float, default=33.0, help="per-RE SNR of the synthesised slots")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="duration of each CPU baseline leg")
+    ap.add_argument("--chunks", type=int, default=1, help="slot groups per step, alternated over two HIP streams (1 = one stream)")
+    ap.add_argument("--chunk-streams", type=int, default=2, help="1: the slot groups run back to back on one stream")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-slot latency leg (keeps profiles to the timed step only)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (other MCS / rates, polar, PCIe-inclusive)")
+    ap.add_argument("--ingest", choices=["local", "scatter"], default=None,
+                    help="scatter: add the single-ingest leg (default with N > 1); local: never")
+    ap.add_argument("--ingest-slots", type=int, default=128, help="slots per rank in the scatter leg")
+    return ap.parse_args()
 
 
 def pusch_workload():
@@ -35,8 +69,38 @@ def pusch_workload():
     return dict(nprb=273, mod=8, nof_layers=1, nsym=273 * 156, tbs=319784, bg=1, rv=0, Nref=0)
 
 
-RNTI, N_ID, DMRS_SCR_ID = 0x4601, 935, 1
-DMRS_SCALING = 1.4125375  # DM-RS boosted by 3 dB with two CDM groups without data (sch_dmrs_power.h)
+def kernel_source_sha():
+    """Hash of the kernel sources: profiles collected on another build must not be quoted."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "srsran_project_23.5_amd", "csrc")
+    for dirpath, _, files in sorted(os.walk(d)):
+        for f in sorted(files):
+            if f.endswith((".hip", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(dirpath, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_children(args):
+    """--gpus N > 1 and no launcher: start the N ranks as a child job (never an exec of this process; nothing here has
+    touched the GPU: torch.cuda.device_count() does not initialise it on this image)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ndev < args.gpus:
+        if args.gpus > 4:
+            print("bench.py: --gpus %d needs %d GPUs (found %d); the shared-GPU rehearsal is limited to 4 ranks" % (args.gpus, args.gpus, ndev),
+                  file=sys.stderr)
+            return 2
+        env["MIPHY_BENCH_REHEARSAL"] = "1"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def build_tx_grids(ctx, miphy, torch, dev, w, n_unique, seed):
@@ -74,74 +138,180 @@ def build_tx_grids(ctx, miphy, torch, dev, w, n_unique, seed):
     return grids, tbs
 
 
-def cpu_baseline(w, llrs, max_iter, early_stop, budget_s):
-    """Times the reference's own pusch_decoder (AVX2 rate dematcher + AVX2 LDPC decoder) on the host cores, or the
-    scalar oracle port when oracle/_ref is unavailable.  Bounded sample; T threads, one decoder instance each."""
+def ev_ms(torch, f, reps, stream=None):
+    """Mean HIP-event time of f() over `reps` back-to-back calls (two untimed calls first)."""
+    st = stream or torch.cuda.current_stream()
+    for _ in range(2):
+        f()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(st)
+    for _ in range(reps):
+        f()
+    b.record(st)
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline legs
+def cpu_legs(w, samples4, llr4, ocfg_args, max_iter, early_stop, seconds):
+    """The reference's receive chain on the host cores (oracle/_ref, the reference compiled in place), driven like its
+    pusch_processor_benchmark (pinned threads, one processor instance per thread): full chain on all cores = `cpu_baseline`, on one
+    core = `cpu_baseline_t1`; pusch_decoder alone (rate dematcher + LDPC decoder, what round 1 reported) on 1 / all cores.
+    Falls back to the scalar oracle port (one thread, decoder only) when oracle/_ref is absent."""
     import oracle_lib as O
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    kind = "reference" if O.ref_available() else "port"
+    cpus, quota = O.host_cpus()
+    t_all = len(cpus) if quota is None else max(1, min(len(cpus), int(round(quota))))
+    model = "unknown"
     try:
-        if kind == "reference":
-            O.ref()
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    out = {}
+    host = dict(cpu_model=model, cpus_in_affinity_mask=len(cpus), cgroup_cpu_quota=quota)
+    kind = "reference"
+    try:
+        if not O.ref_available():
+            raise OSError("no oracle/_ref")
+        O.ref()
     except OSError:
         kind = "port"
-    T = max(1, min(ncores, 16))
-    done = [0] * T
-    stop_at = time.time() + budget_s
-    G = llrs.shape[1]
-
-    def worker(t):
-        if kind == "reference":
-            dec = O.RefPuschDecoder("avx2")
-        k = 0
-        while time.time() < stop_at:
-            slot = llrs[(t + k) % llrs.shape[0]]
-            if kind == "reference":
-                dec.decode_sequence(w["bg"], w["mod"], w["Nref"], w["nof_layers"], w["nsym"], w["tbs"] // 8, [0],
-                                    slot[None, :], max_iter, early_stop)
-            else:
-                od = O.OraclePuschDecoder(w["bg"], w["mod"], w["Nref"], w["nof_layers"], w["nsym"], w["tbs"] // 8)
-                od.decode(slot, 0, True, max_iter, early_stop)
-            k += 1
-        done[t] = k
-
     if kind == "port":
-        T = 1
-    t0 = time.time()
-    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
-    [x.start() for x in th]
-    [x.join() for x in th]
-    dt = time.time() - t0
-    slots = sum(done)
-    return dict(value=slots * w["tbs"] / dt, unit="info_bits/s", cores=T, kind=kind,
-                sample="%d slots (38 CBs each, same LLRs as the GPU run) in %.1f s, %s" %
-                       (slots, dt, "srsRAN pusch_decoder avx2" if kind == "reference" else "scalar C oracle"),
-                host_cores_available=ncores)
+        od = O.OraclePuschDecoder(w["bg"], w["mod"], w["Nref"], w["nof_layers"], w["nsym"], w["tbs"] // 8)
+        t0, k = time.time(), 0
+        while time.time() - t0 < seconds:
+            od.decode(llr4[k % llr4.shape[0]], 0, True, max_iter, early_stop)
+            k += 1
+        dt = time.time() - t0
+        out["cpu_baseline"] = dict(value=k * w["tbs"] / dt, unit="info_bits/s", cores=1, kind="port",
+                                   sample="%d slots in %.1f s, scalar C oracle, rate dematch + LDPC decode only" % (k, dt), **host)
+        return out
+
+    def chain(T, stage):
+        dt, done, ok = O.r_pusch_chain_bench(T, cpus, seconds, stage, samples4, w["nprb"], w["mod"], w["tbs"], RNTI, N_ID, DMRS_SCR_ID, *ocfg_args,
+                                             max_iter, early_stop)
+        return dict(value=done * w["tbs"] / dt, unit="info_bits/s", cores=T, kind="reference",
+                    sample="%d slots (%d TB CRC ok) in %.1f s; srsRAN ofdm_slot_demodulator (generic DFT) + pusch_processor (AVX2 LDPC), one instance per "
+                           "pinned thread, same 4 slots of time-domain samples as the GPU run" % (done, ok, dt), slots_per_s=done / dt, **host)
+
+    def dec(T):
+        dt, done, ok = O.r_pusch_decoder_bench(T, cpus, seconds, llr4, w["mod"], w["nsym"], w["tbs"], max_iter, early_stop)
+        return dict(value=done * w["tbs"] / dt, unit="info_bits/s", cores=T, kind="reference",
+                    sample="%d slots (%d TB CRC ok) in %.1f s; srsRAN pusch_decoder avx2 only (rate dematcher + LDPC decoder) on the GPU's LLRs" % (done, ok, dt))
+
+    out["cpu_baseline"] = chain(t_all, 1)
+    out["cpu_baseline_t1"] = chain(1, 1)
+    out["cpu_baseline_decoder_only"] = {"t1": dec(1), "all_cores": dec(t_all)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ extra GPU legs
+def sch_leg(ctx, miphy, torch, dev, name, bg, mod, nsym, tb_bytes, n_tb, max_iter, sigma, seed):
+    """One SCH configuration through the transport-block level path (prepared plan: rate dematch + LDPC decode + TB assembly): n_tb
+    transport blocks encoded on the device, BPSK-AWGN LLRs on the reference's int8 scale, per-kernel HIP-event times."""
+    sg = miphy.sch_segmentation(tb_bytes, bg)
+    C, G = sg.nof_cbs, nsym * mod
+    rng = np.random.default_rng(seed)
+    n_u = min(n_tb, 8)
+    tb_u = rng.integers(0, 256, (n_u, tb_bytes), dtype=np.uint8)
+    td = np.zeros(n_u, dtype=miphy.PdschTbDesc)
+    for u in range(n_u):
+        td[u] = (bg, 0, mod, 1, 0, nsym, tb_bytes, u * tb_bytes, u * G)
+    cw = torch.zeros(n_u * G, dtype=torch.uint8, device=dev)
+    ctx.pdsch_encode_batch(td, torch.from_numpy(tb_u.reshape(-1)).to(dev), cw)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    idx = torch.arange(n_tb, device=dev) % n_u
+    y = (1.0 - 2.0 * cw.reshape(n_u, G)[idx].to(torch.float32)) + sigma * torch.randn(n_tb, G, device=dev, generator=g)
+    llr = torch.clamp(torch.round(torch.clamp(4.0 * y, -20, 20) * 6.0), -120, 120).to(torch.int8).reshape(-1)
+    del y
+    tbd = np.zeros(n_tb, dtype=miphy.PuschTbDesc)
+    for t in range(n_tb):
+        tbd[t] = (bg, 0, mod, 1, 1, 0, max_iter, 0, nsym, tb_bytes, t * C, t * G, t * tb_bytes)
+    soft = torch.zeros(n_tb * C * miphy.HARQ_CB_STRIDE, dtype=torch.int8, device=dev)
+    msgs = torch.zeros(n_tb * C * miphy.HARQ_MSG_STRIDE, dtype=torch.uint8, device=dev)
+    crc = torch.zeros(n_tb * C, dtype=torch.uint8, device=dev)
+    out = torch.zeros(n_tb * tb_bytes, dtype=torch.uint8, device=dev)
+    res = torch.zeros(n_tb * miphy.PuschResult.itemsize, dtype=torch.uint8, device=dev)
+    plan = ctx.pusch_decode_plan(tbd)
+    plan.enable_timing(16)
+    ms = ev_ms(torch, lambda: plan.run(llr, soft, msgs, crc, out, res), 5)
+    tm = plan.read_timing()
+    r = res.cpu().numpy().view(miphy.PuschResult)
+    ok = int((r["tb_crc_ok"] != 0).sum())
+    same = bool(torch.equal(out.reshape(n_tb, tb_bytes), torch.from_numpy(tb_u).to(dev)[idx])) if ok == n_tb else False
+    plan.close()
+    in_len = min(sg.N, max((22 if bg == 1 else 10) * sg.Z + 2 * sg.Z, -(-(G // C + sg.nof_filler_bits) // sg.Z) * sg.Z))
+    alg = n_tb * C * (in_len + sg.K // 8 + 4)
+    return {"config": name, "transport_blocks": n_tb, "codeblocks": n_tb * C, "Z": sg.Z, "decoder_in_len": in_len, "ldpc_iterations": max_iter,
+            "ms_per_launch": ms, "kernel_ms": tm, "us_per_codeblock": ms * 1e3 / (n_tb * C), "info_bits_per_s": n_tb * tb_bytes * 8 / (ms * 1e-3),
+            "ldpc_decode_algorithmic_GBps": alg / (tm["ldpc_decode"] * 1e-3) / 1e9, "ldpc_decode_hbm_frac": alg / (tm["ldpc_decode"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "tb_crc_ok": ok, "transport_blocks_recovered": same}
+
+
+def polar_leg(ctx, miphy, torch, dev, n=16384, A=40):
+    """BASELINE configs[3]: PDCCH polar encode (CRC24C + interleaver + polar + rate matching), reference-style SSC decode and
+    CRC-aided SCL-8, aggregation levels 1-16; codewords/s and algorithmic GB/s (E in + K/8 out per codeword)."""
+    rng = np.random.default_rng(0)
+    pay = torch.from_numpy(rng.integers(0, 2, (n, A), dtype=np.uint8)).to(dev)
+    rnti_h = rng.integers(1, 65536, n).astype(np.uint16)
+    rnti = torch.from_numpy(rnti_h.view(np.int16)).to(dev)
+    rows = []
+    for AL in (1, 2, 4, 8, 16):
+        E, K = 108 * AL, A + 24
+        out = torch.zeros(n * E, dtype=torch.uint8, device=dev)
+        t_enc = ev_ms(torch, lambda: ctx.pdcch_encode_batch(A, E, n, pay, rnti, out), 5)
+        sigma = {1: 0.75, 2: 1.0, 4: 1.4, 8: 2.0, 16: 2.8}[AL]
+        g = torch.Generator(device=dev)
+        g.manual_seed(AL)
+        y = (1.0 - 2.0 * out.to(torch.float32)) + sigma * torch.randn(n * E, device=dev, generator=g)
+        llr = torch.clamp(torch.round(y * (2.0 / sigma ** 2) * 4), -120, 120).to(torch.int8)
+        code = miphy.PolarCode(K, E, 9, 0)
+        msg = torch.zeros(n * K, dtype=torch.uint8, device=dev)
+        t_ssc = ev_ms(torch, lambda: ctx.polar_decode_batch(code, n, llr, msg), 5)
+        ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+        t_scl = ev_ms(torch, lambda: ctx.polar_decode_list_batch(code, 8, 1, n, llr, rnti, msg, ok), 3)
+        got = msg.reshape(n, K)[:, :A]
+        good = (ok != 0) & (got == pay).all(dim=1)
+        byt = n * (E + (K + 7) // 8)
+        rows.append({"aggregation_level": AL, "K": K, "E": E, "encode_Mcw_per_s": n / t_enc / 1e3, "ssc_decode_Mcw_per_s": n / t_ssc / 1e3,
+                     "scl8_decode_Mcw_per_s": n / t_scl / 1e3, "encode_GBps": byt / t_enc / 1e6, "ssc_GBps": byt / t_ssc / 1e6, "scl8_GBps": byt / t_scl / 1e6,
+                     "scl8_bler": float(1.0 - good.float().mean().item()), "sigma": sigma})
+    return {"codewords_per_call": n, "payload_bits": A, "rows": rows}
+
+
+def load_stamped(name):
+    """profiles/<round>_<name>.json, only if it was collected on this build of the kernels."""
+    path = os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_ROUND, name))
+    try:
+        j = json.load(open(path))
+    except (OSError, ValueError):
+        return None, {"file": os.path.relpath(path, ROOT), "state": "absent"}
+    stamp = {"file": os.path.relpath(path, ROOT), "collected_on_commit": j.get("git_commit"), "kernel_source_sha": j.get("kernel_source_sha")}
+    if j.get("kernel_source_sha") != kernel_source_sha():
+        stamp["state"] = "stale (kernel sources changed since the counters were collected): not quoted"
+        return None, stamp
+    stamp["state"] = "current"
+    return j, stamp
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--slots", type=int, default=1024, help="slots per GPU per step (1024 slots = 38 912 codeblocks = exactly 38 rounds of the 1024 codeblocks the chip holds at once)")
-    ap.add_argument("--max-iter", type=int, default=6)
-    ap.add_argument("--early-stop", type=int, default=0)
-    ap.add_argument("--snr-db", type=float, default=33.0, help="per-RE SNR of the synthesised slots")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--chunks", type=int, default=1, help="slot groups per step, alternated over two HIP streams (1 = one stream)")
-    ap.add_argument("--chunk-streams", type=int, default=2, help="1: the slot groups run back to back on one stream (cache blocking only)")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-latency", action="store_true", help="skip the single-slot latency leg (keeps profiles to the timed step only)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_children(args))
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # Rehearsal knob for a one-GPU box: MIPHY_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo for the barrier and the
-    # MAX reduction of the elapsed time (RCCL refuses two ranks on one device). The measured multi-GPU runs never set it.
+    if world != max(1, args.gpus):
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    # Rehearsal on a machine with fewer GPUs than ranks: every rank on cuda:0, gloo for the barrier, the MAX reduction and the
+    # scatter / gather (RCCL refuses two ranks on one device). Measured multi-GPU runs never set it; the line carries the flag.
     rehearsal = os.environ.get("MIPHY_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
@@ -156,21 +326,20 @@ def main():
 
     import miphy
     import oracle_lib as O
+    from miphy import shard
     ctx = miphy.Context(local_rank)
     w = pusch_workload()
     S = args.slots
-    # Segmentation of the transport block through the library's own host logic (ldpc.h:128-207 restated in csrc/sch.hip); the
-    # rate-matched length of every codeblock is TS 38.212 5.4.2.1 (ldpc_segmenter_impl.cpp:104-141): the first codeblocks get the
-    # floor, the last ones the ceiling of the per-codeblock share of the codeword.
+    # Segmentation of the transport block through the library's own host logic (ldpc.h:128-207 restated in csrc/sch.hip).
     sg = miphy.sch_segmentation(w["tbs"] // 8, w["bg"])
     C, Z, N, K, F = sg.nof_cbs, sg.Z, sg.N, sg.K, sg.nof_filler_bits
     G = w["nsym"] * w["mod"]
+    tb_bytes = w["tbs"] // 8
     unit = w["nof_layers"] * w["mod"]
     n_short = C - (G // unit) % C
     seg_E = [unit * ((G // unit) // C) if c < n_short else unit * (-(-(G // unit) // C)) for c in range(C)]
-    seg_off = [sum(seg_E[:c]) for c in range(C)]
     assert sum(seg_E) == G
-    seg_crc_poly = miphy.CRC24B if C > 1 else (miphy.CRC16 if w["tbs"] <= 3824 else miphy.CRC24A)
+    dec_in_len = [min(N, max((22 + 2) * Z, -(-(seg_E[c] + F) // Z) * Z)) for c in range(C)]
     n_unique = 4
     nsc = w["nprb"] * 12
     grids_tx, tbs_u = build_tx_grids(ctx, miphy, torch, dev, w, n_unique, seed=1234 + rank)
@@ -178,6 +347,7 @@ def main():
 
     # ---- transmit side + channel, once, outside the timed region: OFDM modulation of the S grids on the device and AWGN
     stream = torch.cuda.current_stream()
+    ofdm_args = (4096, 144, 1.0 / 64, 3.5e9)  # dft size, window offset, scale, centre frequency of the receiver
     mcfg = miphy.OfdmConfig(1, w["nprb"], 4096, 0, 1.0 / 64, 0.0, 3.5e9)
     ocfg = miphy.OfdmConfig(1, w["nprb"], 4096, 144, 1.0 / 64, 0.0, 3.5e9)  # unitary pair: demod(mod(grid)) == grid
     slot_samples = ocfg.slot_size(0)
@@ -196,23 +366,24 @@ def main():
     grid_d.zero_()  # from here on: the receiver's resource grid
 
     # ---- device-resident buffers and descriptors of the receive chain (everything below is HBM resident before timing starts)
-    llr_d = torch.zeros(S * G, dtype=torch.int8, device=dev)                # codeword LLRs produced by the demodulator
-    softbuf_d = torch.zeros(S * C * N, dtype=torch.int8, device=dev)        # HARQ soft buffers (device-resident pool)
-    bits_d = torch.zeros(S * C * (K // 8), dtype=torch.uint8, device=dev)   # decoded codeblock messages
-    iters_d = torch.zeros(S * C, dtype=torch.int32, device=dev)
-    rdm = np.zeros(S * C, dtype=miphy.LdpcRdmDesc)
-    dec = np.zeros(S * C, dtype=miphy.LdpcDecDesc)
-    crc_poly = int(seg_crc_poly)
-    # The decoder only needs the part of the soft buffer the dematcher can have written (new data, rv 0: E + fillers,
-    # rounded up to a node); the rest is zero, which the reference trims away itself (ldpc_decoder_impl.cpp:86-99).
-    dec_in_len = [min(N, max((22 + 2) * Z, -(-(seg_E[c] + F) // Z) * Z)) for c in range(C)]
-    for s in range(S):
-        for c in range(C):
-            i = s * C + c
-            rdm[i] = (w["bg"], w["rv"], w["mod"], 1, Z, F, w["Nref"], seg_E[c], s * G + seg_off[c], i * N)
-            dec[i] = (w["bg"], crc_poly if args.early_stop else miphy.CRC_NONE, Z, args.max_iter, F, dec_in_len[c], 0, i * N, i * (K // 8))
-    rdm_d = torch.from_numpy(rdm.view(np.uint8)).to(dev)
-    dec_d = torch.from_numpy(dec.view(np.uint8)).to(dev)
+    llr_d = torch.zeros(S * G, dtype=torch.int8, device=dev)                                  # codeword LLRs produced by the demodulator
+    soft_d = torch.zeros(S * C * miphy.HARQ_CB_STRIDE, dtype=torch.int8, device=dev)          # HARQ soft buffers
+    msgs_d = torch.zeros(S * C * miphy.HARQ_MSG_STRIDE, dtype=torch.uint8, device=dev)        # decoded codeblock messages
+    crc_d = torch.zeros(S * C, dtype=torch.uint8, device=dev)                                 # codeblock CRC flags
+    tb_d = torch.zeros(S * tb_bytes, dtype=torch.uint8, device=dev)                           # transport blocks (the output)
+    res_d = torch.zeros(S * miphy.PuschResult.itemsize, dtype=torch.uint8, device=dev)        # pusch_decoder_result records
+
+    def make_plans(bounds):
+        plans = []
+        for a, b in bounds:
+            td = np.zeros(b - a, dtype=miphy.PuschTbDesc)
+            for i, s in enumerate(range(a, b)):
+                td[i] = (w["bg"], w["rv"], w["mod"], w["nof_layers"], 1, args.early_stop, args.max_iter, w["Nref"], w["nsym"], tb_bytes, s * C, s * G,
+                         s * tb_bytes)
+            p = ctx.pusch_decode_plan(td)
+            p.enable_timing(max(64, args.steps + 8))
+            plans.append(p)
+        return plans
 
     # ---- front end of the slot: 1 rx port, 1 layer, DM-RS type 1 in symbol 2 with two CDM groups without data (like
     # pusch_processor_benchmark.cpp:104-105), all 273 PRB allocated.
@@ -240,21 +411,22 @@ def main():
     cjobs_d = torch.from_numpy(cjobs.view(np.uint8)).to(dev)
     djobs_d = torch.from_numpy(djobs.view(np.uint8)).to(dev)
 
-    stages = ["ofdm_demod", "dmrs_chest", "pusch_demod", "rate_dematch", "ldpc_decode"]
-    ev = {k: [] for k in stages}
+    front = ["ofdm_demod", "dmrs_chest", "pusch_demod"]
+    back = ["rate_dematch", "ldpc_decode", "tb_assemble"]  # inside miphy_pusch_decode_plan_run, timed by the library's own events
+    stages = front + back
+    ev = {k: [] for k in front}
 
     # One step = the whole batch of S slots. With --chunks G > 1 the batch is cut into G groups of slots that alternate between
-    # two HIP streams, so the HBM-bound front end (OFDM, estimator, dematcher) of one group runs under the VALU-bound LDPC
-    # decode of the other; every step still processes all S slots and the timed region ends with a device-wide sync.
+    # two HIP streams; every step still processes all S slots and the timed region ends with a device-wide sync.
     G_ch = max(1, min(args.chunks, S))
     bounds = [(S * i // G_ch, S * (i + 1) // G_ch) for i in range(G_ch)]
     streams = [stream] if (G_ch == 1 or args.chunk_streams == 1) else [torch.cuda.Stream(), torch.cuda.Stream()]
-    max_E, dec_lim = max(seg_E), (Z, max(dec_in_len))
+    plans = make_plans(bounds)
 
     def step(timed):
         for ci, (a, b) in enumerate(bounds):
             st = streams[ci % len(streams)]
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] if timed else None
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(len(front) + 1)] if timed else None
             if timed:
                 e[0].record(st)
             ctx.ofdm_demodulate_slots(ocfg, ojobs_d[a * 24:b * 24], samples_d, grid_d, st)
@@ -266,21 +438,15 @@ def main():
             ctx.pusch_demodulate_batch(djobs_d[a * 104:b * 104], grid_d, ce_d, sc_d, llr_d, st)
             if timed:
                 e[3].record(st)
-            # rate dematch in launches of <= 65535 codeblocks
-            for x in range(a * C, b * C, 65535):
-                y = min(b * C, x + 65535)
-                ctx.ldpc_rate_dematch_batch(rdm_d[x * 32:y * 32], llr_d, softbuf_d, st, max_E=max_E)
-            if timed:
-                e[4].record(st)
-            ctx.ldpc_decode_batch(dec_d[a * C * 32:b * C * 32], softbuf_d, bits_d, iters_d, st, limits=dec_lim)
-            if timed:
-                e[5].record(st)
-                for i, k in enumerate(stages):
+                for i, k in enumerate(front):
                     ev[k].append((e[i], e[i + 1]))
+            plans[ci].run(llr_d, soft_d, msgs_d, crc_d, tb_d, res_d, st)
 
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
+    for p in plans:
+        p.read_timing()  # drop the warm-up samples
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -296,32 +462,22 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    back_ms = {k: 0.0 for k in back}
+    for p in plans:
+        tm = p.read_timing()
+        for k in back:
+            back_ms[k] += tm[k]
 
-    # ---- single-slot latency of the same pipeline (one slot = 38 codeblocks: the real-time unit of work), not part of `value`
-    lat_us = None
-    if rank == 0 and not args.no_latency:
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        for r in range(reps + 3):
-            if r == 3:
-                ev0.record(stream)
-            ctx.ofdm_demodulate_slots(ocfg, ojobs_d[:24], samples_d, grid_d, stream)
-            ctx.dmrs_pusch_estimate_batch(cjobs_d[:96], grid_d, ce_d, sc_d, stream)
-            ctx.pusch_demodulate_batch(djobs_d[:104], grid_d, ce_d, sc_d, llr_d, stream)
-            ctx.ldpc_rate_dematch_batch(rdm_d[:C * 32], llr_d, softbuf_d, stream, max_E=max(seg_E))
-            ctx.ldpc_decode_batch(dec_d[:C * 32], softbuf_d, bits_d, iters_d, stream, limits=(Z, max(dec_in_len)))
-        ev1.record(stream)
-        torch.cuda.synchronize()
-        lat_us = ev0.elapsed_time(ev1) / reps * 1e3
-
-    # ---- correctness guard on what was just computed (not timed). (1) Demodulator: the oracle, fed with the GPU's own resource
-    # grid, channel estimate and noise variance of slot 0, must give the same LLRs bit for bit. (2) Decoder: the oracle decoder on the
-    # GPU's LLRs must give the same codeblock messages. (3) End to end: every checked slot yields the transport block that was sent.
-    checked = min(S, 8)
+    # ---- correctness of what was just computed (not timed). (0) every slot of the step: TB CRC verdict and transport-block bytes on the
+    # device. (1) Demodulator: the oracle, fed with the GPU's own resource grid, channel estimate and noise variance of slot 0, must
+    # give the same LLRs bit for bit. (2) Decoder: the oracle decoder on the GPU's LLRs must give the same codeblock messages and
+    # transport block.
+    exp_tb = torch.from_numpy(np.stack(tbs_u)).to(dev)[torch.from_numpy(slot_src).to(dev)]
+    res_h = res_d.cpu().numpy().view(miphy.PuschResult)
+    all_ok = bool((res_h["tb_crc_ok"] != 0).all()) and bool(torch.equal(tb_d.reshape(S, tb_bytes), exp_tb))
+    checked = min(S, 4 if world > 1 else 8)
     llr_h = llr_d[:checked * G].cpu().numpy().reshape(checked, G)
-    bits = bits_d.cpu().numpy().reshape(S, C, K // 8)
-    iters = iters_d.cpu().numpy().reshape(S, C)
+    msgs_h = msgs_d[:checked * C * miphy.HARQ_MSG_STRIDE].cpu().numpy().reshape(checked, C, miphy.HARQ_MSG_STRIDE)[:, :, :K // 8]
     g0 = grid_d[:14 * nsc].cpu().numpy().reshape(1, 14, nsc)
     h0 = ce_d[:14 * nsc].cpu().numpy().reshape(1, 14, nsc)
     dm = np.zeros(14, np.uint8)
@@ -330,55 +486,73 @@ def main():
     demod_ok = bool(np.array_equal(o_llr, llr_h[0]))
     ok_slots = 0
     for s in range(checked):
-        od = O.OraclePuschDecoder(w["bg"], w["mod"], w["Nref"], w["nof_layers"], w["nsym"], w["tbs"] // 8)
+        od = O.OraclePuschDecoder(w["bg"], w["mod"], w["Nref"], w["nof_layers"], w["nsym"], tb_bytes)
         ok, tb, _ = od.decode(llr_h[s], 0, True, args.max_iter, bool(args.early_stop))
-        same = np.array_equal(od.cb_msgs.reshape(C, -1), bits[s])
+        same = np.array_equal(od.cb_msgs.reshape(C, -1), msgs_h[s])
         ok_slots += int(ok and same and np.array_equal(tb, tbs_u[slot_src[s]]))
-    if not demod_ok:
+    if not (demod_ok and all_ok):
         ok_slots = -1
 
-    # per-launch durations (HIP events on the launching stream); a step has G_ch launches of each kernel
-    launch_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in ev[k]])) for k in stages}
-    kernel_ms = {k: launch_ms[k] * G_ch for k in stages}
+    # ---- single-slot latency of the same pipeline (one slot = 38 codeblocks: the real-time unit of work), not part of `value`
+    lat_us = None
+    if rank == 0 and not args.no_latency:
+        p1 = make_plans([(0, 1)])[0]
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        for r in range(reps + 3):
+            if r == 3:
+                ev0.record(stream)
+            ctx.ofdm_demodulate_slots(ocfg, ojobs_d[:24], samples_d, grid_d, stream)
+            ctx.dmrs_pusch_estimate_batch(cjobs_d[:96], grid_d, ce_d, sc_d, stream)
+            ctx.pusch_demodulate_batch(djobs_d[:104], grid_d, ce_d, sc_d, llr_d, stream)
+            p1.run(llr_d, soft_d, msgs_d, crc_d, tb_d, res_d, stream)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        lat_us = ev0.elapsed_time(ev1) / reps * 1e3
+        p1.close()
+
+    # ---- per-launch durations (HIP events on the launching stream); a step has G_ch launches of each kernel
+    kernel_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in ev[k]])) * G_ch for k in front}
+    kernel_ms.update(back_ms)
     total_slots = S * args.steps * world
-    info_bits = total_slots * w["tbs"]
-    value = info_bits / dt
-    # Roofline of the dominant kernel (LDPC decode): algorithmic bytes per codeblock = N LLR bytes in + K/8 bytes out
-    # + 4 bytes iteration count; units per launch = S*C codeblocks.
-    # Algorithmic bytes per launch: decode = LLRs in + K/8 out + 4 B iterations per codeblock;
-    # dematch = E in + N out per codeblock; OFDM demod = 61440*8 in + 14*3276*8 out per slot-port; estimator = DM-RS REs in
-    # (n_dmrs * 13104 B) + 14*3276*8 out per (slot, port, layer); demodulator = 16 B in + mod B out per data RE and port.
+    value = total_slots * w["tbs"] / dt
+    # Algorithmic bytes per launch: decode = LLRs in + K/8 out + 4 B iterations per codeblock; dematch = E in + N
+    # out per codeblock; OFDM demod = 61440*8 in + 14*3276*8 out per slot-port; estimator = DM-RS REs in (n_dmrs * 13104 B) +
+    # 14*3276*8 out per (slot, port, layer); demodulator = 16 B in + mod B out per data RE and port; TB assembly = K/8 per codeblock in
+    # + TB bytes out.
     alg = {"ldpc_decode": S * sum(dec_in_len[c] + K // 8 + 4 for c in range(C)),
            "rate_dematch": S * (G + C * N),
            "ofdm_demod": S * (slot_samples * 8 + 14 * nsc * 8),
            "dmrs_chest": S * (1 * (nsc // 2) * 8 + 14 * nsc * 8),
-           "pusch_demod": S * (w["nsym"] * (8 + 8) + G)}  # received RE + channel coefficient in, mod LLR bytes out
+           "pusch_demod": S * (w["nsym"] * (8 + 8) + G),
+           "tb_assemble": S * (C * (K // 8) + tb_bytes)}
     gbs = {k: alg[k] / (kernel_ms[k] * 1e-3) / 1e9 for k in stages}
     dom = max(kernel_ms, key=kernel_ms.get)
-    achieved = gbs[dom]
-    # HBM traffic per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE collected offline in separate rocprofv3 passes on
-    # this same workload; the counters cannot be read from inside the process). Scales linearly with the slots per step.
-    traffic = {}
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+    # HBM traffic per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes over this same command:
+    # tools/profile_round.sh writes profiles/r02_traffic.json with the hash of the kernel sources it was collected on).
+    traffic, tstamp = {}, None
+    tj, tstamp = load_stamped("traffic")
+    if tj:
         for k, v in tj["kernels"].items():
             traffic[k] = v["hbm_bytes_per_launch"] * S / tj["slots_per_gpu_per_step"]
-    except (OSError, KeyError, ValueError):
-        pass
-    # VALU-issue roofline of the decoder (it is not an HBM kernel): wave64 VALU instructions per launch from the SQ counters of the
-    # same workload (profiles/r01_pmc_sq_v8_all_kernels.csv, SQ_INSTS_VALU of a 38 912-codeblock launch; scales with the codeblocks) over the launch time, against
-    # 1024 SIMDs x (2.4 GHz / 4 cycles per wave64 instruction).
+    # VALU-issue roofline of the decoder (it is not an HBM kernel): wave64 VALU instructions per codeblock from the SQ counters
+    # (profiles/r02_pmc_sq.json, same stamping), against (a) the guide's peak -- a wave64 VALU instruction occupies its SIMD-32 for 2
+    # cycles once two or more waves are resident (MI355X_MICROARCH.md:54,473) -- and (b) the issue cost measured for the decoder's
+    # own instruction mix with tools/valu_probe (profiles/r02_valu_probe.txt), which is what the kernel can actually reach.
     valu = None
-    try:
-        import csv
-        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_sq_v8_all_kernels.csv"))):
-            if r["kernel"] == "ldpc_decode_pk_kernel" and r["counter"] == "SQ_INSTS_VALU":
-                per_cb = float(r["mean_per_dispatch"]) / 38912.0
-                ach = per_cb * S * C / (kernel_ms["ldpc_decode"] * 1e-3) / 1e9
-                valu = {"kernel": "ldpc_decode", "bound": "valu_issue", "achieved": ach, "peak": 1024 * 2.4 / 4, "unit": "G wave-instr/s",
-                        "frac": ach / (1024 * 2.4 / 4), "valu_wave_instructions_per_codeblock": per_cb}
-    except (OSError, KeyError, ValueError):
-        pass
+    sj, sstamp = load_stamped("pmc_sq")
+    if sj and "ldpc_decode" in sj.get("kernels", {}):
+        kk = sj["kernels"]["ldpc_decode"]
+        per_cb = kk["SQ_INSTS_VALU"] / kk["codeblocks_per_launch"]
+        ach = per_cb * S * C / (kernel_ms["ldpc_decode"] * 1e-3) / 1e9
+        peak = NOF_SIMDS * CLOCK_GHZ / 2.0
+        valu = {"kernel": "ldpc_decode", "bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s", "frac": ach / peak,
+                "peak_note": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md:54,473)",
+                "valu_wave_instructions_per_codeblock": per_cb, "source": sstamp}
+        mix = sj.get("measured_mix_cycles_per_wave_instruction")
+        if mix:
+            valu["measured_issue_cost_cycles"] = mix
+            valu["frac_of_measured_issue_rate"] = ach / (NOF_SIMDS * CLOCK_GHZ / mix)
     out = {
         "metric": "LDPC info-bits/sec + OFDM slots/sec, 100 MHz n78 273-PRB grid",
         "value": value,
@@ -392,10 +566,10 @@ def main():
         "vs_baseline": None,
         "dtype": "int8",
         "data": "synthetic",
-        "config": {"workload": "273-PRB 30kHz PUSCH, 256QAM R=948/1024, 1 layer, 38 CB/slot BG1 Z=384, TBS 319784; "
-                               "per slot, time-domain samples to transport block: OFDM demod (4096-pt, 1 port) + DM-RS channel estimate + "
-                               "equalise/soft-demap/descramble + rate-dematch + LDPC decode (%d it, early_stop=%d); slots synthesised by "
-                               "the transmit chain + AWGN" % (args.max_iter, args.early_stop),
+        "config": {"workload": "273-PRB 30kHz PUSCH, 256QAM R=948/1024, 1 layer, 38 CB/slot BG1 Z=384, TBS 319784; per slot, time-domain "
+                               "samples to transport block: OFDM demod (4096-pt, 1 port) + DM-RS channel estimate + equalise/soft-demap/descramble + "
+                               "rate-dematch + LDPC decode (%d it, early_stop=%d) + TB assembly/CRC24A; slots synthesised by the transmit chain + AWGN"
+                               % (args.max_iter, args.early_stop),
                    "slots_per_gpu_per_step": S, "codeblocks_per_step": S * C * world, "snr_db": args.snr_db,
                    "parallelism": "slots sharded across GPUs, no data-path collective"},
         "slots_per_s": total_slots / dt,
@@ -406,19 +580,100 @@ def main():
                           "frac": gbs["ofdm_demod"] / HBM_PEAK_GBS, "traffic": traffic.get("ofdm_demod")},
         "roofline_valu": valu,
         "single_slot_latency_us": lat_us,
-        "mean_ldpc_iterations": float(iters.mean()) if args.early_stop else float(args.max_iter),
-        "parity_check": "%d/%d slots: LLRs and codeblocks identical to the oracle, transport block recovered" % (ok_slots, checked),
-        "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get(dom), "algorithmic_bytes": alg[dom],
-                     "note": "LDPC decode is LDS/VALU-bound; HBM fraction reported as required"},
+        "parity_check": "%d/%d slots: LLRs and codeblocks identical to the oracle; all %d transport blocks of the last step CRC-ok and equal to the "
+                        "transmitted ones: %s" % (ok_slots, checked, S, all_ok),
+        "roofline": {"kernel": dom, "bound": "hbm", "achieved": gbs[dom], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gbs[dom] / HBM_PEAK_GBS, "traffic": traffic.get(dom), "traffic_source": tstamp, "algorithmic_bytes": alg[dom],
+                     "note": "LDPC decode is VALU/LDS-bound (see roofline_valu); the HBM fraction is reported as the contract asks"},
+        "kernel_source_sha": kernel_source_sha(),
     }
+    if rehearsal:
+        out["rehearsal_shared_gpu"] = True
+        out["config"]["parallelism"] += " (REHEARSAL: all ranks share one GPU over gloo; not a scaling measurement)"
+
+    # ---- single-ingest leg ("RCCL only for the batch scatter/gather"): rank 0 holds the codeword LLRs of world x S_in
+    # slots, scatters them (grouped point-to-point sends, one per xGMI peer), every rank runs rate-dematch + LDPC decode + TB assembly
+    # on its share, the result records are all-gathered. Timed separately; the no-collective weak-scaling number stays `value`.
+    if world > 1 and args.ingest != "local" or (args.ingest == "scatter" and world == 1):
+        S_in = max(1, min(args.ingest_slots, S))
+        units = world * S_in
+        payload = llr_d.reshape(S, G)[torch.arange(units, device=dev) % S].contiguous() if rank == 0 else None
+        pin = make_plans([(0, S_in)])[0]
+        rs = miphy.PuschResult.itemsize
+
+        def ingest(timed_parts=False):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            mine = shard.scatter_units(payload, units, 0, (G,), torch.int8, dev) if world > 1 else payload
+            torch.cuda.synchronize()
+            b = time.perf_counter()
+            pin.run(mine.reshape(-1), soft_d, msgs_d, crc_d, tb_d, res_d, stream)
+            rec = res_d[:S_in * rs].reshape(S_in, rs)
+            allrec = shard.gather_results(rec, units) if world > 1 else rec
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            c = time.perf_counter()
+            return b - a, c - a, allrec
+
+        ingest()
+        runs = [ingest() for _ in range(3)]
+        t_sc, t_all = min(r[0] for r in runs), min(r[1] for r in runs)
+        tt = torch.tensor([t_sc, t_all], dtype=torch.float64, device="cpu" if rehearsal or world == 1 else dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        rec_h = runs[-1][2].cpu().numpy().reshape(-1).view(miphy.PuschResult)
+        out["ingest_scatter"] = {"slots": units, "slots_per_rank": S_in, "scatter_ms": float(tt[0]) * 1e3, "total_ms": float(tt[1]) * 1e3,
+                                 "scatter_GBps": (units - S_in) * G / float(tt[0]) / 1e9, "info_bits_per_s": units * w["tbs"] / float(tt[1]),
+                                 "tb_crc_ok": int((rec_h["tb_crc_ok"] != 0).sum()), "backend": "gloo (rehearsal)" if rehearsal else "rccl",
+                                 "stages": "scatter LLR slabs from rank 0 -> rate dematch + LDPC decode + TB assembly per rank -> all-gather result records"}
+        if int((rec_h["tb_crc_ok"] != 0).sum()) != units:
+            ok_slots = -2
+        pin.close()
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        legs = {}
+        legs["pusch_16qam_r658_273prb"] = sch_leg(ctx, miphy, torch, dev, "273 PRB 16QAM R=658/1024: TBS 108552, 13 CB BG1 Z=384, E=13104 (15 layers)",
+                                                  1, 4, 273 * 156, 108552 // 8, 1024, args.max_iter, 0.32, 7)
+        legs["bg1_z384_rate_one_third"] = sch_leg(ctx, miphy, torch, dev, "BASELINE configs[0]: single codeblock BG1 Z=384, K=8448, full length N=25344 "
+                                                  "(rate 1/3, 46 layers)", 1, 2, 12672, 1050, 8192, args.max_iter, 0.8, 8)
+        legs["polar_pdcch"] = polar_leg(ctx, miphy, torch, dev)
+        out["legs"] = legs
+        # PCIe-inclusive rate (never `value`): the S slots of time-domain samples from pinned host memory, the step, the transport
+        # blocks back to pinned host memory, back to back on one stream.
+        h_in = torch.empty(S * slot_samples, dtype=torch.complex64).pin_memory()
+        h_in.copy_(samples_d)
+        h_out = torch.empty(S * tb_bytes, dtype=torch.uint8).pin_memory()
+
+        def pcie_step():
+            samples_d.copy_(h_in, non_blocking=True)
+            step(False)
+            h_out.copy_(tb_d, non_blocking=True)
+
+        ms_all = ev_ms(torch, pcie_step, 3)
+        ms_h2d = ev_ms(torch, lambda: samples_d.copy_(h_in, non_blocking=True), 3)
+        ms_d2h = ev_ms(torch, lambda: h_out.copy_(tb_d, non_blocking=True), 3)
+        ms_step = dt / args.steps * 1e3
+        out["pcie_inclusive"] = {"bits_per_s": S * w["tbs"] / (ms_all * 1e-3), "ms_h2d_plus_step_plus_d2h": ms_all, "h2d_ms": ms_h2d, "d2h_ms": ms_d2h,
+                                 "h2d_GBps": S * slot_samples * 8 / ms_h2d / 1e6, "d2h_GBps": S * tb_bytes / ms_d2h / 1e6,
+                                 "overlapped_bound_bits_per_s": S * w["tbs"] / (max(ms_h2d, ms_step, ms_d2h) * 1e-3),
+                                 "note": "serial H2D + step + D2H measured; the overlapped bound is the slowest of the three stages"}
+        out["pcie_inclusive_bits_per_s"] = out["pcie_inclusive"]["bits_per_s"]
+        del h_in, h_out
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(w, llr_h[:4], args.max_iter, bool(args.early_stop), args.cpu_seconds)
+        samples4 = samples_d[:4 * slot_samples].cpu().numpy().reshape(4, slot_samples)
+        out.update(cpu_legs(w, samples4, llr_h[:4], ofdm_args, args.max_iter, bool(args.early_stop), args.cpu_seconds))
+        if "cpu_baseline_t1" in out:
+            out["cpu_baseline_all_cores"] = out["cpu_baseline"]
     if rank == 0:
         print(json.dumps(out))
     if ok_slots != checked:
-        print("PARITY FAILURE in bench", file=sys.stderr)
+        print("PARITY FAILURE in bench (%d)" % ok_slots, file=sys.stderr)
         sys.exit(3)
+    for p in plans:
+        p.close()
     if world > 1:
         dist.destroy_process_group()
 

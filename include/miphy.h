@@ -451,6 +451,29 @@ int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
                              miphy_pusch_result*        results,       /* device, n entries */
                              void*                      stream);
 
+/* Prepared form of miphy_pusch_decode_batch for allocations that repeat (semi-static scheduling, benchmarks): _create runs the
+ * segmentation (ldpc_segmenter_impl.cpp:253-334) and uploads the codeblock descriptors once; every _run is kernel launches only
+ * (CRC-flag reset, rate dematching, LDPC decoding, transport-block assembly + TB CRC + result records) with no host
+ * synchronisation, on the arrays passed to that run. A plan belongs to the context it was created on and must not run
+ * concurrently with itself. */
+typedef struct miphy_pusch_decode_plan miphy_pusch_decode_plan;
+int  miphy_pusch_decode_plan_create(miphy_ctx* ctx, const miphy_pusch_tb_desc* tbs /* host */, uint32_t n, miphy_pusch_decode_plan** out);
+int  miphy_pusch_decode_plan_run(miphy_pusch_decode_plan* plan,
+                                 const int8_t*            llrs,          /* device */
+                                 int8_t*                  harq_softbits, /* device, in/out */
+                                 uint8_t*                 harq_msgs,     /* device, in/out */
+                                 uint8_t*                 harq_crc_ok,   /* device, in/out */
+                                 uint8_t*                 tb_out,        /* device */
+                                 miphy_pusch_result*      results,       /* device, n entries */
+                                 void*                    stream);
+void miphy_pusch_decode_plan_destroy(miphy_pusch_decode_plan* plan);
+/* Optional per-kernel timing of the runs of a plan (measurement aid, e.g. bench.py's roofline): _enable_timing makes every run
+ * record HIP events on its stream around the rate dematcher, the LDPC decoder and the transport-block assembly (a ring of max_runs
+ * runs; batches above 65535 codeblocks are refused); _read_timing waits for the recorded runs, returns their mean durations in
+ * milliseconds {rate dematch, LDPC decode, TB assembly} and starts a new series. */
+int  miphy_pusch_decode_plan_enable_timing(miphy_pusch_decode_plan* plan, uint32_t max_runs);
+int  miphy_pusch_decode_plan_read_timing(miphy_pusch_decode_plan* plan, float ms_out[3], uint32_t* runs_out);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * PUSCH processor  --  replaces srsran::pusch_processor::process for PDUs without UCI
  *   include/srsran/phy/upper/channel_processors/pusch_processor.h:84-162

@@ -28,7 +28,11 @@
 #include "srsran/phy/upper/sequence_generators/sequence_generator_factories.h"
 #include "srsran/phy/upper/signal_processors/signal_processor_factories.h"
 #include "lib/phy/generic_functions/dft_processor_generic_impl.h"
+#include <atomic>
 #include <chrono>
+#include <pthread.h>
+#include <sched.h>
+#include <thread>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -1278,4 +1282,201 @@ int ref_csi_rs_map(unsigned numerology, unsigned slot_index, unsigned start_rb, 
   return 0;
 }
 
+// ---------------------------------------------------------------- CPU baseline: the whole receive chain, driven like the reference benchmark
+// T worker threads pinned 1:1 to the CPUs in `cpus`, one instance of every block per thread (ofdm_slot_demodulator over the
+// generic DFT, pusch_processor from the software factories with the AVX2 LDPC decoder / rate dematcher, an rx_softbuffer_pool), each
+// looping over the same `nslots` input slots until `seconds` have passed -- the shape of
+// tests/benchmarks/phy/upper/channel_processors/pusch_processor_benchmark.cpp:576-632 (thread_process / pinned workers).
+// with_ofdm = 1: time-domain samples -> transport block (what bench.py's `value` covers); 0: the grids are demodulated once
+// outside the timed region and only pusch_processor::process is timed; 2: only the pusch_decoder (dematch + decode) on LLRs.
+// samples: [nslots][slot_samples] cf_t. Slot s is slot-in-frame s (its subframe slot index is s % 2). Returns elapsed seconds;
+// slots_done[t] / tb_ok[t] per thread.
+namespace {
+struct chain_notifier : public pusch_processor_result_notifier {
+  bool ok = false;
+  void on_csi(const channel_state_information&) override {}
+  void on_uci(const pusch_processor_result_control&) override {}
+  void on_sch(const pusch_processor_result_data& d) override { ok = d.data.tb_crc_ok; }
+};
+} // namespace
+
+double ref_pusch_chain_bench(unsigned     nthreads,
+                             const int*   cpus,
+                             double       seconds,
+                             int          with_ofdm,
+                             const float* samples,
+                             unsigned     nslots,
+                             unsigned     slot_samples,
+                             unsigned     nof_prb,
+                             int          mod,
+                             unsigned     tbs_bits,
+                             unsigned     rnti,
+                             unsigned     n_id,
+                             unsigned     dmrs_scrambling_id,
+                             unsigned     dft_size,
+                             unsigned     window_offset,
+                             float        ofdm_scale,
+                             double       center_freq_hz,
+                             unsigned     max_iter,
+                             int          early_stop,
+                             uint64_t*    slots_done,
+                             uint64_t*    tb_ok)
+{
+  const unsigned           nsc = nof_prb * 12;
+  std::atomic<int>         ready{0};
+  std::atomic<bool>        go{false}, stop{false};
+  std::vector<std::thread> workers;
+  for (unsigned t = 0; t != nthreads; ++t) {
+    slots_done[t] = 0, tb_ok[t] = 0;
+    workers.emplace_back([&, t]() {
+      if (cpus != nullptr && cpus[t] >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(cpus[t], &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+      }
+      auto                               prg = create_pseudo_random_generator_sw_factory();
+      ofdm_factory_generic_configuration fc;
+      fc.dft_factory = std::make_shared<generic_dft_factory>();
+      ofdm_demodulator_configuration oc;
+      oc.numerology = 1, oc.bw_rb = nof_prb, oc.dft_size = dft_size, oc.cp = cyclic_prefix::NORMAL;
+      oc.nof_samples_window_offset = window_offset, oc.scale = ofdm_scale, oc.center_freq_hz = center_freq_hz;
+      auto ofdm = create_ofdm_demodulator_factory_generic(fc)->create_ofdm_slot_demodulator(oc);
+      pusch_decoder_factory_sw_configuration dc;
+      dc.crc_factory       = create_crc_calculator_factory_sw("auto");
+      dc.decoder_factory   = create_ldpc_decoder_factory_sw("avx2");
+      dc.dematcher_factory = create_ldpc_rate_dematcher_factory_sw("avx2");
+      dc.segmenter_factory = create_ldpc_segmenter_rx_factory_sw();
+      uci_decoder_factory_sw_configuration uc;
+      uc.decoder_factory = create_short_block_detector_factory_sw();
+      pusch_processor_factory_sw_configuration pc;
+      pc.estimator_factory =
+          create_dmrs_pusch_estimator_factory_sw(prg, create_port_channel_estimator_factory_sw(std::make_shared<generic_dft_factory>()));
+      pc.demodulator_factory = create_pusch_demodulator_factory_sw(create_channel_equalizer_factory_zf(), create_channel_modulation_sw_factory(), prg);
+      pc.demux_factory       = create_ulsch_demultiplex_factory_sw();
+      pc.decoder_factory     = create_pusch_decoder_factory_sw(dc);
+      pc.uci_dec_factory     = create_uci_decoder_factory_sw(uc);
+      pc.ch_estimate_dimensions.nof_prb = MAX_RB, pc.ch_estimate_dimensions.nof_symbols = MAX_NSYMB_PER_SLOT;
+      pc.ch_estimate_dimensions.nof_rx_ports = 1, pc.ch_estimate_dimensions.nof_tx_layers = 1;
+      pc.dec_nof_iterations = max_iter, pc.dec_enable_early_stop = early_stop != 0;
+      auto proc = create_pusch_processor_factory_sw(pc)->create();
+      rx_softbuffer_pool_config spc;
+      spc.max_codeblock_size = ldpc::MAX_CODEBLOCK_SIZE, spc.max_softbuffers = 2, spc.max_nof_codeblocks = 128, spc.expire_timeout_slots = 100000;
+      auto                 pool = create_rx_softbuffer_pool(spc);
+      const unsigned       nof_cbs = ldpc::compute_nof_codeblocks(units::bits(tbs_bits), ldpc_base_graph_type::BG1);
+      std::vector<uint8_t> tb(tbs_bits / 8);
+      // Grids: demodulated per iteration (with_ofdm == 1) or once up front.
+      std::vector<std::unique_ptr<resource_grid>> grids;
+      for (unsigned s = 0; s != nslots; ++s) {
+        grids.push_back(create_resource_grid(1, 14, nsc));
+        ofdm->demodulate(*grids[s], span<const cf_t>(reinterpret_cast<const cf_t*>(samples) + size_t(s) * slot_samples, slot_samples), 0, s % 2);
+      }
+      symbol_slot_mask dm(14);
+      dm.set(2);
+      ready.fetch_add(1);
+      while (!go.load()) {
+        std::this_thread::yield();
+      }
+      unsigned k = t;
+      while (!stop.load(std::memory_order_relaxed)) {
+        const unsigned s = k % nslots;
+        if (with_ofdm == 1) {
+          ofdm->demodulate(*grids[s], span<const cf_t>(reinterpret_cast<const cf_t*>(samples) + size_t(s) * slot_samples, slot_samples), 0, s % 2);
+        }
+        pusch_processor::pdu_t pdu;
+        pdu.slot = slot_point(1, s), pdu.rnti = rnti, pdu.bwp_size_rb = nof_prb, pdu.bwp_start_rb = 0, pdu.cp = cyclic_prefix::NORMAL;
+        pdu.mcs_descr.modulation = mod_from_bits(mod), pdu.mcs_descr.target_code_rate = 0.9F;
+        pdu.codeword.emplace();
+        pdu.codeword.value().rv = 0, pdu.codeword.value().ldpc_base_graph = ldpc_base_graph_type::BG1, pdu.codeword.value().new_data = true;
+        pdu.uci = {};
+        pdu.uci.alpha_scaling = 1.0F, pdu.uci.beta_offset_harq_ack = 20.0F, pdu.uci.beta_offset_csi_part1 = 6.25F, pdu.uci.beta_offset_csi_part2 = 6.25F;
+        pdu.n_id = n_id, pdu.nof_tx_layers = 1;
+        pdu.rx_ports.push_back(0);
+        pdu.dmrs_symbol_mask = dm, pdu.dmrs = dmrs_type::TYPE1, pdu.scrambling_id = dmrs_scrambling_id, pdu.n_scid = false;
+        pdu.nof_cdm_groups_without_data = 2;
+        pdu.freq_alloc         = rb_allocation::make_type1(0, nof_prb);
+        pdu.start_symbol_index = 0, pdu.nof_symbols = 14, pdu.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8;
+        rx_softbuffer_identifier id;
+        id.rnti = static_cast<uint16_t>(rnti), id.harq_ack_id = 0;
+        unique_rx_softbuffer sb = pool->reserve_softbuffer(slot_point(1, s), id, nof_cbs);
+        chain_notifier       n;
+        proc->process(tb, sb.get(), n, *grids[s], pdu);
+        sb.release();
+        ++slots_done[t];
+        tb_ok[t] += n.ok ? 1 : 0;
+        ++k;
+      }
+    });
+  }
+  while (ready.load() != (int)nthreads) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  const double t0 = now_s();
+  go.store(true);
+  std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+  stop.store(true);
+  for (auto& w : workers) {
+    w.join();
+  }
+  return now_s() - t0;
+}
+
+// Decoder-only leg (pusch_decoder: rate dematcher + LDPC decoder + CRCs), same threading. llrs: [nslots][cw_len].
+double ref_pusch_decoder_bench(unsigned      nthreads,
+                               const int*    cpus,
+                               double        seconds,
+                               const int8_t* llrs,
+                               unsigned      nslots,
+                               unsigned      cw_len,
+                               int           mod,
+                               unsigned      nof_ch_symbols,
+                               unsigned      tbs_bits,
+                               unsigned      max_iter,
+                               int           early_stop,
+                               uint64_t*     slots_done,
+                               uint64_t*     tb_ok)
+{
+  std::atomic<int>         ready{0};
+  std::atomic<bool>        go{false}, stop{false};
+  std::vector<std::thread> workers;
+  for (unsigned t = 0; t != nthreads; ++t) {
+    slots_done[t] = 0, tb_ok[t] = 0;
+    workers.emplace_back([&, t]() {
+      if (cpus != nullptr && cpus[t] >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(cpus[t], &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+      }
+      void* h   = ref_pusch_decoder_create(1);
+      int   rv0 = 0, ok = 0, mm[2];
+      std::vector<uint8_t> tb(tbs_bits / 8);
+      ready.fetch_add(1);
+      while (!go.load()) {
+        std::this_thread::yield();
+      }
+      unsigned k = t;
+      while (!stop.load(std::memory_order_relaxed)) {
+        ref_pusch_decode(h, 1, mod, 0, 1, nof_ch_symbols, tbs_bits / 8, 1, &rv0, llrs + size_t(k % nslots) * cw_len, cw_len, max_iter, early_stop, tb.data(), &ok, mm);
+        ++slots_done[t];
+        tb_ok[t] += ok;
+        ++k;
+      }
+      ref_pusch_decoder_destroy(h);
+    });
+  }
+  while (ready.load() != (int)nthreads) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  const double t0 = now_s();
+  go.store(true);
+  std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+  stop.store(true);
+  for (auto& w : workers) {
+    w.join();
+  }
+  return now_s() - t0;
+}
+
 } // extern "C"
+

@@ -277,28 +277,37 @@ extern "C" int miphy_sch_segmentation_info(uint32_t tb_bytes, uint32_t bg, miphy
   return MIPHY_OK;
 }
 
-extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
-                                        const miphy_pusch_tb_desc* tbs,
-                                        uint32_t                   n,
-                                        const int8_t*              llrs,
-                                        int8_t*                    harq_softbits,
-                                        uint8_t*                   harq_msgs,
-                                        uint8_t*                   harq_crc_ok,
-                                        uint8_t*                   tb_out,
-                                        miphy_pusch_result*        results,
-                                        void*                      stream)
-{
-  MIPHY_REQUIRE(ctx && tbs && llrs && harq_softbits && harq_msgs && harq_crc_ok && tb_out && results, "miphy_pusch_decode_batch: null argument");
-  if (n == 0)
-    return MIPHY_OK;
-  hipStream_t                      s = (hipStream_t)stream;
+namespace {
+
+// Host-side product of the segmentation of a batch of transport blocks: everything the three launches of a PUSCH decode need.
+struct pusch_decode_build {
   std::vector<miphy_ldpc_rdm_desc> rdm;
   std::vector<miphy_ldpc_dec_desc> dec;
   std::vector<uint32_t>            slots, reset_slots;
-  std::vector<tb_asm_desc>         asmd(n);
-  std::vector<uint64_t>            tmp_off(n);
+  std::vector<tb_asm_desc>         asmd;
+  std::vector<uint64_t>            tmp_off;
   uint64_t                         tmp_bytes = 0;
   uint32_t                         max_Z = 2, max_nodes = 0, max_E = 0;
+};
+
+// Device-side view of a staged build (pointers into one buffer).
+struct pusch_decode_dev {
+  const miphy_ldpc_rdm_desc* rdm;
+  const miphy_ldpc_dec_desc* dec;
+  const uint32_t*            slots;
+  const uint32_t*            reset;
+  const tb_asm_desc*         asmd;
+  const uint64_t*            tmp_off;
+  int32_t*                   iters;
+  uint8_t*                   tmp;
+  size_t                     staged; // bytes to copy host -> device
+  size_t                     total;  // bytes of the whole buffer
+};
+
+int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_build& b)
+{
+  b.asmd.resize(n);
+  b.tmp_off.resize(n);
   for (uint32_t t = 0; t < n; ++t) {
     const miphy_pusch_tb_desc& d = tbs[t];
     seg_t                      sg;
@@ -313,8 +322,8 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
     MIPHY_REQUIRE((sg.cb_info_bits % 8) == 0 || sg.nof_cbs == 1,
                   "pusch_decode: TB %u: TBS %u is not a TS 38.214 transport block size (codeblock payloads are not byte aligned)", t, sg.tbs);
     const uint32_t bgK = (d.bg == 1) ? 22 : 10;
-    tb_asm_desc&   a   = asmd[t];
-    a.first_desc       = (uint32_t)dec.size();
+    tb_asm_desc&   a   = b.asmd[t];
+    a.first_desc       = (uint32_t)b.dec.size();
     a.nof_cbs          = sg.nof_cbs;
     a.harq_cb_index    = d.harq_cb_index;
     a.nof_data_bits    = sg.K - ((sg.nof_cbs == 1) ? sg.nof_tb_crc_bits : 24) - sg.nof_filler_bits; // get_cblk_bit_breakdown
@@ -322,8 +331,8 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
     a.tb_bytes         = d.tb_bytes;
     a.max_iter         = d.nof_ldpc_iterations;
     a.tb_offset        = d.tb_offset;
-    tmp_off[t]         = tmp_bytes;
-    tmp_bytes += ((a.tb_and_crc_bits + 7) / 8 + 8 + 15) & ~15ull;
+    b.tmp_off[t]       = b.tmp_bytes;
+    b.tmp_bytes += ((a.tb_and_crc_bits + 7) / 8 + 8 + 15) & ~15ull;
     uint32_t cw_off = 0, tb_nodes = 0;
     for (uint32_t c = 0; c < sg.nof_cbs; ++c) {
       const uint32_t      E    = rm_length(sg, c, d.mod, d.nof_layers, d.nof_ch_symbols);
@@ -333,8 +342,8 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
       r.nof_filler_bits = (uint16_t)sg.nof_filler_bits, r.Nref = d.Nref, r.E = E;
       r.in_offset = d.llr_offset + cw_off, r.out_offset = (uint64_t)slot * HARQ_CB_STRIDE;
       MIPHY_REQUIRE(E > 0, "pusch_decode: TB %u: empty codeblock", t);
-      max_E = E > max_E ? E : max_E;
-      rdm.push_back(r);
+      b.max_E = E > b.max_E ? E : b.max_E;
+      b.rdm.push_back(r);
       miphy_ldpc_dec_desc q = {};
       q.bg = d.bg, q.crc_poly = (uint8_t)sg.crc_poly, q.Z = (uint16_t)sg.Z, q.max_iter = d.nof_ldpc_iterations;
       q.nof_filler_bits = (uint16_t)sg.nof_filler_bits;
@@ -358,57 +367,238 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
       }
       q.flags           = d.use_early_stop ? 0u : 1u;
       q.llr_offset = (uint64_t)slot * HARQ_CB_STRIDE, q.out_offset = (uint64_t)slot * HARQ_MSG_STRIDE;
-      dec.push_back(q);
-      slots.push_back(slot);
+      b.dec.push_back(q);
+      b.slots.push_back(slot);
       if (d.new_data)
-        reset_slots.push_back(slot);
+        b.reset_slots.push_back(slot);
       cw_off += E;
     }
     MIPHY_REQUIRE(cw_off == d.nof_ch_symbols * d.mod, "pusch_decode: TB %u: codeblock lengths (%u) do not add up to the codeword (%u)", t, cw_off,
                   d.nof_ch_symbols * d.mod);
-    max_Z      = sg.Z > max_Z ? sg.Z : max_Z;
-    max_nodes  = tb_nodes > max_nodes ? tb_nodes : max_nodes;
+    b.max_Z     = sg.Z > b.max_Z ? sg.Z : b.max_Z;
+    b.max_nodes = tb_nodes > b.max_nodes ? tb_nodes : b.max_nodes;
   }
-  const uint32_t ncb = (uint32_t)dec.size();
-  MIPHY_REQUIRE(ncb <= 65535, "pusch_decode: %u codeblocks in one call (max 65535)", ncb);
-  // Workspace: descriptors + per-TB assembly buffers + iteration counts.
-  size_t bytes = 64 + rdm.size() * sizeof(rdm[0]) + dec.size() * sizeof(dec[0]) + (slots.size() + reset_slots.size()) * 4 + asmd.size() * sizeof(asmd[0]) +
-                 tmp_off.size() * 8 + ncb * 4 + tmp_bytes + 16 * 8;
-  std::vector<uint8_t> host(bytes);
-  void*                wsv = nullptr;
-  int                  rc  = miphy_get_workspace(ctx, bytes, s, &wsv);
-  if (rc)
-    return rc;
-  uint8_t *h = host.data(), *dv = (uint8_t*)wsv;
-  size_t   off = 0;
-  auto*    d_rdm   = stage_vec(h, dv, rdm, off);
-  auto*    d_dec   = stage_vec(h, dv, dec, off);
-  auto*    d_slots = stage_vec(h, dv, slots, off);
-  auto*    d_reset = stage_vec(h, dv, reset_slots, off);
-  auto*    d_asm   = stage_vec(h, dv, asmd, off);
-  auto*    d_tmpo  = stage_vec(h, dv, tmp_off, off);
-  const size_t staged = off;
-  off                 = (off + 15) & ~(size_t)15;
-  int32_t* d_iters    = reinterpret_cast<int32_t*>(dv + off);
-  off += (size_t)ncb * 4;
-  off          = (off + 15) & ~(size_t)15;
-  uint8_t* d_tmp = dv + off;
-  // The staging copy is synchronous with respect to the host vector (pageable memory): it completes before returning.
-  MIPHY_HIP_CHECK(hipMemcpyAsync(dv, h, staged, hipMemcpyHostToDevice, s));
-  MIPHY_HIP_CHECK(hipStreamSynchronize(s));
-  if (!reset_slots.empty())
-    hipLaunchKernelGGL(harq_reset_kernel, dim3((unsigned)(reset_slots.size() + 255) / 256), dim3(256), 0, s, d_reset, (uint32_t)reset_slots.size(), harq_crc_ok);
-  miphy_ldpc_rdm_limits rlim = {max_E};
-  if ((rc = miphy_ldpc_rate_dematch_batch(ctx, d_rdm, 1, ncb, llrs, harq_softbits, &rlim, s)))
-    return rc;
+  return MIPHY_OK;
+}
+
+size_t pusch_decode_bytes(const pusch_decode_build& b)
+{
+  return 64 + b.rdm.size() * sizeof(b.rdm[0]) + b.dec.size() * sizeof(b.dec[0]) + (b.slots.size() + b.reset_slots.size()) * 4 +
+         b.asmd.size() * sizeof(b.asmd[0]) + b.tmp_off.size() * 8 + b.dec.size() * 4 + b.tmp_bytes + 16 * 8;
+}
+
+// Lays the build out in a host image `h` of the device buffer `dv` (same offsets) and returns the device pointers.
+pusch_decode_dev layout_pusch_decode(const pusch_decode_build& b, uint8_t* h, uint8_t* dv)
+{
+  pusch_decode_dev v;
+  size_t           off = 0;
+  v.rdm     = stage_vec(h, dv, b.rdm, off);
+  v.dec     = stage_vec(h, dv, b.dec, off);
+  v.slots   = stage_vec(h, dv, b.slots, off);
+  v.reset   = stage_vec(h, dv, b.reset_slots, off);
+  v.asmd    = stage_vec(h, dv, b.asmd, off);
+  v.tmp_off = stage_vec(h, dv, b.tmp_off, off);
+  v.staged  = off;
+  off       = (off + 15) & ~(size_t)15;
+  v.iters   = reinterpret_cast<int32_t*>(dv + off);
+  off += b.dec.size() * 4;
+  off   = (off + 15) & ~(size_t)15;
+  v.tmp = dv + off;
+  v.total = off + b.tmp_bytes;
+  return v;
+}
+
+// The launches of one PUSCH decode on staged descriptors: CRC-flag reset of new transmissions, rate dematching into the HARQ
+// soft buffers, LDPC decoding (codeblocks already decoded are skipped), transport-block assembly + TB CRC + result records.
+// Launches of at most 65535 codeblocks each; transport blocks are never split across launches.
+int launch_pusch_decode(miphy_ctx* ctx, const pusch_decode_build& b, const pusch_decode_dev& v, uint32_t n, const int8_t* llrs, int8_t* harq_softbits,
+                        uint8_t* harq_msgs, uint8_t* harq_crc_ok, uint8_t* tb_out, miphy_pusch_result* results, hipStream_t s,
+                        hipEvent_t* ev = nullptr /* optional: 4 events around dematch / decode / assembly (single-launch batches) */)
+{
+  int rc;
+  if (!b.reset_slots.empty())
+    hipLaunchKernelGGL(harq_reset_kernel, dim3((unsigned)(b.reset_slots.size() + 255) / 256), dim3(256), 0, s, v.reset, (uint32_t)b.reset_slots.size(), harq_crc_ok);
+  miphy_ldpc_rdm_limits rlim = {b.max_E};
   // The decoder derives its LDS size from (max_Z, max_in_len) as ceil((max_in_len + 2 max_Z) / max_Z) nodes: hand it the node
   // bound of the batch expressed in units of the largest lifting size (codeblocks with a smaller Z reach more nodes per LLR).
-  miphy_ldpc_dec_limits lim = {max_Z, (max_nodes - 2) * max_Z};
-  if ((rc = miphy_ldpc_decode_launch(ctx, d_dec, 1, ncb, harq_softbits, harq_msgs, d_iters, &lim, d_slots, harq_crc_ok, s)))
-    return rc;
-  hipLaunchKernelGGL(pusch_tb_assemble_kernel, dim3(n), dim3(1024), 0, s, d_asm, ctx->d_tables, d_iters, harq_msgs, harq_crc_ok, d_tmp, d_tmpo, tb_out, results);
+  miphy_ldpc_dec_limits lim = {b.max_Z, (b.max_nodes - 2) * b.max_Z};
+  uint32_t              t0  = 0;
+  while (t0 < n) {
+    uint32_t t1 = t0, c0 = b.asmd[t0].first_desc, c1 = c0;
+    while (t1 < n && c1 + b.asmd[t1].nof_cbs - c0 <= 65535) {
+      c1 += b.asmd[t1].nof_cbs;
+      ++t1;
+    }
+    if (ev)
+      MIPHY_HIP_CHECK(hipEventRecord(ev[0], s));
+    if ((rc = miphy_ldpc_rate_dematch_batch(ctx, v.rdm + c0, 1, c1 - c0, llrs, harq_softbits, &rlim, s)))
+      return rc;
+    if (ev)
+      MIPHY_HIP_CHECK(hipEventRecord(ev[1], s));
+    if ((rc = miphy_ldpc_decode_launch(ctx, v.dec + c0, 1, c1 - c0, harq_softbits, harq_msgs, v.iters + c0, &lim, v.slots + c0, harq_crc_ok, s)))
+      return rc;
+    t0 = t1;
+  }
+  if (ev)
+    MIPHY_HIP_CHECK(hipEventRecord(ev[2], s));
+  for (uint32_t a = 0; a < n; a += 65535) {
+    const uint32_t m = (n - a < 65535) ? n - a : 65535;
+    hipLaunchKernelGGL(pusch_tb_assemble_kernel, dim3(m), dim3(1024), 0, s, v.asmd + a, ctx->d_tables, v.iters, harq_msgs, harq_crc_ok, v.tmp, v.tmp_off + a,
+                       tb_out, results + a);
+  }
+  if (ev)
+    MIPHY_HIP_CHECK(hipEventRecord(ev[3], s));
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
+}
+
+} // namespace
+
+extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
+                                        const miphy_pusch_tb_desc* tbs,
+                                        uint32_t                   n,
+                                        const int8_t*              llrs,
+                                        int8_t*                    harq_softbits,
+                                        uint8_t*                   harq_msgs,
+                                        uint8_t*                   harq_crc_ok,
+                                        uint8_t*                   tb_out,
+                                        miphy_pusch_result*        results,
+                                        void*                      stream)
+{
+  MIPHY_REQUIRE(ctx && tbs && llrs && harq_softbits && harq_msgs && harq_crc_ok && tb_out && results, "miphy_pusch_decode_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  hipStream_t        s = (hipStream_t)stream;
+  pusch_decode_build b;
+  int                rc = build_pusch_decode(tbs, n, b);
+  if (rc)
+    return rc;
+  const size_t         bytes = pusch_decode_bytes(b);
+  std::vector<uint8_t> host(bytes);
+  void*                wsv = nullptr;
+  if ((rc = miphy_get_workspace(ctx, bytes, s, &wsv)))
+    return rc;
+  const pusch_decode_dev v = layout_pusch_decode(b, host.data(), (uint8_t*)wsv);
+  // The staging copy is synchronous with respect to the host vector (pageable memory): it completes before returning.
+  MIPHY_HIP_CHECK(hipMemcpyAsync(wsv, host.data(), v.staged, hipMemcpyHostToDevice, s));
+  MIPHY_HIP_CHECK(hipStreamSynchronize(s));
+  return launch_pusch_decode(ctx, b, v, n, llrs, harq_softbits, harq_msgs, harq_crc_ok, tb_out, results, s);
+}
+
+// ---- prepared form: the segmentation and the descriptor upload happen once, every run is launches only (no host
+// synchronisation), for allocations that repeat slot after slot.
+struct miphy_pusch_decode_plan {
+  miphy_ctx*         ctx;
+  uint32_t           n;
+  pusch_decode_build b; // host side kept for the launch limits (the descriptor vectors are released after staging)
+  pusch_decode_dev   v;
+  void*              d_buf;
+  uint32_t           ncb;
+  std::vector<hipEvent_t> events; // timing: 4 per run, ring of events.size() / 4 runs
+  uint32_t           timed_runs;
+};
+
+extern "C" int miphy_pusch_decode_plan_create(miphy_ctx* ctx, const miphy_pusch_tb_desc* tbs, uint32_t n, miphy_pusch_decode_plan** out)
+{
+  MIPHY_REQUIRE(ctx && tbs && out && n > 0, "miphy_pusch_decode_plan_create: null argument or empty batch");
+  auto* p = new miphy_pusch_decode_plan();
+  p->ctx = ctx, p->n = n, p->d_buf = nullptr, p->timed_runs = 0;
+  int rc = build_pusch_decode(tbs, n, p->b);
+  p->ncb = (uint32_t)p->b.dec.size();
+  if (rc) {
+    delete p;
+    return rc;
+  }
+  const size_t         bytes = pusch_decode_bytes(p->b);
+  std::vector<uint8_t> host(bytes);
+  hipError_t           e = hipMalloc(&p->d_buf, bytes);
+  if (e != hipSuccess) {
+    miphy_set_error("miphy_pusch_decode_plan_create: hipMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
+    delete p;
+    return MIPHY_EHIP;
+  }
+  p->v = layout_pusch_decode(p->b, host.data(), (uint8_t*)p->d_buf);
+  e    = hipMemcpy(p->d_buf, host.data(), p->v.staged, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    miphy_set_error("miphy_pusch_decode_plan_create: hipMemcpy -> %s", hipGetErrorString(e));
+    (void)hipFree(p->d_buf);
+    delete p;
+    return MIPHY_EHIP;
+  }
+  // only sizes and limits are needed from here on
+  std::vector<miphy_ldpc_rdm_desc>().swap(p->b.rdm);
+  std::vector<miphy_ldpc_dec_desc>().swap(p->b.dec);
+  std::vector<uint32_t>().swap(p->b.slots);
+  *out = p;
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_pusch_decode_plan_run(miphy_pusch_decode_plan* p,
+                                           const int8_t*            llrs,
+                                           int8_t*                  harq_softbits,
+                                           uint8_t*                 harq_msgs,
+                                           uint8_t*                 harq_crc_ok,
+                                           uint8_t*                 tb_out,
+                                           miphy_pusch_result*      results,
+                                           void*                    stream)
+{
+  MIPHY_REQUIRE(p && llrs && harq_softbits && harq_msgs && harq_crc_ok && tb_out && results, "miphy_pusch_decode_plan_run: null argument");
+  hipEvent_t* ev = nullptr;
+  if (!p->events.empty()) {
+    const uint32_t cap = (uint32_t)p->events.size() / 4;
+    ev                 = &p->events[(size_t)(p->timed_runs % cap) * 4];
+    ++p->timed_runs;
+  }
+  return launch_pusch_decode(p->ctx, p->b, p->v, p->n, llrs, harq_softbits, harq_msgs, harq_crc_ok, tb_out, results, (hipStream_t)stream, ev);
+}
+
+extern "C" int miphy_pusch_decode_plan_enable_timing(miphy_pusch_decode_plan* p, uint32_t max_runs)
+{
+  MIPHY_REQUIRE(p && max_runs > 0 && max_runs <= 4096, "miphy_pusch_decode_plan_enable_timing: invalid argument");
+  if (p->ncb > 65535) {
+    miphy_set_error("miphy_pusch_decode_plan_enable_timing: %u codeblocks need several launches per kernel; per-kernel timing is only kept for single-launch batches", p->ncb);
+    return MIPHY_EUNSUPP;
+  }
+  for (hipEvent_t e : p->events)
+    (void)hipEventDestroy(e);
+  p->events.assign((size_t)max_runs * 4, nullptr);
+  for (hipEvent_t& e : p->events)
+    MIPHY_HIP_CHECK(hipEventCreate(&e));
+  p->timed_runs = 0;
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_pusch_decode_plan_read_timing(miphy_pusch_decode_plan* p, float ms_out[3], uint32_t* runs_out)
+{
+  MIPHY_REQUIRE(p && ms_out && runs_out, "miphy_pusch_decode_plan_read_timing: null argument");
+  ms_out[0] = ms_out[1] = ms_out[2] = 0.f;
+  const uint32_t cap  = (uint32_t)p->events.size() / 4;
+  const uint32_t runs = p->timed_runs < cap ? p->timed_runs : cap;
+  for (uint32_t r = 0; r < runs; ++r) {
+    hipEvent_t* ev = &p->events[(size_t)r * 4];
+    MIPHY_HIP_CHECK(hipEventSynchronize(ev[3]));
+    for (int k = 0; k < 3; ++k) {
+      float ms = 0.f;
+      MIPHY_HIP_CHECK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+      ms_out[k] += ms;
+    }
+  }
+  for (int k = 0; k < 3 && runs; ++k)
+    ms_out[k] /= (float)runs;
+  *runs_out     = runs;
+  p->timed_runs = 0;
+  return MIPHY_OK;
+}
+
+extern "C" void miphy_pusch_decode_plan_destroy(miphy_pusch_decode_plan* p)
+{
+  if (!p)
+    return;
+  if (p->d_buf)
+    (void)hipFree(p->d_buf);
+  for (hipEvent_t e : p->events)
+    (void)hipEventDestroy(e);
+  delete p;
 }
 
 extern "C" int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs, uint32_t n, const uint8_t* tb_in, uint8_t* codeword_out, void* stream)

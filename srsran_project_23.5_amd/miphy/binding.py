@@ -49,6 +49,12 @@ def lib():
         l.miphy_pdcch_encode_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_pusch_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
         l.miphy_pdsch_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_pusch_decode_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        l.miphy_pusch_decode_plan_run.argtypes = [C.c_void_p] * 8
+        l.miphy_pusch_decode_plan_destroy.argtypes = [C.c_void_p]
+        l.miphy_pusch_decode_plan_destroy.restype = None
+        l.miphy_pusch_decode_plan_enable_timing.argtypes = [C.c_void_p, C.c_uint32]
+        l.miphy_pusch_decode_plan_read_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_sch_segmentation_info.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         l.miphy_polar_decode_list_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -434,6 +440,10 @@ class Context:
         check(lib().miphy_pusch_decode_batch(self.h, C.c_void_p(tbs.ctypes.data), tbs.size, _dptr(llrs), _dptr(harq_softbits),
                                              _dptr(harq_msgs), _dptr(harq_crc_ok), _dptr(tb_out), _dptr(results), _stream_ptr(stream)))
 
+    def pusch_decode_plan(self, tbs):
+        """Prepared miphy_pusch_decode_batch (descriptors uploaded once): returns a PuschDecodePlan."""
+        return PuschDecodePlan(self, tbs)
+
     def pusch_process_batch(self, pdus, grid, harq_softbits, harq_msgs, harq_crc_ok, tb_out, results, scalars, stream=None):
         """pdus: numpy PuschPdu array (host). results: torch uint8 tensor of n * PuschResult.itemsize bytes; scalars: float32 n x 20."""
         assert isinstance(pdus, np.ndarray) and pdus.dtype == PuschPdu
@@ -456,6 +466,42 @@ class Context:
         check(lib().miphy_polar_decode_list_batch(self.h, C.byref(code), list_size, crc_mode, n, _dptr(llr),
                                                   _dptr(rnti) if rnti is not None else None, _dptr(msg_out), _dptr(crc_ok_out),
                                                   _dptr(metric_out) if metric_out is not None else None, _stream_ptr(stream)))
+
+
+class PuschDecodePlan:
+    """miphy_pusch_decode_plan_*: segmentation and descriptor upload once, run() is launches only."""
+
+    def __init__(self, ctx, tbs):
+        assert isinstance(tbs, np.ndarray) and tbs.dtype == PuschTbDesc
+        tbs = np.ascontiguousarray(tbs)
+        self.ctx, self.n = ctx, tbs.size
+        h = C.c_void_p()
+        check(lib().miphy_pusch_decode_plan_create(ctx.h, C.c_void_p(tbs.ctypes.data), tbs.size, C.byref(h)))
+        self.h = h
+
+    def run(self, llrs, harq_softbits, harq_msgs, harq_crc_ok, tb_out, results, stream=None):
+        check(lib().miphy_pusch_decode_plan_run(self.h, _dptr(llrs), _dptr(harq_softbits), _dptr(harq_msgs), _dptr(harq_crc_ok), _dptr(tb_out),
+                                                _dptr(results), _stream_ptr(stream)))
+
+    def enable_timing(self, max_runs=64):
+        check(lib().miphy_pusch_decode_plan_enable_timing(self.h, max_runs))
+
+    def read_timing(self):
+        """Mean per-kernel milliseconds of the runs since the last call: {"rate_dematch", "ldpc_decode", "tb_assemble", "runs"}."""
+        ms, runs = (C.c_float * 3)(), C.c_uint32()
+        check(lib().miphy_pusch_decode_plan_read_timing(self.h, ms, C.byref(runs)))
+        return {"rate_dematch": float(ms[0]), "ldpc_decode": float(ms[1]), "tb_assemble": float(ms[2]), "runs": int(runs.value)}
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().miphy_pusch_decode_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---------------------------------------------------------------------- HARQ softbuffer pool

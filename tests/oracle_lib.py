@@ -62,6 +62,8 @@ def ref():
         _ref.ref_ldpc_decoder_create.restype = vp
         _ref.ref_pusch_decoder_create.restype = vp
         _ref.ref_ldpc_decode_time.restype = C.c_double
+        _ref.ref_pusch_chain_bench.restype = C.c_double
+        _ref.ref_pusch_decoder_bench.restype = C.c_double
     return _ref
 
 
@@ -349,6 +351,48 @@ class RefPuschDecoder:
             ref().ref_pusch_decoder_destroy(self.h)
         except Exception:
             pass
+
+
+def host_cpus():
+    """CPUs this process may run on, and the CPU budget of its cgroup (cpu.max quota / period) when there is one."""
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return cpus, quota
+
+
+def r_pusch_chain_bench(nthreads, cpus, seconds, stage, samples, nof_prb, mod, tbs_bits, rnti, n_id, dmrs_scr_id, dft_size, window_offset,
+                        scale, center_freq_hz, max_iter, early_stop):
+    """Reference receive chain on `nthreads` pinned threads (ref_capi.cpp::ref_pusch_chain_bench). samples: [nslots][slot_samples]
+    complex64, slot s = slot-in-frame s. stage 1: OFDM demodulation + pusch_processor, 0: pusch_processor only.
+    Returns (elapsed_s, slots_done, tb_ok)."""
+    samples = np.ascontiguousarray(samples, dtype=np.complex64)
+    nslots, slot_samples = samples.shape
+    cp = (C.c_int * nthreads)(*[int(cpus[t % len(cpus)]) if cpus else -1 for t in range(nthreads)])
+    done = (C.c_uint64 * nthreads)()
+    ok = (C.c_uint64 * nthreads)()
+    dt = ref().ref_pusch_chain_bench(C.c_uint(nthreads), cp, C.c_double(seconds), int(stage), _p(samples), C.c_uint(nslots), C.c_uint(slot_samples),
+                                     C.c_uint(nof_prb), int(mod), C.c_uint(tbs_bits), C.c_uint(rnti), C.c_uint(n_id), C.c_uint(dmrs_scr_id),
+                                     C.c_uint(dft_size), C.c_uint(window_offset), C.c_float(scale), C.c_double(center_freq_hz), C.c_uint(max_iter),
+                                     int(early_stop), done, ok)
+    return float(dt), int(sum(done)), int(sum(ok))
+
+
+def r_pusch_decoder_bench(nthreads, cpus, seconds, llrs, mod, nof_ch_symbols, tbs_bits, max_iter, early_stop):
+    """Reference pusch_decoder (AVX2 dematcher + decoder) on `nthreads` pinned threads. llrs: [nslots][cw_len] int8."""
+    llrs = np.ascontiguousarray(llrs, dtype=np.int8)
+    nslots, cw_len = llrs.shape
+    cp = (C.c_int * nthreads)(*[int(cpus[t % len(cpus)]) if cpus else -1 for t in range(nthreads)])
+    done = (C.c_uint64 * nthreads)()
+    ok = (C.c_uint64 * nthreads)()
+    dt = ref().ref_pusch_decoder_bench(C.c_uint(nthreads), cp, C.c_double(seconds), _p(llrs), C.c_uint(nslots), C.c_uint(cw_len), int(mod),
+                                       C.c_uint(nof_ch_symbols), C.c_uint(tbs_bits), C.c_uint(max_iter), int(early_stop), done, ok)
+    return float(dt), int(sum(done)), int(sum(ok))
 
 
 def r_dft(x, inverse=False):

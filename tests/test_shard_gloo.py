@@ -33,22 +33,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nof_units, q):
+def _worker(rank, world, port, nof_units, block, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         payload = torch.arange(nof_units * 6, dtype=torch.int32).reshape(nof_units, 2, 3)
-        if rank == 0:
-            mine = shard.scatter_units(payload, nof_units, 0)
-        else:
-            mine = shard.recv_units(nof_units, 0, torch.int32, torch.device("cpu"))
-        idx = shard.assign(nof_units, world, rank)
+        # every rank makes the same call; only the source's payload is read
+        mine = shard.scatter_units(payload if rank == 0 else None, nof_units, 0, (2, 3), torch.int32, torch.device("cpu"), block=block)
+        idx = shard.assign(nof_units, world, rank, block)
         ok = torch.equal(mine, payload[torch.as_tensor(idx)])
-        # "process" the units (stand-in for the HIP path: a deterministic function of the unit payload) and gather
-        local = mine.reshape(len(idx), -1).sum(dim=1, keepdim=True).to(torch.int64)
-        allres = shard.gather_results(local, nof_units)
-        exp = payload.reshape(nof_units, -1).sum(dim=1, keepdim=True).to(torch.int64)
+        # a per-unit result record (here a checksum of the unit's payload; the HIP path in both ranks is covered by
+        # tests/test_shard_hip_gpu.py) gathered back into unit order
+        local = mine.reshape(len(idx), 6).sum(dim=1, keepdim=True).to(torch.int64)
+        allres = shard.gather_results(local, nof_units, block=block)
+        exp = payload.reshape(nof_units, 6).sum(dim=1, keepdim=True).to(torch.int64)
         ok = ok and torch.equal(allres, exp)
         # the timing reduction bench.py uses
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
@@ -61,13 +60,14 @@ def _worker(rank, world, port, nof_units, q):
 
 
 @pytest.mark.timeout(120)
-def test_scatter_process_gather_world2():
-    world, nof_units = 2, 11
+@pytest.mark.parametrize("nof_units,block", [(11, 1), (38, 4), (1, 1)])
+def test_scatter_process_gather_world2(nof_units, block):
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, nof_units, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nof_units, block, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = [q.get(timeout=100) for _ in range(world)]
+    res = [q.get(timeout=60) for _ in range(world)]
     [p.join(30) for p in procs]
     assert sorted(res) == [(0, True), (1, True)]

@@ -1,90 +1,105 @@
-// Probe: issue cost (cycles per wave64 instruction per SIMD) of the packed-16 VALU instructions the LDPC decoder uses.
+// Probe: VALU issue cost on gfx950 in SHADER CYCLES (s_memtime), independent of any assumed clock: cycles a SIMD spends per wave64
+// instruction when W waves per SIMD run the same independent-instruction stream, W = 1, 2, 3, 4, 8, for the instruction classes the
+// LDPC decoder is made of (VOP3P packed 16-bit, v_perm_b32, plain VOP2 integer) and for the decoder's measured instruction mix.
+// MI355X_MICROARCH.md:54,473 gives 4 cycles for a lone wave and 2 cycles per wave64 VALU instruction once >= 2 waves are resident;
+// this program is the measurement bench.py's `roofline_valu` cites (profiles/r02_valu_probe.txt).
 // build: hipcc -O2 --offload-arch=gfx950 tools/valu_probe.hip -o tools/valu_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <vector>
 
-#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define BODY8(ASM)                                        \
+  asm volatile(ASM "\n" : "+v"(r[0]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[1]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[2]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[3]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[4]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[5]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[6]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[7]) : "v"(a), "v"(b));
 
-#define DEF_KERNEL(NAME, ASM)                                                                             \
-  __global__ void __launch_bounds__(256) NAME(unsigned* out, int iters)                                  \
-  {                                                                                                       \
-    unsigned r[8], a = threadIdx.x * 2654435761u, b = threadIdx.x + 77u;                                  \
-    for (int i = 0; i < 8; ++i)                                                                           \
-      r[i] = a + i;                                                                                       \
-    for (int it = 0; it < iters; ++it) {                                                                  \
-      _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                       \
-      {                                                                                                   \
-        asm volatile(ASM "\n" : "+v"(r[0]) : "v"(a), "v"(b));                                             \
-        asm volatile(ASM "\n" : "+v"(r[1]) : "v"(a), "v"(b));                                             \
-        asm volatile(ASM "\n" : "+v"(r[2]) : "v"(a), "v"(b));                                             \
-        asm volatile(ASM "\n" : "+v"(r[3]) : "v"(a), "v"(b));                                             \
-        asm volatile(ASM "\n" : "+v"(r[4]) : "v"(a), "v"(b));                                             \
-        asm volatile(ASM "\n" : "+v"(r[5]) : "v"(a), "v"(b));                                             \
-        asm volatile(ASM "\n" : "+v"(r[6]) : "v"(a), "v"(b));                                             \
-        asm volatile(ASM "\n" : "+v"(r[7]) : "v"(a), "v"(b));                                             \
-      }                                                                                                   \
-    }                                                                                                     \
-    unsigned acc = 0;                                                                                     \
-    for (int i = 0; i < 8; ++i)                                                                           \
-      acc ^= r[i];                                                                                        \
-    if (acc == 0x12345678)                                                                                \
-      out[0] = acc;                                                                                       \
+#define DEF_KERNEL(NAME, ...)                                                                      \
+  __global__ void __launch_bounds__(256) NAME(unsigned long long* cyc, unsigned* sink, int iters) \
+  {                                                                                                \
+    unsigned r[8], a = threadIdx.x * 2654435761u, b = threadIdx.x + 77u;                           \
+    for (int i = 0; i < 8; ++i)                                                                    \
+      r[i] = a + i;                                                                                \
+    __syncthreads();                                                                               \
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                    \
+    for (int it = 0; it < iters; ++it) {                                                           \
+      __VA_ARGS__                                                                                  \
+    }                                                                                              \
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                    \
+    unsigned acc = 0;                                                                              \
+    for (int i = 0; i < 8; ++i)                                                                    \
+      acc ^= r[i];                                                                                 \
+    if (acc == 0x12345678)                                                                         \
+      sink[0] = acc;                                                                               \
+    if ((threadIdx.x & 63) == 0)                                                                   \
+      cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;                            \
   }
 
-DEF_KERNEL(k_add32, "v_add_u32 %0, %1, %0")
-DEF_KERNEL(k_pk_add, "v_pk_add_u16 %0, %1, %0")
-DEF_KERNEL(k_pk_sub, "v_pk_sub_i16 %0, %1, %0")
-DEF_KERNEL(k_pk_min, "v_pk_min_i16 %0, %1, %0")
-DEF_KERNEL(k_pk_max, "v_pk_max_i16 %0, %1, %0")
-DEF_KERNEL(k_pk_mad, "v_pk_mad_u16 %0, %1, %2, %0")
-DEF_KERNEL(k_pk_mul, "v_pk_mul_lo_u16 %0, %1, %0")
-DEF_KERNEL(k_pk_ashr, "v_pk_ashrrev_i16 %0, 3, %0")
-DEF_KERNEL(k_pk_lshl, "v_pk_lshlrev_b16 %0, 3, %0")
-DEF_KERNEL(k_perm, "v_perm_b32 %0, %1, %0, %2")
-DEF_KERNEL(k_xor, "v_xor_b32 %0, %1, %0")
-DEF_KERNEL(k_bfi, "v_bfi_b32 %0, %1, %2, %0")
-DEF_KERNEL(k_min_u32, "v_min_u32 %0, %1, %0")
-DEF_KERNEL(k_mad_u24, "v_mad_u32_u24 %0, %1, %2, %0")
-DEF_KERNEL(k_mul_lo, "v_mul_lo_u32 %0, %1, %0")
-DEF_KERNEL(k_dep_pk, "v_pk_add_u16 %0, %0, %0\n v_pk_min_i16 %0, %0, %1") /* two dependent packed ops incl. hazard nops? none inserted in asm */
+// 32 instructions per loop iteration in every kernel
+DEF_KERNEL(k_add32, BODY8("v_add_u32 %0, %1, %0") BODY8("v_add_u32 %0, %1, %0") BODY8("v_add_u32 %0, %1, %0") BODY8("v_add_u32 %0, %1, %0"))
+DEF_KERNEL(k_fma32, BODY8("v_fma_f32 %0, %1, %2, %0") BODY8("v_fma_f32 %0, %1, %2, %0") BODY8("v_fma_f32 %0, %1, %2, %0") BODY8("v_fma_f32 %0, %1, %2, %0"))
+DEF_KERNEL(k_pk_add, BODY8("v_pk_add_u16 %0, %1, %0") BODY8("v_pk_add_u16 %0, %1, %0") BODY8("v_pk_add_u16 %0, %1, %0") BODY8("v_pk_add_u16 %0, %1, %0"))
+DEF_KERNEL(k_pk_min, BODY8("v_pk_min_i16 %0, %1, %0") BODY8("v_pk_min_i16 %0, %1, %0") BODY8("v_pk_min_i16 %0, %1, %0") BODY8("v_pk_min_i16 %0, %1, %0"))
+DEF_KERNEL(k_pk_mad, BODY8("v_pk_mad_u16 %0, %1, %2, %0") BODY8("v_pk_mad_u16 %0, %1, %2, %0") BODY8("v_pk_mad_u16 %0, %1, %2, %0") BODY8("v_pk_mad_u16 %0, %1, %2, %0"))
+DEF_KERNEL(k_pk_fma_f32, BODY8("v_xor_b32 %0, %1, %0") BODY8("v_xor_b32 %0, %1, %0") BODY8("v_xor_b32 %0, %1, %0") BODY8("v_xor_b32 %0, %1, %0"))
+DEF_KERNEL(k_perm, BODY8("v_perm_b32 %0, %1, %0, %2") BODY8("v_perm_b32 %0, %1, %0, %2") BODY8("v_perm_b32 %0, %1, %0, %2") BODY8("v_perm_b32 %0, %1, %0, %2"))
+DEF_KERNEL(k_bfi, BODY8("v_bfi_b32 %0, %1, %2, %0") BODY8("v_bfi_b32 %0, %1, %2, %0") BODY8("v_bfi_b32 %0, %1, %2, %0") BODY8("v_bfi_b32 %0, %1, %2, %0"))
+DEF_KERNEL(k_med3_i16, BODY8("v_med3_i16 %0, %1, %2, %0") BODY8("v_med3_i16 %0, %1, %2, %0") BODY8("v_med3_i16 %0, %1, %2, %0") BODY8("v_med3_i16 %0, %1, %2, %0"))
+DEF_KERNEL(k_min3_i16, BODY8("v_min3_i16 %0, %1, %2, %0") BODY8("v_min3_i16 %0, %1, %2, %0") BODY8("v_min3_i16 %0, %1, %2, %0") BODY8("v_min3_i16 %0, %1, %2, %0"))
+// the packed decoder's mix per 32: 16 VOP3P (add/sub/min/max/mad), 4 v_perm_b32, 12 VOP2/VOP3 32-bit integer
+DEF_KERNEL(k_mix, BODY8("v_pk_add_u16 %0, %1, %0") BODY8("v_pk_min_i16 %0, %1, %0")
+           asm volatile("v_perm_b32 %0, %4, %0, %5\n v_perm_b32 %1, %4, %1, %5\n v_perm_b32 %2, %4, %2, %5\n v_perm_b32 %3, %4, %3, %5\n"
+                        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "v"(a), "v"(b));
+           asm volatile("v_xor_b32 %0, %4, %0\n v_add_u32 %1, %4, %1\n v_and_b32 %2, %4, %2\n v_min_u32 %3, %4, %3\n"
+                        : "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(a));
+           BODY8("v_add_u32 %0, %1, %0"))
 
 template <typename K>
-void run(const char* name, K kern, unsigned* d, int per_asm = 1)
+void run(const char* name, K kern, unsigned long long* d_cyc, unsigned* d_sink, int instr_per_iter)
 {
-  const int  iters = 4000, grid = 256 * 3; // 3 WGs of 4 waves per CU -> 3 waves per SIMD
-  hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d, 10);
-  hipEventRecord(e0);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d, iters);
-  hipEventRecord(e1);
-  hipEventSynchronize(e1);
-  float ms;
-  hipEventElapsedTime(&ms, e0, e1);
-  const double instr_per_simd = 3.0 * iters * 32 * per_asm;
-  printf("%-16s %.3f ms -> %.2f cycles per wave64 instruction per SIMD at 2.4 GHz\n", name, ms, ms * 1e6 * 2.4 / instr_per_simd);
+  const int iters = 2000;
+  printf("%-26s", name);
+  for (int W : {1, 2, 3, 4, 8}) {
+    // W workgroups of 4 waves per CU -> W waves per SIMD (256 CUs)
+    const int grid = 256 * W;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d_cyc, d_sink, 10);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d_cyc, d_sink, iters);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(grid * 4);
+    hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum = 0;
+    for (auto v : h)
+      sum += (double)v;
+    const double per_wave = sum / h.size();                         // cycles one wave needed for its stream
+    const double per_simd = per_wave / ((double)iters * instr_per_iter) / W; // SIMD cycles per wave64 instruction with W waves sharing it
+    printf("  W=%d: %5.2f", W, per_simd);
+  }
+  printf("   (SIMD cycles per wave64 instruction)\n");
 }
 
 int main()
 {
-  unsigned* d;
-  hipMalloc(&d, 64);
-  run("v_add_u32", k_add32, d);
-  run("v_pk_add_u16", k_pk_add, d);
-  run("v_pk_sub_i16", k_pk_sub, d);
-  run("v_pk_min_i16", k_pk_min, d);
-  run("v_pk_max_i16", k_pk_max, d);
-  run("v_pk_mad_u16", k_pk_mad, d);
-  run("v_pk_mul_lo_u16", k_pk_mul, d);
-  run("v_pk_ashrrev_i16", k_pk_ashr, d);
-  run("v_pk_lshlrev_b16", k_pk_lshl, d);
-  run("v_perm_b32", k_perm, d);
-  run("v_xor_b32", k_xor, d);
-  run("v_bfi_b32", k_bfi, d);
-  run("v_min_u32", k_min_u32, d);
-  run("v_mad_u32_u24", k_mad_u24, d);
-  run("v_mul_lo_u32", k_mul_lo, d);
-  run("dep pk pair", k_dep_pk, d, 2);
+  unsigned long long* d_cyc;
+  unsigned*           d_sink;
+  hipMalloc(&d_cyc, 256 * 8 * 4 * 8);
+  hipMalloc(&d_sink, 64);
+  hipDeviceProp_t pr;
+  hipGetDeviceProperties(&pr, 0);
+  printf("device %s, %d CUs, clock %d MHz; W = waves per SIMD\n", pr.gcnArchName, pr.multiProcessorCount, pr.clockRate / 1000);
+  run("v_add_u32 (VOP2)", k_add32, d_cyc, d_sink, 32);
+  run("v_fma_f32 (VOP3)", k_fma32, d_cyc, d_sink, 32);
+  run("v_xor_b32 (VOP2)", k_pk_fma_f32, d_cyc, d_sink, 32);
+  run("v_pk_add_u16 (VOP3P)", k_pk_add, d_cyc, d_sink, 32);
+  run("v_pk_min_i16 (VOP3P)", k_pk_min, d_cyc, d_sink, 32);
+  run("v_pk_mad_u16 (VOP3P)", k_pk_mad, d_cyc, d_sink, 32);
+  run("v_perm_b32 (VOP3)", k_perm, d_cyc, d_sink, 32);
+  run("v_bfi_b32 (VOP3)", k_bfi, d_cyc, d_sink, 32);
+  run("v_med3_i16 (VOP3)", k_med3_i16, d_cyc, d_sink, 32);
+  run("v_min3_i16 (VOP3)", k_min3_i16, d_cyc, d_sink, 32);
+  run("decoder mix 16pk/4perm/12i32", k_mix, d_cyc, d_sink, 32);
   return 0;
 }
