@@ -477,7 +477,7 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   if ((force && force[0] == 'p') || g_force_kernel == 2)
     use_pk = pk_ok;
   if (use_pk)
-    return miphy_ldpc_pk_launch((const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, n, pk_threads, pk_lds, llr, out_bits, iters, nodes_all, harq_slot,
+    return miphy_ldpc_pk_launch(ctx, (const miphy_ldpc_dec_desc*)d_descs, n, pk_threads, pk_lds, llr, out_bits, iters, nodes_all, harq_slot,
                                 harq_crc_ok, s);
   // Above the default 64 KB of dynamic LDS the limit has to be raised; it is a per-device attribute of the kernel, so it is set on
   // every such launch (a cache per thread would be wrong for a thread that drives several devices).

@@ -10,6 +10,7 @@
 // 64 consecutive words: conflict-free, immediate offsets, and only one LDS read and one LDS write per TWO edges (measured on
 // gfx950: a DS write costs ~5 cycles of the CU's LDS pipe whatever its width, a read ~2.8 -- tools/lds_probe.hip).
 #include "miphy_internal.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -266,12 +267,18 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                       int32_t* __restrict__ iters_out,
                       int max_nodes,
                       const uint32_t* __restrict__ harq_slot,
-                      uint8_t* __restrict__ harq_crc_ok)
+                      uint8_t* __restrict__ harq_crc_ok,
+                      uint32_t n,
+                      uint32_t* __restrict__ queue)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const miphy_ldpc_dec_desc dsc = descs[blockIdx.x];
-  const int                 tid = threadIdx.x;
-  const int                 nt  = blockDim.x;
+  const int tid = threadIdx.x;
+  const int nt  = blockDim.x;
+  // Persistent workgroups: the grid is what the chip holds at once; a workgroup decodes codeblock blockIdx.x first and then takes
+  // codeblocks gridDim.x, gridDim.x + 1, ... from the launch's queue counter until the batch is exhausted (every wave reaches the
+  // exit: the counter only grows). No workgroup launch / LDS allocation between codeblocks, and heterogeneous batches balance.
+  for (uint32_t cb = blockIdx.x; cb < n;) {
+  const miphy_ldpc_dec_desc dsc = descs[cb];
   const int                 Z   = dsc.Z;
   const int                 H   = (Z + 1) >> 1;
   const int                 bgi = (dsc.bg == 1) ? 0 : 1;
@@ -291,16 +298,22 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   uint32_t* c2v_lane   = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (tid >> 6) * (pairs_all * 64) + (tid & 63);
   uint32_t* red        = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (nt >> 6) * (pairs_all * 64);
 
-  if (harq_crc_ok && harq_crc_ok[harq_slot[blockIdx.x]]) {
+  // Next codeblock of this workgroup (taken now so that the queue round trip is off the critical path).
+  __syncthreads(); // the previous codeblock's readers of red[] / soft[] are done
+  if (tid == 0)
+    red[15] = gridDim.x + atomicAdd(queue, 1u);
+  if (harq_crc_ok && harq_crc_ok[harq_slot[cb]]) {
     if (tid == 0)
-      iters_out[blockIdx.x] = -1;
-    return;
+      iters_out[cb] = -1;
+    __syncthreads();
+    cb = red[15];
+    continue;
   }
   const int8_t* llr    = llr_base + dsc.llr_offset;
   uint8_t*      out    = out_base + dsc.out_offset;
   const int     in_len = (int)dsc.in_len;
 
-  if (tid < 16)
+  if (tid < 15)
     red[tid] = 0;
   for (int k = tid; k < 2 * Z; k += nt)
     soft[k] = 0;
@@ -348,8 +361,9 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       }
     }
     if (tid == 0)
-      iters_out[blockIdx.x] = 0;
-    return;
+      iters_out[cb] = 0;
+    cb = red[15];
+    continue;
   }
   int cb_len = max(last + 2 * Z, K + 4 * Z);
   cb_len     = ((cb_len + Z - 1) / Z) * Z;
@@ -400,10 +414,12 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       out[4 * t + q] = (uint8_t)(w >> (24 - 8 * q));
   }
   if (tid == 0) {
-    iters_out[blockIdx.x] = result_iters;
+    iters_out[cb] = result_iters;
     if (harq_crc_ok && result_iters > 0)
-      harq_crc_ok[harq_slot[blockIdx.x]] = 1;
+      harq_crc_ok[harq_slot[cb]] = 1;
   }
+  cb = red[15];
+  } // codeblock loop
 }
 
 } // namespace
@@ -416,7 +432,7 @@ size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all)
   return ((((size_t)bgK + lay) * Zt + 15) & ~(size_t)15) + waves * (size_t)pairs_all * 256 + 64;
 }
 
-int miphy_ldpc_pk_launch(const miphy_ldpc_dec_desc* d_descs, const miphy_graph_tables* tab, uint32_t n, int threads, size_t lds, const int8_t* llr,
+int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                          uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s)
 {
   static const char* pad = getenv("MIPHY_LDPC_PAD_LDS"); // occupancy experiments only
@@ -427,7 +443,18 @@ int miphy_ldpc_pk_launch(const miphy_ldpc_dec_desc* d_descs, const miphy_graph_t
   if (lds > 48 * 1024) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_pk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL(ldpc_decode_pk_kernel, dim3(n), dim3(threads), lds, s, d_descs, tab, llr, out_bits, iters, nodes_all, harq_slot, harq_crc_ok);
+  // Resident workgroups per CU: LDS, the 12 wavefronts per CU the register budget of the kernel allows (__launch_bounds__), 32 slots.
+  const int waves = threads / 64;
+  int       per_cu = (int)((size_t)160 * 1024 / lds);
+  per_cu           = std::min(per_cu, (4 * LDPC_PK_MIN_WAVES) / waves);
+  per_cu           = std::max(per_cu, 1);
+  const uint32_t grid = std::min<uint32_t>(n, (uint32_t)(ctx->num_cus * per_cu));
+  uint32_t*      queue = nullptr;
+  int            rc    = miphy_next_queue_counter(ctx, s, &queue);
+  if (rc)
+    return rc;
+  hipLaunchKernelGGL(ldpc_decode_pk_kernel, dim3(grid), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot, harq_crc_ok,
+                     n, queue);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

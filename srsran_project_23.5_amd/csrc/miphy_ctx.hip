@@ -141,6 +141,8 @@ extern "C" int miphy_create(int device, miphy_ctx** out)
   c->desc_staging_bytes = 4u << 20;
   MIPHY_HIP_CHECK(hipMalloc(&c->d_desc_staging, c->desc_staging_bytes));
   MIPHY_HIP_CHECK(hipHostMalloc(&c->h_desc_staging, c->desc_staging_bytes, hipHostMallocDefault));
+  MIPHY_HIP_CHECK(hipMalloc((void**)&c->d_queue, MIPHY_NOF_QUEUE_COUNTERS * sizeof(uint32_t)));
+  c->queue_next = 0;
   *out = c;
   return MIPHY_OK;
 }
@@ -155,11 +157,22 @@ extern "C" void miphy_destroy(miphy_ctx* c)
     (void)hipFree(p);
   delete c->ext;
   (void)hipFree(c->d_desc_staging);
+  (void)hipFree(c->d_queue);
   for (void* w : c->d_work)
     (void)hipFree(w);
   (void)hipHostFree(c->h_desc_staging);
   free(c->h_tables);
   delete c;
+}
+
+int miphy_next_queue_counter(miphy_ctx* ctx, hipStream_t s, uint32_t** out)
+{
+  // A launch owns its counter until MIPHY_NOF_QUEUE_COUNTERS later launches of this context have been enqueued; the zeroing is
+  // ordered on the launch's own stream.
+  uint32_t* c = ctx->d_queue + (ctx->queue_next++ % MIPHY_NOF_QUEUE_COUNTERS);
+  MIPHY_HIP_CHECK(hipMemsetAsync(c, 0, sizeof(uint32_t), s));
+  *out = c;
+  return MIPHY_OK;
 }
 
 int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t bytes, hipStream_t s, const void** out)

@@ -98,29 +98,37 @@ __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_de
   const tb_asm_desc d   = descs[blockIdx.x];
   const int         tid = threadIdx.x;
   uint8_t*          tmp = tmp_tb_base + tmp_off[blockIdx.x];
-  if (tid == 0) {
+  if (tid < 64) {
+    // one lane per codeblock (at most 52), reduced across the first wavefront
     int      ok = 1;
     uint32_t mn = 0xffffffffu, mx = 0, cnt = 0, sum = 0;
-    for (uint32_t c = 0; c < d.nof_cbs; ++c) {
-      ok &= harq_crc_ok[d.harq_cb_index + c] != 0;
-      const int it = iters[d.first_desc + c];
+    if ((uint32_t)tid < d.nof_cbs) {
+      ok           = harq_crc_ok[d.harq_cb_index + tid] != 0;
+      const int it = iters[d.first_desc + tid];
       if (it >= 0) { // decoded in this call: stats.update(iterations or max) (pusch_decoder_impl.cpp:188-194)
         const uint32_t v = it > 0 ? (uint32_t)it : d.max_iter;
-        mn = v < mn ? v : mn;
-        mx = v > mx ? v : mx;
-        sum += v;
-        ++cnt;
+        mn = v, mx = v, sum = v, cnt = 1;
       }
     }
-    all_ok = ok;
-    miphy_pusch_result r;
-    r.tb_crc_ok            = 0;
-    r.nof_codeblocks_total = d.nof_cbs;
-    r.iters_min            = cnt ? mn : 0;
-    r.iters_max            = mx;
-    r.iters_mean           = cnt ? (float)sum / (float)cnt : 0.f;
-    r.nof_decoded          = cnt;
-    results[blockIdx.x]    = r;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      ok &= __shfl_xor(ok, off);
+      mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+      mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+      sum += (uint32_t)__shfl_xor((int)sum, off);
+      cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    }
+    if (tid == 0) {
+      all_ok = ok;
+      miphy_pusch_result r;
+      r.tb_crc_ok            = 0;
+      r.nof_codeblocks_total = d.nof_cbs;
+      r.iters_min            = cnt ? mn : 0;
+      r.iters_max            = mx;
+      r.iters_mean           = cnt ? (float)sum / (float)cnt : 0.f;
+      r.nof_decoded          = cnt;
+      results[blockIdx.x]    = r;
+    }
   }
   __syncthreads();
   if (!all_ok)

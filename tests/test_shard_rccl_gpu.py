@@ -25,10 +25,10 @@ def test_collectives_on_device_single_rank(ctx):
         dev = torch.device("cuda", 0)
         nof_units = 38
         payload = torch.arange(nof_units * 6, dtype=torch.int32, device=dev).reshape(nof_units, 2, 3)
-        mine = shard.scatter_units(payload, nof_units, 0)
+        mine = shard.scatter_units(payload, nof_units, 0, (2, 3), torch.int32, dev, block=2)
         assert torch.equal(mine, payload)
         local = mine.reshape(nof_units, -1).sum(dim=1, keepdim=True).to(torch.int64)
-        allres = shard.gather_results(local, nof_units)
+        allres = shard.gather_results(local, nof_units, block=2)
         assert allres.is_cuda and torch.equal(allres, local)
         t = torch.tensor([1.25], dtype=torch.float64, device=dev)
         dist.barrier()

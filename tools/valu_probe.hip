@@ -39,17 +39,37 @@
       cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;                            \
   }
 
-// 32 instructions per loop iteration in every kernel
-DEF_KERNEL(k_add32, BODY8("v_add_u32 %0, %1, %0") BODY8("v_add_u32 %0, %1, %0") BODY8("v_add_u32 %0, %1, %0") BODY8("v_add_u32 %0, %1, %0"))
-DEF_KERNEL(k_fma32, BODY8("v_fma_f32 %0, %1, %2, %0") BODY8("v_fma_f32 %0, %1, %2, %0") BODY8("v_fma_f32 %0, %1, %2, %0") BODY8("v_fma_f32 %0, %1, %2, %0"))
-DEF_KERNEL(k_pk_add, BODY8("v_pk_add_u16 %0, %1, %0") BODY8("v_pk_add_u16 %0, %1, %0") BODY8("v_pk_add_u16 %0, %1, %0") BODY8("v_pk_add_u16 %0, %1, %0"))
-DEF_KERNEL(k_pk_min, BODY8("v_pk_min_i16 %0, %1, %0") BODY8("v_pk_min_i16 %0, %1, %0") BODY8("v_pk_min_i16 %0, %1, %0") BODY8("v_pk_min_i16 %0, %1, %0"))
-DEF_KERNEL(k_pk_mad, BODY8("v_pk_mad_u16 %0, %1, %2, %0") BODY8("v_pk_mad_u16 %0, %1, %2, %0") BODY8("v_pk_mad_u16 %0, %1, %2, %0") BODY8("v_pk_mad_u16 %0, %1, %2, %0"))
-DEF_KERNEL(k_pk_fma_f32, BODY8("v_xor_b32 %0, %1, %0") BODY8("v_xor_b32 %0, %1, %0") BODY8("v_xor_b32 %0, %1, %0") BODY8("v_xor_b32 %0, %1, %0"))
-DEF_KERNEL(k_perm, BODY8("v_perm_b32 %0, %1, %0, %2") BODY8("v_perm_b32 %0, %1, %0, %2") BODY8("v_perm_b32 %0, %1, %0, %2") BODY8("v_perm_b32 %0, %1, %0, %2"))
-DEF_KERNEL(k_bfi, BODY8("v_bfi_b32 %0, %1, %2, %0") BODY8("v_bfi_b32 %0, %1, %2, %0") BODY8("v_bfi_b32 %0, %1, %2, %0") BODY8("v_bfi_b32 %0, %1, %2, %0"))
-DEF_KERNEL(k_med3_i16, BODY8("v_med3_i16 %0, %1, %2, %0") BODY8("v_med3_i16 %0, %1, %2, %0") BODY8("v_med3_i16 %0, %1, %2, %0") BODY8("v_med3_i16 %0, %1, %2, %0"))
-DEF_KERNEL(k_min3_i16, BODY8("v_min3_i16 %0, %1, %2, %0") BODY8("v_min3_i16 %0, %1, %2, %0") BODY8("v_min3_i16 %0, %1, %2, %0") BODY8("v_min3_i16 %0, %1, %2, %0"))
+#define B32(ASM) BODY8(ASM) BODY8(ASM) BODY8(ASM) BODY8(ASM)
+#define B128(ASM) B32(ASM) B32(ASM) B32(ASM) B32(ASM)
+// 128 instructions per loop iteration in the single-instruction kernels (loop overhead < 3 %), 32 in the mix
+DEF_KERNEL(k_add32, B128("v_add_u32 %0, %1, %0"))
+DEF_KERNEL(k_add32_e64, B128("v_add_u32_e64 %0, %1, %0"))
+DEF_KERNEL(k_xor, B128("v_xor_b32 %0, %1, %0"))
+DEF_KERNEL(k_mov, B128("v_mov_b32 %0, %1"))
+DEF_KERNEL(k_addf, B128("v_add_f32 %0, %1, %0"))
+DEF_KERNEL(k_fmac, B128("v_fmac_f32 %0, %1, %2"))
+DEF_KERNEL(k_fma32, B128("v_fma_f32 %0, %1, %2, %0"))
+DEF_KERNEL(k_add16, B128("v_add_u16 %0, %1, %0"))
+DEF_KERNEL(k_min16, B128("v_min_i16 %0, %1, %0"))
+DEF_KERNEL(k_min32, B128("v_min_i32 %0, %1, %0"))
+DEF_KERNEL(k_lshl, B128("v_lshlrev_b32 %0, 3, %0"))
+DEF_KERNEL(k_cndmask, B128("v_cndmask_b32 %0, %1, %0, vcc"))
+DEF_KERNEL(k_add3, B128("v_add3_u32 %0, %1, %2, %0"))
+DEF_KERNEL(k_and_or, B128("v_and_or_b32 %0, %1, %2, %0"))
+DEF_KERNEL(k_lshl_add, B128("v_lshl_add_u32 %0, %1, 2, %0"))
+DEF_KERNEL(k_med3_i32, B128("v_med3_i32 %0, %1, %2, %0"))
+DEF_KERNEL(k_sdwa, B128("v_add_u32_sdwa %0, %1, %0 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:DWORD"))
+DEF_KERNEL(k_dpp, B128("v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf"))
+DEF_KERNEL(k_pk_add, B128("v_pk_add_u16 %0, %1, %0"))
+DEF_KERNEL(k_pk_min, B128("v_pk_min_i16 %0, %1, %0"))
+DEF_KERNEL(k_pk_mad, B128("v_pk_mad_u16 %0, %1, %2, %0"))
+DEF_KERNEL(k_perm, B128("v_perm_b32 %0, %1, %0, %2"))
+DEF_KERNEL(k_bfi, B128("v_bfi_b32 %0, %1, %2, %0"))
+DEF_KERNEL(k_bfe, B128("v_bfe_i32 %0, %0, 3, 8"))
+DEF_KERNEL(k_med3_i16, B128("v_med3_i16 %0, %1, %2, %0"))
+DEF_KERNEL(k_min3_i16, B128("v_min3_i16 %0, %1, %2, %0"))
+DEF_KERNEL(k_sad_u8, B128("v_sad_u8 %0, %1, %2, %0"))
+DEF_KERNEL(k_dot4, B128("v_dot4_i32_i8 %0, %1, %2, %0"))
 // the packed decoder's mix per 32: 16 VOP3P (add/sub/min/max/mad), 4 v_perm_b32, 12 VOP2/VOP3 32-bit integer
 DEF_KERNEL(k_mix, BODY8("v_pk_add_u16 %0, %1, %0") BODY8("v_pk_min_i16 %0, %1, %0")
            asm volatile("v_perm_b32 %0, %4, %0, %5\n v_perm_b32 %1, %4, %1, %5\n v_perm_b32 %2, %4, %2, %5\n v_perm_b32 %3, %4, %3, %5\n"
@@ -61,7 +81,7 @@ DEF_KERNEL(k_mix, BODY8("v_pk_add_u16 %0, %1, %0") BODY8("v_pk_min_i16 %0, %1, %
 template <typename K>
 void run(const char* name, K kern, unsigned long long* d_cyc, unsigned* d_sink, int instr_per_iter)
 {
-  const int iters = 2000;
+  const int iters = instr_per_iter >= 128 ? 500 : 2000;
   printf("%-26s", name);
   for (int W : {1, 2, 3, 4, 8}) {
     // W workgroups of 4 waves per CU -> W waves per SIMD (256 CUs)
@@ -90,16 +110,34 @@ int main()
   hipDeviceProp_t pr;
   hipGetDeviceProperties(&pr, 0);
   printf("device %s, %d CUs, clock %d MHz; W = waves per SIMD\n", pr.gcnArchName, pr.multiProcessorCount, pr.clockRate / 1000);
-  run("v_add_u32 (VOP2)", k_add32, d_cyc, d_sink, 32);
-  run("v_fma_f32 (VOP3)", k_fma32, d_cyc, d_sink, 32);
-  run("v_xor_b32 (VOP2)", k_pk_fma_f32, d_cyc, d_sink, 32);
-  run("v_pk_add_u16 (VOP3P)", k_pk_add, d_cyc, d_sink, 32);
-  run("v_pk_min_i16 (VOP3P)", k_pk_min, d_cyc, d_sink, 32);
-  run("v_pk_mad_u16 (VOP3P)", k_pk_mad, d_cyc, d_sink, 32);
-  run("v_perm_b32 (VOP3)", k_perm, d_cyc, d_sink, 32);
-  run("v_bfi_b32 (VOP3)", k_bfi, d_cyc, d_sink, 32);
-  run("v_med3_i16 (VOP3)", k_med3_i16, d_cyc, d_sink, 32);
-  run("v_min3_i16 (VOP3)", k_min3_i16, d_cyc, d_sink, 32);
+  run("v_add_u32 e32 (VOP2)", k_add32, d_cyc, d_sink, 128);
+  run("v_add_u32 e64 (VOP3)", k_add32_e64, d_cyc, d_sink, 128);
+  run("v_xor_b32 (VOP2)", k_xor, d_cyc, d_sink, 128);
+  run("v_mov_b32 (VOP1)", k_mov, d_cyc, d_sink, 128);
+  run("v_add_f32 (VOP2)", k_addf, d_cyc, d_sink, 128);
+  run("v_fmac_f32 (VOP2)", k_fmac, d_cyc, d_sink, 128);
+  run("v_fma_f32 (VOP3)", k_fma32, d_cyc, d_sink, 128);
+  run("v_add_u16 (VOP2)", k_add16, d_cyc, d_sink, 128);
+  run("v_min_i16 (VOP2)", k_min16, d_cyc, d_sink, 128);
+  run("v_min_i32 (VOP2)", k_min32, d_cyc, d_sink, 128);
+  run("v_lshlrev_b32 (VOP2)", k_lshl, d_cyc, d_sink, 128);
+  run("v_cndmask_b32 (VOP2)", k_cndmask, d_cyc, d_sink, 128);
+  run("v_add3_u32 (VOP3)", k_add3, d_cyc, d_sink, 128);
+  run("v_and_or_b32 (VOP3)", k_and_or, d_cyc, d_sink, 128);
+  run("v_lshl_add_u32 (VOP3)", k_lshl_add, d_cyc, d_sink, 128);
+  run("v_med3_i32 (VOP3)", k_med3_i32, d_cyc, d_sink, 128);
+  run("v_add_u32_sdwa", k_sdwa, d_cyc, d_sink, 128);
+  run("v_add_u32_dpp", k_dpp, d_cyc, d_sink, 128);
+  run("v_pk_add_u16 (VOP3P)", k_pk_add, d_cyc, d_sink, 128);
+  run("v_pk_min_i16 (VOP3P)", k_pk_min, d_cyc, d_sink, 128);
+  run("v_pk_mad_u16 (VOP3P)", k_pk_mad, d_cyc, d_sink, 128);
+  run("v_perm_b32 (VOP3)", k_perm, d_cyc, d_sink, 128);
+  run("v_bfi_b32 (VOP3)", k_bfi, d_cyc, d_sink, 128);
+  run("v_bfe_i32 (VOP3)", k_bfe, d_cyc, d_sink, 128);
+  run("v_med3_i16 (VOP3)", k_med3_i16, d_cyc, d_sink, 128);
+  run("v_min3_i16 (VOP3)", k_min3_i16, d_cyc, d_sink, 128);
+  run("v_sad_u8 (VOP3)", k_sad_u8, d_cyc, d_sink, 128);
+  run("v_dot4_i32_i8 (VOP3P)", k_dot4, d_cyc, d_sink, 128);
   run("decoder mix 16pk/4perm/12i32", k_mix, d_cyc, d_sink, 32);
   return 0;
 }
