@@ -218,6 +218,74 @@ __device__ __forceinline__ uint32_t hard_word(const int8_t* soft, int t, int K)
   return w;
 }
 
+// Hard-decision flags of the 32 soft bits of group t in the layout of crc_zmask: bit (q + 8 b) = (soft[32 t + 4 q + b] <= 0).
+// Per dword of four soft bytes: bit 7 of a byte of ((x & 0x7f..) + 0x7f..) says "low seven bits non-zero"; the byte is <= 0 when
+// its sign bit is set or that bit is clear.
+__device__ __forceinline__ uint32_t hard_flags(const int8_t* soft, int t)
+{
+  const uint4* p  = reinterpret_cast<const uint4*>(soft) + 2 * t;
+  const uint4  lo = p[0], hi = p[1];
+  const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uint32_t       w    = 0;
+#pragma unroll
+  for (int q = 7; q >= 0; --q) {
+    const uint32_t nz  = (x[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    const uint32_t le0 = (x[q] | ~nz) & 0x80808080u;
+    w                  = (w << 1) | (le0 >> 7);
+  }
+  return w;
+}
+
+// Is the checksum of the first L hard bits zero? Mask / popcount form (crc_zmask in miphy_internal.h): no bit-serial division, no
+// position weights. zi = table index of the polynomial, order = its degree.
+__device__ __forceinline__ bool block_crc_is_zero(const int8_t* soft, const miphy_graph_tables* __restrict__ tab, int zi, int order, int L,
+                                                  uint32_t* red, int tid, int nt)
+{
+  const int nw = (L + 31) >> 5;
+  uint32_t  acc[24];
+#pragma unroll
+  for (int k = 0; k < 24; ++k)
+    acc[k] = 0;
+  for (int t = tid; t < nw; t += nt) {
+    uint32_t  w   = hard_flags(soft, t);
+    const int rem = L - 32 * t;
+    if (rem < 32) { // last word: positions 4 q + b >= rem are not message bits
+      uint32_t valid = 0;
+      for (int q = 0; q < 8; ++q) {
+        const int      nb = min(4, max(0, rem - 4 * q));                      // message bits among the four of dword q
+        const uint32_t lo = (nb >= 4) ? 0xffffffffu : ((1u << (8 * nb)) - 1u); // their byte lanes
+        valid |= (0x01010101u & lo) << q;
+      }
+      w &= valid;
+    }
+    const uint4* m = reinterpret_cast<const uint4*>(tab->crc_zmask[zi][nw - 1 - t]);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      const uint4 mk = m[g];
+      acc[4 * g + 0] += __builtin_popcount(w & mk.x);
+      acc[4 * g + 1] += __builtin_popcount(w & mk.y);
+      acc[4 * g + 2] += __builtin_popcount(w & mk.z);
+      acc[4 * g + 3] += __builtin_popcount(w & mk.w);
+    }
+  }
+  uint32_t par = 0;
+#pragma unroll
+  for (int k = 0; k < 24; ++k)
+    par |= (acc[k] & 1u) << k;
+  par &= (1u << order) - 1u;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+    par ^= __shfl_xor(par, off);
+  if ((tid & 63) == 0)
+    red[2 + (tid >> 6)] = par;
+  __syncthreads();
+  uint32_t crc = 0;
+  for (int w = 0; w < (nt >> 6); ++w)
+    crc ^= red[2 + w];
+  __syncthreads();
+  return crc == 0;
+}
+
 // CRC over the first L hard bits, words strided over the block's threads.
 __device__ __forceinline__ uint32_t block_crc(const int8_t* soft, const miphy_graph_tables* __restrict__ tab, int crc_id, uint32_t poly,
                                               uint32_t order, int K, int L, uint32_t* red, int tid, int nt)
@@ -256,6 +324,27 @@ __device__ __forceinline__ uint32_t block_crc(const int8_t* soft, const miphy_gr
   return crc;
 }
 
+// Phase timing for tools/ldpc_phase_probe.py (debug build with -DLDPC_PK_PROFILE only; never compiled into libmiphy.so).
+#ifdef LDPC_PK_PROFILE
+__device__ unsigned long long g_ldpc_prof[2048 * 8]; // per workgroup: 7 phase sums + codeblock count (no atomics: one writer per row)
+#define PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PROF_ADD(slot, a, b) prof_acc[slot] += (unsigned long long)((b) - (a))
+#define PROF_COUNT()                                              \
+  do {                                                            \
+    if (tid == 0 && blockIdx.x < 2048) {                          \
+      for (int q = 0; q < 7; ++q)                                 \
+        g_ldpc_prof[blockIdx.x * 8 + q] += prof_acc[q];           \
+      g_ldpc_prof[blockIdx.x * 8 + 7] += 1;                       \
+    }                                                             \
+    for (int q = 0; q < 7; ++q)                                   \
+      prof_acc[q] = 0;                                            \
+  } while (0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, a, b)
+#define PROF_COUNT()
+#endif
+
 #ifndef LDPC_PK_MIN_WAVES
 #define LDPC_PK_MIN_WAVES 3
 #endif
@@ -277,7 +366,11 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   // Persistent workgroups: the grid is what the chip holds at once; a workgroup decodes codeblock blockIdx.x first and then takes
   // codeblocks gridDim.x, gridDim.x + 1, ... from the launch's queue counter until the batch is exhausted (every wave reaches the
   // exit: the counter only grows). No workgroup launch / LDS allocation between codeblocks, and heterogeneous batches balance.
+#ifdef LDPC_PK_PROFILE
+  unsigned long long prof_acc[7] = {};
+#endif
   for (uint32_t cb = blockIdx.x; cb < n;) {
+  PROF_T(p_start);
   const miphy_ldpc_dec_desc dsc = descs[cb];
   const int                 Z   = dsc.Z;
   const int                 H   = (Z + 1) >> 1;
@@ -380,14 +473,19 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     L     = K - dsc.nof_filler_bits;
   }
   const bool final_only = use_crc && (dsc.flags & 1u);
+  // mask form of the CRC zero test where the polynomial has a table (every polynomial a codeblock carries)
+  const int zi = (use_crc && L <= 32 * MIPHY_CRC_ZMASK_WORDS) ? miphy_crc_zmask_index(dsc.crc_poly) : -1;
 
   int       result_iters = 0;
   const int max_iter     = dsc.max_iter;
+  PROF_T(p_loaded);
+  PROF_ADD(0, p_start, p_loaded);
   for (int it = 0; it < max_iter; ++it) {
     for (int m = 0; m < nof_layers; ++m) {
       const int       e0    = row_start[m];
       const int       d     = row_start[m + 1] - e0;
       const uint32_t* edges = edges_g + 2 * e0;
+      PROF_T(p_l0);
       if (tid < H) {
         uint32_t* cl = c2v_lane + 64 * pair_start[m];
         if (it == 0)
@@ -395,17 +493,26 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
         else
           update_rows_pk_any<false>(d, soft, cl, edges, tid, H, Z);
       }
+      PROF_T(p_l1);
       __syncthreads();
+      PROF_T(p_l2);
+      PROF_ADD(1, p_l0, p_l1);
+      PROF_ADD(2, p_l1, p_l2);
     }
     if (use_crc && !final_only) {
-      if (block_crc(soft, tab, dsc.crc_poly, poly, order, K, L, red, tid, nt) == 0) {
+      if (zi >= 0 ? block_crc_is_zero(soft, tab, zi, (int)order, L, red, tid, nt) : block_crc(soft, tab, dsc.crc_poly, poly, order, K, L, red, tid, nt) == 0) {
         result_iters = it + 1;
         break;
       }
     }
   }
+  PROF_T(p_dec);
   if (final_only)
-    result_iters = (block_crc(soft, tab, dsc.crc_poly, poly, order, K, L, red, tid, nt) == 0) ? max_iter : 0;
+    result_iters = (zi >= 0 ? block_crc_is_zero(soft, tab, zi, (int)order, L, red, tid, nt) : block_crc(soft, tab, dsc.crc_poly, poly, order, K, L, red, tid, nt) == 0)
+                       ? max_iter
+                       : 0;
+  PROF_T(p_crc);
+  PROF_ADD(3, p_dec, p_crc);
 
   for (int t = tid; t < kwords; t += nt) {
     const uint32_t w      = hard_word(soft, t, K);
@@ -418,11 +525,36 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     if (harq_crc_ok && result_iters > 0)
       harq_crc_ok[harq_slot[cb]] = 1;
   }
+  PROF_T(p_end);
+  PROF_ADD(4, p_crc, p_end);
+  PROF_ADD(5, p_start, p_end);
+  PROF_COUNT();
   cb = red[15];
   } // codeblock loop
 }
 
 } // namespace
+
+#ifdef LDPC_PK_PROFILE
+extern "C" int miphy_debug_ldpc_profile(unsigned long long out[8], int reset)
+{
+  static unsigned long long h[2048 * 8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ldpc_prof), sizeof(h)) != hipSuccess)
+    return -1;
+  for (int q = 0; q < 8; ++q) {
+    out[q] = 0;
+    for (int b = 0; b < 2048; ++b)
+      out[q] += h[b * 8 + q];
+  }
+  if (reset) {
+    for (auto& v : h)
+      v = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ldpc_prof), h, sizeof(h)) != hipSuccess)
+      return -1;
+  }
+  return 0;
+}
+#endif
 
 // LDS bytes the packed kernel needs for a given geometry (Zt >= Z of every codeblock, lay = layer bound, pairs_all = message
 // dwords per lane of those layers).

@@ -116,6 +116,26 @@ static void build_tables(miphy_graph_tables* t)
       t->crc_pow2[p][b] = v;
       v                 = gf2_mulmod(v, v, POLY[p], ORDER[p]);
     }
+    const int zi = miphy_crc_zmask_index(p);
+    if (zi >= 0) {
+      // weight of the bit at distance j from the end of the message: x^(j + order) mod P
+      uint32_t c = 1;
+      for (unsigned i = 0; i < ORDER[p]; ++i) {
+        c <<= 1;
+        if (c & top)
+          c ^= POLY[p];
+      }
+      for (int u = 0; u < MIPHY_CRC_ZMASK_WORDS; ++u)
+        for (int jl = 0; jl < 32; ++jl) { // j = 32 u + jl
+          const int i_local = 31 - jl, q = i_local >> 2, b = i_local & 3;
+          for (unsigned k = 0; k < ORDER[p]; ++k)
+            if ((c >> k) & 1u)
+              t->crc_zmask[zi][u][k] |= 1u << (q + 8 * b);
+          c <<= 1;
+          if (c & top)
+            c ^= POLY[p];
+        }
+    }
   }
 }
 

@@ -10,6 +10,7 @@
 #define MIPHY_BG1_EDGES 316
 #define MIPHY_BG2_EDGES 197
 #define MIPHY_MAX_EDGES 316
+#define MIPHY_CRC_ZMASK_WORDS 264 // 8448 bits: the largest codeblock
 
 // Per-(base graph, lifting size) edge table entry: low 16 bits = column*Z (LDS byte offset of the variable node),
 // high 16 bits = cyclic shift (already reduced modulo Z).
@@ -26,7 +27,18 @@ struct miphy_graph_tables {
   uint32_t crc_pow32_hi[5][256]; // x^(32 * 256 * k) mod poly: with crc_pow32[k & 255] covers messages up to 2 Mbit in one product
   uint32_t crc_poly[5];
   uint32_t crc_order[5];
+  // Zero test of a codeblock CRC by masks (LDPC decoders): for the polynomials a codeblock can carry (index 0 = CRC24A, 1 = CRC24B,
+  // 2 = CRC16) and word u counted from the END of the message padded with zeros to a multiple of 32 bits, crc_zmask[.][u][k] selects
+  // the bits of that word whose weight x^(distance to the end + order) mod P has bit k set; bit k of the checksum of the padded
+  // message is the parity of the sum over u of popcount(word & mask). (M(x) x^r mod P == 0 <=> M(x) mod P == 0, so the padding
+  // does not change the verdict.) Word layout: bit (q + 8 b) of a word is message bit 4 q + b of its group of 32 (see hard_flags()).
+  uint32_t crc_zmask[3][MIPHY_CRC_ZMASK_WORDS][24];
 };
+// index into crc_zmask for a MIPHY_CRC_* id, -1 if the polynomial has no mask table
+static inline __host__ __device__ int miphy_crc_zmask_index(int crc_id)
+{
+  return crc_id == 0 ? 0 : (crc_id == 1 ? 1 : (crc_id == 3 ? 2 : -1));
+}
 
 struct miphy_ctx_ext; // C++ side caches (twiddle tables, OFDM plans), see miphy_ext.h
 

@@ -1,0 +1,49 @@
+"""Where a packed-decoder codeblock spends its shader cycles (debug build with -DLDPC_PK_PROFILE: s_memtime stamps taken by lane 0 of
+wave 0 of every workgroup, summed over the launch). Builds tools/_prof/libmiphy.so when missing (hipcc, here or on the GPU box).
+usage: python tools/ldpc_phase_probe.py [layers ...]     (default: the 4-layer headline codeblock and 15 / 46 layers)"""
+import ctypes as C, glob, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "srsran_project_23.5_amd")
+sys.path.insert(0, PKG)
+so = os.path.join(ROOT, "tools", "_prof", "libmiphy.so")
+if not os.path.exists(so) or "--rebuild" in sys.argv:
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-DLDPC_PK_PROFILE", "-shared",
+                           "-o", so] + sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip"))))
+if "--build-only" in sys.argv:
+    sys.exit(0)
+import torch
+import miphy
+import miphy.binding as B
+B.lib_path = so
+ctx = miphy.Context()
+lib = miphy.lib()
+n = 38912
+names = ["prologue (descriptor, zero fill, LLR load)", "layer work (wave 0)", "barrier wait after a layer (wave 0)", "final CRC", "hard decision + output",
+         "whole codeblock"]
+for lay in [int(a) for a in sys.argv[1:] if a.isdigit()] or [4, 15, 46]:
+    bg, Z = 1, 384
+    N, K = 66 * Z, 22 * Z
+    in_len = min(N, (22 + lay - 2) * Z)
+    m = n if lay <= 6 else n // 4
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    llr = (torch.randn(m * in_len, device="cuda", generator=g) * 8 + 10).clamp(-120, 120).to(torch.int8)
+    out = torch.zeros(m * (K // 8), dtype=torch.uint8, device="cuda")
+    it = torch.zeros(m, dtype=torch.int32, device="cuda")
+    d = np.zeros(m, dtype=miphy.LdpcDecDesc)
+    for i in range(m):
+        d[i] = (bg, miphy.CRC24B, Z, 6, 0, in_len, 1, i * in_len, i * (K // 8))   # flags = 1: CRC once after the last iteration
+    dd = torch.from_numpy(d.view(np.uint8)).cuda()
+    for rep in range(2):
+        buf = (C.c_ulonglong * 8)()
+        lib.miphy_debug_ldpc_profile(buf, 1)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ctx.ldpc_decode_batch(dd, llr, out, it, limits=(Z, in_len))
+        b.record(); torch.cuda.synchronize()
+        lib.miphy_debug_ldpc_profile(buf, 0)
+    cnt = max(1, buf[7])
+    print("BG1 Z=384 %d layers, %d codeblocks, %.3f ms (%.3f us/CB amortised); %d codeblocks stamped" % (lay, m, a.elapsed_time(b), a.elapsed_time(b) * 1e3 / m, cnt))
+    for k, nm in enumerate(names):
+        print("   %-46s %9.0f cycles per codeblock  (%5.1f %%)" % (nm, buf[k] / cnt, 100.0 * buf[k] / max(1, buf[5])))
