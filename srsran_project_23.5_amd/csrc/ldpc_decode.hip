@@ -386,7 +386,11 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
                              const miphy_ldpc_dec_limits* limits,
                              const uint32_t*              harq_slot,
                              uint8_t*                     harq_crc_ok,
-                             void*                        stream)
+                             void*                        stream,
+                             int                          force_scalar,
+                             const miphy_ldpc_rdm_desc*   fuse_rdm,
+                             const int8_t*                fuse_in,
+                             const miphy_ldpc_rdm_limits* fuse_rlim)
 {
   MIPHY_REQUIRE(ctx && descs && llr && out_bits && iters, "ldpc_decode: null argument");
   if (n == 0)
@@ -472,13 +476,19 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
     return wgs * threads * rows_per_lane;
   };
   bool use_pk = pk_ok && 1.6 * rows_in_flight(pk_lds, pk_threads, 4, 2) >= 1.0 * rows_in_flight(max_lds, max_threads, 8, 1);
-  if ((force && force[0] == 's') || g_force_kernel == 1)
+  if ((force && force[0] == 's') || g_force_kernel == 1 || force_scalar)
     use_pk = false;
   if ((force && force[0] == 'p') || g_force_kernel == 2)
     use_pk = pk_ok;
+  // The fused form needs 16-byte aligned soft buffers (its write-back is vectorised); otherwise the dematcher runs on its own.
+  const bool fuse = fuse_rdm && use_pk && ((uintptr_t)llr & 15) == 0;
+  if (fuse_rdm && !fuse) {
+    if ((rc = miphy_ldpc_rate_dematch_batch(ctx, fuse_rdm, 1, n, fuse_in, const_cast<int8_t*>(llr), fuse_rlim, s)))
+      return rc;
+  }
   if (use_pk)
     return miphy_ldpc_pk_launch(ctx, (const miphy_ldpc_dec_desc*)d_descs, n, pk_threads, pk_lds, llr, out_bits, iters, nodes_all, harq_slot,
-                                harq_crc_ok, s);
+                                harq_crc_ok, s, fuse ? fuse_rdm : nullptr, fuse ? fuse_in : nullptr);
   // Above the default 64 KB of dynamic LDS the limit has to be raised; it is a per-device attribute of the kernel, so it is set on
   // every such launch (a cache per thread would be wrong for a thread that drives several devices).
   if (max_lds > 48 * 1024) {

@@ -10,6 +10,7 @@
 // 64 consecutive words: conflict-free, immediate offsets, and only one LDS read and one LDS write per TWO edges (measured on
 // gfx950: a DS write costs ~5 cycles of the CU's LDS pipe whatever its width, a read ~2.8 -- tools/lds_probe.hip).
 #include "miphy_internal.h"
+#include "rdm_device.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -348,6 +349,35 @@ __device__ unsigned long long g_ldpc_prof[2048 * 8]; // per workgroup: 7 phase s
 #ifndef LDPC_PK_MIN_WAVES
 #define LDPC_PK_MIN_WAVES 3
 #endif
+// Raw form of load_in16(): the dword-aligned 16 bytes and the following dword of input vector v, not yet funnel-shifted, so that a
+// prefetch keeps them in flight (the shift happens where the vector is consumed).
+struct raw_in16 {
+  uint32_t a0, a1, a2, a3, e;
+};
+__device__ __forceinline__ raw_in16 load_in16_raw(const int8_t* __restrict__ in, int mb, int v)
+{
+  const uint32_t* p4 = reinterpret_cast<const uint32_t*>(in - mb) + 4 * v;
+  const rdm_u4    a  = *reinterpret_cast<const rdm_u4*>(p4);
+  raw_in16        r;
+  r.a0 = a.x, r.a1 = a.y, r.a2 = a.z, r.a3 = a.w;
+  r.e  = (mb != 0) ? p4[4] : 0u;
+  return r;
+}
+__device__ __forceinline__ uint4 shift_in16(const raw_in16& r, int mb)
+{
+  if (mb == 0)
+    return make_uint4(r.a0, r.a1, r.a2, r.a3);
+  return make_uint4(__builtin_amdgcn_alignbyte(r.a1, r.a0, mb), __builtin_amdgcn_alignbyte(r.a2, r.a1, mb), __builtin_amdgcn_alignbyte(r.a3, r.a2, mb),
+                    __builtin_amdgcn_alignbyte(r.e, r.a3, mb));
+}
+constexpr int PK_PRE = 3; // rate-matched input vectors per lane fetched one codeblock ahead (3 x 192 lanes x 16 B = 9216 B)
+
+// FUSED = the codeblock's first transmission is rate-dematched while it is loaded (ldpc_rate_dematcher_impl.cpp:43-254 for
+// new data, redundancy version 0, full circular buffer, E + fillers <= N): `llr_base` is then the HARQ soft-buffer array, which
+// receives the dematched codeblock exactly as the reference's dematcher leaves it (data, fillers at +127, zeros behind), and the
+// rate-matched LLRs come from `rm_in_base` through the descriptors `rdm` (same index as `descs`). The input of the NEXT codeblock
+// of the workgroup is fetched into registers while the current one decodes.
+template <bool FUSED>
 __global__ void __launch_bounds__(192, LDPC_PK_MIN_WAVES)
 ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                       const miphy_graph_tables* __restrict__ tab,
@@ -358,11 +388,26 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                       const uint32_t* __restrict__ harq_slot,
                       uint8_t* __restrict__ harq_crc_ok,
                       uint32_t n,
-                      uint32_t* __restrict__ queue)
+                      uint32_t* __restrict__ queue,
+                      const miphy_ldpc_rdm_desc* __restrict__ rdm,
+                      const int8_t* __restrict__ rm_in_base)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int nt  = blockDim.x;
+  raw_in16  pre[PK_PRE];
+  if (FUSED) {
+    if (blockIdx.x < n) {
+      const miphy_ldpc_rdm_desc r0 = rdm[blockIdx.x];
+      const int8_t*             in = rm_in_base + r0.in_offset;
+      const int                 mb = (int)(((uintptr_t)in) & 3), E = (int)r0.E;
+      const int                 nq = (mb == 0) ? (E >> 4) : ((E >= 4) ? ((E - 4) >> 4) : 0);
+#pragma unroll
+      for (int k = 0; k < PK_PRE; ++k)
+        if (tid + k * nt < nq)
+          pre[k] = load_in16_raw(in, mb, tid + k * nt);
+    }
+  }
   // Persistent workgroups: the grid is what the chip holds at once; a workgroup decodes codeblock blockIdx.x first and then takes
   // codeblocks gridDim.x, gridDim.x + 1, ... from the launch's queue counter until the batch is exhausted (every wave reaches the
   // exit: the counter only grows). No workgroup launch / LDS allocation between codeblocks, and heterogeneous batches balance.
@@ -395,7 +440,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   __syncthreads(); // the previous codeblock's readers of red[] / soft[] are done
   if (tid == 0)
     red[15] = gridDim.x + atomicAdd(queue, 1u);
-  if (harq_crc_ok && harq_crc_ok[harq_slot[cb]]) {
+  if (!FUSED && harq_crc_ok && harq_crc_ok[harq_slot[cb]]) {
     if (tid == 0)
       iters_out[cb] = -1;
     __syncthreads();
@@ -408,12 +453,95 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 
   if (tid < 15)
     red[tid] = 0;
+  int last = 0;
+  // (re)fills pre[] with the first input vectors of codeblock c
+  auto prefetch = [&](uint32_t c) {
+    if (c < n) {
+      const miphy_ldpc_rdm_desc rn  = rdm[c];
+      const int8_t*             inn = rm_in_base + rn.in_offset;
+      const int                 mbn = (int)(((uintptr_t)inn) & 3), En = (int)rn.E;
+      const int                 nqn = (mbn == 0) ? (En >> 4) : ((En >= 4) ? ((En - 4) >> 4) : 0);
+#pragma unroll
+      for (int k = 0; k < PK_PRE; ++k)
+        if (tid + k * nt < nqn)
+          pre[k] = load_in16_raw(inn, mbn, tid + k * nt);
+    }
+  };
+  if (FUSED) {
+    // ---- rate dematching into the LDS image soft[2Z + j] = buffer position j
+    // (the lane index is made opaque here: the compiler would otherwise hoist every per-lane staging address out of the
+    // codeblock loop and keep dozens of them alive across the decoder)
+    int stid = tid;
+    asm volatile("" : "+v"(stid));
+    const miphy_ldpc_rdm_desc rd  = rdm[cb];
+    const int                 E   = (int)rd.E, F = (int)dsc.nof_filler_bits;
+    const int8_t*             in  = rm_in_base + rd.in_offset;
+    const int                 mb  = (int)(((uintptr_t)in) & 3);
+    const int                 nq  = (mb == 0) ? (E >> 4) : ((E >= 4) ? ((E - 4) >> 4) : 0);
+    int8_t*                   img = soft + 2 * Z;
+    rm_geom                   g;
+    g.r0 = 0, g.f1 = (bgK - 2) * Z, g.f0 = g.f1 - F, g.F = F, g.E = E, g.mod = rd.mod, g.Kq = E / rd.mod;
+    image_access ia;
+    ia.jbase = 0;
+    {
+      uint4* z4 = reinterpret_cast<uint4*>(soft);
+      for (int k = stid; k < (2 * Z) >> 4; k += nt) // the two punctured nodes (Z is a multiple of 16 for every Z >= 128)
+        z4[k] = make_uint4(0, 0, 0, 0);
+      for (int k = g.f0 + stid; k < g.f1; k += nt)
+        img[k] = 127; // fillers
+      for (int k = 2 * Z + E + F + stid; k < soft_bytes; k += nt)
+        soft[k] = 0; // never transmitted
+    }
+    switch (rd.mod) {
+#define PK_STAGE(MOD)                                                                         \
+  case MOD:                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < PK_PRE; ++k) if (stid + k * nt < nq)                 \
+        stage_vector<MOD>(ia, img, g, F, stid + k * nt, shift_in16(pre[k], mb));               \
+    for (int v = stid + PK_PRE * nt; v < nq; v += nt)                                          \
+      stage_vector<MOD>(ia, img, g, F, v, load_in16(in, mb, v));                              \
+    break;
+      PK_STAGE(8)
+      PK_STAGE(6)
+      PK_STAGE(4)
+      PK_STAGE(2)
+      default:
+        PK_STAGE(1)
+#undef PK_STAGE
+    }
+    for (int k = (nq << 4) + stid; k < E; k += nt) {
+      const int p = k / (int)rd.mod, q = k - p * (int)rd.mod;
+      const int r = q * g.Kq + p;
+      img[r + ((r >= g.f0) ? F : 0)] = in[k];
+    }
+    __syncthreads();
+    // ---- the image goes to the HARQ soft buffer (what the reference's dematcher leaves there) while the last non-zero soft bit
+    // is found (ldpc_decoder_impl.cpp:86-99)
+    {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      u32x4*       dst  = reinterpret_cast<u32x4*>(const_cast<int8_t*>(llr));
+      const uint4* src  = reinterpret_cast<const uint4*>(img);
+      const int    nimg = in_len >> 4, nall = (((bgi ? 50 : 66) * Z) >> 4);
+      for (int q = tid; q < nimg; q += nt) {
+        const uint4 v = src[q];
+        const u32x4 o = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(o, dst + q);
+        int hi = -1;
+        hi     = v.x ? 3 - (__clz((int)v.x) >> 3) : hi;
+        hi     = v.y ? 7 - (__clz((int)v.y) >> 3) : hi;
+        hi     = v.z ? 11 - (__clz((int)v.z) >> 3) : hi;
+        hi     = v.w ? 15 - (__clz((int)v.w) >> 3) : hi;
+        last   = (hi >= 0) ? 16 * q + hi + 1 : last;
+      }
+      const u32x4 zero = {0, 0, 0, 0};
+      for (int q = nimg + tid; q < nall; q += nt)
+        __builtin_nontemporal_store(zero, dst + q);
+    }
+  } else {
   for (int k = tid; k < 2 * Z; k += nt)
     soft[k] = 0;
   for (int k = 2 * Z + in_len + tid; k < soft_bytes; k += nt)
     soft[k] = 0;
   __syncthreads();
-  int last = 0;
   if ((((uintptr_t)llr | (uintptr_t)(2 * Z)) & 15) == 0) {
     const uint4* src = reinterpret_cast<const uint4*>(llr);
     uint4*       dst = reinterpret_cast<uint4*>(soft + 2 * Z);
@@ -440,6 +568,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       last            = (v != 0) ? k + 1 : last;
     }
   }
+  }
   atomicMax(reinterpret_cast<int*>(&red[0]), last);
   __syncthreads();
   last = (int)red[0];
@@ -455,6 +584,8 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     }
     if (tid == 0)
       iters_out[cb] = 0;
+    if (FUSED)
+      prefetch(red[15]);
     cb = red[15];
     continue;
   }
@@ -507,6 +638,11 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     }
   }
   PROF_T(p_dec);
+  if (FUSED) {
+    // The input of this workgroup's next codeblock is requested now: the loads fly while the CRC and the hard decision run, and
+    // the registers that hold them are not live inside the layer loop.
+    prefetch(red[15]);
+  }
   if (final_only)
     result_iters = (zi >= 0 ? block_crc_is_zero(soft, tab, zi, (int)order, L, red, tid, nt) : block_crc(soft, tab, dsc.crc_poly, poly, order, K, L, red, tid, nt) == 0)
                        ? max_iter
@@ -565,15 +701,15 @@ size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all)
 }
 
 int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
-                         uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s)
+                         uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
+                         const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in)
 {
-  static const char* pad = getenv("MIPHY_LDPC_PAD_LDS"); // occupancy experiments only
-  if (pad)
-    lds += (size_t)atoi(pad);
+  const bool  fused = d_rdm != nullptr;
+  const void* kern  = fused ? (const void*)ldpc_decode_pk_kernel<true> : (const void*)ldpc_decode_pk_kernel<false>;
   // Above the default 64 KB of dynamic LDS the limit has to be raised; it is a per-device attribute of the kernel, so it is set on
   // every such launch (a cache per thread would be wrong for a thread that drives several devices).
   if (lds > 48 * 1024) {
-    MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_pk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MIPHY_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   // Resident workgroups per CU: LDS, the 12 wavefronts per CU the register budget of the kernel allows (__launch_bounds__), 32 slots.
   const int waves = threads / 64;
@@ -585,8 +721,12 @@ int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uin
   int            rc    = miphy_next_queue_counter(ctx, s, &queue);
   if (rc)
     return rc;
-  hipLaunchKernelGGL(ldpc_decode_pk_kernel, dim3(grid), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot, harq_crc_ok,
-                     n, queue);
+  if (fused)
+    hipLaunchKernelGGL(ldpc_decode_pk_kernel<true>, dim3(grid), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot,
+                       harq_crc_ok, n, queue, d_rdm, rm_in);
+  else
+    hipLaunchKernelGGL(ldpc_decode_pk_kernel<false>, dim3(grid), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot,
+                       harq_crc_ok, n, queue, d_rdm, rm_in);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

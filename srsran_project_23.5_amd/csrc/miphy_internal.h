@@ -81,9 +81,15 @@ void miphy_set_error(const char* fmt, ...);
 int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t bytes, hipStream_t s, const void** out);
 
 // Decoder launch shared by miphy_ldpc_decode_batch and the transport-block level PUSCH decoder.
+// force_scalar: the batch holds odd lifting sizes the packed kernel cannot take (device descriptors hide them from the launcher).
+// fuse_rdm / fuse_in / fuse_rlim (device descriptors with the same index as descs): every codeblock is a first transmission that
+// can be rate-dematched while the decoder loads it (conditions in ldpc_decode_pk.hip); `llr` is then the HARQ soft-buffer array the
+// dematched codeblocks are written to. When the packed kernel is not the one selected, the rate dematcher runs as its own launch
+// first -- the result is the same either way.
 int miphy_ldpc_decode_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* descs, int descs_on_device, uint32_t n, const int8_t* llr,
                              uint8_t* out_bits, int32_t* iters, const miphy_ldpc_dec_limits* limits, const uint32_t* harq_slot,
-                             uint8_t* harq_crc_ok, void* stream);
+                             uint8_t* harq_crc_ok, void* stream, int force_scalar = 0, const miphy_ldpc_rdm_desc* fuse_rdm = nullptr,
+                             const int8_t* fuse_in = nullptr, const miphy_ldpc_rdm_limits* fuse_rlim = nullptr);
 
 // Returns a device scratch buffer of at least `bytes` (reallocated, after a stream sync, when it has to grow).
 int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out, int which = 0);
@@ -91,6 +97,7 @@ int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out,
 // Packed (two rows per lane) LDPC decoder kernel, ldpc_decode_pk.hip.
 size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all);
 int    miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
-                            uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s);
+                            uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
+                            const miphy_ldpc_rdm_desc* d_rdm = nullptr, const int8_t* rm_in = nullptr);
 // Zeroes (on the stream) and returns the next work-queue counter of the context.
 int miphy_next_queue_counter(miphy_ctx* ctx, hipStream_t s, uint32_t** out);

@@ -296,6 +296,8 @@ struct pusch_decode_build {
   std::vector<uint64_t>            tmp_off;
   uint64_t                         tmp_bytes = 0;
   uint32_t                         max_Z = 2, max_nodes = 0, max_E = 0;
+  bool                             any_odd_Z = false; // the packed decoder pairs rows l and l + Z/2
+  bool                             fusable   = true;  // every codeblock can be rate-dematched by the decoder while it loads
 };
 
 // Device-side view of a staged build (pointers into one buffer).
@@ -373,6 +375,11 @@ int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_
         const uint32_t nodes = (q.in_len + 2 * sg.Z + sg.Z - 1) / sg.Z; // variable nodes this codeblock can reach
         tb_nodes             = nodes > tb_nodes ? nodes : tb_nodes;
       }
+      // Dematching while the decoder loads: first transmission at redundancy version 0 into the full circular buffer, the E bits
+      // neither wrap around it nor stop inside the systematic part, soft-buffer slots 16-byte aligned (HARQ_CB_STRIDE is).
+      b.fusable &= d.new_data && d.rv == 0 && !(d.Nref > 0 && d.Nref < sg.N) && E + sg.nof_filler_bits <= sg.N &&
+                   E >= (bgK - 2) * sg.Z - sg.nof_filler_bits && (sg.Z % 16) == 0;
+      b.any_odd_Z |= (sg.Z & 1u) != 0;
       q.flags           = d.use_early_stop ? 0u : 1u;
       q.llr_offset = (uint64_t)slot * HARQ_CB_STRIDE, q.out_offset = (uint64_t)slot * HARQ_MSG_STRIDE;
       b.dec.push_back(q);
@@ -439,11 +446,14 @@ int launch_pusch_decode(miphy_ctx* ctx, const pusch_decode_build& b, const pusch
     }
     if (ev)
       MIPHY_HIP_CHECK(hipEventRecord(ev[0], s));
-    if ((rc = miphy_ldpc_rate_dematch_batch(ctx, v.rdm + c0, 1, c1 - c0, llrs, harq_softbits, &rlim, s)))
-      return rc;
+    if (!b.fusable) {
+      if ((rc = miphy_ldpc_rate_dematch_batch(ctx, v.rdm + c0, 1, c1 - c0, llrs, harq_softbits, &rlim, s)))
+        return rc;
+    }
     if (ev)
       MIPHY_HIP_CHECK(hipEventRecord(ev[1], s));
-    if ((rc = miphy_ldpc_decode_launch(ctx, v.dec + c0, 1, c1 - c0, harq_softbits, harq_msgs, v.iters + c0, &lim, v.slots + c0, harq_crc_ok, s)))
+    if ((rc = miphy_ldpc_decode_launch(ctx, v.dec + c0, 1, c1 - c0, harq_softbits, harq_msgs, v.iters + c0, &lim, v.slots + c0, harq_crc_ok, s,
+                                       b.any_odd_Z ? 1 : 0, b.fusable ? v.rdm + c0 : nullptr, b.fusable ? llrs : nullptr, &rlim)))
       return rc;
     t0 = t1;
   }

@@ -100,3 +100,70 @@ def test_pusch_decode_batch_with_harq(ctx, early_stop, max_iter):
                 assert np.array_equal(got, tbo) and np.array_equal(got, x["tb"]), key
             elif not np.all(x["od"].cb_crc):
                 assert np.all(got == 0xEE), key  # untouched unless every codeblock passed
+
+
+FUSABLE = [  # bg, mod, nof_layers, nprb, tbs bits, sigma: every codeblock Z >= 128 (a multiple of 16), rv 0 fits the circular buffer
+    (2, 1, 1, 100, 3848, 0.9),
+    (2, 2, 1, 60, 3848, 0.75),
+    (1, 4, 1, 106, 42016, 0.45),
+    (1, 6, 1, 106, 83976, 0.62),
+    (1, 8, 1, 273, 319784, 0.3),
+    (2, 2, 1, 100, 9984, 1.3),
+    (1, 4, 2, 50, 40976, 0.45),
+    (1, 2, 1, 81, 8400, 0.8),  # one codeblock, rate 1/3: E = N - fillers... (full circular buffer)
+]
+
+
+@pytest.mark.parametrize("early_stop", [0, 1])
+def test_first_transmission_dematched_by_the_decoder(ctx, early_stop):
+    """A batch of first transmissions (rv 0, new data) takes the path where the LDPC decoder rate-dematches while it loads its
+    codeblock: the HARQ soft buffers must hold exactly what the reference's dematcher leaves there (oracle, pinned against the
+    reference), results and transport blocks as the oracle; a retransmission (separate dematcher launch, combining into those
+    buffers) then also matches."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(77 + early_stop)
+    tbs, slot = [], 0
+    for bg, mod, nl, nprb, tbs_bits, sigma in FUSABLE:
+        nsym = nprb * 156 * nl
+        tb = rng.integers(0, 256, tbs_bits // 8, dtype=np.uint8)
+        seg = o_segmentation(tbs_bits, bg, mod, nl, nsym)
+        assert seg.Z >= 128 and seg.Z % 16 == 0
+        llrs = [noisy(o_pdsch_encode(bg, rv, mod, 0, nl, nsym, tb), sigma, rng) for rv in (0, 2)]
+        od = OraclePuschDecoder(bg, mod, 0, nl, nsym, tbs_bits // 8)
+        od.softbuf[:] = 33
+        tbs.append(dict(bg=bg, mod=mod, nl=nl, nsym=nsym, tb=tb, llrs=llrs, slot=slot, ncb=seg.nof_cbs, N=seg.N, od=od))
+        slot += seg.nof_cbs
+    n = len(tbs)
+    soft_d = torch.full((slot * miphy.HARQ_CB_STRIDE,), 33, dtype=torch.int8, device="cuda")
+    msgs_d = torch.zeros(slot * miphy.HARQ_MSG_STRIDE, dtype=torch.uint8, device="cuda")
+    crc_d = torch.ones(slot, dtype=torch.uint8, device="cuda")
+    res_d = torch.zeros(n * miphy.PuschResult.itemsize, dtype=torch.uint8, device="cuda")
+    for t, rv in enumerate((0, 2)):
+        d = np.zeros(n, dtype=miphy.PuschTbDesc)
+        llr_off, tb_off, chunks = 0, 0, []
+        for i, x in enumerate(tbs):
+            d[i] = (x["bg"], rv, x["mod"], x["nl"], 1 if t == 0 else 0, early_stop, 6, 0, x["nsym"], x["tb"].size, x["slot"], llr_off + 3, tb_off)
+            chunks.append(x["llrs"][t])
+            llr_off += x["llrs"][t].size
+            tb_off += x["tb"].size
+        tb_d = torch.full((tb_off,), 0xEE, dtype=torch.uint8, device="cuda")
+        llr_all = np.concatenate([np.zeros(3, np.int8)] + chunks)  # every codeword starts at an odd offset
+        ctx.pusch_decode_batch(d, torch.from_numpy(llr_all).cuda(), soft_d, msgs_d, crc_d, tb_d, res_d)
+        torch.cuda.synchronize()
+        res = res_d.cpu().numpy().view(miphy.PuschResult)
+        tb_out = tb_d.cpu().numpy()
+        soft = soft_d.cpu().numpy().reshape(slot, miphy.HARQ_CB_STRIDE)
+        for i, x in enumerate(tbs):
+            ok, tbo, mm = x["od"].decode(x["llrs"][t], rv, t == 0, 6, bool(early_stop))
+            r = res[i]
+            key = (i, t, x["bg"], x["mod"], x["tb"].size * 8)
+            assert bool(r["tb_crc_ok"]) == ok and (int(r["iters_min"]), int(r["iters_max"])) == mm, (key, r, mm)
+            exp_soft = x["od"].softbuf.reshape(x["ncb"], x["N"])
+            for c in range(x["ncb"]):
+                bad = np.nonzero(soft[x["slot"] + c, :x["N"]] != exp_soft[c])[0]
+                assert bad.size == 0, (key, c, bad[:8], soft[x["slot"] + c, bad[:8]], exp_soft[c, bad[:8]])
+            if ok:
+                o0 = int(d[i]["tb_offset"])
+                assert np.array_equal(tb_out[o0:o0 + x["tb"].size], x["tb"]), key
+    assert any(bool(r["tb_crc_ok"]) for r in res)
