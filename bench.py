@@ -387,7 +387,7 @@ def main():
 
     # ---- front end of the slot: 1 rx port, 1 layer, DM-RS type 1 in symbol 2 with two CDM groups without data (like
     # pusch_processor_benchmark.cpp:104-105), all 273 PRB allocated.
-    ce_d = torch.zeros(S * 14 * nsc, dtype=torch.complex64, device=dev)
+    ce_d = torch.zeros(S * nsc, dtype=torch.complex64, device=dev)  # compact estimate: one row per (slot, port), see miphy.h ce_compact
     sc_d = torch.zeros(S * 5, dtype=torch.float32, device=dev)
     cjobs = np.zeros(S, dtype=miphy.PuschChestJob)
     djobs = np.zeros(S, dtype=miphy.PuschDemodJob)
@@ -397,16 +397,16 @@ def main():
         j["numerology"], j["slot_in_frame"], j["scrambling_id"], j["scaling"] = 1, s % 20, DMRS_SCR_ID, DMRS_SCALING
         j["nof_tx_layers"], j["nof_rx_ports"], j["first_symbol"], j["nof_symbols"] = 1, 1, 0, 14
         j["rx_ports"] = [0, 1, 2, 3]
-        j["symbols_mask"], j["grid_nof_prb"] = 1 << 2, w["nprb"]
+        j["symbols_mask"], j["grid_nof_prb"], j["ce_compact"] = 1 << 2, w["nprb"], 1
         j["rb_mask"] = rb_words
-        j["grid_offset"], j["ce_offset"], j["scalars_offset"] = s * 14 * nsc, s * 14 * nsc, s * 5
+        j["grid_offset"], j["ce_offset"], j["scalars_offset"] = s * 14 * nsc, s * nsc, s * 5
         q = djobs[s]
         q["rnti"], q["n_id"], q["mod"], q["nof_rx_ports"], q["start_symbol"], q["nof_symbols"] = RNTI, N_ID, w["mod"], 1, 0, 14
-        q["dmrs_type"], q["nof_cdm_groups_without_data"], q["ce_nof_symbols"] = 1, 2, 14
+        q["dmrs_type"], q["nof_cdm_groups_without_data"], q["ce_nof_symbols"], q["ce_compact"] = 1, 2, 14, 1
         q["rx_ports"] = [0, 1, 2, 3]
         q["dmrs_symbols_mask"], q["grid_nof_prb"], q["nof_llr"] = 1 << 2, w["nprb"], G
         q["rb_mask"] = rb_words
-        q["grid_offset"], q["ce_offset"], q["scalars_offset"], q["llr_offset"] = s * 14 * nsc, s * 14 * nsc, s * 5, s * G
+        q["grid_offset"], q["ce_offset"], q["scalars_offset"], q["llr_offset"] = s * 14 * nsc, s * nsc, s * 5, s * G
     assert miphy.pusch_demod_nof_llr(djobs[0]) == G
     cjobs_d = torch.from_numpy(cjobs.view(np.uint8)).to(dev)
     djobs_d = torch.from_numpy(djobs.view(np.uint8)).to(dev)
@@ -479,7 +479,7 @@ def main():
     llr_h = llr_d[:checked * G].cpu().numpy().reshape(checked, G)
     msgs_h = msgs_d[:checked * C * miphy.HARQ_MSG_STRIDE].cpu().numpy().reshape(checked, C, miphy.HARQ_MSG_STRIDE)[:, :, :K // 8]
     g0 = grid_d[:14 * nsc].cpu().numpy().reshape(1, 14, nsc)
-    h0 = ce_d[:14 * nsc].cpu().numpy().reshape(1, 14, nsc)
+    h0 = np.ascontiguousarray(np.broadcast_to(ce_d[:nsc].cpu().numpy().reshape(1, 1, nsc), (1, 14, nsc)))  # the reference's layout: a copy per symbol
     dm = np.zeros(14, np.uint8)
     dm[2] = 1
     o_llr, _, _ = O.o_pusch_demodulate(RNTI, N_ID, w["mod"], 0, 14, dm, 0, 2, np.ones(w["nprb"], np.uint8), g0, h0, float(sc_d[2].item()))
@@ -523,8 +523,8 @@ def main():
     alg = {"ldpc_decode": S * sum(dec_in_len[c] + K // 8 + 4 for c in range(C)),
            "rate_dematch": S * (G + C * N),
            "ofdm_demod": S * (slot_samples * 8 + 14 * nsc * 8),
-           "dmrs_chest": S * (1 * (nsc // 2) * 8 + 14 * nsc * 8),
-           "pusch_demod": S * (w["nsym"] * (8 + 8) + G),
+           "dmrs_chest": S * (1 * (nsc // 2) * 8 + nsc * 8),          # DM-RS REs in, one estimate row out (compact form)
+           "pusch_demod": S * (w["nsym"] * 8 + nsc * 8 + G),          # data REs + the estimate row in, LLRs out
            "tb_assemble": S * (C * (K // 8) + tb_bytes)}
     gbs = {k: alg[k] / (kernel_ms[k] * 1e-3) / 1e9 for k in stages}
     dom = max(kernel_ms, key=kernel_ms.get)

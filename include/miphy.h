@@ -247,13 +247,17 @@ typedef struct {
   uint8_t  first_symbol;
   uint8_t  nof_symbols;
   uint8_t  rx_ports[4];
-  uint8_t  reserved[3];
+  uint8_t  ce_compact;     /* 0: the estimate is copied to every symbol of the allocation like the reference does
+                              (port_channel_estimator_average_impl.cpp:216-224); 1: one row per (layer, rx port) -- the copies are
+                              identical, so a consumer that knows it (miphy_pusch_demodulate_batch with ce_compact) needs no more */
+  uint8_t  reserved[2];
   uint16_t symbols_mask;   /* bit l = OFDM symbol l carries DM-RS */
   uint16_t grid_nof_prb;   /* width of the resource grid / rb_mask.size() */
   uint64_t rb_mask[5];     /* bit i = PRB i belongs to the allocation */
   uint64_t grid_offset;    /* cf_t offset of grid port 0: [port][14][grid_nof_prb*12] */
   uint64_t ce_offset;      /* cf_t offset of the estimate: [layer][rx port][first_symbol+nof_symbols][grid_nof_prb*12];
-                              only the allocated PRBs of symbols [first_symbol, first_symbol+nof_symbols) are written */
+                              only the allocated PRBs of symbols [first_symbol, first_symbol+nof_symbols) are written.
+                              With ce_compact: [layer][rx port][grid_nof_prb*12] */
   uint64_t scalars_offset; /* float offset: per (rx port, layer) {rsrp, epre, noise_var, snr, time_alignment_s} */
 } miphy_pusch_chest_job;
 
@@ -282,7 +286,8 @@ typedef struct {
   uint8_t  dmrs_type;      /* 1 or 2 */
   uint8_t  nof_cdm_groups_without_data;
   uint8_t  ce_nof_symbols; /* symbols per (port) block of the channel estimate = first_symbol + nof_symbols of the estimator job */
-  uint8_t  reserved;
+  uint8_t  ce_compact;     /* 1: the channel estimate has one row per rx port ([rx port][grid_nof_prb*12], an estimator job with
+                              ce_compact) used for every symbol; ce_nof_symbols is then ignored */
   uint8_t  rx_ports[4];
   uint16_t dmrs_symbols_mask; /* bit l = OFDM symbol l carries DM-RS */
   uint16_t grid_nof_prb;

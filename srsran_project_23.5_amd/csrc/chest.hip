@@ -247,8 +247,9 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
 
   // ---- linear interpolation over the concatenated allocated PRBs (interpolator_linear_impl.cpp:58-78; offset = delta,
   // stride 2, edges held) written straight to every OFDM symbol of the allocation (:216-224).
-  const int nout = nprb * 12;
-  float2*   dst0 = ce_out + job.ce_offset + ((size_t)(layer * job.nof_rx_ports + port) * nsymb_out) * nsc;
+  const int  nout    = nprb * 12;
+  const bool compact = job.ce_compact != 0;
+  float2*    dst0    = ce_out + job.ce_offset + ((size_t)(layer * job.nof_rx_ports + port) * (compact ? 1 : nsymb_out)) * nsc;
   for (int k = tid; k < nout; k += nt) {
     cplx v;
     const int kk = k - delta;
@@ -266,9 +267,14 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
     }
     const int    r   = prb_of[k / 12];
     const size_t col = (size_t)r * 12 + (k % 12);
-    for (int l = first; l < nsymb_out; ++l)
-      if (l % ngrp == sgrp)
-        dst0[(size_t)l * nsc + col] = make_float2(v.x, v.y);
+    if (compact) {
+      if (sgrp == 0)
+        dst0[col] = make_float2(v.x, v.y);
+    } else {
+      for (int l = first; l < nsymb_out; ++l)
+        if (l % ngrp == sgrp)
+          dst0[(size_t)l * nsc + col] = make_float2(v.x, v.y);
+    }
   }
 
   // ---- side-band scalars (:118-144)

@@ -33,6 +33,9 @@ struct miphy_graph_tables {
   // message is the parity of the sum over u of popcount(word & mask). (M(x) x^r mod P == 0 <=> M(x) mod P == 0, so the padding
   // does not change the verdict.) Word layout: bit (q + 8 b) of a word is message bit 4 q + b of its group of 32 (see hard_flags()).
   uint32_t crc_zmask[3][MIPHY_CRC_ZMASK_WORDS][24];
+  // The same for CRC24A over PACKED message bytes read as little-endian dwords (transport-block assembly): bit 8 k + 7 - j of a
+  // word is message bit 8 k + j of its group of 32.
+  uint32_t crc_zmask_packed24a[MIPHY_CRC_ZMASK_WORDS][24];
 };
 // index into crc_zmask for a MIPHY_CRC_* id, -1 if the polynomial has no mask table
 static inline __host__ __device__ int miphy_crc_zmask_index(int crc_id)

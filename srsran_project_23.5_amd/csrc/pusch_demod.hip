@@ -156,7 +156,7 @@ __device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* 
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     gp[p] = a.grid + ((size_t)((a.rxp >> (8 * p)) & 0xffu) * 14 + sy) * nsc;
-    hp[p] = a.ce + ((size_t)p * a.ce_nof_symbols + sy) * nsc;
+    hp[p] = a.ce + ((size_t)p * a.ce_nof_symbols + (a.ce_nof_symbols == 1 ? 0 : sy)) * nsc;
   }
   int8_t*    o       = a.llr + (size_t)prefix * MOD;
   const bool aligned = ((uintptr_t)o % (MOD == 8 ? 8 : MOD == 4 ? 4 : MOD == 1 ? 1 : 2)) == 0;
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) pusch_demod_kernel(const miphy_pusch_demo
   demod_args a;
   a.nsc            = nprb_grid * 12;
   a.nports         = jp->nof_rx_ports;
-  a.ce_nof_symbols = jp->ce_nof_symbols;
+  a.ce_nof_symbols = jp->ce_compact ? 1 : jp->ce_nof_symbols; // compact estimate: one row per port, valid for every symbol
   a.rxp            = (uint32_t)jp->rx_ports[0] | ((uint32_t)jp->rx_ports[1] << 8) | ((uint32_t)jp->rx_ports[2] << 16) | ((uint32_t)jp->rx_ports[3] << 24);
   a.grid           = grid + jp->grid_offset;
   a.ce             = ce + jp->ce_offset;
@@ -350,7 +350,8 @@ extern "C" int miphy_pusch_demodulate_batch(miphy_ctx* ctx, const miphy_pusch_de
       MIPHY_REQUIRE(j.mod == 1 || j.mod == 2 || j.mod == 4 || j.mod == 6 || j.mod == 8, "pusch_demodulate: job %u: invalid modulation order %u", i, j.mod);
       MIPHY_REQUIRE(j.nof_rx_ports >= 1 && j.nof_rx_ports <= 4, "pusch_demodulate: job %u: invalid number of receive ports", i);
       MIPHY_REQUIRE(j.nof_symbols >= 1 && j.start_symbol + j.nof_symbols <= 14, "pusch_demodulate: job %u: invalid time allocation", i);
-      MIPHY_REQUIRE(j.ce_nof_symbols >= j.start_symbol + j.nof_symbols && j.ce_nof_symbols <= 14, "pusch_demodulate: job %u: channel estimate too short", i);
+      MIPHY_REQUIRE(j.ce_compact || (j.ce_nof_symbols >= j.start_symbol + j.nof_symbols && j.ce_nof_symbols <= 14),
+                    "pusch_demodulate: job %u: channel estimate too short", i);
       MIPHY_REQUIRE(j.dmrs_type == 1 || j.dmrs_type == 2, "pusch_demodulate: job %u: invalid DM-RS type", i);
       MIPHY_REQUIRE(j.nof_cdm_groups_without_data >= 1 && j.nof_cdm_groups_without_data <= (j.dmrs_type == 1 ? 2 : 3),
                     "pusch_demodulate: job %u: invalid number of CDM groups without data", i);

@@ -35,10 +35,11 @@ extern "C" int miphy_pusch_process_batch(miphy_ctx* ctx, const miphy_pusch_pdu* 
     c.scaling = powf(10.0f, 3.0f / 20.0f);
     c.n_scid = p.n_scid, c.nof_tx_layers = 1, c.nof_rx_ports = p.nof_rx_ports, c.first_symbol = p.start_symbol, c.nof_symbols = p.nof_symbols;
     c.symbols_mask = p.dmrs_symbols_mask, c.grid_nof_prb = p.grid_nof_prb;
+    c.ce_compact   = 1; // the estimate only feeds the demodulator below: one row per port instead of a copy per symbol
     miphy_pusch_demod_job& d = dj[i];
     d                        = {};
     d.rnti = p.rnti, d.n_id = p.n_id, d.mod = p.mod, d.nof_rx_ports = p.nof_rx_ports, d.start_symbol = p.start_symbol, d.nof_symbols = p.nof_symbols;
-    d.dmrs_type = 1, d.nof_cdm_groups_without_data = 2, d.ce_nof_symbols = (uint8_t)nsym_ce;
+    d.dmrs_type = 1, d.nof_cdm_groups_without_data = 2, d.ce_nof_symbols = (uint8_t)nsym_ce, d.ce_compact = 1;
     d.dmrs_symbols_mask = p.dmrs_symbols_mask, d.grid_nof_prb = p.grid_nof_prb;
     for (int k = 0; k < 4; ++k)
       c.rx_ports[k] = p.rx_ports[k], d.rx_ports[k] = p.rx_ports[k];
@@ -55,7 +56,7 @@ extern "C" int miphy_pusch_process_batch(miphy_ctx* ctx, const miphy_pusch_pdu* 
     t.bg = p.bg, t.rv = p.rv, t.mod = p.mod, t.nof_layers = 1, t.new_data = p.new_data, t.use_early_stop = p.use_early_stop;
     t.nof_ldpc_iterations = p.nof_ldpc_iterations, t.Nref = p.Nref, t.nof_ch_symbols = d.nof_llr / p.mod, t.tb_bytes = p.tb_bytes;
     t.harq_cb_index = p.harq_cb_index, t.llr_offset = llr_bytes, t.tb_offset = p.tb_offset;
-    ce_elems += (size_t)p.nof_rx_ports * nsym_ce * nsc;
+    ce_elems += (size_t)p.nof_rx_ports * nsc;
     llr_bytes += (d.nof_llr + 15u) & ~15u;
   }
   // [channel estimates cf_t | LLRs] in a workspace of the context; the estimator scalars go straight to the caller's array.

@@ -62,7 +62,7 @@ uint32_t rm_length(const seg_t& s, uint32_t i_seg, uint32_t mod, uint32_t nof_la
   return t * nof_layers * mod;
 }
 
-struct tb_asm_desc { // per transport block, consumed by pusch_tb_assemble_kernel
+struct tb_asm_desc { // per transport block, consumed by pusch_tb_part_kernel / pusch_tb_finish_kernel
   uint32_t first_desc;  // first codeblock descriptor / iters entry of this TB
   uint32_t nof_cbs;
   uint32_t harq_cb_index;
@@ -81,23 +81,25 @@ __global__ void harq_reset_kernel(const uint32_t* __restrict__ slots, uint32_t n
     harq_crc_ok[slots[i]] = 0; // pusch_decoder_impl.cpp:146-149
 }
 
-// One workgroup per transport block (pusch_decoder_impl.cpp:198-222): concatenates the codeblock data bits, checks the TB
-// CRC24A when there are several codeblocks, writes the TB and the result record, resets the CRC flags on a TB CRC failure.
+// Transport-block assembly (pusch_decoder_impl.cpp:198-222): one workgroup per transport block, one WAVEFRONT per codeblock
+// (round robin). When every codeblock passed its CRC, a wavefront copies the data bits of its codeblock to their place in the
+// transport block and computes their part of the TB checksum by masks and popcounts (crc_zmask_packed24a: the remainder of the
+// codeblock's bits as if the message ended with them), which one lane then weights with the bits that follow in TB + CRC24A.
+// The XOR of the parts is zero exactly when CRC24A passes (all parts carry the same invertible factor x^24, see below).
+// Then: decoder statistics, result record, CRC flags reset on a TB CRC failure.
 __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_desc* __restrict__ descs,
                                                                 const miphy_graph_tables* __restrict__ tab,
                                                                 const int32_t* __restrict__ iters,
                                                                 const uint8_t* __restrict__ harq_msgs,
                                                                 uint8_t* __restrict__ harq_crc_ok,
-                                                                uint8_t* __restrict__ tmp_tb_base, // workspace: per TB, tb_and_crc bytes (+8 pad)
-                                                                const uint64_t* __restrict__ tmp_off,
                                                                 uint8_t* __restrict__ tb_out,
                                                                 miphy_pusch_result* __restrict__ results)
 {
-  __shared__ uint32_t red[16];
+  __shared__ uint32_t wpart[16];
   __shared__ int      all_ok;
-  const tb_asm_desc d   = descs[blockIdx.x];
-  const int         tid = threadIdx.x;
-  uint8_t*          tmp = tmp_tb_base + tmp_off[blockIdx.x];
+  const tb_asm_desc d    = descs[blockIdx.x];
+  const int         tid  = threadIdx.x;
+  const int         lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   if (tid < 64) {
     // one lane per codeblock (at most 52), reduced across the first wavefront
     int      ok = 1;
@@ -130,53 +132,98 @@ __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_de
       results[blockIdx.x]    = r;
     }
   }
+  if (tid < 16)
+    wpart[tid] = 0;
   __syncthreads();
   if (!all_ok)
     return; // nothing is copied, flags stay as they are (multiple codeblocks) / tb_crc_ok = false (single codeblock)
-  // tmp_tb_bits: nof_new_bits = min(free, nof_data_bits) from every codeblock message, bit-granular.
-  const uint32_t nbytes = (d.tb_and_crc_bits + 7) / 8;
-  const bool     bytewise = (d.nof_data_bits % 8) == 0 || d.nof_cbs == 1; // always true for TS 38.214 transport block sizes
-  const uint32_t cb_bytes = d.nof_data_bits / 8;
-  for (uint32_t b = tid; b < nbytes + 8; b += blockDim.x) {
-    uint32_t v = 0;
-    if (b < nbytes && bytewise) {
-      const uint32_t c = (d.nof_cbs == 1) ? 0u : b / cb_bytes, o = b - c * cb_bytes;
-      v                = harq_msgs[(size_t)(d.harq_cb_index + c) * HARQ_MSG_STRIDE + o];
-      const uint32_t last = d.tb_and_crc_bits - 8 * b; // bits of this byte that belong to the transport block
+  const uint32_t tb_bits = d.tb_bytes * 8;
+  const bool     mask_crc = d.nof_cbs > 1 && d.nof_data_bits <= 32u * MIPHY_CRC_ZMASK_WORDS && (d.nof_data_bits & 7u) == 0;
+  uint32_t       acc_wave = 0;
+  for (uint32_t c = wave; c < d.nof_cbs; c += nwaves) {
+    const uint8_t* msg   = harq_msgs + (size_t)(d.harq_cb_index + c) * HARQ_MSG_STRIDE;
+    const uint32_t bit0  = c * d.nof_data_bits; // first TB(+CRC) bit of this codeblock
+    const uint32_t nbits = min(d.nof_data_bits, d.tb_and_crc_bits - min(bit0, d.tb_and_crc_bits));
+    const uint32_t after = d.tb_and_crc_bits - (bit0 + nbits);
+    // ---- copy: whole bytes (codeblock payloads are byte aligned for every TS 38.214 transport block size; a single codeblock
+    // starts at bit 0, only its last byte can be partial and is masked)
+    const uint32_t o0 = bit0 >> 3;
+    const uint32_t e0 = (min(bit0 + nbits, tb_bits) + 7) >> 3; // end byte in the transport block
+    for (uint32_t b = o0 + lane; b < e0; b += 64) {
+      uint32_t       v    = msg[b - o0];
+      const uint32_t last = tb_bits - 8 * b; // bits of this byte that belong to the transport block
       if (last < 8)
         v &= 0xffu << (8 - last);
-    } else if (b < nbytes) {
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t bit = 8 * b + k;
-        if (bit >= d.tb_and_crc_bits)
-          break;
-        const uint32_t c   = bit / d.nof_data_bits, o = bit - c * d.nof_data_bits;
-        const uint8_t* msg = harq_msgs + (size_t)(d.harq_cb_index + c) * HARQ_MSG_STRIDE;
-        v |= (uint32_t)((msg[o >> 3] >> (7 - (o & 7))) & 1u) << (7 - k);
-      }
+      tb_out[d.tb_offset + b] = (uint8_t)v;
     }
-    tmp[b] = (uint8_t)v;
+    // ---- checksum part
+    if (mask_crc) {
+      const uint32_t  nw = (nbits + 31) >> 5, r = 32 * nw - nbits; // zero bits the mask table assumes behind the message
+      const uint32_t* mw = reinterpret_cast<const uint32_t*>(msg); // slots are 1056 B apart: dword aligned
+      uint32_t        acc[24];
+#pragma unroll
+      for (int k = 0; k < 24; ++k)
+        acc[k] = 0;
+      for (uint32_t t = lane; t < nw; t += 64) {
+        uint32_t w = mw[t];
+        if (32 * t + 32 > nbits) { // last word: keep the first nbits - 32 t message bits = the leading bytes (byte aligned)
+          const uint32_t nb = (nbits - 32 * t) >> 3;
+          w &= (nb >= 4) ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+        }
+        const uint4* m = reinterpret_cast<const uint4*>(tab->crc_zmask_packed24a[nw - 1 - t]);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+          const uint4 mk = m[g];
+          acc[4 * g + 0] += __builtin_popcount(w & mk.x);
+          acc[4 * g + 1] += __builtin_popcount(w & mk.y);
+          acc[4 * g + 2] += __builtin_popcount(w & mk.z);
+          acc[4 * g + 3] += __builtin_popcount(w & mk.w);
+        }
+      }
+      uint32_t par = 0;
+#pragma unroll
+      for (int k = 0; k < 24; ++k)
+        par |= (acc[k] & 1u) << k;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+        par ^= __shfl_xor(par, off);
+      // par = D(x) x^(r + 24) mod P. Every part is brought to the common factor x^24: times x^(after + 24 - r), r <= 24.
+      const uint32_t poly = tab->crc_poly[MIPHY_CRC24A], order = 24, top = 1u << 24;
+      const uint32_t sh   = after + 24 - r;
+      par                 = crc_gf2_mulmod(par, crc_pow32(tab, MIPHY_CRC24A, sh >> 5, poly, order), poly, order);
+      for (uint32_t b = 0; b < (sh & 31u); ++b) {
+        par <<= 1;
+        par ^= (par & top) ? poly : 0u;
+      }
+      acc_wave ^= par;
+    } else if (d.nof_cbs > 1) {
+      uint32_t par = crc_partial(tab, MIPHY_CRC24A, msg, 0, nbits, lane, 64);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+        par ^= __shfl_xor(par, off);
+      const uint32_t poly = tab->crc_poly[MIPHY_CRC24A], order = 24, top = 1u << 24;
+      const uint32_t sh   = after + 24; // the same common factor as the mask form
+      par                 = crc_gf2_mulmod(par, crc_pow32(tab, MIPHY_CRC24A, sh >> 5, poly, order), poly, order);
+      for (uint32_t b = 0; b < (sh & 31u); ++b) {
+        par <<= 1;
+        par ^= (par & top) ? poly : 0u;
+      }
+      acc_wave ^= par;
+    }
+  }
+  if (lane == 0)
+    wpart[wave] = acc_wave;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t rem = 0;
+    for (int w = 0; w < nwaves; ++w)
+      rem ^= wpart[w];
+    const int tb_ok               = (d.nof_cbs == 1) || (rem == 0);
+    results[blockIdx.x].tb_crc_ok = tb_ok;
+    all_ok                        = tb_ok;
   }
   __syncthreads();
-  int tb_ok = 1;
-  if (d.nof_cbs > 1) {
-    uint32_t part = crc_partial(tab, MIPHY_CRC24A, tmp, 0, d.tb_and_crc_bits, tid, blockDim.x);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-      part ^= __shfl_xor(part, off);
-    if ((tid & 63) == 0)
-      red[tid >> 6] = part;
-    __syncthreads();
-    uint32_t r = 0;
-    for (unsigned w = 0; w < blockDim.x / 64; ++w)
-      r ^= red[w];
-    tb_ok = (r == 0);
-  }
-  for (uint32_t b = tid; b < d.tb_bytes; b += blockDim.x)
-    tb_out[d.tb_offset + b] = tmp[b];
-  if (tid == 0)
-    results[blockIdx.x].tb_crc_ok = tb_ok;
-  if (!tb_ok) // pusch_decoder_impl.cpp:218-220: at least one codeblock is a false negative, reset all of them
+  if (!all_ok) // pusch_decoder_impl.cpp:218-220: at least one codeblock is a false negative, reset all of them
     for (uint32_t c = tid; c < d.nof_cbs; c += blockDim.x)
       harq_crc_ok[d.harq_cb_index + c] = 0;
 }
@@ -293,8 +340,7 @@ struct pusch_decode_build {
   std::vector<miphy_ldpc_dec_desc> dec;
   std::vector<uint32_t>            slots, reset_slots;
   std::vector<tb_asm_desc>         asmd;
-  std::vector<uint64_t>            tmp_off;
-  uint64_t                         tmp_bytes = 0;
+  std::vector<uint32_t>            cb_tb; // transport block of each codeblock
   uint32_t                         max_Z = 2, max_nodes = 0, max_E = 0;
   bool                             any_odd_Z = false; // the packed decoder pairs rows l and l + Z/2
   bool                             fusable   = true;  // every codeblock can be rate-dematched by the decoder while it loads
@@ -307,9 +353,9 @@ struct pusch_decode_dev {
   const uint32_t*            slots;
   const uint32_t*            reset;
   const tb_asm_desc*         asmd;
-  const uint64_t*            tmp_off;
+  const uint32_t*            cb_tb;
   int32_t*                   iters;
-  uint8_t*                   tmp;
+  uint32_t*                  part; // per codeblock: its part of the TB checksum
   size_t                     staged; // bytes to copy host -> device
   size_t                     total;  // bytes of the whole buffer
 };
@@ -317,7 +363,6 @@ struct pusch_decode_dev {
 int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_build& b)
 {
   b.asmd.resize(n);
-  b.tmp_off.resize(n);
   for (uint32_t t = 0; t < n; ++t) {
     const miphy_pusch_tb_desc& d = tbs[t];
     seg_t                      sg;
@@ -341,8 +386,6 @@ int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_
     a.tb_bytes         = d.tb_bytes;
     a.max_iter         = d.nof_ldpc_iterations;
     a.tb_offset        = d.tb_offset;
-    b.tmp_off[t]       = b.tmp_bytes;
-    b.tmp_bytes += ((a.tb_and_crc_bits + 7) / 8 + 8 + 15) & ~15ull;
     uint32_t cw_off = 0, tb_nodes = 0;
     for (uint32_t c = 0; c < sg.nof_cbs; ++c) {
       const uint32_t      E    = rm_length(sg, c, d.mod, d.nof_layers, d.nof_ch_symbols);
@@ -383,6 +426,7 @@ int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_
       q.flags           = d.use_early_stop ? 0u : 1u;
       q.llr_offset = (uint64_t)slot * HARQ_CB_STRIDE, q.out_offset = (uint64_t)slot * HARQ_MSG_STRIDE;
       b.dec.push_back(q);
+      b.cb_tb.push_back(t);
       b.slots.push_back(slot);
       if (d.new_data)
         b.reset_slots.push_back(slot);
@@ -399,7 +443,7 @@ int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_
 size_t pusch_decode_bytes(const pusch_decode_build& b)
 {
   return 64 + b.rdm.size() * sizeof(b.rdm[0]) + b.dec.size() * sizeof(b.dec[0]) + (b.slots.size() + b.reset_slots.size()) * 4 +
-         b.asmd.size() * sizeof(b.asmd[0]) + b.tmp_off.size() * 8 + b.dec.size() * 4 + b.tmp_bytes + 16 * 8;
+         b.asmd.size() * sizeof(b.asmd[0]) + b.cb_tb.size() * 4 + b.dec.size() * 8 + 16 * 8;
 }
 
 // Lays the build out in a host image `h` of the device buffer `dv` (same offsets) and returns the device pointers.
@@ -412,14 +456,14 @@ pusch_decode_dev layout_pusch_decode(const pusch_decode_build& b, uint8_t* h, ui
   v.slots   = stage_vec(h, dv, b.slots, off);
   v.reset   = stage_vec(h, dv, b.reset_slots, off);
   v.asmd    = stage_vec(h, dv, b.asmd, off);
-  v.tmp_off = stage_vec(h, dv, b.tmp_off, off);
+  v.cb_tb   = stage_vec(h, dv, b.cb_tb, off);
   v.staged  = off;
   off       = (off + 15) & ~(size_t)15;
   v.iters   = reinterpret_cast<int32_t*>(dv + off);
   off += b.dec.size() * 4;
   off   = (off + 15) & ~(size_t)15;
-  v.tmp = dv + off;
-  v.total = off + b.tmp_bytes;
+  v.part  = reinterpret_cast<uint32_t*>(dv + off);
+  v.total = off + b.dec.size() * 4;
   return v;
 }
 
@@ -459,11 +503,7 @@ int launch_pusch_decode(miphy_ctx* ctx, const pusch_decode_build& b, const pusch
   }
   if (ev)
     MIPHY_HIP_CHECK(hipEventRecord(ev[2], s));
-  for (uint32_t a = 0; a < n; a += 65535) {
-    const uint32_t m = (n - a < 65535) ? n - a : 65535;
-    hipLaunchKernelGGL(pusch_tb_assemble_kernel, dim3(m), dim3(1024), 0, s, v.asmd + a, ctx->d_tables, v.iters, harq_msgs, harq_crc_ok, v.tmp, v.tmp_off + a,
-                       tb_out, results + a);
-  }
+  hipLaunchKernelGGL(pusch_tb_assemble_kernel, dim3(n), dim3(1024), 0, s, v.asmd, ctx->d_tables, v.iters, harq_msgs, harq_crc_ok, tb_out, results);
   if (ev)
     MIPHY_HIP_CHECK(hipEventRecord(ev[3], s));
   MIPHY_HIP_CHECK(hipGetLastError());
@@ -547,6 +587,7 @@ extern "C" int miphy_pusch_decode_plan_create(miphy_ctx* ctx, const miphy_pusch_
   std::vector<miphy_ldpc_rdm_desc>().swap(p->b.rdm);
   std::vector<miphy_ldpc_dec_desc>().swap(p->b.dec);
   std::vector<uint32_t>().swap(p->b.slots);
+  std::vector<uint32_t>().swap(p->b.cb_tb);
   *out = p;
   return MIPHY_OK;
 }

@@ -124,7 +124,7 @@ class OfdmConfig(C.Structure):
 # Mirrors miphy_pusch_chest_job.
 PuschChestJob = np.dtype([("numerology", np.uint32), ("slot_in_frame", np.uint32), ("scrambling_id", np.uint32), ("scaling", np.float32),
                           ("n_scid", np.uint8), ("nof_tx_layers", np.uint8), ("nof_rx_ports", np.uint8), ("first_symbol", np.uint8),
-                          ("nof_symbols", np.uint8), ("rx_ports", np.uint8, 4), ("reserved", np.uint8, 3), ("symbols_mask", np.uint16),
+                          ("nof_symbols", np.uint8), ("rx_ports", np.uint8, 4), ("ce_compact", np.uint8), ("reserved", np.uint8, 2), ("symbols_mask", np.uint16),
                           ("grid_nof_prb", np.uint16), ("rb_mask", np.uint64, 5), ("grid_offset", np.uint64), ("ce_offset", np.uint64),
                           ("scalars_offset", np.uint64)], align=True)
 assert PuschChestJob.itemsize == 96, PuschChestJob.itemsize
@@ -134,7 +134,7 @@ assert PuschChestJob.fields["rb_mask"][1] == 32 and PuschChestJob.fields["symbol
 # Mirrors miphy_pusch_demod_job.
 PuschDemodJob = np.dtype([("rnti", np.uint32), ("n_id", np.uint32), ("mod", np.uint8), ("nof_rx_ports", np.uint8), ("start_symbol", np.uint8),
                           ("nof_symbols", np.uint8), ("dmrs_type", np.uint8), ("nof_cdm_groups_without_data", np.uint8),
-                          ("ce_nof_symbols", np.uint8), ("reserved", np.uint8), ("rx_ports", np.uint8, 4), ("dmrs_symbols_mask", np.uint16),
+                          ("ce_nof_symbols", np.uint8), ("ce_compact", np.uint8), ("rx_ports", np.uint8, 4), ("dmrs_symbols_mask", np.uint16),
                           ("grid_nof_prb", np.uint16), ("nof_llr", np.uint32), ("rb_mask", np.uint64, 5), ("grid_offset", np.uint64),
                           ("ce_offset", np.uint64), ("scalars_offset", np.uint64), ("llr_offset", np.uint64)], align=True)
 assert PuschDemodJob.itemsize == 104 and PuschDemodJob.fields["rb_mask"][1] == 32, PuschDemodJob.itemsize
