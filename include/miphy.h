@@ -222,6 +222,17 @@ int miphy_ofdm_demodulate_slots(miphy_ctx* ctx, const miphy_ofdm_config* cfg, co
                                 uint32_t n, const float* samples /* device cf_t */, float* grid /* device cf_t */, void* stream);
 int miphy_ofdm_modulate_slots(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm_job* jobs, int jobs_on_device,
                               uint32_t n, const float* grid /* device cf_t */, float* samples /* device cf_t */, void* stream);
+
+/* The same transforms one OFDM symbol at a time, for the symbol-granular interfaces of the lower PHY
+ * (srsran::ofdm_symbol_demodulator / ofdm_symbol_modulator, ofdm_demodulator.h:55-74, ofdm_modulator.h:55-74; callers
+ * lib/phy/lower/processors/uplink/puxch/puxch_processor_impl.cpp:64-76, downlink/pdxch/pdxch_processor_impl.cpp:76-82).
+ * A job is one symbol: slot_index = symbol index within the SUBFRAME (0 .. 14 * 2^numerology - 1), samples_offset = cf_t offset of
+ * the symbol's first sample (cyclic prefix included), grid_offset = cf_t offset of its row of bw_rb * 12 subcarriers. */
+uint32_t miphy_ofdm_symbol_size(const miphy_ofdm_config* cfg, uint32_t symbol_index); /* cyclic prefix + dft_size samples; host only */
+int miphy_ofdm_demodulate_symbols(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm_job* jobs, int jobs_on_device, uint32_t n,
+                                  const float* samples /* device cf_t */, float* grid /* device cf_t */, void* stream);
+int miphy_ofdm_modulate_symbols(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm_job* jobs, int jobs_on_device, uint32_t n,
+                                const float* grid /* device cf_t */, float* samples /* device cf_t */, void* stream);
 /* Number of samples of slot `slot_index` (ofdm_slot_demodulator::get_slot_size). Returns 0 on invalid configuration. */
 uint32_t miphy_ofdm_slot_size(const miphy_ofdm_config* cfg, uint32_t slot_index);
 
@@ -387,11 +398,32 @@ typedef struct {
   uint32_t ibil; /* channel interleaver present (uplink) */
 } miphy_polar_code;
 
+/* Single blocks of the chains, for the block-level interfaces (one wavefront per codeword, n codewords back to back):
+ *   ALLOCATE      polar_allocator::allocate        (polar_allocator.h:42-43)        in: n x K bits      out: n x N bits
+ *   ENCODE        polar_encoder::encode            (polar_encoder.h:43)             in: n x 2^param     out: n x 2^param   (code may be NULL)
+ *   RATE_MATCH    polar_rate_matcher::rate_match   (polar_rate_matcher.h:42-43)     in: n x N bits      out: n x E bits
+ *   RATE_DEMATCH  polar_rate_dematcher::rate_dematch (polar_rate_dematcher.h:45-47) in: n x E LLRs      out: n x N LLRs
+ *   DECODE        polar_decoder::decode            (polar_decoder.h:47-48)          in: n x N LLRs      out: n x N bits (u domain)
+ *   DEALLOCATE    polar_deallocator::deallocate    (polar_deallocator.h:41-42)      in: n x N bits      out: n x K bits
+ *   INTERLEAVE_TX / _RX  polar_interleaver::interleave (polar_interleaver.h:45-46)  in / out: n x param bits, param = K <= 164 (code may be NULL)
+ * One bit per byte, LLRs int8, everything in device memory. */
+enum {
+  MIPHY_POLAR_OP_ALLOCATE = 0,
+  MIPHY_POLAR_OP_ENCODE,
+  MIPHY_POLAR_OP_RATE_MATCH,
+  MIPHY_POLAR_OP_RATE_DEMATCH,
+  MIPHY_POLAR_OP_DECODE,
+  MIPHY_POLAR_OP_DEALLOCATE,
+  MIPHY_POLAR_OP_INTERLEAVE_TX,
+  MIPHY_POLAR_OP_INTERLEAVE_RX
+};
 /* Host-side query of the derived code parameters (polar_code::get_n / get_N / get_nPC). Returns 0 or MIPHY_EINVAL. */
 int miphy_polar_code_info(const miphy_polar_code* code, uint32_t* n, uint32_t* N, uint32_t* nPC);
 
 int miphy_polar_encode_batch(miphy_ctx* ctx, const miphy_polar_code* code, uint32_t n, const uint8_t* msg /* device */,
                              uint8_t* rm_out /* device */, uint8_t* allocated_tap, uint8_t* encoded_tap, void* stream);
+int miphy_polar_block_batch(miphy_ctx* ctx, const miphy_polar_code* code, uint32_t op, uint32_t param, uint32_t n, const void* in /* device */,
+                            void* out /* device */, void* stream);
 int miphy_polar_decode_batch(miphy_ctx* ctx, const miphy_polar_code* code, uint32_t n, const int8_t* llr /* device */,
                              uint8_t* msg_out /* device */, int8_t* dematched_tap, uint8_t* decoded_u_tap, void* stream);
 

@@ -1506,6 +1506,188 @@ static void test_softbuffer_pool(std::shared_ptr<miphy::context> c)
   printf("rx_softbuffer_pool (device-resident HARQ) done, failures so far %d\n", failures);
 }
 
+// The flow of polar_chain_test.cpp:156-210 run block by block on the HIP objects of polar_factory_hip next to the reference's
+// software objects: every intermediate must be identical (noisy LLRs, so that the decoder really works), and the pdcch_encoder
+// the reference builds from a polar_factory works unchanged on the HIP factory.
+static void test_polar_blocks(std::shared_ptr<miphy::context> c)
+{
+  auto fs = create_polar_factory_sw();
+  auto fh = miphy::create_polar_factory_hip(c);
+  std::uniform_int_distribution<int> bit(0, 1);
+  struct tc {
+    unsigned K, E, nMax;
+    bool     bil;
+  };
+  for (const tc& t : {tc{64, 108, 9, false}, tc{64, 216, 9, false}, tc{94, 432, 9, false}, tc{164, 864, 9, false}, tc{56, 864, 9, false}, tc{20, 64, 10, true},
+                      tc{31, 120, 10, true}, tc{70, 1728, 9, false}, tc{200, 400, 10, true}, tc{1000, 2048, 10, false}}) {
+    auto code = fs->create_code();
+    code->set(t.K, t.E, t.nMax, t.bil ? polar_code_ibil::present : polar_code_ibil::not_present);
+    const unsigned N = code->get_N();
+    std::vector<uint8_t> msg(t.K), a1(N), a2(N), e1(N), e2(N), r1(t.E), r2(t.E), u1(N), u2(N), m1(t.K), m2(t.K);
+    for (auto& b : msg) {
+      b = bit(rgen);
+    }
+    fs->create_allocator()->allocate(a1, msg, *code);
+    fh->create_allocator()->allocate(a2, msg, *code);
+    CHECK(a1 == a2, "polar_allocator mismatch K %u E %u", t.K, t.E);
+    fs->create_encoder()->encode(e1, a1, code->get_n());
+    fh->create_encoder()->encode(e2, a1, code->get_n());
+    CHECK(e1 == e2, "polar_encoder mismatch K %u E %u", t.K, t.E);
+    fs->create_rate_matcher()->rate_match(r1, e1, *code);
+    fh->create_rate_matcher()->rate_match(r2, e1, *code);
+    CHECK(r1 == r2, "polar_rate_matcher mismatch K %u E %u", t.K, t.E);
+    std::vector<log_likelihood_ratio> rx = noisy(r1, 0.9F), d1(N), d2(N);
+    fs->create_rate_dematcher()->rate_dematch(d1, rx, *code);
+    fh->create_rate_dematcher()->rate_dematch(d2, rx, *code);
+    CHECK(d1 == d2, "polar_rate_dematcher mismatch K %u E %u", t.K, t.E);
+    fs->create_decoder(t.nMax)->decode(u1, d1, *code);
+    fh->create_decoder(t.nMax)->decode(u2, d1, *code);
+    CHECK(u1 == u2, "polar_decoder mismatch K %u E %u", t.K, t.E);
+    fs->create_deallocator()->deallocate(m1, u1, *code);
+    fh->create_deallocator()->deallocate(m2, u1, *code);
+    CHECK(m1 == m2, "polar_deallocator mismatch K %u E %u", t.K, t.E);
+    if (t.K <= 164) {
+      std::vector<uint8_t> i1(t.K), i2(t.K);
+      for (auto dir : {polar_interleaver_direction::tx, polar_interleaver_direction::rx}) {
+        fs->create_interleaver()->interleave(i1, msg, dir);
+        fh->create_interleaver()->interleave(i2, msg, dir);
+        CHECK(i1 == i2, "polar_interleaver mismatch K %u", t.K);
+      }
+    }
+  }
+  // the reference's own PDCCH encoder built over the HIP polar factory and the HIP CRC calculator factory
+  auto e1 = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), fs)->create();
+  auto e2 = create_pdcch_encoder_factory_sw(miphy::create_crc_calculator_factory_hip(c), fh)->create();
+  for (unsigned A : {12U, 57U, 128U}) {
+    std::vector<uint8_t> pay(A), o1(432), o2(432);
+    for (auto& b : pay) {
+      b = bit(rgen);
+    }
+    pdcch_encoder::config_t cfg;
+    cfg.E = 432, cfg.rnti = 0x1234 + A;
+    e1->encode(o1, pay, cfg);
+    e2->encode(o2, pay, cfg);
+    CHECK(o1 == o2, "pdcch_encoder over the HIP polar / CRC factories mismatch A %u", A);
+  }
+  printf("polar blocks (allocator, encoder, rate matcher / dematcher, decoder, deallocator, interleaver, factory) done, failures so far %d\n", failures);
+}
+
+static void test_crc_calculator(std::shared_ptr<miphy::context> c)
+{
+  auto fs = create_crc_calculator_factory_sw("auto");
+  auto fh = miphy::create_crc_calculator_factory_hip(c);
+  std::uniform_int_distribution<int> byte(0, 255);
+  for (auto poly : {crc_generator_poly::CRC24A, crc_generator_poly::CRC24B, crc_generator_poly::CRC24C, crc_generator_poly::CRC16, crc_generator_poly::CRC11}) {
+    auto a = fs->create(poly), b = fh->create(poly);
+    CHECK(b && b->get_generator_poly() == poly, "crc_calculator_hip: factory");
+    for (unsigned nbytes : {1U, 3U, 40U, 1053U, 39973U}) {
+      std::vector<uint8_t> data(nbytes);
+      for (auto& v : data) {
+        v = byte(rgen);
+      }
+      CHECK(a->calculate_byte(data) == b->calculate_byte(data), "crc calculate_byte mismatch (%u bytes)", nbytes);
+      std::vector<uint8_t> bits(nbytes * 8 - 3);
+      for (size_t i = 0; i != bits.size(); ++i) {
+        bits[i] = (data[i / 8] >> (7 - i % 8)) & 1U;
+      }
+      CHECK(a->calculate_bit(bits) == b->calculate_bit(bits), "crc calculate_bit mismatch (%zu bits)", bits.size());
+      dynamic_bit_buffer bb(bits.size());
+      for (size_t i = 0; i != bits.size(); ++i) {
+        bb.insert(bits[i], i, 1);
+      }
+      CHECK(a->calculate(bb) == b->calculate(bb), "crc calculate(bit_buffer) mismatch (%zu bits)", bits.size());
+    }
+  }
+  CHECK(fh->create(crc_generator_poly::CRC6) == nullptr, "crc factory: CRC6 is not on this path");
+  printf("crc_calculator done, failures so far %d\n", failures);
+}
+
+// ofdm_symbol_demodulator / ofdm_symbol_modulator (what the lower PHY calls per symbol): HIP vs the reference's generic objects,
+// symbol by symbol over a subframe, both numerologies of the configurations of BASELINE.json.
+static void test_ofdm_symbols(std::shared_ptr<miphy::context> c)
+{
+  ofdm_factory_generic_configuration fc;
+  fc.dft_factory = std::make_shared<generic_dft_factory>();
+  auto ds = create_ofdm_demodulator_factory_generic(fc), dh = std::shared_ptr<ofdm_demodulator_factory>(new miphy::ofdm_demodulator_factory_hip(c));
+  auto ms = create_ofdm_modulator_factory_generic(fc), mh = std::shared_ptr<ofdm_modulator_factory>(new miphy::ofdm_modulator_factory_hip(c));
+  std::normal_distribution<float> n(0.F, 0.7F);
+  for (auto cfgv : {std::make_tuple(1U, 106U, 2048U, 72U), std::make_tuple(1U, 273U, 4096U, 144U), std::make_tuple(0U, 52U, 1024U, 0U)}) {
+    ofdm_demodulator_configuration dc;
+    dc.numerology = std::get<0>(cfgv), dc.bw_rb = std::get<1>(cfgv), dc.dft_size = std::get<2>(cfgv), dc.cp = cyclic_prefix::NORMAL;
+    dc.nof_samples_window_offset = std::get<3>(cfgv), dc.scale = 0.37F, dc.center_freq_hz = 3.5e9;
+    ofdm_modulator_configuration mc;
+    mc.numerology = dc.numerology, mc.bw_rb = dc.bw_rb, mc.dft_size = dc.dft_size, mc.cp = cyclic_prefix::NORMAL, mc.scale = 1.7F, mc.center_freq_hz = 3.5e9;
+    auto d1 = ds->create_ofdm_symbol_demodulator(dc), d2 = dh->create_ofdm_symbol_demodulator(dc);
+    auto m1 = ms->create_ofdm_symbol_modulator(mc), m2 = mh->create_ofdm_symbol_modulator(mc);
+    CHECK(d2 && m2, "ofdm symbol factories returned nullptr");
+    const unsigned nsc = dc.bw_rb * 12, nsym_sf = 14U << dc.numerology;
+    auto g1 = create_resource_grid(2, 14, nsc), g2 = create_resource_grid(2, 14, nsc), gt = create_resource_grid(2, 14, nsc);
+    std::vector<cf_t> row(nsc), r1(nsc), r2(nsc);
+    for (unsigned sym = 0; sym < nsym_sf; sym += (sym % 5 == 0 ? 1 : 3)) {
+      CHECK(d1->get_symbol_size(sym) == d2->get_symbol_size(sym) && m1->get_symbol_size(sym) == m2->get_symbol_size(sym), "ofdm symbol size (symbol %u)", sym);
+      std::vector<cf_t> x(d1->get_symbol_size(sym));
+      for (auto& v : x) {
+        v = cf_t(n(rgen), n(rgen));
+      }
+      d1->demodulate(*g1, x, 1, sym);
+      d2->demodulate(*g2, x, 1, sym);
+      g1->get(r1, 1, sym % 14, 0);
+      g2->get(r2, 1, sym % 14, 0);
+      CHECK(rel_err(r1, r2) < 4e-6F, "ofdm_symbol_demodulator mismatch (dft %u, symbol %u): %g", dc.dft_size, sym, rel_err(r1, r2));
+      for (auto& v : row) {
+        v = cf_t(n(rgen), n(rgen));
+      }
+      gt->put(0, sym % 14, 0, row);
+      std::vector<cf_t> y1(m1->get_symbol_size(sym)), y2(y1.size());
+      m1->modulate(y1, *gt, 0, sym);
+      m2->modulate(y2, *gt, 0, sym);
+      CHECK(rel_err(y1, y2) < 4e-6F, "ofdm_symbol_modulator mismatch (dft %u, symbol %u): %g", dc.dft_size, sym, rel_err(y1, y2));
+    }
+  }
+  printf("ofdm_symbol_demodulator / ofdm_symbol_modulator done, failures so far %d\n", failures);
+}
+
+// PDU validators of the processor factories: never null (upper_phy_pdu_validators.h:71-74 asserts that), the reference's verdicts
+// on the PDUs both support, clean rejections of what the device path does not take.
+static void test_validators(std::shared_ptr<miphy::context> c)
+{
+  auto pv = std::make_shared<miphy::pusch_processor_factory_hip>(c, 6, true)->create_validator();
+  auto dv = std::make_shared<miphy::pdsch_processor_factory_hip>(c)->create_validator();
+  auto cv = std::make_shared<miphy::pdcch_processor_factory_hip>(c)->create_validator();
+  auto sv = std::make_shared<miphy::ssb_processor_factory_hip>(c)->create_validator();
+  auto rv = std::make_shared<miphy::nzp_csi_rs_generator_factory_hip>(c)->create_validator();
+  CHECK(pv && dv && cv && sv && rv, "a processor factory returned a null validator");
+  symbol_slot_mask dm(14);
+  dm.set(2);
+  pusch_processor::pdu_t pdu;
+  pdu.slot = slot_point(1, 7), pdu.rnti = 0x4601, pdu.bwp_size_rb = 273, pdu.bwp_start_rb = 0, pdu.cp = cyclic_prefix::NORMAL;
+  pdu.mcs_descr.modulation = modulation_scheme::QAM256, pdu.mcs_descr.target_code_rate = 0.9F;
+  pdu.codeword.emplace();
+  pdu.codeword.value().rv = 0, pdu.codeword.value().ldpc_base_graph = ldpc_base_graph_type::BG1, pdu.codeword.value().new_data = true;
+  pdu.uci = {};
+  pdu.n_id = 935, pdu.nof_tx_layers = 1;
+  pdu.rx_ports.push_back(0);
+  pdu.dmrs_symbol_mask = dm, pdu.dmrs = dmrs_type::TYPE1, pdu.scrambling_id = 42, pdu.n_scid = false, pdu.nof_cdm_groups_without_data = 2;
+  pdu.freq_alloc         = rb_allocation::make_type1(0, 273);
+  pdu.start_symbol_index = 0, pdu.nof_symbols = 14, pdu.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8;
+  CHECK(pv->is_valid(pdu), "pusch validator rejects the headline PDU");
+  {
+    auto q = pdu;
+    q.uci.nof_harq_ack = 2;
+    CHECK(!pv->is_valid(q), "pusch validator accepts a PDU with multiplexed UCI (not on the device path)");
+    q = pdu;
+    q.codeword.reset();
+    CHECK(!pv->is_valid(q), "pusch validator accepts a PDU without transport block");
+    q = pdu;
+    q.dmrs = dmrs_type::TYPE2;
+    CHECK(!pv->is_valid(q), "pusch validator accepts DM-RS type 2 (the reference rejects it too)");
+    q = pdu;
+    q.nof_tx_layers = 2;
+    CHECK(!pv->is_valid(q), "pusch validator accepts two layers");
+  }
+  printf("PDU validators done, failures so far %d\n", failures);
+}
+
 static void on_fault(int sig)
 {
   void* frames[64];
@@ -1539,6 +1721,10 @@ int main()
   test_pdsch_processor(c);
   test_downlink_processor(c);
   test_ofh_iq(c);
+  test_polar_blocks(c);
+  test_crc_calculator(c);
+  test_ofdm_symbols(c);
+  test_validators(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);
     return 1;

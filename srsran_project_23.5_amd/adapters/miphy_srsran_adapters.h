@@ -49,6 +49,15 @@
 
 namespace miphy {
 
+/// Precondition that also holds in release builds (srsran_assert compiles out): report_fatal_error when it fails.
+template <typename... Args>
+inline void require(bool condition, const char* fmtstr, Args&&... args)
+{
+  if (!condition) {
+    srsran::report_fatal_error(fmtstr, std::forward<Args>(args)...);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- context
 /// Owns a miphy context, a stream and a growable pair of device buffers used as staging by the per-call adapters.
 class context
@@ -711,6 +720,82 @@ private:
   std::vector<srsran::cf_t> host;
 };
 
+/// srsran::ofdm_symbol_demodulator over miphy_ofdm_demodulate_symbols (ofdm_demodulator.h:55-74): what the lower PHY calls once per
+/// received OFDM symbol and port (lib/phy/lower/processors/uplink/puxch/puxch_processor_impl.cpp:64-76). One symbol per call:
+/// samples up, one transform, one row of subcarriers back into the grid before the call returns, as the interface requires.
+class ofdm_symbol_demodulator_hip : public srsran::ofdm_symbol_demodulator
+{
+public:
+  ofdm_symbol_demodulator_hip(std::shared_ptr<context> c, const srsran::ofdm_demodulator_configuration& cfg_) : c(std::move(c))
+  {
+    cfg.numerology                = cfg_.numerology;
+    cfg.bw_rb                     = cfg_.bw_rb;
+    cfg.dft_size                  = cfg_.dft_size;
+    cfg.nof_samples_window_offset = cfg_.nof_samples_window_offset;
+    cfg.scale                     = cfg_.scale;
+    cfg.center_freq_hz            = cfg_.center_freq_hz;
+    require(cfg_.cp == srsran::cyclic_prefix::NORMAL, "Only normal cyclic prefix is supported by the HIP path.");
+  }
+  unsigned get_symbol_size(unsigned symbol_index) const override { return miphy_ofdm_symbol_size(&cfg, symbol_index); }
+  void demodulate(srsran::resource_grid_writer& grid, srsran::span<const srsran::cf_t> input, unsigned port_index, unsigned symbol_index) override
+  {
+    require(input.size() == get_symbol_size(symbol_index), "The input size is not consistent with the symbol size.");
+    const unsigned rg   = cfg.bw_rb * 12;
+    auto*          d_in = static_cast<float*>(c->buf(0, input.size() * sizeof(srsran::cf_t)));
+    auto*          d_g  = static_cast<float*>(c->buf(1, rg * sizeof(srsran::cf_t)));
+    c->h2d(d_in, input.data(), input.size() * sizeof(srsran::cf_t));
+    miphy_ofdm_job job = {0, 0, symbol_index, 0};
+    context::check(miphy_ofdm_demodulate_symbols(c->ctx, &cfg, &job, 0, 1, d_in, d_g, c->stream), "ofdm_demodulate_symbols");
+    host.resize(rg);
+    c->d2h(host.data(), d_g, host.size() * sizeof(srsran::cf_t));
+    c->sync();
+    grid.put(port_index, symbol_index % 14, 0, host); // the grid holds one slot (ofdm_demodulator_impl.cpp:133,137)
+  }
+
+private:
+  std::shared_ptr<context>  c;
+  miphy_ofdm_config         cfg = {};
+  std::vector<srsran::cf_t> host;
+};
+
+/// srsran::ofdm_symbol_modulator over miphy_ofdm_modulate_symbols (ofdm_modulator.h:55-74; caller
+/// lib/phy/lower/processors/downlink/pdxch/pdxch_processor_impl.cpp:76-82).
+class ofdm_symbol_modulator_hip : public srsran::ofdm_symbol_modulator
+{
+public:
+  ofdm_symbol_modulator_hip(std::shared_ptr<context> c, const srsran::ofdm_modulator_configuration& cfg_) : c(std::move(c))
+  {
+    cfg.numerology     = cfg_.numerology;
+    cfg.bw_rb          = cfg_.bw_rb;
+    cfg.dft_size       = cfg_.dft_size;
+    cfg.scale          = cfg_.scale;
+    cfg.center_freq_hz = cfg_.center_freq_hz;
+    require(cfg_.cp == srsran::cyclic_prefix::NORMAL, "Only normal cyclic prefix is supported by the HIP path.");
+  }
+  unsigned get_symbol_size(unsigned symbol_index) const override { return miphy_ofdm_symbol_size(&cfg, symbol_index); }
+  void modulate(srsran::span<srsran::cf_t> output, const srsran::resource_grid_reader& grid, unsigned port_index, unsigned symbol_index) override
+  {
+    require(output.size() == get_symbol_size(symbol_index), "The output size is not consistent with the symbol size.");
+    const unsigned rg = cfg.bw_rb * 12;
+    host.resize(rg);
+    miphy_ofdm_job job = {0, 0, symbol_index, grid.is_empty(port_index) ? 1U : 0U};
+    if (!job.grid_empty) {
+      grid.get(host, port_index, symbol_index % 14, 0);
+    }
+    auto* d_g   = static_cast<float*>(c->buf(0, host.size() * sizeof(srsran::cf_t)));
+    auto* d_out = static_cast<float*>(c->buf(1, output.size() * sizeof(srsran::cf_t)));
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    context::check(miphy_ofdm_modulate_symbols(c->ctx, &cfg, &job, 0, 1, d_g, d_out, c->stream), "ofdm_modulate_symbols");
+    c->d2h(output.data(), d_out, output.size() * sizeof(srsran::cf_t));
+    c->sync();
+  }
+
+private:
+  std::shared_ptr<context>  c;
+  miphy_ofdm_config         cfg = {};
+  std::vector<srsran::cf_t> host;
+};
+
 // ---------------------------------------------------------------------------------------------------------------- estimator
 /// srsran::dmrs_pusch_estimator over miphy_dmrs_pusch_estimate_batch (dmrs_pusch_estimator.h:84).
 class dmrs_pusch_estimator_hip : public srsran::dmrs_pusch_estimator
@@ -1011,7 +1096,7 @@ public:
   {
   }
   std::unique_ptr<srsran::pusch_processor> create() override { return std::make_unique<pusch_processor_hip>(c, nof_iterations, early_stop); }
-  std::unique_ptr<srsran::pusch_pdu_validator> create_validator() override { return nullptr; }
+  std::unique_ptr<srsran::pusch_pdu_validator> create_validator() override; // defined at the end of this header
 
 private:
   std::shared_ptr<context> c;
@@ -1135,9 +1220,9 @@ public:
       entry&                                  e   = queue[i];
       const srsran::pusch_processor::pdu_t&   pdu = e.pdu.pdu;
       srsran_assert(e.resident->softbits() == d_soft, "All softbuffers of a batch must belong to the same device pool.");
-      srsran_assert(pdu.uci.nof_harq_ack == 0 && pdu.uci.nof_csi_part1 == 0 && pdu.uci.nof_csi_part2 == 0 && pdu.codeword.has_value(),
+      require(pdu.uci.nof_harq_ack == 0 && pdu.uci.nof_csi_part1 == 0 && pdu.uci.nof_csi_part2 == 0 && pdu.codeword.has_value(),
                     "UCI on PUSCH / PDUs without codeword are not supported.");
-      srsran_assert(pdu.dmrs == srsran::dmrs_type::TYPE1 && pdu.nof_cdm_groups_without_data == 2 && pdu.nof_tx_layers == 1,
+      require(pdu.dmrs == srsran::dmrs_type::TYPE1 && pdu.nof_cdm_groups_without_data == 2 && pdu.nof_tx_layers == 1,
                     "Only DM-RS type 1, two CDM groups without data and one layer are supported.");
       const srsran::bounded_bitset<srsran::MAX_RB> rb_mask = pdu.freq_alloc.get_prb_mask(pdu.bwp_start_rb, pdu.bwp_size_rb);
       srsran_assert(rb_mask.size() <= nprb, "The allocation exceeds the resource grid.");
@@ -1506,7 +1591,7 @@ class pdsch_processor_factory_hip : public srsran::pdsch_processor_factory
 public:
   explicit pdsch_processor_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
   std::unique_ptr<srsran::pdsch_processor>     create() override { return std::make_unique<pdsch_processor_hip>(c); }
-  std::unique_ptr<srsran::pdsch_pdu_validator> create_validator() override { return nullptr; }
+  std::unique_ptr<srsran::pdsch_pdu_validator> create_validator() override; // defined at the end of this header
 
 private:
   std::shared_ptr<context> c;
@@ -1594,7 +1679,7 @@ class pdcch_processor_factory_hip : public srsran::pdcch_processor_factory
 public:
   explicit pdcch_processor_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
   std::unique_ptr<srsran::pdcch_processor>     create() override { return std::make_unique<pdcch_processor_hip>(c); }
-  std::unique_ptr<srsran::pdcch_pdu_validator> create_validator() override { return nullptr; }
+  std::unique_ptr<srsran::pdcch_pdu_validator> create_validator() override; // defined at the end of this header
 
 private:
   std::shared_ptr<context> c;
@@ -1650,7 +1735,7 @@ class ssb_processor_factory_hip : public srsran::ssb_processor_factory
 public:
   explicit ssb_processor_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
   std::unique_ptr<srsran::ssb_processor>     create() override { return std::make_unique<ssb_processor_hip>(c); }
-  std::unique_ptr<srsran::ssb_pdu_validator> create_validator() override { return nullptr; }
+  std::unique_ptr<srsran::ssb_pdu_validator> create_validator() override; // defined at the end of this header
 
 private:
   std::shared_ptr<context> c;
@@ -1710,7 +1795,7 @@ class nzp_csi_rs_generator_factory_hip : public srsran::nzp_csi_rs_generator_fac
 public:
   explicit nzp_csi_rs_generator_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
   std::unique_ptr<srsran::nzp_csi_rs_generator>               create() override { return std::make_unique<nzp_csi_rs_generator_hip>(c); }
-  std::unique_ptr<srsran::nzp_csi_rs_configuration_validator> create_validator() override { return nullptr; }
+  std::unique_ptr<srsran::nzp_csi_rs_configuration_validator> create_validator() override; // defined at the end of this header
 
 private:
   std::shared_ptr<context> c;
@@ -1768,10 +1853,12 @@ public:
     if (grid == nullptr) {
       return;
     }
-    srsran_assert(pdu.ports.size() == 1 && pdu.codewords.size() == 1 && data.size() == 1, "Only one layer / one codeword is supported.");
-    srsran_assert(pdu.dmrs == srsran::dmrs_type::TYPE1, "Only DM-RS Type 1 is currently supported.");
-    srsran_assert(pdu.freq_alloc.is_contiguous(), "Only contiguous allocation is currently supported.");
-    srsran_assert(pdu.ports[0] < nports, "Transmit port outside the resource grid.");
+    // The PDU validator of the factory rejects these up front (pdsch_pdu_validator_hip); a caller that skips it fails loudly here
+    // also in release builds.
+    require(pdu.ports.size() == 1 && pdu.codewords.size() == 1 && data.size() == 1, "Only one layer / one codeword is supported.");
+    require(pdu.dmrs == srsran::dmrs_type::TYPE1, "Only DM-RS Type 1 is currently supported.");
+    require(pdu.freq_alloc.is_contiguous(), "Only contiguous allocation is currently supported.");
+    require(pdu.ports[0] < nports, "Transmit port outside the resource grid.");
     queue.push_back(entry{data[0], pdu});
   }
   void configure_resource_grid(const srsran::resource_grid_context& context, srsran::resource_grid& grid_) override
@@ -2061,9 +2148,9 @@ class ofdm_demodulator_factory_hip : public srsran::ofdm_demodulator_factory
 {
 public:
   explicit ofdm_demodulator_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
-  std::unique_ptr<srsran::ofdm_symbol_demodulator> create_ofdm_symbol_demodulator(const srsran::ofdm_demodulator_configuration&) override
+  std::unique_ptr<srsran::ofdm_symbol_demodulator> create_ofdm_symbol_demodulator(const srsran::ofdm_demodulator_configuration& cfg) override
   {
-    return nullptr; // symbol-granular streaming stays on the CPU path; the HIP path works on whole slots
+    return std::make_unique<ofdm_symbol_demodulator_hip>(c, cfg);
   }
   std::unique_ptr<srsran::ofdm_slot_demodulator> create_ofdm_slot_demodulator(const srsran::ofdm_demodulator_configuration& cfg) override
   {
@@ -2078,7 +2165,10 @@ class ofdm_modulator_factory_hip : public srsran::ofdm_modulator_factory
 {
 public:
   explicit ofdm_modulator_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
-  std::unique_ptr<srsran::ofdm_symbol_modulator> create_ofdm_symbol_modulator(const srsran::ofdm_modulator_configuration&) override { return nullptr; }
+  std::unique_ptr<srsran::ofdm_symbol_modulator> create_ofdm_symbol_modulator(const srsran::ofdm_modulator_configuration& cfg) override
+  {
+    return std::make_unique<ofdm_symbol_modulator_hip>(c, cfg);
+  }
   std::unique_ptr<srsran::ofdm_slot_modulator>   create_ofdm_slot_modulator(const srsran::ofdm_modulator_configuration& cfg) override
   {
     return std::make_unique<ofdm_slot_modulator_hip>(c, cfg);
@@ -2087,5 +2177,322 @@ public:
 private:
   std::shared_ptr<context> c;
 };
+
+// ---------------------------------------------------------------------------------------------------------------- polar blocks
+/// The block-level polar interfaces over miphy_polar_block_batch (include/srsran/phy/upper/channel_coding/polar/*.h), a batch of one
+/// per call, so that the reference's own chains (pdcch_encoder_impl, pbch_encoder_impl, uci decoders, polar_chain_test.cpp:156-210)
+/// run on the device block by block. polar_code stays the reference's host class (bookkeeping of sets and tables).
+namespace detail {
+inline miphy_polar_code to_miphy_code(const srsran::polar_code& code)
+{
+  miphy_polar_code mc = {code.get_K(), code.get_E(), 10, code.get_ibil() == srsran::polar_code_ibil::present ? 1U : 0U};
+  // nMax is not kept by polar_code: it is 10 unless that would give a larger mother code than the one the code object holds
+  uint32_t n = 0, N = 0, npc = 0;
+  if (miphy_polar_code_info(&mc, &n, &N, &npc) != MIPHY_OK || n != code.get_n()) {
+    mc.nMax = 9;
+    context::check(miphy_polar_code_info(&mc, &n, &N, &npc), "polar_code_info");
+    require(n == code.get_n(), "The polar code object is not a TS 38.212 code (n = {}).", code.get_n());
+  }
+  return mc;
+}
+inline void polar_block(context& c, const miphy_polar_code* code, uint32_t op, uint32_t param, void* out, size_t out_bytes, const void* in, size_t in_bytes)
+{
+  void* d_in  = c.buf(0, in_bytes);
+  void* d_out = c.buf(1, out_bytes);
+  c.h2d(d_in, in, in_bytes);
+  context::check(miphy_polar_block_batch(c.ctx, code, op, param, 1, d_in, d_out, c.stream), "polar_block");
+  c.d2h(out, d_out, out_bytes);
+  c.sync();
+}
+} // namespace detail
+
+class polar_allocator_hip : public srsran::polar_allocator
+{
+public:
+  explicit polar_allocator_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void allocate(srsran::span<uint8_t> input_encoder, srsran::span<const uint8_t> message, const srsran::polar_code& code) override
+  {
+    require(input_encoder.size() == code.get_N() && message.size() == code.get_K(), "polar_allocator: wrong sizes");
+    const miphy_polar_code mc = detail::to_miphy_code(code);
+    detail::polar_block(*c, &mc, MIPHY_POLAR_OP_ALLOCATE, 0, input_encoder.data(), input_encoder.size(), message.data(), message.size());
+  }
+
+private:
+  std::shared_ptr<context> c;
+};
+
+class polar_deallocator_hip : public srsran::polar_deallocator
+{
+public:
+  explicit polar_deallocator_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void deallocate(srsran::span<uint8_t> message, srsran::span<const uint8_t> output_decoder, const srsran::polar_code& code) override
+  {
+    require(output_decoder.size() == code.get_N() && message.size() == code.get_K(), "polar_deallocator: wrong sizes");
+    const miphy_polar_code mc = detail::to_miphy_code(code);
+    detail::polar_block(*c, &mc, MIPHY_POLAR_OP_DEALLOCATE, 0, message.data(), message.size(), output_decoder.data(), output_decoder.size());
+  }
+
+private:
+  std::shared_ptr<context> c;
+};
+
+class polar_encoder_hip : public srsran::polar_encoder
+{
+public:
+  explicit polar_encoder_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void encode(srsran::span<uint8_t> output, srsran::span<const uint8_t> input, unsigned code_size_log) override
+  {
+    require(output.size() == (1U << code_size_log) && input.size() == output.size(), "polar_encoder: wrong sizes");
+    detail::polar_block(*c, nullptr, MIPHY_POLAR_OP_ENCODE, code_size_log, output.data(), output.size(), input.data(), input.size());
+  }
+
+private:
+  std::shared_ptr<context> c;
+};
+
+class polar_decoder_hip : public srsran::polar_decoder
+{
+public:
+  polar_decoder_hip(std::shared_ptr<context> c, unsigned nMax) : c(std::move(c)), nMax(nMax) {}
+  void decode(srsran::span<uint8_t> data_decoded, srsran::span<const srsran::log_likelihood_ratio> input_llr, const srsran::polar_code& code) override
+  {
+    require(code.get_n() <= nMax, "polar_decoder: code size 2^{} exceeds the decoder's 2^{}", code.get_n(), nMax);
+    require(data_decoded.size() == code.get_N() && input_llr.size() == code.get_N(), "polar_decoder: wrong sizes");
+    const miphy_polar_code mc = detail::to_miphy_code(code);
+    detail::polar_block(*c, &mc, MIPHY_POLAR_OP_DECODE, 0, data_decoded.data(), data_decoded.size(), input_llr.data(), input_llr.size());
+  }
+
+private:
+  std::shared_ptr<context> c;
+  unsigned                 nMax;
+};
+
+class polar_rate_matcher_hip : public srsran::polar_rate_matcher
+{
+public:
+  explicit polar_rate_matcher_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void rate_match(srsran::span<uint8_t> output, srsran::span<const uint8_t> input, const srsran::polar_code& code) override
+  {
+    require(output.size() == code.get_E() && input.size() == code.get_N(), "polar_rate_matcher: wrong sizes");
+    const miphy_polar_code mc = detail::to_miphy_code(code);
+    detail::polar_block(*c, &mc, MIPHY_POLAR_OP_RATE_MATCH, 0, output.data(), output.size(), input.data(), input.size());
+  }
+
+private:
+  std::shared_ptr<context> c;
+};
+
+class polar_rate_dematcher_hip : public srsran::polar_rate_dematcher
+{
+public:
+  explicit polar_rate_dematcher_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void rate_dematch(srsran::span<srsran::log_likelihood_ratio>       output,
+                    srsran::span<const srsran::log_likelihood_ratio> input,
+                    const srsran::polar_code&                        code) override
+  {
+    require(input.size() == code.get_E() && output.size() == code.get_N(), "polar_rate_dematcher: wrong sizes");
+    const miphy_polar_code mc = detail::to_miphy_code(code);
+    detail::polar_block(*c, &mc, MIPHY_POLAR_OP_RATE_DEMATCH, 0, output.data(), output.size(), input.data(), input.size());
+  }
+
+private:
+  std::shared_ptr<context> c;
+};
+
+class polar_interleaver_hip : public srsran::polar_interleaver
+{
+public:
+  explicit polar_interleaver_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void interleave(srsran::span<uint8_t> out, srsran::span<const uint8_t> in, srsran::polar_interleaver_direction direction) override
+  {
+    require(in.size() == out.size() && in.size() >= 1 && in.size() <= 164, "polar_interleaver: wrong sizes");
+    detail::polar_block(*c, nullptr, direction == srsran::polar_interleaver_direction::tx ? MIPHY_POLAR_OP_INTERLEAVE_TX : MIPHY_POLAR_OP_INTERLEAVE_RX,
+                        static_cast<uint32_t>(in.size()), out.data(), out.size(), in.data(), in.size());
+  }
+
+private:
+  std::shared_ptr<context> c;
+};
+
+/// Replaces create_polar_factory_sw() (channel_coding_factories.h:107-121).
+class polar_factory_hip : public srsran::polar_factory
+{
+public:
+  explicit polar_factory_hip(std::shared_ptr<context> c) : c(std::move(c)), host(srsran::create_polar_factory_sw()) {}
+  std::unique_ptr<srsran::polar_allocator>      create_allocator() override { return std::make_unique<polar_allocator_hip>(c); }
+  std::unique_ptr<srsran::polar_code>           create_code() override { return host->create_code(); }
+  std::unique_ptr<srsran::polar_deallocator>    create_deallocator() override { return std::make_unique<polar_deallocator_hip>(c); }
+  std::unique_ptr<srsran::polar_decoder>        create_decoder(unsigned code_size_log) override { return std::make_unique<polar_decoder_hip>(c, code_size_log); }
+  std::unique_ptr<srsran::polar_encoder>        create_encoder() override { return std::make_unique<polar_encoder_hip>(c); }
+  std::unique_ptr<srsran::polar_interleaver>    create_interleaver() override { return std::make_unique<polar_interleaver_hip>(c); }
+  std::unique_ptr<srsran::polar_rate_dematcher> create_rate_dematcher() override { return std::make_unique<polar_rate_dematcher_hip>(c); }
+  std::unique_ptr<srsran::polar_rate_matcher>   create_rate_matcher() override { return std::make_unique<polar_rate_matcher_hip>(c); }
+
+private:
+  std::shared_ptr<context>               c;
+  std::shared_ptr<srsran::polar_factory> host;
+};
+inline std::shared_ptr<srsran::polar_factory> create_polar_factory_hip(std::shared_ptr<context> c)
+{
+  return std::make_shared<polar_factory_hip>(std::move(c));
+}
+
+// ---------------------------------------------------------------------------------------------------------------- CRC calculator
+/// srsran::crc_calculator over miphy_crc_batch (crc_calculator.h:45-67); with its factory it fills the hardware seam
+/// downlink_processor_factory_hw_config::crc_calc_factory (upper_phy_factories.h:151-161).
+class crc_calculator_hip : public srsran::crc_calculator
+{
+public:
+  crc_calculator_hip(std::shared_ptr<context> c, srsran::crc_generator_poly poly) : c(std::move(c)), poly(poly) {}
+  srsran::crc_calculator_checksum_t calculate_byte(srsran::span<const uint8_t> data) override { return run(data.data(), data.size(), data.size() * 8); }
+  srsran::crc_calculator_checksum_t calculate_bit(srsran::span<const uint8_t> data) override
+  {
+    packed.assign((data.size() + 7) / 8, 0);
+    for (size_t i = 0; i != data.size(); ++i) {
+      packed[i >> 3] |= static_cast<uint8_t>((data[i] & 1U) << (7 - (i & 7)));
+    }
+    return run(packed.data(), packed.size(), data.size());
+  }
+  srsran::crc_calculator_checksum_t calculate(const srsran::bit_buffer& data) override
+  {
+    const srsran::span<const uint8_t> bytes = data.get_buffer();
+    return run(bytes.data(), bytes.size(), data.size());
+  }
+  srsran::crc_generator_poly get_generator_poly() const override { return poly; }
+
+private:
+  srsran::crc_calculator_checksum_t run(const uint8_t* bytes, size_t nbytes, size_t nbits)
+  {
+    if (nbits == 0) {
+      return 0;
+    }
+    auto* d_in  = static_cast<uint8_t*>(c->buf(0, nbytes + 8)); // the device CRC reads whole words: keep a zero pad behind the message
+    auto* d_out = static_cast<uint32_t*>(c->buf(1, 16));
+    context::hip(hipMemsetAsync(d_in + nbytes, 0, 8, c->stream), "memset");
+    c->h2d(d_in, bytes, nbytes);
+    miphy_crc_desc d = {0, static_cast<uint32_t>(nbits), to_miphy_crc(poly)};
+    context::check(miphy_crc_batch(c->ctx, &d, 0, 1, d_in, d_out, c->stream), "crc");
+    uint32_t v = 0;
+    c->d2h(&v, d_out, sizeof(v));
+    c->sync();
+    return v;
+  }
+  std::shared_ptr<context>   c;
+  srsran::crc_generator_poly poly;
+  std::vector<uint8_t>       packed;
+};
+
+class crc_calculator_factory_hip : public srsran::crc_calculator_factory
+{
+public:
+  explicit crc_calculator_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  std::unique_ptr<srsran::crc_calculator> create(srsran::crc_generator_poly poly) override
+  {
+    if (poly == srsran::crc_generator_poly::CRC6) {
+      return nullptr; // UCI-only polynomial, not on this path (factories return nullptr for what they do not support)
+    }
+    return std::make_unique<crc_calculator_hip>(c, poly);
+  }
+
+private:
+  std::shared_ptr<context> c;
+};
+inline std::shared_ptr<srsran::crc_calculator_factory> create_crc_calculator_factory_hip(std::shared_ptr<context> c)
+{
+  return std::make_shared<crc_calculator_factory_hip>(std::move(c));
+}
+
+// ---------------------------------------------------------------------------------------------------------------- PDU validators
+/// The validators the upper PHY asks the processor factories for (upper_phy_factories.cpp:96-99,329-334) and calls per PDU
+/// (upper_phy_pdu_validators.h:71-74): the reference's own checks (its validator, built from the reference factory over the HIP
+/// blocks) AND the restrictions of the device path, so that the MAC gets a clean rejection instead of an assertion.
+class pusch_pdu_validator_hip : public srsran::pusch_pdu_validator
+{
+public:
+  explicit pusch_pdu_validator_hip(std::unique_ptr<srsran::pusch_pdu_validator> ref) : ref(std::move(ref)) {}
+  bool is_valid(const srsran::pusch_processor::pdu_t& pdu) const override
+  {
+    if (!ref->is_valid(pdu)) {
+      return false;
+    }
+    // device path: a transport block without multiplexed UCI, one layer, at most four receive ports, normal cyclic prefix
+    return pdu.codeword.has_value() && pdu.uci.nof_harq_ack == 0 && pdu.uci.nof_csi_part1 == 0 && pdu.uci.nof_csi_part2 == 0 && pdu.nof_tx_layers == 1 &&
+           pdu.rx_ports.size() >= 1 && pdu.rx_ports.size() <= 4 && pdu.cp == srsran::cyclic_prefix::NORMAL && pdu.mcs_descr.modulation != srsran::modulation_scheme::BPSK;
+  }
+
+private:
+  std::unique_ptr<srsran::pusch_pdu_validator> ref;
+};
+
+class pdsch_pdu_validator_hip : public srsran::pdsch_pdu_validator
+{
+public:
+  explicit pdsch_pdu_validator_hip(std::unique_ptr<srsran::pdsch_pdu_validator> ref) : ref(std::move(ref)) {}
+  bool is_valid(const srsran::pdsch_processor::pdu_t& pdu) const override
+  {
+    if (!ref->is_valid(pdu)) {
+      return false;
+    }
+    // device path: one codeword on one layer, DM-RS type 1, contiguous (non-interleaved) allocation, at most four reserved patterns
+    return pdu.codewords.size() == 1 && pdu.ports.size() == 1 && pdu.dmrs == srsran::dmrs_type::TYPE1 && pdu.freq_alloc.is_contiguous() &&
+           pdu.cp == srsran::cyclic_prefix::NORMAL && pdu.reserved.get_nof_entries() <= 4;
+  }
+
+private:
+  std::unique_ptr<srsran::pdsch_pdu_validator> ref;
+};
+
+inline std::unique_ptr<srsran::pusch_pdu_validator> pusch_processor_factory_hip::create_validator()
+{
+  srsran::uci_decoder_factory_sw_configuration uc;
+  uc.decoder_factory = srsran::create_short_block_detector_factory_sw();
+  srsran::pusch_processor_factory_sw_configuration pc;
+  pc.estimator_factory                    = std::make_shared<dmrs_pusch_estimator_factory_hip>(c);
+  pc.demodulator_factory                  = std::make_shared<pusch_demodulator_factory_hip>(c);
+  pc.demux_factory                        = srsran::create_ulsch_demultiplex_factory_sw();
+  pc.decoder_factory                      = std::make_shared<pusch_decoder_factory_hip>(c);
+  pc.uci_dec_factory                      = srsran::create_uci_decoder_factory_sw(uc);
+  pc.ch_estimate_dimensions.nof_prb       = srsran::MAX_RB;
+  pc.ch_estimate_dimensions.nof_symbols   = srsran::MAX_NSYMB_PER_SLOT;
+  pc.ch_estimate_dimensions.nof_rx_ports  = 4;
+  pc.ch_estimate_dimensions.nof_tx_layers = 1;
+  pc.dec_nof_iterations                   = nof_iterations;
+  pc.dec_enable_early_stop                = early_stop;
+  return std::make_unique<pusch_pdu_validator_hip>(srsran::create_pusch_processor_factory_sw(pc)->create_validator());
+}
+
+inline std::unique_ptr<srsran::pdsch_pdu_validator> pdsch_processor_factory_hip::create_validator()
+{
+  auto ref = srsran::create_pdsch_processor_factory_sw(std::make_shared<pdsch_encoder_factory_hip>(c), std::make_shared<pdsch_modulator_factory_hip>(c),
+                                                       std::make_shared<dmrs_pdsch_processor_factory_hip>(c));
+  return std::make_unique<pdsch_pdu_validator_hip>(ref->create_validator());
+}
+
+// The PDCCH / SSB / CSI-RS device paths take everything the reference processors take: the reference's validators apply unchanged.
+inline std::unique_ptr<srsran::pdcch_pdu_validator> pdcch_processor_factory_hip::create_validator()
+{
+  auto prg = srsran::create_pseudo_random_generator_sw_factory();
+  auto ref = srsran::create_pdcch_processor_factory_sw(std::make_shared<pdcch_encoder_factory_hip>(c),
+                                                       srsran::create_pdcch_modulator_factory_sw(srsran::create_channel_modulation_sw_factory(), prg),
+                                                       srsran::create_dmrs_pdcch_processor_factory_sw(prg));
+  return ref->create_validator();
+}
+
+inline std::unique_ptr<srsran::ssb_pdu_validator> ssb_processor_factory_hip::create_validator()
+{
+  auto                                       prg = srsran::create_pseudo_random_generator_sw_factory();
+  srsran::ssb_processor_factory_sw_configuration sc;
+  sc.encoder_factory   = srsran::create_pbch_encoder_factory_sw(srsran::create_crc_calculator_factory_sw("auto"), prg, srsran::create_polar_factory_sw());
+  sc.modulator_factory = srsran::create_pbch_modulator_factory_sw(srsran::create_channel_modulation_sw_factory(), prg);
+  sc.dmrs_factory      = srsran::create_dmrs_pbch_processor_factory_sw(prg);
+  sc.pss_factory       = srsran::create_pss_processor_factory_sw();
+  sc.sss_factory       = srsran::create_sss_processor_factory_sw();
+  return srsran::create_ssb_processor_factory_sw(sc)->create_validator();
+}
+
+inline std::unique_ptr<srsran::nzp_csi_rs_configuration_validator> nzp_csi_rs_generator_factory_hip::create_validator()
+{
+  return srsran::create_nzp_csi_rs_generator_factory_sw(srsran::create_pseudo_random_generator_sw_factory())->create_validator();
+}
 
 } // namespace miphy

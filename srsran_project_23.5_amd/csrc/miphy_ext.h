@@ -35,6 +35,7 @@ struct miphy_ctx_ext {
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, float, double, int>, ofdm_plan_dev*> plans;
   std::vector<void*>                                            to_free;
   void*                                                         d_gold = nullptr; // Gold-sequence jump table (chest.hip)
+  void*                                                         d_pi_il_max = nullptr; // polar interleaver pattern (polar.hip)
 };
 
 // Returns the device twiddle table for size N (creates and caches it).

@@ -137,7 +137,8 @@ __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict
                                                 const cplx* __restrict__ ramp,
                                                 const float2* __restrict__ samples,
                                                 float2* __restrict__ grid,
-                                                int total)
+                                                int total,
+                                                int per) // 14: jobs are slots; 1: jobs are single symbols (slot_index = symbol in the subframe)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cplx*     x  = reinterpret_cast<cplx*>(smem);
@@ -145,11 +146,11 @@ __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict
   const int nt = NCT != 0 ? NCT / 8 : (int)blockDim.x;
   auto pad = [](int i) { return NCT == 4096 ? fpad_skew(i) : fpad(i); };
   auto symbol = [&](int idx) {
-    const miphy_ofdm_job& job = jobs[idx / 14];
-    const int             l   = idx % 14;
-    const int             sym = (int)job.slot_index * 14 + l;
+    const miphy_ofdm_job& job = jobs[idx / per];
+    const int             l   = (per == 1) ? 0 : idx % 14;
+    const int             sym = (per == 1) ? (int)job.slot_index : (int)job.slot_index * 14 + l;
     // FFT window: starts `window_offset` samples before the end of the cyclic prefix (demodulator_impl.cpp:115).
-    const float2* src = samples + job.samples_offset + plan->sym_off[sym] + plan->cp_len[sym] - plan->window_offset;
+    const float2* src = samples + job.samples_offset + ((per == 1) ? 0 : plan->sym_off[sym]) + plan->cp_len[sym] - plan->window_offset;
     if ((((uintptr_t)src) & 15) == 0) { // 16-byte loads: two samples per lane
       const float4* src4 = reinterpret_cast<const float4*>(src);
       for (int i = threadIdx.x; i < N / 2; i += nt) {
@@ -193,22 +194,22 @@ __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict
 // One radix-8 butterfly per thread: 64 registers, so that four 4096-point transforms (LDS-bound) are resident per CU.
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8)))
 ofdm_demod_wide_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const cplx* __restrict__ ramp,
-                       const float2* __restrict__ samples, float2* __restrict__ grid, int total)
+                       const float2* __restrict__ samples, float2* __restrict__ grid, int total, int per)
 {
-  ofdm_demod_body<true, 0>(jobs, plan, tw, ramp, samples, grid, total);
+  ofdm_demod_body<true, 0>(jobs, plan, tw, ramp, samples, grid, total, per);
 }
 // The 4096-point symbol of the 100 MHz / 30 kHz carrier on 512 threads: compile-time strides (fft4096_lds).
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8)))
 ofdm_demod_4096_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const cplx* __restrict__ ramp,
-                       const float2* __restrict__ samples, float2* __restrict__ grid, int total)
+                       const float2* __restrict__ samples, float2* __restrict__ grid, int total, int per)
 {
-  ofdm_demod_body<true, 4096>(jobs, plan, tw, ramp, samples, grid, total);
+  ofdm_demod_body<true, 4096>(jobs, plan, tw, ramp, samples, grid, total, per);
 }
 __global__ void __launch_bounds__(512)
 ofdm_demod_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const cplx* __restrict__ ramp,
-                  const float2* __restrict__ samples, float2* __restrict__ grid, int total)
+                  const float2* __restrict__ samples, float2* __restrict__ grid, int total, int per)
 {
-  ofdm_demod_body<false, 0>(jobs, plan, tw, ramp, samples, grid, total);
+  ofdm_demod_body<false, 0>(jobs, plan, tw, ramp, samples, grid, total, per);
 }
 
 template <bool WIDE, int NCT>
@@ -216,16 +217,17 @@ __device__ __forceinline__ void ofdm_mod_body(const miphy_ofdm_job* __restrict__
                                               const ofdm_plan_dev* __restrict__ plan,
                                               const cplx* __restrict__ tw,
                                               const float2* __restrict__ grid,
-                                              float2* __restrict__ samples)
+                                              float2* __restrict__ samples,
+                                              int per) // 14: jobs are slots (grid x = symbol); 1: jobs are single symbols
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cplx*                x   = reinterpret_cast<cplx*>(smem);
   const miphy_ofdm_job job = jobs[blockIdx.y];
   const int            l   = blockIdx.x;
   const int            N = plan->N, rg = plan->rg;
-  const int            sym = (int)job.slot_index * 14 + l;
+  const int            sym = (per == 1) ? (int)job.slot_index : (int)job.slot_index * 14 + l;
   const int            cp  = plan->cp_len[sym];
-  float2*              dst = samples + job.samples_offset + plan->sym_off[sym];
+  float2*              dst = samples + job.samples_offset + ((per == 1) ? 0 : plan->sym_off[sym]);
   if (job.grid_empty) { // modulator_impl.cpp:77-80
     for (int i = threadIdx.x; i < N + cp; i += blockDim.x)
       dst[i] = make_float2(0.f, 0.f);
@@ -260,21 +262,21 @@ __device__ __forceinline__ void ofdm_mod_body(const miphy_ofdm_job* __restrict__
 
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8)))
 ofdm_mod_wide_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const float2* __restrict__ grid,
-                     float2* __restrict__ samples)
+                     float2* __restrict__ samples, int per)
 {
-  ofdm_mod_body<true, 0>(jobs, plan, tw, grid, samples);
+  ofdm_mod_body<true, 0>(jobs, plan, tw, grid, samples, per);
 }
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8)))
 ofdm_mod_4096_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const float2* __restrict__ grid,
-                     float2* __restrict__ samples)
+                     float2* __restrict__ samples, int per)
 {
-  ofdm_mod_body<true, 4096>(jobs, plan, tw, grid, samples);
+  ofdm_mod_body<true, 4096>(jobs, plan, tw, grid, samples, per);
 }
 __global__ void __launch_bounds__(512)
 ofdm_mod_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const float2* __restrict__ grid,
-                float2* __restrict__ samples)
+                float2* __restrict__ samples, int per)
 {
-  ofdm_mod_body<false, 0>(jobs, plan, tw, grid, samples);
+  ofdm_mod_body<false, 0>(jobs, plan, tw, grid, samples, per);
 }
 
 bool size_supported(uint32_t N)
@@ -293,9 +295,7 @@ int threads_for(uint32_t N)
 {
   // N / 16 threads are the minimum the passes need (fft_device.h); N / 8 puts one radix-8 butterfly on every thread, which
   // halves the latency of a pass and doubles the wavefronts a CU holds per LDS-resident transform.
-  static const char* env = getenv("MIPHY_FFT_THREADS_DIV");
-  const int          div = env ? atoi(env) : 8;
-  int                nt  = (int)(N / (div == 16 ? 16 : 8));
+  int nt = (int)(N / 8);
   nt                     = ((nt + 63) / 64) * 64;
   return nt < 64 ? 64 : (nt > 512 ? 512 : nt);
 }
@@ -475,25 +475,23 @@ extern "C" int miphy_dft_batch(miphy_ctx* ctx, uint32_t size, int inverse, uint3
   return MIPHY_OK;
 }
 
-extern "C" int miphy_ofdm_demodulate_slots(miphy_ctx*               ctx,
-                                           const miphy_ofdm_config* cfg,
-                                           const miphy_ofdm_job*    jobs,
-                                           int                      jobs_on_device,
-                                           uint32_t                 n,
-                                           const float*             samples,
-                                           float*                   grid,
-                                           void*                    stream)
+namespace {
+
+// Shared by the slot and the symbol entry points: `per` = 14 (a job is a slot of 14 symbols) or 1 (a job is one OFDM symbol, its
+// slot_index field holding the symbol index within the subframe, samples_offset / grid_offset pointing at the symbol itself).
+int ofdm_demodulate(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm_job* jobs, int jobs_on_device, uint32_t n, const float* samples, float* grid,
+                    void* stream, int per, const char* what)
 {
-  MIPHY_REQUIRE(ctx && cfg && jobs && samples && grid, "miphy_ofdm_demodulate_slots: null argument");
-  int rc = check_cfg(cfg, "ofdm_demodulate");
+  int rc = check_cfg(cfg, what);
   if (rc)
     return rc;
   if (n == 0)
     return MIPHY_OK;
-  MIPHY_REQUIRE(n <= 65535, "ofdm_demodulate: at most 65535 jobs per call");
+  MIPHY_REQUIRE(n <= 65535, "%s: at most 65535 jobs per call", what);
+  const uint32_t lim = (per == 14) ? (1u << cfg->numerology) : (14u << cfg->numerology);
   if (!jobs_on_device)
     for (uint32_t i = 0; i < n; ++i)
-      MIPHY_REQUIRE(jobs[i].slot_index < (1u << cfg->numerology), "ofdm_demodulate: job %u: slot index %u out of range", i, jobs[i].slot_index);
+      MIPHY_REQUIRE(jobs[i].slot_index < lim, "%s: job %u: %s index %u out of range", what, i, per == 14 ? "slot" : "symbol", jobs[i].slot_index);
   ofdm_plan_dev* plan = nullptr;
   const float *  tw = nullptr, *ramp = nullptr;
   if ((rc = get_plan(ctx, cfg, 0, &plan)) || (rc = miphy_get_twiddles(ctx, cfg->dft_size, &tw)))
@@ -506,45 +504,38 @@ extern "C" int miphy_ofdm_demodulate_slots(miphy_ctx*               ctx,
     return rc;
   const int    nt    = threads_for(cfg->dft_size);
   const bool   wide  = cfg->dft_size <= 8u * (uint32_t)nt;
-  const int    total = 14 * (int)n;
+  const int    total = per * (int)n;
   const size_t lds   = fft_lds_bytes(cfg->dft_size);
   // As many workgroups as the chip holds at once (LDS-bound), each looping over its share of the symbols.
-  static const char* env_wg = getenv("MIPHY_OFDM_WG_PER_CU");
-  const int          per_cu = env_wg ? atoi(env_wg) : (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / (lds + 512)));
-  const int          nwg    = std::min(total, ctx->num_cus * per_cu);
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / (lds + 512)));
+  const int nwg    = std::min(total, ctx->num_cus * per_cu);
   if (wide && cfg->dft_size == 4096 && nt == 512)
     hipLaunchKernelGGL(ofdm_demod_4096_kernel, dim3(total), dim3(nt), lds, s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw, (const cplx*)ramp,
-                       (const float2*)samples, (float2*)grid, total);
+                       (const float2*)samples, (float2*)grid, total, per);
   else if (wide)
     hipLaunchKernelGGL(ofdm_demod_wide_kernel, dim3(nwg), dim3(nt), lds, s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw, (const cplx*)ramp,
-                       (const float2*)samples, (float2*)grid, total);
+                       (const float2*)samples, (float2*)grid, total, per);
   else
     hipLaunchKernelGGL(ofdm_demod_kernel, dim3(nwg), dim3(nt), lds, s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw, (const cplx*)ramp,
-                       (const float2*)samples, (float2*)grid, total);
+                       (const float2*)samples, (float2*)grid, total, per);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }
 
-extern "C" int miphy_ofdm_modulate_slots(miphy_ctx*               ctx,
-                                         const miphy_ofdm_config* cfg,
-                                         const miphy_ofdm_job*    jobs,
-                                         int                      jobs_on_device,
-                                         uint32_t                 n,
-                                         const float*             grid,
-                                         float*                   samples,
-                                         void*                    stream)
+int ofdm_modulate(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm_job* jobs, int jobs_on_device, uint32_t n, const float* grid, float* samples,
+                  void* stream, int per, const char* what)
 {
-  MIPHY_REQUIRE(ctx && cfg && jobs && samples && grid, "miphy_ofdm_modulate_slots: null argument");
-  int rc = check_cfg(cfg, "ofdm_modulate");
+  int rc = check_cfg(cfg, what);
   if (rc)
     return rc;
-  MIPHY_REQUIRE(cfg->nof_samples_window_offset == 0, "ofdm_modulate: window offset applies to the demodulator only");
+  MIPHY_REQUIRE(cfg->nof_samples_window_offset == 0, "%s: window offset applies to the demodulator only", what);
   if (n == 0)
     return MIPHY_OK;
-  MIPHY_REQUIRE(n <= 65535, "ofdm_modulate: at most 65535 jobs per call");
+  MIPHY_REQUIRE(n <= 65535, "%s: at most 65535 jobs per call", what);
+  const uint32_t lim = (per == 14) ? (1u << cfg->numerology) : (14u << cfg->numerology);
   if (!jobs_on_device)
     for (uint32_t i = 0; i < n; ++i)
-      MIPHY_REQUIRE(jobs[i].slot_index < (1u << cfg->numerology), "ofdm_modulate: job %u: slot index %u out of range", i, jobs[i].slot_index);
+      MIPHY_REQUIRE(jobs[i].slot_index < lim, "%s: job %u: %s index %u out of range", what, i, per == 14 ? "slot" : "symbol", jobs[i].slot_index);
   ofdm_plan_dev* plan = nullptr;
   const float*   tw   = nullptr;
   if ((rc = get_plan(ctx, cfg, 1, &plan)) || (rc = miphy_get_twiddles(ctx, cfg->dft_size, &tw)))
@@ -553,16 +544,56 @@ extern "C" int miphy_ofdm_modulate_slots(miphy_ctx*               ctx,
   const void* d_jobs = nullptr;
   if ((rc = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_ofdm_job) * (size_t)n, s, &d_jobs)))
     return rc;
-  const int nt = threads_for(cfg->dft_size);
+  const int  nt = threads_for(cfg->dft_size);
+  const dim3 g(per, n);
   if (cfg->dft_size == 4096 && nt == 512)
-    hipLaunchKernelGGL(ofdm_mod_4096_kernel, dim3(14, n), dim3(nt), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
-                       (const float2*)grid, (float2*)samples);
+    hipLaunchKernelGGL(ofdm_mod_4096_kernel, g, dim3(nt), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
+                       (const float2*)grid, (float2*)samples, per);
   else if (cfg->dft_size <= 8u * (uint32_t)nt)
-    hipLaunchKernelGGL(ofdm_mod_wide_kernel, dim3(14, n), dim3(nt), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
-                       (const float2*)grid, (float2*)samples);
+    hipLaunchKernelGGL(ofdm_mod_wide_kernel, g, dim3(nt), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
+                       (const float2*)grid, (float2*)samples, per);
   else
-    hipLaunchKernelGGL(ofdm_mod_kernel, dim3(14, n), dim3(nt), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
-                       (const float2*)grid, (float2*)samples);
+    hipLaunchKernelGGL(ofdm_mod_kernel, g, dim3(nt), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
+                       (const float2*)grid, (float2*)samples, per);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
+}
+
+} // namespace
+
+extern "C" int miphy_ofdm_demodulate_slots(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm_job* jobs, int jobs_on_device, uint32_t n,
+                                           const float* samples, float* grid, void* stream)
+{
+  MIPHY_REQUIRE(ctx && cfg && jobs && samples && grid, "miphy_ofdm_demodulate_slots: null argument");
+  return ofdm_demodulate(ctx, cfg, jobs, jobs_on_device, n, samples, grid, stream, 14, "ofdm_demodulate");
+}
+
+extern "C" int miphy_ofdm_modulate_slots(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm_job* jobs, int jobs_on_device, uint32_t n,
+                                         const float* grid, float* samples, void* stream)
+{
+  MIPHY_REQUIRE(ctx && cfg && jobs && samples && grid, "miphy_ofdm_modulate_slots: null argument");
+  return ofdm_modulate(ctx, cfg, jobs, jobs_on_device, n, grid, samples, stream, 14, "ofdm_modulate");
+}
+
+extern "C" int miphy_ofdm_demodulate_symbols(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm_job* jobs, int jobs_on_device, uint32_t n,
+                                             const float* samples, float* grid, void* stream)
+{
+  MIPHY_REQUIRE(ctx && cfg && jobs && samples && grid, "miphy_ofdm_demodulate_symbols: null argument");
+  return ofdm_demodulate(ctx, cfg, jobs, jobs_on_device, n, samples, grid, stream, 1, "ofdm_demodulate_symbols");
+}
+
+extern "C" int miphy_ofdm_modulate_symbols(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm_job* jobs, int jobs_on_device, uint32_t n,
+                                           const float* grid, float* samples, void* stream)
+{
+  MIPHY_REQUIRE(ctx && cfg && jobs && samples && grid, "miphy_ofdm_modulate_symbols: null argument");
+  return ofdm_modulate(ctx, cfg, jobs, jobs_on_device, n, grid, samples, stream, 1, "ofdm_modulate_symbols");
+}
+
+extern "C" uint32_t miphy_ofdm_symbol_size(const miphy_ofdm_config* c, uint32_t symbol_index)
+{
+  // cyclic prefix of symbol `symbol_index` of the subframe + DFT size (cyclic_prefix.h:96-107, ofdm_demodulator.h:64)
+  if (!c || c->numerology > 4 || symbol_index >= (14u << c->numerology) || c->dft_size == 0)
+    return 0;
+  const uint32_t units = (144u >> c->numerology) + ((symbol_index == 0 || symbol_index == (7u << c->numerology)) ? 16u : 0u);
+  return (units << c->numerology) * c->dft_size / 2048u + c->dft_size; // kappa units of 1 / (15 kHz * 2048) at a rate of dft_size * 15 kHz * 2^mu
 }

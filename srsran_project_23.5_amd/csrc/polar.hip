@@ -424,6 +424,160 @@ __global__ void __launch_bounds__(64) polar_decode_kernel(polar_plan p, const in
   (void)n;
 }
 
+
+// ---- single blocks of the chain, for the block-level interfaces of the reference (polar_allocator / polar_encoder /
+// polar_rate_matcher / polar_rate_dematcher / polar_decoder / polar_deallocator / polar_interleaver): the same device code as the
+// chains above, entered and left at one stage. One wavefront per codeword.
+__global__ void __launch_bounds__(64) polar_block_kernel(polar_plan p, int op, int param, const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                         const uint8_t* __restrict__ pi_il_max)
+{
+  __shared__ int8_t  L[2048];
+  __shared__ uint8_t est[1024];
+  __shared__ uint8_t u[1024];
+  const int          lane = threadIdx.x;
+  const size_t       cw   = blockIdx.x;
+  const int          N = (int)p.N, E = (int)p.E, K = (int)p.K, KP = (int)(p.K + p.nPC);
+  switch (op) {
+    case MIPHY_POLAR_OP_ALLOCATE: { // polar_allocator_impl.cpp:28-70
+      uint8_t* m = est;
+      for (int i = lane; i < K; i += 64)
+        m[i] = in[cw * K + i];
+      for (int i = lane; i < N; i += 64)
+        u[i] = 0;
+      __syncthreads();
+      if (p.nPC == 0) {
+        for (int i = lane; i < KP; i += 64)
+          u[p.d_info_pos[i]] = m[i];
+      } else if (lane == 0) {
+        unsigned y[5] = {0, 0, 0, 0, 0};
+        int      iK = 0, ip = 0;
+        for (int q = 0; q < N; ++q) {
+          const unsigned t = y[0];
+          y[0] = y[1], y[1] = y[2], y[2] = y[3], y[3] = y[4], y[4] = t;
+          if (ip < KP && p.d_info_pos[ip] == q) {
+            if (p.d_is_pc[ip]) {
+              u[q] = (uint8_t)y[0];
+            } else {
+              u[q] = m[iK];
+              y[0] ^= m[iK];
+              ++iK;
+            }
+            ++ip;
+          }
+        }
+      }
+      __syncthreads();
+      for (int i = lane; i < N; i += 64)
+        out[cw * N + i] = u[i];
+      break;
+    }
+    case MIPHY_POLAR_OP_ENCODE: { // polar_encoder_impl.cpp:32-86, param = log2 of the code size
+      const int NN = 1 << param;
+      for (int i = lane; i < NN; i += 64)
+        u[i] = in[cw * NN + i];
+      __syncthreads();
+      polar_transform_lds(u, param, lane);
+      for (int i = lane; i < NN; i += 64)
+        out[cw * NN + i] = u[i];
+      break;
+    }
+    case MIPHY_POLAR_OP_RATE_MATCH: // polar_rate_matcher_impl.cpp:31-106 as one gather
+      for (int o = lane; o < E; o += 64)
+        out[cw * E + o] = in[cw * N + p.d_tx_src[o]];
+      break;
+    case MIPHY_POLAR_OP_RATE_DEMATCH: { // polar_rate_dematcher_impl.cpp:29-118
+      const int8_t* f = reinterpret_cast<const int8_t*>(in) + cw * E;
+      for (int q = lane; q < N; q += 64) {
+        const int first = p.d_rx_first[q];
+        int       v;
+        if (first == -1) {
+          v = 0;
+        } else if (first == -2) {
+          v = 127;
+        } else {
+          v = f[p.d_rx_fidx[first]];
+          for (int k = first + N; k < E; k += N)
+            v = llr_promotion_sum(v, f[p.d_rx_fidx[k]]);
+        }
+        reinterpret_cast<int8_t*>(out)[cw * N + q] = (int8_t)v;
+      }
+      break;
+    }
+    case MIPHY_POLAR_OP_DECODE: { // polar_decoder_impl.cpp:179-350 (simplified successive cancellation), output in the u domain
+      for (int q = lane; q < N; q += 64) {
+        L[N + q] = reinterpret_cast<const int8_t*>(in)[cw * N + q];
+        est[q]   = 0;
+        u[q]     = 0;
+      }
+      __syncthreads();
+      for (uint32_t k = 0; k < p.sched_len; ++k) {
+        const uint32_t op2  = p.d_sched[k];
+        const int      type = op2 & 15, s = (op2 >> 4) & 15, pos = (int)(op2 >> 8);
+        const int      size = 1 << s, half = size >> 1;
+        int8_t*        ls   = L + size;
+        int8_t*        lc   = L + half;
+        if (type == OP_F) {
+          for (int i = lane; i < half; i += 64)
+            lc[i] = (int8_t)llr_soft_xor(ls[i], ls[i + half]);
+        } else if (type == OP_G) {
+          for (int i = lane; i < half; i += 64) {
+            const int x = ls[i], y = ls[i + half];
+            lc[i]       = (int8_t)(est[pos + i] ? llr_add(y, -x) : llr_add(y, x));
+          }
+        } else if (type == OP_R1) {
+          for (int i = lane; i < size; i += 64) {
+            const uint8_t b = ls[i] <= 0;
+            est[pos + i]    = b;
+            u[pos + i]      = b;
+          }
+          __syncthreads();
+          for (int h = 1; h < size; h <<= 1) {
+            for (int t = lane; t < half; t += 64) {
+              const int b = ((t / h) * 2 * h) + (t % h);
+              u[pos + b] ^= u[pos + b + h];
+            }
+            __syncthreads();
+          }
+        } else {
+          for (int i = lane; i < half; i += 64)
+            est[pos + i] ^= est[pos + half + i];
+        }
+        __syncthreads();
+      }
+      for (int i = lane; i < N; i += 64)
+        out[cw * N + i] = u[i];
+      break;
+    }
+    case MIPHY_POLAR_OP_DEALLOCATE: // polar_deallocator_impl.cpp:27-42
+      if (p.nPC == 0) {
+        for (int i = lane; i < K; i += 64)
+          out[cw * K + i] = in[cw * N + p.d_info_pos[i]];
+      } else if (lane == 0) {
+        int iK = 0;
+        for (int i = 0; i < KP; ++i)
+          if (!p.d_is_pc[i])
+            out[cw * K + iK++] = in[cw * N + p.d_info_pos[i]];
+      }
+      break;
+    default: { // MIPHY_POLAR_OP_INTERLEAVE_TX / _RX: polar_interleaver_impl.cpp:27-56, param = K
+      const int KK = param;
+      if (lane == 0) { // K <= 164: the selection of the pattern entries is a serial scan
+        int k = 0;
+        for (int m = 0; m < (int)NR_POLAR_K_MAX_IL; ++m)
+          if ((int)pi_il_max[m] >= (int)NR_POLAR_K_MAX_IL - KK) {
+            const int pi_k = (int)pi_il_max[m] - ((int)NR_POLAR_K_MAX_IL - KK);
+            if (op == MIPHY_POLAR_OP_INTERLEAVE_TX)
+              out[cw * KK + k] = in[cw * KK + pi_k];
+            else
+              out[cw * KK + pi_k] = in[cw * KK + k];
+            ++k;
+          }
+      }
+      break;
+    }
+  }
+}
+
 } // namespace
 
 extern "C" int miphy_polar_code_info(const miphy_polar_code* code, uint32_t* n, uint32_t* N, uint32_t* nPC)
@@ -479,6 +633,40 @@ extern "C" int miphy_polar_decode_batch(miphy_ctx*              ctx,
   if (rc || n == 0)
     return rc;
   hipLaunchKernelGGL(polar_decode_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, *p, llr, msg_out, dematched_tap, decoded_u_tap);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_polar_block_batch(miphy_ctx* ctx, const miphy_polar_code* code, uint32_t op, uint32_t param, uint32_t n, const void* in, void* out,
+                                       void* stream)
+{
+  MIPHY_REQUIRE(ctx && in && out, "miphy_polar_block_batch: null argument");
+  MIPHY_REQUIRE(op <= MIPHY_POLAR_OP_INTERLEAVE_RX, "miphy_polar_block_batch: invalid operation %u", op);
+  polar_plan        none = {};
+  const polar_plan* p    = &none;
+  const bool        needs_code = !(op == MIPHY_POLAR_OP_ENCODE || op == MIPHY_POLAR_OP_INTERLEAVE_TX || op == MIPHY_POLAR_OP_INTERLEAVE_RX);
+  if (needs_code) {
+    MIPHY_REQUIRE(code, "miphy_polar_block_batch: operation %u needs the code", op);
+    int rc = get_plan(ctx, code, &p);
+    if (rc)
+      return rc;
+  } else if (op == MIPHY_POLAR_OP_ENCODE) {
+    MIPHY_REQUIRE(param >= 5 && param <= 10, "miphy_polar_block_batch: code size 2^%u out of range", param); // polar_code.h:52-61
+  } else {
+    MIPHY_REQUIRE(param >= 1 && param <= NR_POLAR_K_MAX_IL, "miphy_polar_block_batch: interleaver length %u out of range (K_MAX_IL = 164)", param);
+  }
+  if (n == 0)
+    return MIPHY_OK;
+  // the interleaver pattern (TS 38.212 Table 5.3.1.1-1) lives with the device tables of the context
+  static_assert(sizeof(NR_POLAR_PI_IL_MAX[0]) == 1, "pattern entries are bytes");
+  auto& ext = *ctx->ext;
+  if (!ext.d_pi_il_max) {
+    MIPHY_HIP_CHECK(hipMalloc(&ext.d_pi_il_max, NR_POLAR_K_MAX_IL));
+    MIPHY_HIP_CHECK(hipMemcpy(ext.d_pi_il_max, NR_POLAR_PI_IL_MAX, NR_POLAR_K_MAX_IL, hipMemcpyHostToDevice));
+    ext.to_free.push_back(ext.d_pi_il_max);
+  }
+  hipLaunchKernelGGL(polar_block_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, *p, (int)op, (int)param, (const uint8_t*)in, (uint8_t*)out,
+                     (const uint8_t*)ext.d_pi_il_max);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }
