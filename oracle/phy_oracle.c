@@ -1415,6 +1415,60 @@ typedef struct {
   int     pm;
 } scl_path_t;
 
+/* Textbook successive cancellation (Arikan 2009, LLR form with the min-sum f of the reference's algebra): the recursion over the
+ * code tree with NO node pruning and NO list -- f = soft_xor on the upper branch, g = y +- x (saturating, infinities sticky:
+ * log_likelihood_ratio.cpp:38-70) on the lower one, a leaf decides (llr <= 0) on an information / parity-check position and 0 on
+ * a frozen one (log_likelihood_ratio.h:86). Written from the definition, independently of the kernels and of the reference's
+ * simplified decoder: it is what list size 1 of the list decoder must reproduce, and it coincides with the reference's SSC
+ * decoder (polar_decoder_impl.cpp:179-350, rate-1 nodes decided at once) whenever no information leaf sees an LLR of exactly
+ * zero: a zero is a tie the two orders of evaluation break differently (SSC thresholds the node input, SC the leaf value).
+ * *zero_seen reports such a tie. */
+static void sc_textbook_rec(const int8_t* alpha, unsigned size, unsigned pos, const uint8_t* K_set, uint8_t* u, uint8_t* x, int* zero_seen)
+{
+  if (size == 1) {
+    if (alpha[0] == 0 && K_set[pos])
+      *zero_seen = 1; /* a tie at a decision (a zero anywhere in the input of a rate-1 node reaches one of its leaves as a zero) */
+    u[pos] = K_set[pos] ? (uint8_t)(alpha[0] <= 0) : 0;
+    x[0]   = u[pos];
+    return;
+  }
+  const unsigned half = size / 2;
+  int8_t         a[512];
+  uint8_t        xl[512], xr[512];
+  for (unsigned j = 0; j < half; ++j)
+    a[j] = llr_soft_xor(alpha[j], alpha[j + half]);
+  sc_textbook_rec(a, half, pos, K_set, u, xl, zero_seen);
+  for (unsigned j = 0; j < half; ++j)
+    a[j] = xl[j] ? llr_add(alpha[j + half], (int8_t)-alpha[j]) : llr_add(alpha[j + half], alpha[j]);
+  sc_textbook_rec(a, half, pos + half, K_set, u, xr, zero_seen);
+  for (unsigned j = 0; j < half; ++j) {
+    x[j]        = xl[j] ^ xr[j];
+    x[j + half] = xr[j];
+  }
+}
+
+int orc_polar_sc_textbook(unsigned K, unsigned E, unsigned nMax, int ibil, const int8_t* llr, uint8_t* msg, int* zero_seen)
+{
+  orc_polar_code_t c;
+  if (orc_polar_code_set(&c, K, E, nMax, ibil))
+    return -1;
+  int8_t  ch[1024];
+  uint8_t u[1024], x[1024];
+  polar_dematch(&c, llr, ch);
+  *zero_seen = 0;
+  sc_textbook_rec(ch, c.N, 0, c.K_set, u, x, zero_seen);
+  unsigned iPC = 0, iK = 0;
+  for (unsigned q = 0; q < c.N; ++q) { /* polar_deallocator_impl.cpp:27-42 */
+    if (!c.K_set[q])
+      continue;
+    if (q == c.PC_set[iPC])
+      ++iPC;
+    else
+      msg[iK++] = u[q];
+  }
+  return (int)c.N;
+}
+
 int orc_polar_scl_decode(unsigned K, unsigned E, unsigned nMax, int ibil, unsigned L, int crc_mode, unsigned rnti, const int8_t* llr,
                          uint8_t* msg, int* crc_ok)
 {

@@ -117,6 +117,7 @@ typedef struct {
 int orc_polar_code_set(orc_polar_code_t* c, unsigned K, unsigned E, unsigned nMax, int ibil);
 int orc_polar_encode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, const uint8_t* msg, uint8_t* out, uint8_t* allocated_out,
                            uint8_t* encoded_out);
+int orc_polar_sc_textbook(unsigned K, unsigned E, unsigned nMax, int ibil, const int8_t* llr, uint8_t* msg, int* zero_seen);
 int orc_polar_decode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, const int8_t* llr, uint8_t* msg, int8_t* dematched_out,
                            uint8_t* decoded_u_out);
 void orc_polar_interleave(const uint8_t* in, uint8_t* out, unsigned K, int rx);

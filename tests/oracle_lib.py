@@ -231,6 +231,16 @@ def o_polar_decode_chain(K, E, nMax, ibil, llr):
     return msg, dem[:N], u[:N]
 
 
+def o_polar_sc_textbook(K, E, nMax, ibil, llr):
+    """Plain successive cancellation written from the definition (no pruning, no list). Returns (message, zero_seen)."""
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    msg = np.zeros(K, np.uint8)
+    z = C.c_int(0)
+    N = oracle().orc_polar_sc_textbook(C.c_uint(K), C.c_uint(E), C.c_uint(nMax), int(ibil), _p(llr), _p(msg), C.byref(z))
+    assert N > 0, N
+    return msg, bool(z.value)
+
+
 def o_polar_scl_decode(K, E, nMax, ibil, L, crc_mode, rnti, llr):
     llr = np.ascontiguousarray(llr, dtype=np.int8)
     msg = np.zeros(K, np.uint8)

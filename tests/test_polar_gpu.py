@@ -189,3 +189,34 @@ def test_scl_pbch_and_uplink_codes(ctx):
         for i in range(nb):
             em, eok, epm = o_polar_scl_decode(K, E, nMax, ibil, 8, mode, 0, llrs[i])
             assert np.array_equal(msg[i], em) and bool(ok[i]) == eok and int(pm[i]) == epm, (K, E, i)
+
+
+@pytest.mark.parametrize("K,E,nMax,ibil", polar_cases())
+def test_scl_list1_is_pinned_to_the_reference_style_decoder(ctx, K, E, nMax, ibil):
+    """List size 1 of polar_scl_kernel (plain mode) against (a) the successive-cancellation decoder written from the definition
+    (oracle: orc_polar_sc_textbook) -- always identical -- and (b) the SSC kernel, which is pinned to the reference's decoder: identical
+    on every codeword without a tie (an LLR of exactly zero at an information leaf), noiseless, AWGN and full-range inputs incl.
+    +-127. The ties are the one principled divergence (tests/test_polar_sc_pinning.py); L > 1 stays parity unpinned."""
+    import torch
+    import miphy
+    from oracle_lib import o_polar_sc_textbook
+    from test_polar_sc_pinning import stimuli
+    rng = np.random.default_rng(K * 13 + E + ibil)
+    msgs, llrs = stimuli(K, E, nMax, ibil, rng, nb=8)
+    nb = llrs.shape[0]
+    code = miphy.PolarCode(K, E, nMax, ibil)
+    l_d = torch.from_numpy(llrs.reshape(-1)).cuda()
+    m1 = torch.zeros(nb * K, dtype=torch.uint8, device="cuda")
+    ok = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    ctx.polar_decode_list_batch(code, 1, 0, nb, l_d, None, m1, ok)
+    m2 = torch.zeros(nb * K, dtype=torch.uint8, device="cuda")
+    ctx.polar_decode_batch(code, nb, l_d, m2)
+    torch.cuda.synchronize()
+    scl1, ssc = m1.cpu().numpy().reshape(nb, K), m2.cpu().numpy().reshape(nb, K)
+    for i in range(nb):
+        ref_sc, tie = o_polar_sc_textbook(K, E, nMax, ibil, llrs[i])
+        assert np.array_equal(scl1[i], ref_sc), (K, E, i)
+        if not tie:
+            assert np.array_equal(scl1[i], ssc[i]), (K, E, i)
+        if i < 2:
+            assert np.array_equal(scl1[i], msgs[i])
