@@ -638,7 +638,7 @@ def main():
         legs["pusch_16qam_r658_273prb"] = sch_leg(ctx, miphy, torch, dev, "273 PRB 16QAM R=658/1024: TBS 108552, 13 CB BG1 Z=384, E=13104 (15 layers)",
                                                   1, 4, 273 * 156, 108552 // 8, 1024, args.max_iter, 0.32, 7)
         legs["bg1_z384_rate_one_third"] = sch_leg(ctx, miphy, torch, dev, "BASELINE configs[0]: single codeblock BG1 Z=384, K=8448, full length N=25344 "
-                                                  "(rate 1/3, 46 layers)", 1, 2, 12672, 1050, 8192, args.max_iter, 0.8, 8)
+                                                  "(rate 1/3, 46 layers)", 1, 2, 12672, 1050, 8192, args.max_iter, 0.7, 8)
         legs["polar_pdcch"] = polar_leg(ctx, miphy, torch, dev)
         out["legs"] = legs
         # PCIe-inclusive rate (never `value`): the S slots of time-domain samples from pinned host memory, the step, the transport

@@ -348,12 +348,9 @@ extern "C" int miphy_dmrs_pusch_estimate_batch(miphy_ctx*                   ctx,
     if (rc)
       return rc;
   }
-  // Small batches cannot fill 256 CUs with one workgroup per (job, port, layer): split the broadcast store over symbol groups.
-  static const char* genv = getenv("MIPHY_CHEST_GROUPS");
-  int                ngrp = genv ? atoi(genv) : 1; // measured: splitting does not pay once the per-workgroup prologue is parallel
-  ngrp                    = ngrp < 1 ? 1 : (ngrp > 14 ? 14 : ngrp);
-  static const char* tenv = getenv("MIPHY_CHEST_THREADS");
-  const int          cthreads = (tenv && atoi(tenv) == 256) ? 256 : 512;
+  // One workgroup of 512 threads per (job, port, layer). (Splitting the broadcast store over symbol groups -- gridDim.z -- was
+  // measured and does not pay once the per-workgroup prologue is parallel; 256 threads are slower for the 4096-point IDFT.)
+  const int ngrp = 1, cthreads = 512;
   hipLaunchKernelGGL(chest_kernel, dim3(n, 4 * max_layers, ngrp), dim3(cthreads), lds, s, (const miphy_pusch_chest_job*)d_jobs,
                      (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw,
                      (const float2*)grid, (float2*)ce, scalars);

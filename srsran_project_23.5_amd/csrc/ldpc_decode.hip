@@ -451,11 +451,11 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   // row but needs more LDS per codeblock; at low code rates / mid lifting sizes that leaves one small workgroup per CU, and the
   // one-row-per-lane kernel (compressed messages, twice the wavefronts) wins. Both are scored by the check rows a CU holds in
   // flight (workgroups per CU limited by LDS, wavefront slots and registers), the packed one weighted by its instruction advantage;
-  // measured crossovers: tools/ldpc_rate_sweep.py. MIPHY_LDPC_KERNEL=scalar|packed or miphy_debug_force_ldpc_kernel() override.
-  static const char* force = getenv("MIPHY_LDPC_KERNEL");
+  // measured crossovers: tools/ldpc_rate_sweep.py. miphy_debug_force_ldpc_kernel() overrides (parity tests run both kernels).
   const bool         pk_ok = max_threads >= 128 && all_even && (!descs_on_device || limits);
   const int          pk_threads = ((max_threads / 2 + 63) / 64) * 64; // max_threads >= max Z, a multiple of 64
-  size_t             pk_lds     = 0;
+  size_t             pk_lds     = 0, pk_lds_g = 0;                    // with the messages in LDS / in global memory
+  int                pk_pairs   = 0;
   if (pk_ok) {
     for (int b = 0; b < 2; ++b) {
       if (!max_nodes[b])
@@ -463,10 +463,22 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
       const int bgK = b ? 10 : 22, bgM = b ? 42 : 46;
       int       lay = nodes_all - bgK;
       lay           = lay < 4 ? 4 : (lay > bgM ? bgM : lay);
-      const size_t l = miphy_ldpc_pk_lds_bytes(bgK, lay, (size_t)max_threads, ctx->h_tables->pair_start[b][lay]);
-      pk_lds         = l > pk_lds ? l : pk_lds;
+      const int    pairs = ctx->h_tables->pair_start[b][lay];
+      const size_t l     = miphy_ldpc_pk_lds_bytes(bgK, lay, (size_t)max_threads, pairs);
+      const size_t lg    = miphy_ldpc_pk_lds_bytes(bgK, lay, (size_t)max_threads, 0);
+      pk_lds             = l > pk_lds ? l : pk_lds;
+      pk_lds_g           = lg > pk_lds_g ? lg : pk_lds_g;
+      pk_pairs           = pairs > pk_pairs ? pairs : pk_pairs;
     }
   }
+  // Messages in LDS while that keeps as many codeblocks resident per CU as the registers allow (3 wavefronts per SIMD); otherwise
+  // (more than ~6 layers at Z = 384) in global memory, where they cost an L2 round trip per layer visit but leave room for four
+  // codeblocks per CU: measured 2.0x at rate 1/3, tools/ldpc_rate_sweep.py.
+  const int  pk_waves   = pk_threads / 64;
+  auto       pk_per_cu  = [&](size_t lds) { return std::max(1, std::min((int)((size_t)160 * 1024 / (lds ? lds : 1)), 12 / pk_waves)); };
+  const bool pk_gmsg    = pk_ok && pk_per_cu(pk_lds_g) > pk_per_cu(pk_lds);
+  if (pk_gmsg)
+    pk_lds = pk_lds_g;
   auto rows_in_flight = [](size_t lds, int threads, int waves_per_simd_by_regs, int rows_per_lane) {
     const int waves = threads / 64;
     int       wgs   = (int)((size_t)160 * 1024 / (lds ? lds : 1));
@@ -476,9 +488,9 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
     return wgs * threads * rows_per_lane;
   };
   bool use_pk = pk_ok && 1.6 * rows_in_flight(pk_lds, pk_threads, 4, 2) >= 1.0 * rows_in_flight(max_lds, max_threads, 8, 1);
-  if ((force && force[0] == 's') || g_force_kernel == 1 || force_scalar)
+  if (g_force_kernel == 1 || force_scalar)
     use_pk = false;
-  if ((force && force[0] == 'p') || g_force_kernel == 2)
+  if (g_force_kernel == 2 && !force_scalar)
     use_pk = pk_ok;
   // The fused form needs 16-byte aligned soft buffers (its write-back is vectorised); otherwise the dematcher runs on its own.
   const bool fuse = fuse_rdm && use_pk && ((uintptr_t)llr & 15) == 0;
@@ -488,7 +500,7 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   }
   if (use_pk)
     return miphy_ldpc_pk_launch(ctx, (const miphy_ldpc_dec_desc*)d_descs, n, pk_threads, pk_lds, llr, out_bits, iters, nodes_all, harq_slot,
-                                harq_crc_ok, s, fuse ? fuse_rdm : nullptr, fuse ? fuse_in : nullptr);
+                                harq_crc_ok, s, fuse ? fuse_rdm : nullptr, fuse ? fuse_in : nullptr, pk_gmsg ? pk_pairs : 0);
   // Above the default 64 KB of dynamic LDS the limit has to be raised; it is a per-device attribute of the kernel, so it is set on
   // every such launch (a cache per thread would be wrong for a thread that drives several devices).
   if (max_lds > 48 * 1024) {

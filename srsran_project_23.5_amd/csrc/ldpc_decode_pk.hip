@@ -377,7 +377,11 @@ constexpr int PK_PRE = 3; // rate-matched input vectors per lane fetched one cod
 // receives the dematched codeblock exactly as the reference's dematcher leaves it (data, fillers at +127, zeros behind), and the
 // rate-matched LLRs come from `rm_in_base` through the descriptors `rdm` (same index as `descs`). The input of the NEXT codeblock
 // of the workgroup is fetched into registers while the current one decodes.
-template <bool FUSED>
+// GMSG = the check-to-variable messages live in global memory instead of LDS (`gmsg`: per resident workgroup
+// [wave][edge pair][64 lanes] dwords, `gmsg_pairs` pairs per wave): a lane only ever touches its own messages, one coalesced dword
+// per two edges and layer visit, re-read an iteration later out of L2 / Infinity Cache. Low-rate codeblocks (many layers) then
+// need LDS for their soft bits only, so that four of them stay resident per CU instead of one.
+template <bool FUSED, bool GMSG>
 __global__ void __launch_bounds__(192, LDPC_PK_MIN_WAVES)
 ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                       const miphy_graph_tables* __restrict__ tab,
@@ -390,7 +394,9 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                       uint32_t n,
                       uint32_t* __restrict__ queue,
                       const miphy_ldpc_rdm_desc* __restrict__ rdm,
-                      const int8_t* __restrict__ rm_in_base)
+                      const int8_t* __restrict__ rm_in_base,
+                      uint32_t* __restrict__ gmsg,
+                      int gmsg_pairs)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -433,8 +439,9 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   const int lay_alloc  = min(bgM, max(4, max_nodes - bgK));
   const int soft_bytes = ((bgK + lay_alloc) * Z + 15) & ~15;
   const int pairs_all  = tab->pair_start[bgi][lay_alloc];
-  uint32_t* c2v_lane   = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (tid >> 6) * (pairs_all * 64) + (tid & 63);
-  uint32_t* red        = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (nt >> 6) * (pairs_all * 64);
+  uint32_t* c2v_lane   = GMSG ? gmsg + ((size_t)blockIdx.x * (nt >> 6) + (tid >> 6)) * ((size_t)gmsg_pairs * 64) + (tid & 63)
+                              : reinterpret_cast<uint32_t*>(smem + soft_bytes) + (tid >> 6) * (pairs_all * 64) + (tid & 63);
+  uint32_t* red        = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (GMSG ? 0 : (nt >> 6) * (pairs_all * 64));
 
   // Next codeblock of this workgroup (taken now so that the queue round trip is off the critical path).
   __syncthreads(); // the previous codeblock's readers of red[] / soft[] are done
@@ -702,10 +709,11 @@ size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all)
 
 int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                          uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
-                         const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in)
+                         const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in, int gmsg_pairs)
 {
-  const bool  fused = d_rdm != nullptr;
-  const void* kern  = fused ? (const void*)ldpc_decode_pk_kernel<true> : (const void*)ldpc_decode_pk_kernel<false>;
+  const bool  fused = d_rdm != nullptr, gm = gmsg_pairs > 0;
+  const void* kern  = fused ? (gm ? (const void*)ldpc_decode_pk_kernel<true, true> : (const void*)ldpc_decode_pk_kernel<true, false>)
+                            : (gm ? (const void*)ldpc_decode_pk_kernel<false, true> : (const void*)ldpc_decode_pk_kernel<false, false>);
   // Above the default 64 KB of dynamic LDS the limit has to be raised; it is a per-device attribute of the kernel, so it is set on
   // every such launch (a cache per thread would be wrong for a thread that drives several devices).
   if (lds > 48 * 1024) {
@@ -721,12 +729,21 @@ int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uin
   int            rc    = miphy_next_queue_counter(ctx, s, &queue);
   if (rc)
     return rc;
-  if (fused)
-    hipLaunchKernelGGL(ldpc_decode_pk_kernel<true>, dim3(grid), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot,
-                       harq_crc_ok, n, queue, d_rdm, rm_in);
+  void* gmsg = nullptr;
+  if (gm && (rc = miphy_get_workspace(ctx, (size_t)grid * waves * (size_t)gmsg_pairs * 256, s, &gmsg, 3)))
+    return rc;
+#define PK_LAUNCH(F, G)                                                                                                                              \
+  hipLaunchKernelGGL((ldpc_decode_pk_kernel<F, G>), dim3(grid), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot, \
+                     harq_crc_ok, n, queue, d_rdm, rm_in, (uint32_t*)gmsg, gmsg_pairs)
+  if (fused && gm)
+    PK_LAUNCH(true, true);
+  else if (fused)
+    PK_LAUNCH(true, false);
+  else if (gm)
+    PK_LAUNCH(false, true);
   else
-    hipLaunchKernelGGL(ldpc_decode_pk_kernel<false>, dim3(grid), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot,
-                       harq_crc_ok, n, queue, d_rdm, rm_in);
+    PK_LAUNCH(false, false);
+#undef PK_LAUNCH
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

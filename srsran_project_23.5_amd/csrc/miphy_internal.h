@@ -53,8 +53,9 @@ struct miphy_ctx {
   void*                d_desc_staging;
   size_t               desc_staging_bytes;
   void*                h_desc_staging; // pinned
-  void*                d_work[3];      // scratch workspaces, grown on demand: [0] the transport-block level entry points, DFT, polar;
-  size_t               work_bytes[3];  // [1] intermediate buffers of miphy_pusch_process_batch, [2] codewords of miphy_pdsch_process_batch
+  void*                d_work[4];      // scratch workspaces, grown on demand: [0] the transport-block level entry points, DFT, polar;
+  size_t               work_bytes[4];  // [1] intermediate buffers of miphy_pusch_process_batch, [2] codewords of miphy_pdsch_process_batch,
+                                       // [3] check-to-variable messages of the LDPC decoder when they do not stay in LDS
   int                  num_cus; // compute units of the device (persistent-kernel grid sizing)
   uint32_t*            d_queue; // work-queue counters of the persistent kernels: a ring of MIPHY_NOF_QUEUE_COUNTERS words, one per launch
   uint32_t             queue_next;
@@ -98,9 +99,9 @@ int miphy_ldpc_decode_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* descs, i
 int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out, int which = 0);
 
 // Packed (two rows per lane) LDPC decoder kernel, ldpc_decode_pk.hip.
-size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all);
+size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all); // pairs_all = 0: messages in global memory
 int    miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                             uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
-                            const miphy_ldpc_rdm_desc* d_rdm = nullptr, const int8_t* rm_in = nullptr);
+                            const miphy_ldpc_rdm_desc* d_rdm = nullptr, const int8_t* rm_in = nullptr, int gmsg_pairs = 0);
 // Zeroes (on the stream) and returns the next work-queue counter of the context.
 int miphy_next_queue_counter(miphy_ctx* ctx, hipStream_t s, uint32_t** out);
