@@ -475,7 +475,8 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   // (more than ~6 layers at Z = 384) in global memory, where they cost an L2 round trip per layer visit but leave room for four
   // codeblocks per CU: measured 2.0x at rate 1/3, tools/ldpc_rate_sweep.py.
   const int  pk_waves   = pk_threads / 64;
-  auto       pk_per_cu  = [&](size_t lds) { return std::max(1, std::min((int)((size_t)160 * 1024 / (lds ? lds : 1)), 12 / pk_waves)); };
+  const bool will_fuse  = fuse_rdm && ((uintptr_t)llr & 15) == 0;
+  auto       pk_per_cu  = [&](size_t lds) { return std::max(1, std::min((int)((size_t)160 * 1024 / (lds ? lds : 1)), miphy_ldpc_pk_waves_per_cu(will_fuse) / pk_waves)); };
   const bool pk_gmsg    = pk_ok && pk_per_cu(pk_lds_g) > pk_per_cu(pk_lds);
   if (pk_gmsg)
     pk_lds = pk_lds_g;

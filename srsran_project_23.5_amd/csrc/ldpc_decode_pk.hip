@@ -346,9 +346,11 @@ __device__ unsigned long long g_ldpc_prof[2048 * 8]; // per workgroup: 7 phase s
 #define PROF_COUNT()
 #endif
 
-#ifndef LDPC_PK_MIN_WAVES
-#define LDPC_PK_MIN_WAVES 3
-#endif
+// Wavefronts per SIMD the register allocation is held to: 4 (128 registers, five 3-wavefront codeblocks per CU with the messages in
+// global memory) measured 11 % faster for the plain decoder; the variant that dematches while loading needs 168 registers to stay
+// out of scratch memory in its layer loop and is faster at 3 (4.05 vs 4.21 ms per 38 912 codeblocks).
+#define LDPC_PK_MIN_WAVES_PLAIN 4
+#define LDPC_PK_MIN_WAVES_FUSED 3
 // Raw form of load_in16(): the dword-aligned 16 bytes and the following dword of input vector v, not yet funnel-shifted, so that a
 // prefetch keeps them in flight (the shift happens where the vector is consumed).
 struct raw_in16 {
@@ -382,7 +384,7 @@ constexpr int PK_PRE = 3; // rate-matched input vectors per lane fetched one cod
 // per two edges and layer visit, re-read an iteration later out of L2 / Infinity Cache. Low-rate codeblocks (many layers) then
 // need LDS for their soft bits only, so that four of them stay resident per CU instead of one.
 template <bool FUSED, bool GMSG>
-__global__ void __launch_bounds__(192, LDPC_PK_MIN_WAVES)
+__global__ void __launch_bounds__(192, FUSED ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN)
 ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                       const miphy_graph_tables* __restrict__ tab,
                       const int8_t* __restrict__ llr_base,
@@ -701,6 +703,11 @@ extern "C" int miphy_debug_ldpc_profile(unsigned long long out[8], int reset)
 
 // LDS bytes the packed kernel needs for a given geometry (Zt >= Z of every codeblock, lay = layer bound, pairs_all = message
 // dwords per lane of those layers).
+int miphy_ldpc_pk_waves_per_cu(bool fused)
+{
+  return 4 * (fused ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN); // what __launch_bounds__ of the kernel guarantees per CU
+}
+
 size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all)
 {
   const size_t waves = ((Zt + 1) / 2 + 63) / 64;
@@ -722,7 +729,7 @@ int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uin
   // Resident workgroups per CU: LDS, the 12 wavefronts per CU the register budget of the kernel allows (__launch_bounds__), 32 slots.
   const int waves = threads / 64;
   int       per_cu = (int)((size_t)160 * 1024 / lds);
-  per_cu           = std::min(per_cu, (4 * LDPC_PK_MIN_WAVES) / waves);
+  per_cu           = std::min(per_cu, miphy_ldpc_pk_waves_per_cu(fused) / waves);
   per_cu           = std::max(per_cu, 1);
   const uint32_t grid = std::min<uint32_t>(n, (uint32_t)(ctx->num_cus * per_cu));
   uint32_t*      queue = nullptr;

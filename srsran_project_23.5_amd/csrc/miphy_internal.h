@@ -100,6 +100,7 @@ int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out,
 
 // Packed (two rows per lane) LDPC decoder kernel, ldpc_decode_pk.hip.
 size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all); // pairs_all = 0: messages in global memory
+int    miphy_ldpc_pk_waves_per_cu(bool fused);
 int    miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                             uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
                             const miphy_ldpc_rdm_desc* d_rdm = nullptr, const int8_t* rm_in = nullptr, int gmsg_pairs = 0);
