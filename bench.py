@@ -435,7 +435,7 @@ def main():
             ctx.dmrs_pusch_estimate_batch(cjobs_d[a * 96:b * 96], grid_d, ce_d, sc_d, st)
             if timed:
                 e[2].record(st)
-            ctx.pusch_demodulate_batch(djobs_d[a * 104:b * 104], grid_d, ce_d, sc_d, llr_d, st)
+            ctx.pusch_demodulate_batch(djobs_d[a * 120:b * 120], grid_d, ce_d, sc_d, llr_d, st)
             if timed:
                 e[3].record(st)
                 for i, k in enumerate(front):
@@ -504,7 +504,7 @@ def main():
                 ev0.record(stream)
             ctx.ofdm_demodulate_slots(ocfg, ojobs_d[:24], samples_d, grid_d, stream)
             ctx.dmrs_pusch_estimate_batch(cjobs_d[:96], grid_d, ce_d, sc_d, stream)
-            ctx.pusch_demodulate_batch(djobs_d[:104], grid_d, ce_d, sc_d, llr_d, stream)
+            ctx.pusch_demodulate_batch(djobs_d[:120], grid_d, ce_d, sc_d, llr_d, stream)
             p1.run(llr_d, soft_d, msgs_d, crc_d, tb_d, res_d, stream)
         ev1.record(stream)
         torch.cuda.synchronize()

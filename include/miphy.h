@@ -308,10 +308,20 @@ typedef struct {
   uint64_t ce_offset;      /* cf_t offset of the channel estimate: [rx port][ce_nof_symbols][grid_nof_prb*12] */
   uint64_t scalars_offset; /* float offset of the estimator scalars of this transmission */
   uint64_t llr_offset;     /* int8 offset of the output codeword */
+  /* UCI multiplexed on the PUSCH (pusch_demodulator::configuration::placeholders, pusch_demodulator_impl.cpp:99-152): indices, in
+   * codeword order, of the resource elements that carry a repetition placeholder (ulsch_placeholder_list; from
+   * miphy_ulsch_placeholders). In such an element bit 0 is descrambled normally, bit 1 with the chip of bit 0, the others not at all. */
+  uint32_t placeholders_offset; /* uint16 offset into the `placeholders` array of miphy_pusch_demodulate_batch_ex */
+  uint32_t nof_placeholders;    /* 0: none */
+  uint64_t evm_offset;          /* float offset into `evm_sums` of 14 per-symbol sums of |hard-decided symbol - equalised symbol|^2
+                                   (pusch_demodulator_impl.cpp:89-90, evm_calculator_generic_impl.cpp:31-47): EVM = sqrt(sum / data REs) */
 } miphy_pusch_demod_job;
 
 /* Number of LLRs the allocation of `job` produces (data REs x mod); 0 on an invalid job. Host function. */
 uint32_t miphy_pusch_demod_nof_llr(const miphy_pusch_demod_job* job);
+/* _ex: with the placeholder lists (device, may be NULL when no job has any) and the EVM sums (device, may be NULL: no EVM). */
+int miphy_pusch_demodulate_batch_ex(miphy_ctx* ctx, const miphy_pusch_demod_job* jobs, int jobs_on_device, uint32_t n, const float* grid,
+                                    const float* ce, const float* scalars, int8_t* llr, const uint16_t* placeholders, float* evm_sums, void* stream);
 int miphy_pusch_demodulate_batch(miphy_ctx* ctx, const miphy_pusch_demod_job* jobs, int jobs_on_device, uint32_t n,
                                  const float* grid /* device cf_t */, const float* ce /* device cf_t */, const float* scalars /* device */,
                                  int8_t* llr_out /* device */, void* stream);
@@ -548,9 +558,65 @@ typedef struct {
   uint64_t tb_offset;           /* byte offset of the transport block inside `tb_out` */
 } miphy_pusch_pdu;
 
+/* UCI multiplexed on the PUSCH of a PDU (pusch_processor::uci_description + the lengths ulsch_information derives from it,
+ * include/srsran/ran/pusch/ulsch_info.h: the caller -- the adapter through the reference's own get_ulsch_information() -- supplies them). */
+typedef struct {
+  uint32_t nof_harq_ack_bits, nof_csi_part1_bits, nof_csi_part2_bits;             /* O: information bits (0: field absent) */
+  uint32_t nof_enc_harq_ack_bits, nof_enc_csi_part1_bits, nof_enc_csi_part2_bits; /* G: encoded, rate-matched bits */
+  uint32_t nof_harq_ack_rvd;                                                      /* G^HARQ-ACK_rvd */
+  uint32_t has_codeword;                                                          /* 0: the PDU carries no transport block (UCI only) */
+  uint64_t harq_ack_offset, csi_part1_offset, csi_part2_offset;                   /* int8 offsets of the three soft-bit streams in uci_llr_out */
+} miphy_pusch_uci;
+
+/* _ex: PDUs with multiplexed UCI and the EVM. `uci`: NULL or n entries (host). The soft bits of the UCI fields go to `uci_llr_out`
+ * (device; decoding them stays with the caller: uci_decoder is not on this path), `evm_out` (device, n floats, may be NULL) receives
+ * the error vector magnitude of every PDU (pusch_demodulator::demodulation_status::evm). PDUs without codeword are demodulated and
+ * demultiplexed only; their result record is zero. */
+int miphy_pusch_process_batch_ex(miphy_ctx* ctx, const miphy_pusch_pdu* pdus /* host */, const miphy_pusch_uci* uci /* host or NULL */, uint32_t n,
+                                 const float* grid, int8_t* harq_softbits, uint8_t* harq_msgs, uint8_t* harq_crc_ok, uint8_t* tb_out,
+                                 miphy_pusch_result* results, float* scalars_out, int8_t* uci_llr_out, float* evm_out, void* stream);
 int miphy_pusch_process_batch(miphy_ctx* ctx, const miphy_pusch_pdu* pdus /* host */, uint32_t n, const float* grid /* device cf_t */,
                               int8_t* harq_softbits, uint8_t* harq_msgs, uint8_t* harq_crc_ok, uint8_t* tb_out /* device */,
                               miphy_pusch_result* results /* device, n */, float* scalars_out /* device, n x 20 */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * UL-SCH demultiplexer  --  replaces srsran::ulsch_demultiplex::demultiplex / get_placeholders (UCI multiplexed on PUSCH)
+ *   include/srsran/phy/upper/channel_processors/ulsch_demultiplex.h:38-110, ulsch_placeholder_list.h:35-105
+ *   lib/phy/upper/channel_processors/ulsch_demultiplex_impl.cpp:74-453 (TS 38.212 6.2.7)
+ * One job = one PUSCH codeword: the descrambled LLRs of the demodulator are split into the UL-SCH data stream (all-zero
+ * elements where HARQ-ACK punctures reserved resource elements) and the HARQ-ACK / CSI part 1 / CSI part 2 streams. */
+typedef struct {
+  uint8_t  mod;                         /* bits per symbol */
+  uint8_t  nof_layers;                  /* 1..4 */
+  uint8_t  start_symbol;
+  uint8_t  nof_symbols;
+  uint8_t  dmrs_type;                   /* 1 or 2 */
+  uint8_t  nof_cdm_groups_without_data;
+  uint16_t dmrs_symbols_mask;           /* bit l = OFDM symbol l carries DM-RS */
+  uint16_t nof_prb;                     /* PRBs allocated to the transmission */
+  uint16_t reserved;
+  uint32_t nof_harq_ack_rvd;            /* G^HARQ-ACK_rvd: bits reserved for HARQ-ACK (0 when more than two HARQ-ACK bits are sent) */
+  uint32_t nof_enc_harq_ack_bits;       /* G^HARQ-ACK: encoded, rate-matched bits of each field = length of its output stream */
+  uint32_t nof_enc_csi_part1_bits;
+  uint32_t nof_enc_csi_part2_bits;
+  uint32_t nof_harq_ack_bits;           /* O: information bits of each field (a field with exactly one bit has repetition placeholders) */
+  uint32_t nof_csi_part1_bits;
+  uint32_t nof_csi_part2_bits;
+  uint64_t in_offset;                   /* int8 offset of the codeword LLRs */
+  uint64_t sch_offset;                  /* int8 offsets of the four output streams */
+  uint64_t harq_ack_offset;
+  uint64_t csi_part1_offset;
+  uint64_t csi_part2_offset;
+} miphy_ulsch_demux_job;
+
+/* Host: number of LLRs of the codeword (input) and of the UL-SCH data stream (output) of a job. MIPHY_EINVAL for an impossible
+ * configuration (the reference asserts: fields that do not fit the allocation). */
+int miphy_ulsch_demux_sizes(const miphy_ulsch_demux_job* job, uint32_t* nof_in_llr, uint32_t* nof_sch_llr);
+/* Host: ulsch_demultiplex::get_placeholders -- indices (in the order of the input resource elements) of the elements that carry a
+ * repetition placeholder; at most `cap` are written, *n is the full count. */
+int miphy_ulsch_placeholders(const miphy_ulsch_demux_job* job, uint16_t* re_indices, uint32_t cap, uint32_t* n);
+int miphy_ulsch_demultiplex_batch(miphy_ctx* ctx, const miphy_ulsch_demux_job* jobs /* host */, uint32_t n, const int8_t* llr_in /* device */,
+                                  int8_t* sch_out, int8_t* harq_ack_out, int8_t* csi_part1_out, int8_t* csi_part2_out /* device */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * PDSCH encoder (whole transport blocks)  --  replaces srsran::pdsch_encoder::encode

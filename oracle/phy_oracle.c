@@ -1715,11 +1715,18 @@ static unsigned dmrs_prb_mask(int type2, unsigned nof_cdm_groups_without_data)
   return m;
 }
 
-int orc_pusch_demodulate(unsigned rnti, unsigned n_id, int mod, unsigned start_symbol, unsigned nof_symbols, const uint8_t* dmrs_symbols_mask,
-                         int dmrs_type2, unsigned nof_cdm_groups_without_data, const uint8_t* rb_mask, unsigned nof_prb_grid,
-                         unsigned nof_rx_ports, const float* grid, const float* ce, unsigned ce_nof_symbols, float noise_var, int8_t* llr_out,
-                         float* eq_out, float* nvar_out)
+static void mod_symbol(int mod, const uint8_t* b, unsigned sym_idx, float* re, float* im);
+
+/* placeholders: sorted resource-element indices carrying a repetition placeholder (ulsch_placeholder_list), nof_ph of them;
+ * evm_out: error vector magnitude of pusch_demodulator_impl.cpp:89-90 (NULL: not computed). */
+int orc_pusch_demodulate_ex(unsigned rnti, unsigned n_id, int mod, unsigned start_symbol, unsigned nof_symbols, const uint8_t* dmrs_symbols_mask,
+                            int dmrs_type2, unsigned nof_cdm_groups_without_data, const uint8_t* rb_mask, unsigned nof_prb_grid,
+                            unsigned nof_rx_ports, const float* grid, const float* ce, unsigned ce_nof_symbols, float noise_var, int8_t* llr_out,
+                            float* eq_out, float* nvar_out, const uint16_t* placeholders, unsigned nof_ph, float* evm_out)
 {
+  float* eq_own = NULL;
+  if (evm_out && !eq_out)
+    eq_out = eq_own = (float*)malloc(sizeof(float) * 2 * (size_t)nof_prb_grid * 12 * 14);
   const unsigned nsc   = nof_prb_grid * 12;
   const unsigned dmask = dmrs_prb_mask(dmrs_type2, nof_cdm_groups_without_data);
   unsigned       n     = 0;
@@ -1764,15 +1771,49 @@ int orc_pusch_demodulate(unsigned rnti, unsigned n_id, int mod, unsigned start_s
       }
     }
   }
-  /* descrambling (pusch_demodulator_impl.cpp:99-152, no UCI placeholders) */
   const unsigned nbits = n * (unsigned)mod;
-  uint8_t*       c     = (uint8_t*)malloc(nbits ? nbits : 1);
+  if (evm_out) { /* evm_calculator_generic_impl.cpp:31-47: hard decision of the soft bits (before descrambling), modulation, error power */
+    float acc = 0.f;
+    for (unsigned i = 0; i < n; ++i) {
+      uint8_t hb[8];
+      float   re, im;
+      for (int b = 0; b < mod; ++b)
+        hb[b] = llr_out[(size_t)i * (unsigned)mod + (unsigned)b] <= 0;
+      mod_symbol(mod, hb, i, &re, &im);
+      const float er = re - eq_out[2 * i], ei = im - eq_out[2 * i + 1];
+      acc += er * er + ei * ei;
+    }
+    *evm_out = n ? sqrtf(acc / (float)n) : 0.f;
+  }
+  free(eq_own);
+  /* descrambling (pusch_demodulator_impl.cpp:99-152). In an element with a repetition placeholder the first soft bit takes its own
+   * chip, the second one the SAME chip (y repeats the bit before it) and the x placeholders behind them are left as they are;
+   * the sequence advances over all of them. */
+  uint8_t* c = (uint8_t*)malloc(nbits ? nbits : 1);
   orc_gold_sequence((rnti << 15) + n_id, 0, nbits, c);
-  for (unsigned i = 0; i < nbits; ++i)
-    if (c[i])
-      llr_out[i] = (int8_t)-llr_out[i];
+  unsigned ip = 0;
+  for (unsigned re = 0; re < n; ++re) {
+    while (ip < nof_ph && placeholders[ip] < re)
+      ++ip;
+    const int ph = mod >= 2 && ip < nof_ph && placeholders[ip] == re;
+    for (int b = 0; b < mod; ++b) {
+      const size_t i    = (size_t)re * (unsigned)mod + (unsigned)b;
+      const int    chip = ph ? (b < 2 ? c[(size_t)re * (unsigned)mod] : 0) : c[i];
+      if (chip)
+        llr_out[i] = (int8_t)-llr_out[i];
+    }
+  }
   free(c);
   return (int)nbits;
+}
+
+int orc_pusch_demodulate(unsigned rnti, unsigned n_id, int mod, unsigned start_symbol, unsigned nof_symbols, const uint8_t* dmrs_symbols_mask,
+                         int dmrs_type2, unsigned nof_cdm_groups_without_data, const uint8_t* rb_mask, unsigned nof_prb_grid,
+                         unsigned nof_rx_ports, const float* grid, const float* ce, unsigned ce_nof_symbols, float noise_var, int8_t* llr_out,
+                         float* eq_out, float* nvar_out)
+{
+  return orc_pusch_demodulate_ex(rnti, n_id, mod, start_symbol, nof_symbols, dmrs_symbols_mask, dmrs_type2, nof_cdm_groups_without_data, rb_mask,
+                                 nof_prb_grid, nof_rx_ports, grid, ce, ce_nof_symbols, noise_var, llr_out, eq_out, nvar_out, NULL, 0, NULL);
 }
 
 /* ================================================================================================= PDSCH modulator + DM-RS
@@ -2223,4 +2264,149 @@ int orc_csi_rs_map(unsigned slot_in_frame, unsigned scrambling_id, float amplitu
   }
   free(c), free(seq);
   return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ UL-SCH demultiplexing (UCI on PUSCH)
+ * ulsch_demultiplex_impl.cpp:74-453 (TS 38.212 6.2.7) as the serial scan it is: symbol by symbol, subcarrier by subcarrier, every
+ * resource element goes to SCH data, HARQ-ACK, CSI part 1 or CSI part 2; HARQ-ACK on RESERVED elements (G_rvd != 0) punctures SCH /
+ * CSI part 2, which receive an all-zero element there. One pass serves both users of the reference: demultiplexing (in != NULL)
+ * and the list of repetition placeholders (elements of a field that carries exactly one information bit, in input order).
+ * Returns the number of input LLRs, or -1 where the reference asserts. */
+int orc_ulsch_demultiplex(int mod, unsigned nof_layers, unsigned nof_prb, unsigned start_symbol, unsigned nof_symbols, unsigned G_rvd, int dmrs_type,
+                          unsigned dmrs_symbols_mask, unsigned cdm_groups, unsigned G_ack, unsigned G_csi1, unsigned G_csi2, unsigned O_ack, unsigned O_csi1,
+                          unsigned O_csi2, const int8_t* in, int8_t* sch, int8_t* ack, int8_t* csi1, int8_t* csi2, unsigned* nof_sch_llr,
+                          uint16_t* placeholders, unsigned* nof_placeholders)
+{
+  const unsigned bpr  = (unsigned)mod * nof_layers;
+  const unsigned mask = dmrs_symbols_mask & 0x3fffu;
+  if (!mask || nof_symbols == 0 || start_symbol + nof_symbols > 14)
+    return -1;
+  unsigned first_dmrs = 0, l1, l1_csi = 0;
+  while (!((mask >> first_dmrs) & 1u))
+    ++first_dmrs;
+  for (l1 = first_dmrs; l1 < 14 && ((mask >> l1) & 1u); ++l1) {
+  }
+  if (l1 >= 14)
+    return -1;
+  while ((mask >> l1_csi) & 1u)
+    ++l1_csi;
+  const unsigned re_dmrs = (12u - cdm_groups * (dmrs_type == 1 ? 6u : 4u)) * nof_prb;
+  const int      want_ph = mod >= 2 && (O_ack == 1 || O_csi1 == 1 || O_csi2 == 1);
+  unsigned       m_rvd = 0, m_ack = 0, m_c1 = 0, m_c2 = 0;
+  unsigned       n_in = 0, n_sch = 0, n_ack = 0, n_c1 = 0, n_c2 = 0, n_ph = 0; /* consumed / produced resource elements */
+#define ORC_TAKE(dst, cnt)                                   \
+  do {                                                       \
+    if (in && (dst))                                         \
+      memcpy((dst) + (size_t)(cnt)*bpr, in + (size_t)n_in * bpr, bpr); \
+    ++(cnt), ++n_in;                                         \
+  } while (0)
+#define ORC_ZERO(dst, cnt)                      \
+  do {                                          \
+    if (in && (dst))                            \
+      memset((dst) + (size_t)(cnt)*bpr, 0, bpr); \
+    ++(cnt);                                    \
+  } while (0)
+  for (unsigned l = start_symbol; l < start_symbol + nof_symbols; ++l) {
+    if ((mask >> l) & 1u) {
+      for (unsigned i = 0; i < re_dmrs; ++i)
+        ORC_TAKE(sch, n_sch);
+      continue;
+    }
+    const unsigned M = nof_prb * 12u;
+    unsigned       M_uci = M, M_rvd = 0;
+    unsigned       ack_d = 0, ack_n = 0, rvd_d = 0, rvd_n = 0, c1_d = 0, c1_n = 0, c2_d = 0, c2_n = 0;
+    if (l >= l1) {
+      const unsigned rvd_left = G_rvd - m_rvd, ack_left = G_ack - m_ack;
+      if (G_rvd != 0 && rvd_left != 0) {
+        rvd_d = 1, rvd_n = M_uci;
+        if (rvd_left < M_uci * bpr)
+          rvd_d = (M_uci * bpr) / rvd_left, rvd_n = (rvd_left + bpr - 1) / bpr;
+        M_rvd = rvd_n;
+        if (ack_left != 0) {
+          ack_d = 1, ack_n = M_rvd;
+          if (ack_left < M_rvd * bpr)
+            ack_d = (M_rvd * bpr) / ack_left, ack_n = (ack_left + bpr - 1) / bpr;
+        }
+      } else if (ack_left != 0) {
+        ack_d = 1, ack_n = M_uci;
+        if (ack_left < M_uci * bpr)
+          ack_d = (M_uci * bpr) / ack_left, ack_n = (ack_left + bpr - 1) / bpr;
+        M_uci -= ack_n;
+      }
+    }
+    if (l >= l1_csi) {
+      const unsigned c1_left = G_csi1 - m_c1, c2_left = G_csi2 - m_c2;
+      if (M_uci > M_rvd && c1_left != 0) {
+        c1_d = 1, c1_n = M_uci - M_rvd;
+        if (c1_left < (M_uci - M_rvd) * bpr)
+          c1_d = ((M_uci - M_rvd) * bpr) / c1_left, c1_n = (c1_left + bpr - 1) / bpr;
+        M_uci -= c1_n;
+      }
+      if (M_uci > 0 && c2_left != 0) {
+        c2_d = 1, c2_n = M_uci;
+        if (c2_left < M_uci * bpr)
+          c2_d = (M_uci * bpr) / c2_left, c2_n = (c2_left + bpr - 1) / bpr;
+        M_uci -= c2_n;
+      }
+    }
+    unsigned sch_left = M_uci;
+    m_rvd += rvd_n * bpr, m_ack += ack_n * bpr, m_c1 += c1_n * bpr, m_c2 += c2_n * bpr;
+    for (unsigned i = 0, i_c1 = 0, i_c2 = 0, i_ack = 0; i < M; ++i) {
+      const int reserved = (rvd_n != 0) && (i % rvd_d == 0);
+      int       zero     = 0;
+      if (reserved)
+        --rvd_n;
+      if (G_rvd != 0) {
+        if (reserved && ack_n != 0 && ((i_ack++) % ack_d == 0)) {
+          if (want_ph && O_ack == 1)
+            placeholders[n_ph++] = (uint16_t)n_in;
+          ORC_TAKE(ack, n_ack);
+          --ack_n;
+          zero = 1;
+        }
+      } else if (ack_n != 0 && ((i_ack++) % ack_d == 0)) {
+        if (want_ph && O_ack == 1)
+          placeholders[n_ph++] = (uint16_t)n_in;
+        ORC_TAKE(ack, n_ack);
+        --ack_n;
+        continue;
+      }
+      if (!reserved && c1_n != 0 && ((i_c1++) % c1_d == 0)) {
+        if (want_ph && O_csi1 == 1)
+          placeholders[n_ph++] = (uint16_t)n_in;
+        ORC_TAKE(csi1, n_c1);
+        --c1_n;
+        continue;
+      }
+      if (c2_n != 0 && ((i_c2++) % c2_d == 0)) {
+        if (zero) {
+          ORC_ZERO(csi2, n_c2);
+        } else {
+          if (want_ph && O_csi2 == 1)
+            placeholders[n_ph++] = (uint16_t)n_in;
+          ORC_TAKE(csi2, n_c2);
+        }
+        --c2_n;
+        continue;
+      }
+      if (sch_left == 0)
+        return -1;
+      if (zero)
+        ORC_ZERO(sch, n_sch);
+      else
+        ORC_TAKE(sch, n_sch);
+      --sch_left;
+    }
+    if (ack_n || c1_n || c2_n || sch_left)
+      return -1;
+  }
+#undef ORC_TAKE
+#undef ORC_ZERO
+  if (m_rvd != G_rvd || m_ack != G_ack || m_c1 != G_csi1 || m_c2 != G_csi2)
+    return -1;
+  if (nof_sch_llr)
+    *nof_sch_llr = n_sch * bpr;
+  if (nof_placeholders)
+    *nof_placeholders = n_ph;
+  return (int)(n_in * bpr);
 }

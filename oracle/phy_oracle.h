@@ -117,6 +117,10 @@ typedef struct {
 int orc_polar_code_set(orc_polar_code_t* c, unsigned K, unsigned E, unsigned nMax, int ibil);
 int orc_polar_encode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, const uint8_t* msg, uint8_t* out, uint8_t* allocated_out,
                            uint8_t* encoded_out);
+int orc_ulsch_demultiplex(int mod, unsigned nof_layers, unsigned nof_prb, unsigned start_symbol, unsigned nof_symbols, unsigned G_rvd, int dmrs_type,
+                          unsigned dmrs_symbols_mask, unsigned cdm_groups, unsigned G_ack, unsigned G_csi1, unsigned G_csi2, unsigned O_ack, unsigned O_csi1,
+                          unsigned O_csi2, const int8_t* in, int8_t* sch, int8_t* ack, int8_t* csi1, int8_t* csi2, unsigned* nof_sch_llr,
+                          uint16_t* placeholders, unsigned* nof_placeholders);
 int orc_polar_sc_textbook(unsigned K, unsigned E, unsigned nMax, int ibil, const int8_t* llr, uint8_t* msg, int* zero_seen);
 int orc_polar_decode_chain(unsigned K, unsigned E, unsigned nMax, int ibil, const int8_t* llr, uint8_t* msg, int8_t* dematched_out,
                            uint8_t* decoded_u_out);
@@ -144,6 +148,10 @@ void orc_demodulate_soft(int mod, unsigned nsym, const float* symbols, const flo
  * ZF/MRC equalisation over nof_rx_ports, soft demapping, descrambling (c_init = rnti*2^15 + n_id). grid: [port][14][nsc] cf_t,
  * ce: [port][ce_nof_symbols][nsc] cf_t (absolute symbol index), noise_var: estimator's value for port 0. Returns the number of
  * LLRs written. eq_out / nvar_out (optional): equalised symbols and post-equalisation noise variances. */
+int orc_pusch_demodulate_ex(unsigned rnti, unsigned n_id, int mod, unsigned start_symbol, unsigned nof_symbols, const uint8_t* dmrs_symbols_mask,
+                            int dmrs_type2, unsigned nof_cdm_groups_without_data, const uint8_t* rb_mask, unsigned nof_prb_grid,
+                            unsigned nof_rx_ports, const float* grid, const float* ce, unsigned ce_nof_symbols, float noise_var, int8_t* llr_out,
+                            float* eq_out, float* nvar_out, const uint16_t* placeholders, unsigned nof_ph, float* evm_out);
 int orc_pusch_demodulate(unsigned rnti, unsigned n_id, int mod, unsigned start_symbol, unsigned nof_symbols, const uint8_t* dmrs_symbols_mask,
                          int dmrs_type2, unsigned nof_cdm_groups_without_data, const uint8_t* rb_mask, unsigned nof_prb_grid,
                          unsigned nof_rx_ports, const float* grid, const float* ce, unsigned ce_nof_symbols, float noise_var, int8_t* llr_out,

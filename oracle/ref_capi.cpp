@@ -728,6 +728,86 @@ int ref_pusch_demodulate(unsigned       rnti,
   return 0;
 }
 
+// The same with repetition placeholders in the descrambler and the EVM of the demodulation status.
+int ref_pusch_demodulate_ex(unsigned       rnti,
+                         unsigned       n_id,
+                         int            mod,
+                         unsigned       start_symbol,
+                         unsigned       nof_symbols,
+                         const uint8_t* dmrs_symbols_mask,
+                         int            dmrs_type2,
+                         unsigned       nof_cdm_groups_without_data,
+                         const uint8_t* rb_mask,
+                         unsigned       nof_prb_grid,
+                         unsigned       nof_rx_ports,
+                         const float*   grid_in,
+                         const float*   ce_in,
+                         unsigned       ce_nof_symbols,
+                         float          noise_var,
+                         int8_t*        llr_out,
+                         unsigned       nof_llr,
+                         const uint16_t* placeholders,
+                         unsigned        nof_placeholders,
+                         float*          evm_out)
+{
+  auto dem = create_pusch_demodulator_factory_sw(
+                 create_channel_equalizer_factory_zf(), create_channel_modulation_sw_factory(), create_pseudo_random_generator_sw_factory(), evm_out != nullptr)
+                 ->create();
+  unsigned nsc  = nof_prb_grid * 12;
+  auto     grid = create_resource_grid(nof_rx_ports, 14, nsc);
+  for (unsigned p = 0; p != nof_rx_ports; ++p) {
+    for (unsigned l = 0; l != 14; ++l) {
+      grid->put(p, l, 0, span<const cf_t>(reinterpret_cast<const cf_t*>(grid_in) + (size_t(p) * 14 + l) * nsc, nsc));
+    }
+  }
+  channel_estimate::channel_estimate_dimensions dims;
+  dims.nof_prb       = nof_prb_grid;
+  dims.nof_symbols   = ce_nof_symbols;
+  dims.nof_rx_ports  = nof_rx_ports;
+  dims.nof_tx_layers = 1;
+  channel_estimate ce(dims);
+  for (unsigned p = 0; p != nof_rx_ports; ++p) {
+    for (unsigned l = 0; l != ce_nof_symbols; ++l) {
+      span<cf_t> v = ce.get_symbol_ch_estimate(l, p, 0);
+      std::memcpy(v.data(), ce_in + 2 * ((size_t(p) * ce_nof_symbols + l) * nsc), sizeof(cf_t) * nsc);
+    }
+    ce.set_noise_variance(noise_var, p, 0);
+  }
+  pusch_demodulator::configuration cfg;
+  cfg.rnti    = rnti;
+  cfg.rb_mask = bounded_bitset<MAX_RB>(nof_prb_grid);
+  for (unsigned r = 0; r != nof_prb_grid; ++r) {
+    if (rb_mask[r]) {
+      cfg.rb_mask.set(r);
+    }
+  }
+  cfg.modulation         = mod_from_bits(mod);
+  cfg.start_symbol_index = start_symbol;
+  cfg.nof_symbols        = nof_symbols;
+  for (unsigned l = 0; l != 14; ++l) {
+    cfg.dmrs_symb_pos[l] = dmrs_symbols_mask[l] != 0;
+  }
+  cfg.dmrs_config_type            = dmrs_type2 ? dmrs_type::TYPE2 : dmrs_type::TYPE1;
+  cfg.nof_cdm_groups_without_data = nof_cdm_groups_without_data;
+  cfg.n_id                        = n_id;
+  cfg.nof_tx_layers               = 1;
+  for (unsigned p = 0; p != nof_rx_ports; ++p) {
+    cfg.rx_ports.push_back(p);
+  }
+  for (unsigned i = 0; i != nof_placeholders; ++i) {
+    cfg.placeholders.push_back(placeholders[i]);
+  }
+  std::vector<log_likelihood_ratio> out(nof_llr);
+  pusch_demodulator::demodulation_status st = dem->demodulate(out, *grid, ce, cfg);
+  if (evm_out != nullptr) {
+    *evm_out = st.evm.has_value() ? st.evm.value() : -1.0F;
+  }
+  for (unsigned i = 0; i != nof_llr; ++i) {
+    llr_out[i] = out[i].to_value_type();
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------- PDSCH modulator + DM-RS PDSCH
 // vrb_mask: [bwp_size] bytes (type-0 allocation relative to the BWP); interleaved: 0 = none, 1 = create_interleaved_other(L_i = 2).
 // grid_out: [nof_grid_ports][14][nof_prb_grid*12] (zero where nothing was mapped); prb_list_out: the PRB indices in mapping order.
@@ -1478,5 +1558,49 @@ double ref_pusch_decoder_bench(unsigned      nthreads,
   return now_s() - t0;
 }
 
-} // extern "C"
+// ---------------------------------------------------------------- UL-SCH demultiplexer (UCI on PUSCH)
+// ulsch_demultiplex_impl through its factory: demultiplex() and get_placeholders(). Stream lengths: n_sch / G_ack / G_csi1 / G_csi2 LLRs.
+int ref_ulsch_demultiplex(int mod, unsigned nof_layers, unsigned nof_prb, unsigned start_symbol, unsigned nof_symbols, unsigned G_rvd, int dmrs_type2,
+                          unsigned dmrs_symbols_mask, unsigned cdm_groups, unsigned G_ack, unsigned G_csi1, unsigned G_csi2, unsigned O_ack, unsigned O_csi1,
+                          unsigned O_csi2, const int8_t* in, unsigned n_in, int8_t* sch, unsigned n_sch, int8_t* ack, int8_t* csi1, int8_t* csi2,
+                          uint16_t* placeholders, unsigned* nof_placeholders)
+{
+  auto                             dm = create_ulsch_demultiplex_factory_sw()->create();
+  ulsch_demultiplex::configuration cfg;
+  cfg.modulation = mod_from_bits(mod), cfg.nof_layers = nof_layers, cfg.nof_prb = nof_prb, cfg.start_symbol_index = start_symbol, cfg.nof_symbols = nof_symbols;
+  cfg.nof_harq_ack_rvd = G_rvd, cfg.dmrs = dmrs_type2 ? dmrs_type::TYPE2 : dmrs_type::TYPE1, cfg.nof_cdm_groups_without_data = cdm_groups;
+  cfg.dmrs_symbol_mask = symbol_slot_mask(14);
+  for (unsigned l = 0; l != 14; ++l) {
+    if ((dmrs_symbols_mask >> l) & 1U) {
+      cfg.dmrs_symbol_mask.set(l);
+    }
+  }
+  std::vector<log_likelihood_ratio> vin(n_in), vsch(n_sch), vack(G_ack), vc1(G_csi1), vc2(G_csi2);
+  for (unsigned i = 0; i != n_in; ++i) {
+    vin[i] = log_likelihood_ratio(in[i]);
+  }
+  dm->demultiplex(vsch, vack, vc1, vc2, vin, cfg);
+  for (unsigned i = 0; i != n_sch; ++i) {
+    sch[i] = vsch[i].to_value_type();
+  }
+  for (unsigned i = 0; i != G_ack; ++i) {
+    ack[i] = vack[i].to_value_type();
+  }
+  for (unsigned i = 0; i != G_csi1; ++i) {
+    csi1[i] = vc1[i].to_value_type();
+  }
+  for (unsigned i = 0; i != G_csi2; ++i) {
+    csi2[i] = vc2[i].to_value_type();
+  }
+  ulsch_demultiplex::message_information mi;
+  mi.nof_harq_ack_bits = O_ack, mi.nof_enc_harq_ack_bits = G_ack, mi.nof_csi_part1_bits = O_csi1, mi.nof_enc_csi_part1_bits = G_csi1;
+  mi.nof_csi_part2_bits = O_csi2, mi.nof_enc_csi_part2_bits = G_csi2;
+  ulsch_placeholder_list pl = dm->get_placeholders(mi, cfg);
+  unsigned               k  = 0;
+  // the list only exposes its entries as bit positions: bit = bits_per_symbol * (layers * re + layer) + 1
+  pl.for_each(cfg.modulation, 1, [&](unsigned y_bit, unsigned) { placeholders[k++] = static_cast<uint16_t>((y_bit - 1) / mod); });
+  *nof_placeholders = k;
+  return 0;
+}
 
+} // extern "C"

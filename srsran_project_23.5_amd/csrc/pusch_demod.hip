@@ -13,6 +13,7 @@
 // so the LLRs are reproducible bit for bit by a scalar CPU restatement; against the reference AVX2 build they are within one step.
 #define NR_DEMOD_TABLE_ATTR __device__
 #include "gold_device.h"
+#include "mod_device.h"
 #include "miphy_ext.h"
 #include "tables/nr_demod_tables.h"
 #include <cmath>
@@ -141,6 +142,9 @@ struct demod_args {
   const float2* ce;
   int8_t*       llr;
   float         noise_var;
+  const uint16_t* ph;  // repetition placeholders of this transmission (sorted RE indices), nph of them
+  int             nph;
+  float*          evm; // sum of |hard-decided symbol - equalised symbol|^2 of this OFDM symbol, or nullptr
 };
 
 template <int MOD>
@@ -161,6 +165,7 @@ __device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* 
   int8_t*    o       = a.llr + (size_t)prefix * MOD;
   const bool aligned = ((uintptr_t)o % (MOD == 8 ? 8 : MOD == 4 ? 4 : MOD == 1 ? 1 : 2)) == 0;
   const uint32_t npp_magic = (uint32_t)((0x100000000ull + (uint32_t)npp - 1u) / (uint32_t)npp); // r / npp for r < 2^16
+  float          evm_acc   = 0.f;
   for (int r = tid; r < n_re; r += nt) {
     const int pi  = (int)__umulhi((uint32_t)r, npp_magic);
     const int prb = prb_of[pi], k = r - pi * npp;
@@ -195,10 +200,38 @@ __device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* 
       demod_symbol<MOD, true>(z_re, z_im, nv, (unsigned)(prefix + r), tab, l);
     else
       demod_symbol<MOD, false>(z_re, z_im, nv, (unsigned)(prefix + r), tab, l);
+    if (a.evm) { // evm_calculator_generic_impl.cpp:31-47 on the soft bits BEFORE descrambling: hard decision, modulation, error power
+      uint32_t hb = 0;
+#pragma unroll
+      for (int b = 0; b < MOD; ++b)
+        hb |= (uint32_t)(l[b] <= 0) << b;
+      const float2 id = map_symbol(MOD, hb, (unsigned)(prefix + r));
+      const float  er = id.x - z_re, ei = id.y - z_im;
+      evm_acc += er * er + ei * ei;
+    }
     // descramble: bit b of this RE is sequence bit (prefix + r) * MOD + b; cw holds the bits of this OFDM symbol from r = 0
     const int      bi   = r * MOD;
     const uint64_t two  = (uint64_t)cw[bi >> 5] | ((uint64_t)cw[(bi >> 5) + 1] << 32);
-    const uint32_t bits = (uint32_t)(two >> (bi & 31));
+    uint32_t       bits = (uint32_t)(two >> (bi & 31));
+    if (a.nph) { // binary search of this element in the placeholder list (pusch_demodulator_impl.cpp:117-149)
+      const unsigned re = (unsigned)(prefix + r);
+      int            lo = 0, hi = a.nph - 1;
+      bool           found = false;
+      while (lo <= hi) {
+        const int      mid = (lo + hi) >> 1;
+        const unsigned v   = a.ph[mid];
+        if (v == re) {
+          found = true;
+          break;
+        }
+        if (v < re)
+          lo = mid + 1;
+        else
+          hi = mid - 1;
+      }
+      if (found)
+        bits = (bits & 1u) ? 3u : 0u; // y repeats the chip of bit 0, the x placeholders behind it are not scrambled
+    }
 #pragma unroll
     for (int b = 0; b < MOD; ++b) {
       const int m = -(int)((bits >> b) & 1u); // 0 / -1
@@ -227,11 +260,23 @@ __device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* 
         q[b] = (int8_t)(w >> (8 * b));
     }
   }
+  if (a.evm) { // deterministic order: wavefront shuffle tree, then the four wavefronts in sequence
+    __shared__ float evm_red[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+      evm_acc += __shfl_xor(evm_acc, off);
+    if ((tid & 63) == 0)
+      evm_red[tid >> 6] = evm_acc;
+    __syncthreads();
+    if (tid == 0)
+      *a.evm = ((evm_red[0] + evm_red[1]) + evm_red[2]) + evm_red[3];
+  }
 }
 
 __global__ void __launch_bounds__(256) pusch_demod_kernel(const miphy_pusch_demod_job* __restrict__ jobs, const gold_tables* __restrict__ gt,
                                                           const float2* __restrict__ grid, const float2* __restrict__ ce,
-                                                          const float* __restrict__ scalars, int8_t* __restrict__ llr)
+                                                          const float* __restrict__ scalars, int8_t* __restrict__ llr,
+                                                          const uint16_t* __restrict__ placeholders, float* __restrict__ evm_sums)
 {
   __shared__ uint32_t w1[MAX_SYM_WORDS], w2[MAX_SYM_WORDS];
   __shared__ uint16_t prb_of[276];
@@ -245,6 +290,9 @@ __global__ void __launch_bounds__(256) pusch_demod_kernel(const miphy_pusch_demo
   const int sy  = blockIdx.y;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int start_symbol = jp->start_symbol, nof_symbols = jp->nof_symbols;
+  float* evm_out = evm_sums ? evm_sums + jp->evm_offset + sy : nullptr;
+  if (evm_out && tid == 0)
+    *evm_out = 0.f; // symbols without data contribute nothing
   if (sy < start_symbol || sy >= start_symbol + nof_symbols)
     return;
   const unsigned dmask     = dmrs_prb_mask(jp->dmrs_type, jp->nof_cdm_groups_without_data);
@@ -296,6 +344,9 @@ __global__ void __launch_bounds__(256) pusch_demod_kernel(const miphy_pusch_demo
   a.ce             = ce + jp->ce_offset;
   a.llr            = llr + jp->llr_offset;
   a.noise_var      = scalars[jp->scalars_offset + 2];
+  a.nph            = placeholders ? (int)jp->nof_placeholders : 0;
+  a.ph             = placeholders ? placeholders + jp->placeholders_offset : nullptr;
+  a.evm            = evm_out;
   switch (mod) {
     case 8:
       demod_tables_to_lds<8>(tab, tid);
@@ -340,6 +391,13 @@ extern "C" uint32_t miphy_pusch_demod_nof_llr(const miphy_pusch_demod_job* j)
 extern "C" int miphy_pusch_demodulate_batch(miphy_ctx* ctx, const miphy_pusch_demod_job* jobs, int jobs_on_device, uint32_t n, const float* grid,
                                             const float* ce, const float* scalars, int8_t* llr, void* stream)
 {
+  return miphy_pusch_demodulate_batch_ex(ctx, jobs, jobs_on_device, n, grid, ce, scalars, llr, nullptr, nullptr, stream);
+}
+
+extern "C" int miphy_pusch_demodulate_batch_ex(miphy_ctx* ctx, const miphy_pusch_demod_job* jobs, int jobs_on_device, uint32_t n, const float* grid,
+                                               const float* ce, const float* scalars, int8_t* llr, const uint16_t* placeholders, float* evm_sums,
+                                               void* stream)
+{
   MIPHY_REQUIRE(ctx && jobs && grid && ce && scalars && llr, "miphy_pusch_demodulate_batch: null argument");
   if (n == 0)
     return MIPHY_OK;
@@ -361,6 +419,7 @@ extern "C" int miphy_pusch_demodulate_batch(miphy_ctx* ctx, const miphy_pusch_de
       // pusch_demodulator_impl.cpp:76-80: the codeword length must match the number of data REs
       MIPHY_REQUIRE(j.nof_llr == miphy_pusch_demod_nof_llr(&j), "pusch_demodulate: job %u: %u LLRs requested, the allocation holds %u", i, j.nof_llr,
                     miphy_pusch_demod_nof_llr(&j));
+      MIPHY_REQUIRE(j.nof_placeholders == 0 || (placeholders && j.mod >= 2), "pusch_demodulate: job %u: placeholders need the list and a modulation order of at least 2", i);
     }
   }
   hipStream_t        s  = (hipStream_t)stream;
@@ -373,7 +432,7 @@ extern "C" int miphy_pusch_demodulate_batch(miphy_ctx* ctx, const miphy_pusch_de
   if (rc)
     return rc;
   hipLaunchKernelGGL(pusch_demod_kernel, dim3(n, 14), dim3(256), 0, s, (const miphy_pusch_demod_job*)d_jobs, gt, (const float2*)grid, (const float2*)ce,
-                     scalars, llr);
+                     scalars, llr, placeholders, evm_sums);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

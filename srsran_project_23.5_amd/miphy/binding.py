@@ -87,6 +87,16 @@ def lib():
         l.miphy_harq_pool_free_codeblocks.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         l.miphy_harq_pool_arrays.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 3
         l.miphy_pusch_demod_nof_llr.restype = C.c_uint32
+        l.miphy_pusch_process_batch_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 10
+        l.miphy_pusch_demodulate_batch_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32] + [C.c_void_p] * 7
+        l.miphy_ulsch_demux_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_ulsch_placeholders.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        l.miphy_ulsch_demultiplex_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        l.miphy_polar_block_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        for name in ("miphy_ofdm_demodulate_symbols", "miphy_ofdm_modulate_symbols"):
+            getattr(l, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_ofdm_symbol_size.argtypes = [C.c_void_p, C.c_uint32]
+        l.miphy_ofdm_symbol_size.restype = C.c_uint32
         _lib = l
     return _lib
 
@@ -136,8 +146,9 @@ PuschDemodJob = np.dtype([("rnti", np.uint32), ("n_id", np.uint32), ("mod", np.u
                           ("nof_symbols", np.uint8), ("dmrs_type", np.uint8), ("nof_cdm_groups_without_data", np.uint8),
                           ("ce_nof_symbols", np.uint8), ("ce_compact", np.uint8), ("rx_ports", np.uint8, 4), ("dmrs_symbols_mask", np.uint16),
                           ("grid_nof_prb", np.uint16), ("nof_llr", np.uint32), ("rb_mask", np.uint64, 5), ("grid_offset", np.uint64),
-                          ("ce_offset", np.uint64), ("scalars_offset", np.uint64), ("llr_offset", np.uint64)], align=True)
-assert PuschDemodJob.itemsize == 104 and PuschDemodJob.fields["rb_mask"][1] == 32, PuschDemodJob.itemsize
+                          ("ce_offset", np.uint64), ("scalars_offset", np.uint64), ("llr_offset", np.uint64), ("placeholders_offset", np.uint32),
+                          ("nof_placeholders", np.uint32), ("evm_offset", np.uint64)], align=True)
+assert PuschDemodJob.itemsize == 120 and PuschDemodJob.fields["rb_mask"][1] == 32, PuschDemodJob.itemsize
 
 
 def pusch_demod_nof_llr(job):
@@ -215,6 +226,14 @@ PuschPdu = np.dtype([("numerology", np.uint32), ("slot_in_frame", np.uint32), ("
 assert PuschPdu.itemsize == 112 and PuschPdu.fields["rb_mask"][1] == 56, PuschPdu.itemsize
 
 
+# Mirrors miphy_pusch_uci.
+PuschUci = np.dtype([("nof_harq_ack_bits", np.uint32), ("nof_csi_part1_bits", np.uint32), ("nof_csi_part2_bits", np.uint32),
+                     ("nof_enc_harq_ack_bits", np.uint32), ("nof_enc_csi_part1_bits", np.uint32), ("nof_enc_csi_part2_bits", np.uint32),
+                     ("nof_harq_ack_rvd", np.uint32), ("has_codeword", np.uint32), ("harq_ack_offset", np.uint64), ("csi_part1_offset", np.uint64),
+                     ("csi_part2_offset", np.uint64)], align=True)
+assert PuschUci.itemsize == 56
+
+
 class PolarCode(C.Structure):
     """Mirrors miphy_polar_code (the arguments of srsran::polar_code::set)."""
     _fields_ = [("K", C.c_uint32), ("E", C.c_uint32), ("nMax", C.c_uint32), ("ibil", C.c_uint32)]
@@ -262,6 +281,33 @@ assert PbchMsg.itemsize == 56
 SsbPdu = np.dtype([("msg", PbchMsg), ("ssb_first_subcarrier", np.uint32), ("ssb_first_symbol", np.uint32), ("beta_pss_dB", np.float32),
                    ("grid_nof_prb", np.uint16), ("nof_ports", np.uint8), ("ports", np.uint8, 4), ("pad", np.uint8), ("grid_offset", np.uint64)], align=True)
 assert SsbPdu.itemsize == 88 and SsbPdu.fields["grid_offset"][1] == 80, SsbPdu.itemsize
+
+
+# Mirrors miphy_ulsch_demux_job.
+UlschDemuxJob = np.dtype([("mod", np.uint8), ("nof_layers", np.uint8), ("start_symbol", np.uint8), ("nof_symbols", np.uint8), ("dmrs_type", np.uint8),
+                          ("nof_cdm_groups_without_data", np.uint8), ("dmrs_symbols_mask", np.uint16), ("nof_prb", np.uint16), ("reserved", np.uint16),
+                          ("nof_harq_ack_rvd", np.uint32), ("nof_enc_harq_ack_bits", np.uint32), ("nof_enc_csi_part1_bits", np.uint32),
+                          ("nof_enc_csi_part2_bits", np.uint32), ("nof_harq_ack_bits", np.uint32), ("nof_csi_part1_bits", np.uint32),
+                          ("nof_csi_part2_bits", np.uint32), ("in_offset", np.uint64), ("sch_offset", np.uint64), ("harq_ack_offset", np.uint64),
+                          ("csi_part1_offset", np.uint64), ("csi_part2_offset", np.uint64)], align=True)
+assert UlschDemuxJob.itemsize == 80, UlschDemuxJob.itemsize
+
+
+def ulsch_demux_sizes(job):
+    """(codeword LLRs in, UL-SCH LLRs out) of a UlschDemuxJob record (host function)."""
+    a, b = C.c_uint32(), C.c_uint32()
+    j = np.ascontiguousarray(np.asarray(job).reshape(1))
+    check(lib().miphy_ulsch_demux_sizes(C.c_void_p(j.ctypes.data), C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def ulsch_placeholders(job):
+    """RE indices of the repetition placeholders (ulsch_demultiplex::get_placeholders), host function."""
+    j = np.ascontiguousarray(np.asarray(job).reshape(1))
+    out = np.zeros(275 * 12 * 14, np.uint16)
+    n = C.c_uint32()
+    check(lib().miphy_ulsch_placeholders(C.c_void_p(j.ctypes.data), C.c_void_p(out.ctypes.data), out.size, C.byref(n)))
+    return out[:n.value].copy()
 
 
 # Mirrors miphy_crc_desc.
@@ -409,6 +455,13 @@ class Context:
         check(lib().miphy_ofh_iq_compress_batch(self.h, ptr, on_dev, n, _dptr(grid), float(iq_scaling), _dptr(payload), _stream_ptr(stream)))
 
     # ------------------------------------------------------------------ PUSCH demodulator (equalise + soft-demap + descramble)
+    def pusch_demodulate_batch_ex(self, jobs, grid, ce, scalars, llr, placeholders=None, evm_sums=None, stream=None):
+        """With the repetition placeholders (device uint16) and / or the per-symbol EVM sums (device float32, 14 per job at evm_offset)."""
+        jobs, n, ptr, on_dev = self._descs(jobs, PuschDemodJob)
+        check(lib().miphy_pusch_demodulate_batch_ex(self.h, ptr, on_dev, n, _dptr(grid), _dptr(ce), _dptr(scalars), _dptr(llr),
+                                                    _dptr(placeholders) if placeholders is not None else None,
+                                                    _dptr(evm_sums) if evm_sums is not None else None, _stream_ptr(stream)))
+
     def pusch_demodulate_batch(self, jobs, grid, ce, scalars, llr, stream=None):
         jobs, n, ptr, on_dev = self._descs(jobs, PuschDemodJob)
         check(lib().miphy_pusch_demodulate_batch(self.h, ptr, on_dev, n, _dptr(grid), _dptr(ce), _dptr(scalars), _dptr(llr), _stream_ptr(stream)))
@@ -440,6 +493,23 @@ class Context:
         check(lib().miphy_pusch_decode_batch(self.h, C.c_void_p(tbs.ctypes.data), tbs.size, _dptr(llrs), _dptr(harq_softbits),
                                              _dptr(harq_msgs), _dptr(harq_crc_ok), _dptr(tb_out), _dptr(results), _stream_ptr(stream)))
 
+    def ulsch_demultiplex_batch(self, jobs, llr_in, sch, harq_ack, csi1, csi2, stream=None):
+        assert isinstance(jobs, np.ndarray) and jobs.dtype == UlschDemuxJob
+        jobs = np.ascontiguousarray(jobs)
+        check(lib().miphy_ulsch_demultiplex_batch(self.h, C.c_void_p(jobs.ctypes.data), jobs.size, _dptr(llr_in), _dptr(sch), _dptr(harq_ack),
+                                                  _dptr(csi1), _dptr(csi2), _stream_ptr(stream)))
+
+    def polar_block_batch(self, code, op, param, n, x, out, stream=None):
+        check(lib().miphy_polar_block_batch(self.h, C.byref(code) if code is not None else None, op, param, n, _dptr(x), _dptr(out), _stream_ptr(stream)))
+
+    def ofdm_demodulate_symbols(self, cfg, jobs, samples, grid, stream=None):
+        jobs, n, ptr, on_dev = self._descs(jobs, OfdmJob)
+        check(lib().miphy_ofdm_demodulate_symbols(self.h, C.byref(cfg), ptr, on_dev, n, _dptr(samples), _dptr(grid), _stream_ptr(stream)))
+
+    def ofdm_modulate_symbols(self, cfg, jobs, grid, samples, stream=None):
+        jobs, n, ptr, on_dev = self._descs(jobs, OfdmJob)
+        check(lib().miphy_ofdm_modulate_symbols(self.h, C.byref(cfg), ptr, on_dev, n, _dptr(grid), _dptr(samples), _stream_ptr(stream)))
+
     def pusch_decode_plan(self, tbs):
         """Prepared miphy_pusch_decode_batch (descriptors uploaded once): returns a PuschDecodePlan."""
         return PuschDecodePlan(self, tbs)
@@ -450,6 +520,20 @@ class Context:
         pdus = np.ascontiguousarray(pdus)
         check(lib().miphy_pusch_process_batch(self.h, C.c_void_p(pdus.ctypes.data), pdus.size, _dptr(grid), _dptr(harq_softbits), _dptr(harq_msgs),
                                               _dptr(harq_crc_ok), _dptr(tb_out), _dptr(results), _dptr(scalars), _stream_ptr(stream)))
+
+    def pusch_process_batch_ex(self, pdus, uci, grid, harq_softbits, harq_msgs, harq_crc_ok, tb_out, results, scalars, uci_llr, evm, stream=None):
+        """PDUs with multiplexed UCI (uci: numpy PuschUci array or None) and the EVM (evm: float32 device tensor of n or None)."""
+        assert isinstance(pdus, np.ndarray) and pdus.dtype == PuschPdu
+        pdus = np.ascontiguousarray(pdus)
+        up = None
+        if uci is not None:
+            assert isinstance(uci, np.ndarray) and uci.dtype == PuschUci and uci.size == pdus.size
+            uci = np.ascontiguousarray(uci)
+            up = C.c_void_p(uci.ctypes.data)
+        check(lib().miphy_pusch_process_batch_ex(self.h, C.c_void_p(pdus.ctypes.data), up, pdus.size, _dptr(grid), _dptr(harq_softbits), _dptr(harq_msgs),
+                                                 _dptr(harq_crc_ok), _dptr(tb_out), _dptr(results), _dptr(scalars),
+                                                 _dptr(uci_llr) if uci_llr is not None else None, _dptr(evm) if evm is not None else None,
+                                                 _stream_ptr(stream)))
 
     def pdsch_encode_batch(self, tbs, tb_in, codeword_out, stream=None):
         assert isinstance(tbs, np.ndarray) and tbs.dtype == PdschTbDesc

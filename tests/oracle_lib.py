@@ -537,6 +537,24 @@ def o_pusch_demodulate(*a):
     return llr, eq, nv
 
 
+def o_pusch_demodulate_ex(*a, placeholders=(), want_evm=True):
+    """orc_pusch_demodulate with repetition placeholders (sorted RE indices) and the EVM. Returns (llr, evm)."""
+    args, llr, n, keep = _demod_args(*a)
+    ph = np.ascontiguousarray(placeholders, dtype=np.uint16)
+    evm = C.c_float(0)
+    got = oracle().orc_pusch_demodulate_ex(*args, None, None, _p(ph) if ph.size else None, C.c_uint(ph.size), C.byref(evm) if want_evm else None)
+    assert got == llr.size, (got, llr.size)
+    return llr, float(evm.value)
+
+
+def r_pusch_demodulate_ex(*a, placeholders=()):
+    args, llr, n, keep = _demod_args(*a)
+    ph = np.ascontiguousarray(placeholders, dtype=np.uint16)
+    evm = C.c_float(0)
+    assert ref().ref_pusch_demodulate_ex(*args, C.c_uint(llr.size), _p(ph) if ph.size else None, C.c_uint(ph.size), C.byref(evm)) == 0
+    return llr, float(evm.value)
+
+
 def r_pusch_demodulate(*a):
     args, llr, n, keep = _demod_args(*a)
     assert ref().ref_pusch_demodulate(*args, C.c_uint(llr.size)) == 0
@@ -857,3 +875,66 @@ def o_csi_rs_map(slot, scr_id, amplitude, start_rb, nof_rb, bes, row, cdm, densi
     return oracle().orc_csi_rs_map(C.c_uint(slot), C.c_uint(scr_id), C.c_float(amplitude), C.c_uint(start_rb), C.c_uint(nof_rb), C.c_uint(bes[0]), C.c_uint(bes[1]),
                                    C.c_uint(bes[2]), C.c_uint(row), C.c_uint(cdm), C.c_uint(density), C.c_uint(pt.size), _p(pt), _p(rm), _p(sm), C.c_uint(nprb_grid),
                                    _p(grid))
+
+
+# ---------------------------------------------------------------------------------------------- UL-SCH demultiplexing (UCI on PUSCH)
+def o_ulsch_demultiplex(mod, nof_layers, nof_prb, start, nof, G_rvd, dmrs_type, dmrs_mask, cdm, G, O, llr=None):
+    """G = (G_ack, G_csi1, G_csi2) encoded bits, O = (O_ack, O_csi1, O_csi2) information bits. Returns (n_in, n_sch, streams or None,
+    placeholder RE indices) or None where the reference asserts (fields that do not fit)."""
+    cap = nof_prb * 12 * 14 * mod * nof_layers
+    sch, ack, c1, c2 = np.zeros(cap, np.int8), np.zeros(max(G[0], 1), np.int8), np.zeros(max(G[1], 1), np.int8), np.zeros(max(G[2], 1), np.int8)
+    ph = np.zeros(nof_prb * 12 * 14, np.uint16)
+    n_sch, n_ph = C.c_uint(0), C.c_uint(0)
+    lin = None if llr is None else np.ascontiguousarray(llr, dtype=np.int8)
+    n = oracle().orc_ulsch_demultiplex(int(mod), C.c_uint(nof_layers), C.c_uint(nof_prb), C.c_uint(start), C.c_uint(nof), C.c_uint(G_rvd), int(dmrs_type),
+                                       C.c_uint(dmrs_mask), C.c_uint(cdm), C.c_uint(G[0]), C.c_uint(G[1]), C.c_uint(G[2]), C.c_uint(O[0]), C.c_uint(O[1]),
+                                       C.c_uint(O[2]), _p(lin) if lin is not None else None, _p(sch), _p(ack), _p(c1), _p(c2), C.byref(n_sch), _p(ph),
+                                       C.byref(n_ph))
+    if n < 0:
+        return None
+    streams = None if llr is None else (sch[:n_sch.value].copy(), ack[:G[0]].copy(), c1[:G[1]].copy(), c2[:G[2]].copy())
+    return n, n_sch.value, streams, ph[:n_ph.value].copy()
+
+
+def r_ulsch_demultiplex(mod, nof_layers, nof_prb, start, nof, G_rvd, dmrs_type, dmrs_mask, cdm, G, O, llr, n_sch):
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    sch, ack, c1, c2 = np.zeros(max(n_sch, 1), np.int8), np.zeros(max(G[0], 1), np.int8), np.zeros(max(G[1], 1), np.int8), np.zeros(max(G[2], 1), np.int8)
+    ph = np.zeros(nof_prb * 12 * 14, np.uint16)
+    n_ph = C.c_uint(0)
+    rc = ref().ref_ulsch_demultiplex(int(mod), C.c_uint(nof_layers), C.c_uint(nof_prb), C.c_uint(start), C.c_uint(nof), C.c_uint(G_rvd), int(dmrs_type == 2),
+                                     C.c_uint(dmrs_mask), C.c_uint(cdm), C.c_uint(G[0]), C.c_uint(G[1]), C.c_uint(G[2]), C.c_uint(O[0]), C.c_uint(O[1]),
+                                     C.c_uint(O[2]), _p(llr), C.c_uint(llr.size), _p(sch), C.c_uint(n_sch), _p(ack), _p(c1), _p(c2), _p(ph), C.byref(n_ph))
+    assert rc == 0
+    return (sch[:n_sch].copy(), ack[:G[0]].copy(), c1[:G[1]].copy(), c2[:G[2]].copy()), ph[:n_ph.value].copy()
+
+
+def ulsch_cases(rng, n):
+    """Random but valid UCI-on-PUSCH configurations: (mod, layers, nprb, start, nof, G_rvd, dmrs_type, dmrs_mask, cdm, G, O)."""
+    out = []
+    while len(out) < n:
+        mod = int(rng.choice([1, 2, 4, 6, 8]))
+        nprb = int(rng.integers(1, 60))
+        start = int(rng.integers(0, 3))
+        nof = int(rng.integers(6, 15 - start))
+        dm = 0
+        for l in sorted(set(int(x) for x in rng.integers(start, start + nof, int(rng.integers(1, 4))))):
+            dm |= 1 << l
+        if dm == ((1 << nof) - 1) << start:
+            continue
+        dtype, cdm = (1, int(rng.integers(1, 3))) if rng.random() < 0.7 else (2, int(rng.integers(1, 4)))
+        bpr = mod
+        re_sym = nprb * 12
+        O_ack = int(rng.choice([0, 1, 2, 5, 11]))
+        G_ack = 0 if O_ack == 0 else bpr * int(rng.integers(1, max(2, re_sym // 2)))
+        G_rvd = 0
+        if O_ack <= 2 and rng.random() < 0.6:
+            G_rvd = bpr * int(rng.integers(max(1, G_ack // bpr), max(2, G_ack // bpr + re_sym // 2)))
+        O_c1 = int(rng.choice([0, 0, 1, 4, 11]))
+        G_c1 = 0 if O_c1 == 0 else bpr * int(rng.integers(1, max(2, re_sym)))
+        O_c2 = int(rng.choice([0, 0, 0, 1, 7]))
+        G_c2 = 0 if O_c2 == 0 else bpr * int(rng.integers(1, max(2, re_sym)))
+        case = (mod, 1, nprb, start, nof, G_rvd, dtype, dm, cdm, (G_ack, G_c1, G_c2), (O_ack, O_c1, O_c2))
+        if o_ulsch_demultiplex(*case) is None:
+            continue
+        out.append(case)
+    return out

@@ -200,6 +200,46 @@ def test_pusch_demodulator():
         assert diff.max() <= 1 and (diff == 0).mean() > 0.99, (mod, ports, diff.max(), (diff == 0).mean())
 
 
+def test_pusch_demodulator_placeholders_and_evm():
+    """UCI on PUSCH in the demodulator (pusch_demodulator_impl.cpp:89-152): repetition placeholders in the descrambler and the EVM of
+    the demodulation status, oracle vs reference. LLRs within one quantisation step (the reference's approximate reciprocal), EVM
+    within 1e-3 relative (a hard decision that flips with such a step moves one symbol)."""
+    rng = np.random.default_rng(78)
+    for mod, ports, cdm in ((2, 1, 2), (4, 2, 2), (6, 1, 1), (8, 2, 2), (1, 1, 2)):
+        nprb = 20
+        nsc = nprb * 12
+        rb = np.zeros(nprb, np.uint8)
+        rb[2:19] = 1
+        dm = np.zeros(14, np.uint8)
+        dm[[2, 9]] = 1
+        n_re = O.pusch_nof_re(0, 14, dm, 0, cdm, rb)
+        bits = rng.integers(0, 2, n_re * mod, dtype=np.uint8)
+        tx = O.nr_modulate(bits, mod)
+        h = (rng.standard_normal((ports, 1, nsc)) + 1j * rng.standard_normal((ports, 1, nsc))).astype(np.complex64) * 0.8
+        ce = np.ascontiguousarray(np.broadcast_to(h, (ports, 14, nsc)))
+        grid = np.zeros((ports, 14, nsc), np.complex64)
+        k = 0
+        dmask = [(q % 2) < cdm for q in range(12)]
+        for sy in range(14):
+            for r in np.nonzero(rb)[0]:
+                for q in range(12):
+                    if dm[sy] and dmask[q]:
+                        continue
+                    grid[:, sy, r * 12 + q] = ce[:, sy, r * 12 + q] * tx[k]
+                    k += 1
+        assert k == n_re
+        grid += ((rng.standard_normal(grid.shape) + 1j * rng.standard_normal(grid.shape)) * 0.05).astype(np.complex64)
+        ph = np.sort(rng.choice(n_re, 37, replace=False)).astype(np.uint16) if mod >= 2 else np.zeros(0, np.uint16)
+        args = (0x4601, 935, mod, 0, 14, dm, 0, cdm, rb, grid, ce, 0.01)
+        (o, oe), (r, re_) = O.o_pusch_demodulate_ex(*args, placeholders=ph), O.r_pusch_demodulate_ex(*args, placeholders=ph)
+        diff = np.abs(o.astype(int) - r.astype(int))
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.97, (mod, diff.max(), (diff == 0).mean())  # 97-99.6 % identical: approximate reciprocal
+        assert re_ > 0 and abs(oe - re_) <= 1e-3 * re_, (mod, oe, re_)
+        if ph.size:  # the placeholders matter: without them the LLRs of those elements differ
+            o2, _ = O.o_pusch_demodulate_ex(*args, placeholders=(), want_evm=False)
+            assert (o2 != o).sum() > 0 and set(np.nonzero(o2 != o)[0] // mod) <= set(int(x) for x in ph)
+
+
 def test_pdsch_modulator_and_dmrs():
     """Modulation mapper, pdsch_modulator_impl (one layer, contiguous allocation: what 23.5 can do) and dmrs_pdsch_processor_impl
     against the oracle: bit-exact single-precision grids."""

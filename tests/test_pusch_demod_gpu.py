@@ -124,3 +124,40 @@ def test_rejections(ctx):
             j[k] = v
         with pytest.raises(RuntimeError):
             ctx.pusch_demodulate_batch(np.array([j], dtype=miphy.PuschDemodJob), x, x, f, o)
+
+
+@pytest.mark.parametrize("mod,ports,cdm", [(2, 1, 2), (4, 2, 2), (6, 1, 1), (8, 4, 2), (1, 1, 2)])
+def test_placeholders_and_evm_match_oracle(ctx, mod, ports, cdm):
+    """UCI on PUSCH: repetition placeholders in the descrambler (bit-exact LLRs against the oracle) and the per-symbol EVM sums
+    (EVM within 2e-6 relative of the oracle's sequential sum: the kernel adds in a tree)."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(900 + mod)
+    nprb = 31
+    nsc = nprb * 12
+    rb = np.zeros(nprb, np.uint8)
+    rb[1:27] = 1
+    dm = np.zeros(14, np.uint8)
+    dm[[3, 10]] = 1
+    grid = (rng.standard_normal((ports, 14, nsc)) + 1j * rng.standard_normal((ports, 14, nsc))).astype(np.complex64)
+    ce = (rng.standard_normal((ports, 14, nsc)) + 1j * rng.standard_normal((ports, 14, nsc))).astype(np.complex64)
+    n_re = O.pusch_nof_re(1, 12, dm, 0, cdm, rb)
+    ph = np.sort(rng.choice(n_re, 53, replace=False)).astype(np.uint16) if mod >= 2 else np.zeros(0, np.uint16)
+    j = _job(miphy, 0x1234, 77, mod, 1, 12, dm, 0, cdm, rb, ports, 14)
+    j["placeholders_offset"], j["nof_placeholders"], j["evm_offset"] = 5, ph.size, 3
+    g = torch.from_numpy(grid.reshape(-1)).cuda()
+    h = torch.from_numpy(ce.reshape(-1)).cuda()
+    sc = np.zeros(5, np.float32)
+    sc[2] = 0.07
+    out = torch.full((int(j["nof_llr"]) + 64,), 99, dtype=torch.int8, device="cuda")
+    ph_d = torch.from_numpy(np.concatenate([np.zeros(5, np.uint16), ph, np.zeros(3, np.uint16)]).view(np.int16)).cuda()
+    evm_d = torch.full((3 + 14 + 2,), -1.0, dtype=torch.float32, device="cuda")
+    ctx.pusch_demodulate_batch_ex(np.array([j], dtype=miphy.PuschDemodJob), g, h, torch.from_numpy(sc).cuda(), out, ph_d, evm_d)
+    torch.cuda.synchronize()
+    o, oe = O.o_pusch_demodulate_ex(0x1234, 77, mod, 1, 12, dm, 0, cdm, rb, grid, ce, 0.07, placeholders=ph)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:o.size], o) and np.all(got[o.size:] == 99)
+    e = evm_d.cpu().numpy()
+    assert np.all(e[:3] == -1.0) and np.all(e[17:] == -1.0) and e[3] == 0.0 and e[3 + 13] == 0.0  # symbols outside the allocation contribute 0
+    evm = float(np.sqrt(e[3:17].astype(np.float64).sum() / n_re))
+    assert abs(evm - oe) <= 2e-6 * oe + 1e-7, (evm, oe)

@@ -1,0 +1,132 @@
+"""GPU: PUSCH PDUs with multiplexed UCI through miphy_pusch_process_batch_ex (descrambling placeholders, UL-SCH
+demultiplexing, EVM) against the oracle chain estimator -> demodulator (placeholders, EVM) -> demultiplexer -> decoder, every stage of
+which is pinned against the reference (tests/test_oracle_vs_ref.py, tests/test_ulsch_demux.py): UCI soft-bit streams bit-exact, transport
+block and CRC verdict, EVM within 2e-6 relative. The transmit side multiplexes the UCI with the multiplexing map read off the oracle's
+demultiplexer (the reference has a demultiplexer only: the gNB receives)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+RB_ALL = lambda nprb: [(0xFFFFFFFFFFFFFFFF if nprb >= 64 * (k + 1) else ((1 << max(0, nprb - 64 * k)) - 1)) for k in range(5)]
+
+
+def _mux_map(case, n_in):
+    """Position of every input soft bit in its output stream: demultiplex three 'digits' of the input index."""
+    idx = np.arange(n_in)
+    digs = []
+    for d in range(3):
+        v = ((idx // (100 ** d)) % 100 + 1).astype(np.int8)
+        digs.append(O.o_ulsch_demultiplex(*case, llr=v)[2])
+    maps = []
+    for k in range(4):
+        a = [digs[d][k].astype(np.int64) for d in range(3)]
+        src = (a[0] - 1) + 100 * (a[1] - 1) + 10000 * (a[2] - 1)
+        src[a[0] == 0] = -1  # punctured (all-zero) elements have no source
+        maps.append(src)
+    return maps  # per stream: input index of every output position (-1: none)
+
+
+@pytest.mark.parametrize("mod,O_ack,G_ack_re,rvd_re,O_c1,G_c1_re,O_c2,G_c2_re,with_tb", [
+    (4, 1, 20, 44, 0, 0, 0, 0, True),      # one HARQ-ACK bit on reserved elements: placeholders + punctured UL-SCH
+    (6, 2, 18, 40, 5, 60, 0, 0, True),     # two HARQ-ACK bits (reserved) + CSI part 1
+    (2, 4, 50, 0, 1, 31, 7, 90, True),     # HARQ-ACK without reservation, one-bit CSI part 1 (placeholders), CSI part 2
+    (8, 1, 12, 0, 0, 0, 0, 0, True),
+    (4, 3, 25, 0, 4, 40, 0, 0, False),     # UCI only: no transport block
+])
+def test_pusch_with_uci_matches_oracle_chain(ctx, mod, O_ack, G_ack_re, rvd_re, O_c1, G_c1_re, O_c2, G_c2_re, with_tb):
+    import torch
+    import miphy
+    rng = np.random.default_rng(7000 + mod + O_ack)
+    nprb, slot, rnti, n_id, scr = 24, 5, 0x3311, 411, 17
+    nsc = nprb * 12
+    dm = np.zeros(14, np.uint8)
+    dm[2] = 1
+    rb = np.ones(nprb, np.uint8)
+    G = (G_ack_re * mod, G_c1_re * mod, G_c2_re * mod)
+    case = (mod, 1, nprb, 0, 14, rvd_re * mod, 1, 1 << 2, 2, G, (O_ack, O_c1, O_c2))
+    info = O.o_ulsch_demultiplex(*case)
+    assert info is not None
+    n_in, n_sch, _, ph = info
+    n_re = n_in // mod
+    assert n_re == nprb * 156
+    # ---- transmit side
+    tbs_bits = {2: 2976, 4: 6016, 6: 9736, 8: 14600}[mod]
+    tb = rng.integers(0, 256, tbs_bits // 8, dtype=np.uint8)
+    bg = 1 if tbs_bits > 3824 else 2
+    sch_bits = O.o_pdsch_encode(bg, 0, mod, 0, 1, n_sch // mod, tb) if with_tb else rng.integers(0, 2, n_sch, dtype=np.uint8)
+    uci_bits = [rng.integers(0, 2, g, dtype=np.uint8) for g in G]
+    maps = _mux_map(case, n_in)
+    cw = np.zeros(n_in, np.uint8)
+    for k, bits in enumerate([sch_bits] + uci_bits):
+        m = maps[k]
+        assert m.size == bits.size
+        cw[m[m >= 0]] = bits[m >= 0]
+    c = O.o_gold((rnti << 15) + n_id, 0, n_in)
+    sc_bits = cw ^ c
+    for re in ph:  # TS 38.211 6.3.1.1: y repeats the previous scrambled bit, x is 1
+        sc_bits[re * mod + 1] = sc_bits[re * mod]
+        sc_bits[re * mod + 2:re * mod + mod] = 1
+    sym = O.nr_modulate(sc_bits, mod)
+    h = (0.9 * np.exp(1j * 0.4) * (1 + 0.1 * np.cos(np.arange(nsc) / 40.0))).astype(np.complex64)
+    grid = np.zeros((1, 14, nsc), np.complex64)
+    k = 0
+    for sy in range(14):
+        for q in range(nsc):
+            if sy == 2:
+                continue
+            grid[0, sy, q] = sym[k] * h[q]
+            k += 1
+    assert k == n_re
+    g3 = np.zeros((1, 14, nsc), np.complex64)
+    O.o_dmrs_pdsch_map(slot, 0, 0, scr, 0, 10 ** (3 / 20), dm, rb, [0], g3)
+    grid[0, 2] = g3[0, 2] * h
+    grid += ((rng.standard_normal(grid.shape) + 1j * rng.standard_normal(grid.shape)) * 0.02).astype(np.complex64)
+    # ---- oracle receive chain
+    ce, sc = O.o_dmrs_pusch_estimate(1, slot, 0, scr, 0, np.float32(10.0) ** np.float32(3.0 / 20.0), dm, rb, 0, 14, 1, grid)
+    llr, evm = O.o_pusch_demodulate_ex(rnti, n_id, mod, 0, 14, dm, 0, 2, rb, grid, ce[0], float(sc[0, 0, 2]), placeholders=ph)
+    _, _, streams, _ = O.o_ulsch_demultiplex(*case, llr=llr)
+    # ---- device
+    pdus = np.zeros(1, dtype=miphy.PuschPdu)
+    p = pdus[0]
+    p["numerology"], p["slot_in_frame"], p["rnti"], p["n_id"], p["dmrs_scrambling_id"] = 1, slot, rnti, n_id, scr
+    p["tb_bytes"], p["harq_cb_index"], p["mod"], p["nof_rx_ports"], p["start_symbol"], p["nof_symbols"] = tb.size, 0, mod, 1, 0, 14
+    p["bg"], p["rv"], p["new_data"], p["rx_ports"], p["use_early_stop"], p["nof_ldpc_iterations"] = bg, 0, 1, [0, 1, 2, 3], 1, 6
+    p["dmrs_symbols_mask"], p["grid_nof_prb"], p["rb_mask"], p["grid_offset"], p["tb_offset"] = 1 << 2, nprb, RB_ALL(nprb), 0, 0
+    uci = np.zeros(1, dtype=miphy.PuschUci)
+    u = uci[0]
+    u["nof_harq_ack_bits"], u["nof_csi_part1_bits"], u["nof_csi_part2_bits"] = O_ack, O_c1, O_c2
+    u["nof_enc_harq_ack_bits"], u["nof_enc_csi_part1_bits"], u["nof_enc_csi_part2_bits"] = G
+    u["nof_harq_ack_rvd"], u["has_codeword"] = rvd_re * mod, int(with_tb)
+    u["harq_ack_offset"], u["csi_part1_offset"], u["csi_part2_offset"] = 7, 7 + G[0] + 3, 7 + G[0] + 3 + G[1] + 5
+    ncb = miphy.sch_segmentation(tb.size, bg).nof_cbs
+    soft = torch.zeros(ncb * miphy.HARQ_CB_STRIDE, dtype=torch.int8, device="cuda")
+    msgs = torch.zeros(ncb * miphy.HARQ_MSG_STRIDE, dtype=torch.uint8, device="cuda")
+    crc = torch.zeros(ncb, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(tb.size, dtype=torch.uint8, device="cuda")
+    res = torch.full((miphy.PuschResult.itemsize,), 0x55, dtype=torch.uint8, device="cuda")
+    scal = torch.zeros(20, dtype=torch.float32, device="cuda")
+    uci_llr = torch.full((7 + sum(G) + 3 + 5 + 9,), 99, dtype=torch.int8, device="cuda")
+    evm_d = torch.zeros(1, dtype=torch.float32, device="cuda")
+    ctx.pusch_process_batch_ex(pdus, uci, torch.from_numpy(grid.reshape(-1)).cuda(), soft, msgs, crc, out, res, scal, uci_llr, evm_d)
+    torch.cuda.synchronize()
+    ul = uci_llr.cpu().numpy()
+    o0 = 7
+    for k, gk in enumerate(G):
+        seg = ul[o0:o0 + gk]
+        assert np.array_equal(seg, streams[1 + k]), ("uci stream", k)
+        if gk and not (k == 0 and O_ack == 1) and not (k == 1 and O_c1 == 1) and not (k == 2 and O_c2 == 1):
+            assert np.array_equal((seg < 0).astype(np.uint8), uci_bits[k])  # clean channel: the soft bits carry the transmitted UCI
+        o0 += gk + (3 if k == 0 else 5)
+    assert np.all(ul[:7] == 99)
+    e = float(evm_d.item())
+    assert abs(e - evm) <= 2e-6 * evm + 1e-7 and 0 < e < 0.2, (e, evm)
+    r = res.cpu().numpy().view(miphy.PuschResult)[0]
+    if with_tb:
+        od = O.OraclePuschDecoder(bg, mod, 0, 1, n_sch // mod, tb.size)
+        ok, tbo, mm = od.decode(streams[0], 0, True, 6, True)
+        assert ok and bool(r["tb_crc_ok"]) and np.array_equal(out.cpu().numpy(), tb) and np.array_equal(tbo, tb)
+        assert (int(r["iters_min"]), int(r["iters_max"])) == mm
+    else:
+        assert r["tb_crc_ok"] == 0 and r["nof_codeblocks_total"] == 0
