@@ -8,6 +8,8 @@
 #include "miphy_srsran_adapters.h"
 #include "srsran/ofh/compression/compression_factory.h"
 #include "srsran/phy/support/support_factories.h"
+#include "srsran/phy/upper/channel_coding/short/short_block_encoder.h"
+#include "srsran/ran/pusch/ulsch_info.h"
 #include "srsran/phy/upper/channel_modulation/channel_modulation_factories.h"
 #include "srsran/phy/upper/equalization/equalization_factories.h"
 #include "srsran/phy/upper/rx_softbuffer_pool.h"
@@ -1688,6 +1690,195 @@ static void test_validators(std::shared_ptr<miphy::context> c)
   printf("PDU validators done, failures so far %d\n", failures);
 }
 
+// PUSCH with multiplexed UCI (HARQ-ACK + CSI part 1 on a 16QAM transport block): the reference processor (software factories, EVM
+// enabled) and pusch_processor_hip (device estimator / demodulator with placeholders and EVM / UL-SCH demultiplexer / decoder, the
+// reference's UCI decoder on the demultiplexed soft bits). The transmit side multiplexes with the map read off the reference's own
+// demultiplexer (the gNB side of the reference has no multiplexer).
+namespace {
+struct uci_spy : public pusch_processor_result_notifier {
+  channel_state_information      csi;
+  pusch_processor_result_data    sch;
+  pusch_processor_result_control uci;
+  bool                           got_csi = false, got_sch = false, got_uci = false;
+  void on_csi(const channel_state_information& c) override { csi = c, got_csi = true; }
+  void on_uci(const pusch_processor_result_control& u) override { uci = u, got_uci = true; }
+  void on_sch(const pusch_processor_result_data& d) override { sch = d, got_sch = true; }
+};
+} // namespace
+
+static void test_pusch_processor_uci(std::shared_ptr<miphy::context> c)
+{
+  auto prg  = create_pseudo_random_generator_sw_factory();
+  auto crcf = create_crc_calculator_factory_sw("auto");
+  // reference processor with EVM
+  pusch_decoder_factory_sw_configuration dc;
+  dc.crc_factory = crcf, dc.decoder_factory = create_ldpc_decoder_factory_sw("avx2"), dc.dematcher_factory = create_ldpc_rate_dematcher_factory_sw("avx2");
+  dc.segmenter_factory = create_ldpc_segmenter_rx_factory_sw();
+  uci_decoder_factory_sw_configuration uc;
+  uc.decoder_factory = create_short_block_detector_factory_sw();
+  pusch_processor_factory_sw_configuration pc;
+  pc.estimator_factory = create_dmrs_pusch_estimator_factory_sw(prg, create_port_channel_estimator_factory_sw(std::make_shared<generic_dft_factory>()));
+  pc.demodulator_factory = create_pusch_demodulator_factory_sw(create_channel_equalizer_factory_zf(), create_channel_modulation_sw_factory(), prg, true);
+  pc.demux_factory = create_ulsch_demultiplex_factory_sw(), pc.decoder_factory = create_pusch_decoder_factory_sw(dc), pc.uci_dec_factory = create_uci_decoder_factory_sw(uc);
+  pc.ch_estimate_dimensions.nof_prb = MAX_RB, pc.ch_estimate_dimensions.nof_symbols = MAX_NSYMB_PER_SLOT;
+  pc.ch_estimate_dimensions.nof_rx_ports = 1, pc.ch_estimate_dimensions.nof_tx_layers = 1;
+  pc.dec_nof_iterations = 6, pc.dec_enable_early_stop = true;
+  auto p_ref = create_pusch_processor_factory_sw(pc)->create();
+  uci_decoder_factory_sw_configuration uc2;
+  uc2.decoder_factory = create_short_block_detector_factory_sw();
+  auto f_hip = std::make_shared<miphy::pusch_processor_factory_hip>(c, 6, true, create_uci_decoder_factory_sw(uc2), true);
+  auto p_hip = f_hip->create();
+  auto v_hip = f_hip->create_validator();
+
+  const unsigned nprb = 30, nsc = nprb * 12, Qm = 4, tbs = 8456;
+  const modulation_scheme modsch = modulation_scheme::QAM16;
+  symbol_slot_mask dm(14);
+  dm.set(2);
+  pusch_processor::pdu_t pdu;
+  pdu.slot = slot_point(1, 7), pdu.rnti = 0x4601, pdu.bwp_size_rb = nprb, pdu.bwp_start_rb = 0, pdu.cp = cyclic_prefix::NORMAL;
+  pdu.mcs_descr.modulation = modsch, pdu.mcs_descr.target_code_rate = 0.5F;
+  pdu.codeword.emplace();
+  pdu.codeword.value().rv = 0, pdu.codeword.value().ldpc_base_graph = ldpc_base_graph_type::BG1, pdu.codeword.value().new_data = true;
+  pdu.uci = {};
+  pdu.uci.nof_harq_ack = 4, pdu.uci.nof_csi_part1 = 5, pdu.uci.nof_csi_part2 = 0;
+  pdu.uci.alpha_scaling = 1.0F, pdu.uci.beta_offset_harq_ack = 20.0F, pdu.uci.beta_offset_csi_part1 = 6.25F, pdu.uci.beta_offset_csi_part2 = 6.25F;
+  pdu.n_id = 935, pdu.nof_tx_layers = 1;
+  pdu.rx_ports.push_back(0);
+  pdu.dmrs_symbol_mask = dm, pdu.dmrs = dmrs_type::TYPE1, pdu.scrambling_id = 42, pdu.n_scid = false, pdu.nof_cdm_groups_without_data = 2;
+  pdu.freq_alloc         = rb_allocation::make_type1(0, nprb);
+  pdu.start_symbol_index = 0, pdu.nof_symbols = 14, pdu.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8;
+  CHECK(v_hip->is_valid(pdu), "pusch validator (with a UCI decoder) rejects a PDU with multiplexed UCI");
+
+  ulsch_configuration ucfg;
+  ucfg.tbs = units::bits(tbs), ucfg.mcs_descr = pdu.mcs_descr, ucfg.nof_harq_ack_bits = units::bits(4), ucfg.nof_csi_part1_bits = units::bits(5);
+  ucfg.nof_csi_part2_bits = units::bits(0), ucfg.alpha_scaling = 1.0F, ucfg.beta_offset_harq_ack = 20.0F, ucfg.beta_offset_csi_part1 = 6.25F;
+  ucfg.beta_offset_csi_part2 = 6.25F, ucfg.nof_rb = nprb, ucfg.start_symbol_index = 0, ucfg.nof_symbols = 14, ucfg.dmrs_type = dmrs_config_type::type1;
+  ucfg.dmrs_symbol_mask = dm, ucfg.nof_cdm_groups_without_data = 2, ucfg.nof_layers = 1;
+  const ulsch_information info = get_ulsch_information(ucfg);
+  const unsigned G_ack = info.nof_harq_ack_bits.value(), G_c1 = info.nof_csi_part1_bits.value(), G_sch = info.nof_ul_sch_bits.value();
+  const unsigned n_in = nprb * 156 * Qm;
+  // multiplexing map: demultiplex three "digits" of the input index with the reference's demultiplexer
+  ulsch_demultiplex::configuration xc;
+  xc.modulation = modsch, xc.nof_layers = 1, xc.nof_prb = nprb, xc.start_symbol_index = 0, xc.nof_symbols = 14;
+  xc.nof_harq_ack_rvd = info.nof_harq_ack_rvd.value(), xc.dmrs = dmrs_type::TYPE1, xc.dmrs_symbol_mask = dm, xc.nof_cdm_groups_without_data = 2;
+  auto                  dmx = create_ulsch_demultiplex_factory_sw()->create();
+  std::vector<unsigned> src_sch(G_sch, 0), src_ack(G_ack, 0), src_c1(G_c1, 0);
+  std::vector<bool>     punct(G_sch, false);
+  unsigned              mul = 1;
+  for (unsigned d = 0; d != 3; ++d, mul *= 100) {
+    std::vector<log_likelihood_ratio> vin(n_in), vs(G_sch), va(G_ack), v1(G_c1), v2;
+    for (unsigned i = 0; i != n_in; ++i) {
+      vin[i] = log_likelihood_ratio(static_cast<int>((i / mul) % 100) + 1);
+    }
+    dmx->demultiplex(vs, va, v1, v2, vin, xc);
+    for (unsigned i = 0; i != G_sch; ++i) {
+      punct[i] = vs[i].to_value_type() == 0;
+      src_sch[i] += punct[i] ? 0 : (vs[i].to_value_type() - 1) * mul;
+    }
+    for (unsigned i = 0; i != G_ack; ++i) {
+      src_ack[i] += (va[i].to_value_type() - 1) * mul;
+    }
+    for (unsigned i = 0; i != G_c1; ++i) {
+      src_c1[i] += (v1[i].to_value_type() - 1) * mul;
+    }
+  }
+  // transmit side: SCH encoder, short block encoder for the two UCI fields, multiplex, scramble, modulate, map, DM-RS, noise
+  std::uniform_int_distribution<int> byte(0, 255), bit(0, 1);
+  std::vector<uint8_t>               tb(tbs / 8), ack(4), csi1(5), e_ack(G_ack), e_c1(G_c1), cw_sch(G_sch), cw(n_in, 0);
+  for (auto& b : tb) {
+    b = byte(rgen);
+  }
+  for (auto& b : ack) {
+    b = bit(rgen);
+  }
+  for (auto& b : csi1) {
+    b = bit(rgen);
+  }
+  pdsch_encoder_factory_sw_configuration ec;
+  ec.encoder_factory = create_ldpc_encoder_factory_sw("avx2"), ec.rate_matcher_factory = create_ldpc_rate_matcher_factory_sw();
+  ec.segmenter_factory = create_ldpc_segmenter_tx_factory_sw(crcf);
+  segmenter_config sc;
+  sc.base_graph = ldpc_base_graph_type::BG1, sc.rv = 0, sc.mod = modsch, sc.Nref = 0, sc.nof_layers = 1, sc.nof_ch_symbols = G_sch / Qm;
+  create_pdsch_encoder_factory_sw(ec)->create()->encode(cw_sch, tb, sc);
+  auto sbe = create_short_block_encoder();
+  sbe->encode(e_ack, ack, modsch);
+  sbe->encode(e_c1, csi1, modsch);
+  for (unsigned i = 0; i != G_sch; ++i) {
+    if (!punct[i]) {
+      cw[src_sch[i]] = cw_sch[i] & 1U;
+    }
+  }
+  for (unsigned i = 0; i != G_ack; ++i) {
+    cw[src_ack[i]] = e_ack[i] & 1U;
+  }
+  for (unsigned i = 0; i != G_c1; ++i) {
+    cw[src_c1[i]] = e_c1[i] & 1U;
+  }
+  auto seq = prg->create();
+  seq->init((0x4601U << 15U) + 935U);
+  std::vector<uint8_t> scr(n_in);
+  seq->apply_xor(scr, cw);
+  dynamic_bit_buffer packed(n_in);
+  for (unsigned i = 0; i != n_in; ++i) {
+    packed.insert(scr[i] & 1U, i, 1);
+  }
+  std::vector<cf_t> sym(n_in / Qm);
+  create_channel_modulation_sw_factory()->create_modulation_mapper()->modulate(sym, packed, modsch);
+  auto grid = create_resource_grid(1, 14, nsc);
+  grid->set_all_zero();
+  unsigned k = 0;
+  for (unsigned l = 0; l != 14; ++l) {
+    if (l == 2) {
+      continue;
+    }
+    grid->put(0, l, 0, span<const cf_t>(sym.data() + k, nsc));
+    k += nsc;
+  }
+  dmrs_pdsch_processor::config_t dcfg;
+  dcfg.slot = slot_point(1, 7), dcfg.reference_point_k_rb = 0, dcfg.type = dmrs_type::TYPE1, dcfg.scrambling_id = 42, dcfg.n_scid = false;
+  dcfg.amplitude = convert_dB_to_amplitude(3.0F), dcfg.symbols_mask = dm;
+  dcfg.rb_mask   = bounded_bitset<MAX_RB>(nprb);
+  dcfg.rb_mask.fill(0, nprb, true);
+  dcfg.ports.push_back(0);
+  create_dmrs_pdsch_processor_factory_sw(prg)->create()->map(*grid, dcfg);
+  std::normal_distribution<float> nz(0.F, 0.05F * 0.7071F);
+  std::vector<cf_t>               row(nsc);
+  for (unsigned l = 0; l != 14; ++l) {
+    grid->get(row, 0, l, 0);
+    for (auto& v : row) {
+      v += cf_t(nz(rgen), nz(rgen));
+    }
+    grid->put(0, l, 0, row);
+  }
+  rx_softbuffer_pool_config spc;
+  spc.max_codeblock_size = ldpc::MAX_CODEBLOCK_SIZE, spc.max_softbuffers = 2, spc.max_nof_codeblocks = 16, spc.expire_timeout_slots = 1000;
+  auto                     pool1 = create_rx_softbuffer_pool(spc), pool2 = create_rx_softbuffer_pool(spc);
+  rx_softbuffer_identifier id;
+  id.rnti = 1, id.harq_ack_id = 0;
+  const unsigned nof_cbs = ldpc::compute_nof_codeblocks(units::bits(tbs), ldpc_base_graph_type::BG1);
+  auto           sb1 = pool1->reserve_softbuffer(slot_point(1, 7), id, nof_cbs), sb2 = pool2->reserve_softbuffer(slot_point(1, 7), id, nof_cbs);
+  std::vector<uint8_t> o1(tb.size(), 0), o2(tb.size(), 0);
+  uci_spy              n1, n2;
+  p_ref->process(o1, sb1.get(), n1, *grid, pdu);
+  p_hip->process(o2, sb2.get(), n2, *grid, pdu);
+  CHECK(n1.got_uci && n2.got_uci && n1.got_sch && n2.got_sch && n1.got_csi && n2.got_csi, "pusch_processor (UCI): notifications differ");
+  CHECK(n1.sch.data.tb_crc_ok && n2.sch.data.tb_crc_ok && o1 == tb && o2 == tb, "pusch_processor (UCI): transport block ref %d hip %d", (int)n1.sch.data.tb_crc_ok,
+        (int)n2.sch.data.tb_crc_ok);
+  auto same_field = [](const pusch_uci_field& a, const pusch_uci_field& b) {
+    return a.status == b.status && a.payload.size() == b.payload.size() && std::equal(a.payload.begin(), a.payload.end(), b.payload.begin());
+  };
+  CHECK(same_field(n1.uci.harq_ack, n2.uci.harq_ack) && same_field(n1.uci.csi_part1, n2.uci.csi_part1) && same_field(n1.uci.csi_part2, n2.uci.csi_part2),
+        "pusch_processor (UCI): decoded UCI fields differ");
+  CHECK(n1.uci.harq_ack.status == uci_status::valid && std::equal(ack.begin(), ack.end(), n2.uci.harq_ack.payload.begin()) &&
+            std::equal(csi1.begin(), csi1.end(), n2.uci.csi_part1.payload.begin()),
+        "pusch_processor (UCI): the transmitted HARQ-ACK / CSI part 1 bits do not come back");
+  CHECK(n1.uci.evm.has_value() && n2.uci.evm.has_value() && std::abs(n1.uci.evm.value() - n2.uci.evm.value()) < 2e-3F * n1.uci.evm.value(),
+        "pusch_processor (UCI): EVM ref %g hip %g", (n1.uci.evm.has_value() ? n1.uci.evm.value() : -1.F), (n2.uci.evm.has_value() ? n2.uci.evm.value() : -1.F));
+  CHECK(std::abs(n1.csi.sinr_dB - n2.csi.sinr_dB) < 0.02F, "pusch_processor (UCI): SINR from EVM ref %g hip %g", n1.csi.sinr_dB, n2.csi.sinr_dB);
+  printf("pusch_processor with multiplexed UCI and EVM done (EVM ref %.5f hip %.5f), failures so far %d\n", (n1.uci.evm.has_value() ? n1.uci.evm.value() : -1.F), (n2.uci.evm.has_value() ? n2.uci.evm.value() : -1.F),
+         failures);
+}
+
 static void on_fault(int sig)
 {
   void* frames[64];
@@ -1725,6 +1916,7 @@ int main()
   test_crc_calculator(c);
   test_ofdm_symbols(c);
   test_validators(c);
+  test_pusch_processor_uci(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);
     return 1;

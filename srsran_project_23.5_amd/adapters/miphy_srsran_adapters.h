@@ -28,6 +28,7 @@
 #include "srsran/phy/upper/upper_phy_rg_gateway.h"
 #include "srsran/ran/csi_rs/csi_rs_pattern.h"
 #include "srsran/ran/pdcch/cce_to_prb_mapping.h"
+#include "srsran/ran/pusch/ulsch_info.h"
 #include "srsran/ran/ssb_mapping.h"
 #include "srsran/ran/precoding/precoding_codebooks.h"
 #include "srsran/phy/upper/rx_softbuffer.h"
@@ -957,8 +958,11 @@ private:
 class pusch_processor_hip : public srsran::pusch_processor
 {
 public:
-  pusch_processor_hip(std::shared_ptr<context> c, unsigned nof_iterations, bool early_stop) :
-    c(std::move(c)), dec_nof_iterations(nof_iterations), dec_enable_early_stop(early_stop)
+  /// \c uci_dec: the reference's UCI decoder (short block / polar decoding of the demultiplexed soft bits stays a CPU block);
+  /// without it PDUs with multiplexed UCI are refused. \c enable_evm as in create_pusch_demodulator_factory_sw.
+  pusch_processor_hip(std::shared_ptr<context> c, unsigned nof_iterations, bool early_stop, std::unique_ptr<srsran::uci_decoder> uci_dec_ = nullptr,
+                      bool enable_evm_ = false) :
+    c(std::move(c)), dec_nof_iterations(nof_iterations), dec_enable_early_stop(early_stop), uci_dec(std::move(uci_dec_)), enable_evm(enable_evm_)
   {
   }
   void process(srsran::span<uint8_t>                    data,
@@ -967,11 +971,11 @@ public:
                const srsran::resource_grid_reader&      grid,
                const pdu_t&                             pdu) override
   {
-    if (pdu.uci.nof_harq_ack != 0 || pdu.uci.nof_csi_part1 != 0 || pdu.uci.nof_csi_part2 != 0 || !pdu.codeword.has_value()) {
-      srsran::report_fatal_error("pusch_processor_hip: UCI on PUSCH / PDUs without codeword are not supported.");
-    }
-    srsran_assert(pdu.dmrs == srsran::dmrs_type::TYPE1 && pdu.nof_cdm_groups_without_data == 2 && pdu.nof_tx_layers == 1,
-                  "Only DM-RS type 1, two CDM groups without data and one layer are supported.");
+    const bool has_uci = pdu.uci.nof_harq_ack != 0 || pdu.uci.nof_csi_part1 != 0 || pdu.uci.nof_csi_part2 != 0;
+    require(!has_uci || uci_dec != nullptr, "pusch_processor_hip: a PDU with multiplexed UCI needs the UCI decoder (see the factory).");
+    require(has_uci || pdu.codeword.has_value(), "pusch_processor_hip: the PDU carries neither a codeword nor UCI.");
+    require(pdu.dmrs == srsran::dmrs_type::TYPE1 && pdu.nof_cdm_groups_without_data == 2 && pdu.nof_tx_layers == 1,
+            "Only DM-RS type 1, two CDM groups without data and one layer are supported.");
     const srsran::bounded_bitset<srsran::MAX_RB> rb_mask = pdu.freq_alloc.get_prb_mask(pdu.bwp_start_rb, pdu.bwp_size_rb);
     const unsigned nprb = rb_mask.size(), nsc = nprb * 12, nports = pdu.rx_ports.size();
     miphy_pusch_pdu p = {};
@@ -979,7 +983,11 @@ public:
     p.dmrs_scrambling_id = pdu.scrambling_id, p.Nref = pdu.tbs_lbrm_bytes * 8, p.tb_bytes = data.size(), p.harq_cb_index = 0;
     p.n_scid = pdu.n_scid, p.mod = srsran::get_bits_per_symbol(pdu.mcs_descr.modulation), p.nof_rx_ports = nports;
     p.start_symbol = pdu.start_symbol_index, p.nof_symbols = pdu.nof_symbols;
-    p.bg = bg_id(pdu.codeword.value().ldpc_base_graph), p.rv = pdu.codeword.value().rv, p.new_data = pdu.codeword.value().new_data;
+    if (pdu.codeword.has_value()) {
+      p.bg = bg_id(pdu.codeword.value().ldpc_base_graph), p.rv = pdu.codeword.value().rv, p.new_data = pdu.codeword.value().new_data;
+    } else {
+      p.bg = 1, p.tb_bytes = 1; // unused: no transport block is decoded
+    }
     p.use_early_stop = dec_enable_early_stop, p.nof_ldpc_iterations = dec_nof_iterations, p.grid_nof_prb = nprb;
     for (unsigned i = 0; i != nports; ++i) {
       p.rx_ports[i] = i; // the staging grid is ordered by rx_ports
@@ -990,9 +998,30 @@ public:
       }
     }
     rb_mask.for_each(0, nprb, [&p](unsigned r) { p.rb_mask[r >> 6] |= 1ULL << (r & 63); });
-    miphy_sch_segmentation sg;
-    context::check(miphy_sch_segmentation_info(data.size(), p.bg, &sg), "segmentation");
-    srsran_assert(sg.nof_cbs == softbuffer.get_nof_codeblocks(), "Wrong number of codeblocks.");
+    // UCI lengths through the reference's own get_ulsch_information (pusch_processor_impl.cpp:152-170)
+    miphy_pusch_uci u = {};
+    u.has_codeword    = pdu.codeword.has_value() ? 1U : 0U;
+    if (has_uci) {
+      srsran::ulsch_configuration uc;
+      uc.tbs = srsran::units::bytes(data.size()).to_bits(), uc.mcs_descr = pdu.mcs_descr;
+      uc.nof_harq_ack_bits = srsran::units::bits(pdu.uci.nof_harq_ack), uc.nof_csi_part1_bits = srsran::units::bits(pdu.uci.nof_csi_part1);
+      uc.nof_csi_part2_bits = srsran::units::bits(pdu.uci.nof_csi_part2), uc.alpha_scaling = pdu.uci.alpha_scaling;
+      uc.beta_offset_harq_ack = pdu.uci.beta_offset_harq_ack, uc.beta_offset_csi_part1 = pdu.uci.beta_offset_csi_part1;
+      uc.beta_offset_csi_part2 = pdu.uci.beta_offset_csi_part2, uc.nof_rb = pdu.freq_alloc.get_nof_rb();
+      uc.start_symbol_index = pdu.start_symbol_index, uc.nof_symbols = pdu.nof_symbols, uc.dmrs_type = srsran::dmrs_config_type::type1;
+      uc.dmrs_symbol_mask = pdu.dmrs_symbol_mask, uc.nof_cdm_groups_without_data = pdu.nof_cdm_groups_without_data, uc.nof_layers = pdu.nof_tx_layers;
+      const srsran::ulsch_information info = srsran::get_ulsch_information(uc);
+      u.nof_harq_ack_bits = pdu.uci.nof_harq_ack, u.nof_csi_part1_bits = pdu.uci.nof_csi_part1, u.nof_csi_part2_bits = pdu.uci.nof_csi_part2;
+      u.nof_enc_harq_ack_bits = info.nof_harq_ack_bits.value(), u.nof_enc_csi_part1_bits = info.nof_csi_part1_bits.value();
+      u.nof_enc_csi_part2_bits = info.nof_csi_part2_bits.value(), u.nof_harq_ack_rvd = info.nof_harq_ack_rvd.value();
+      u.harq_ack_offset = 0, u.csi_part1_offset = u.nof_enc_harq_ack_bits, u.csi_part2_offset = u.csi_part1_offset + u.nof_enc_csi_part1_bits;
+    }
+    const size_t nof_uci_llr = static_cast<size_t>(u.nof_enc_harq_ack_bits) + u.nof_enc_csi_part1_bits + u.nof_enc_csi_part2_bits;
+    miphy_sch_segmentation sg = {};
+    if (pdu.codeword.has_value()) {
+      context::check(miphy_sch_segmentation_info(data.size(), p.bg, &sg), "segmentation");
+      require(sg.nof_cbs == softbuffer.get_nof_codeblocks(), "Wrong number of codeblocks.");
+    }
     const size_t CBS = 66 * 384, MSG = 1056;
     host.resize(static_cast<size_t>(nports) * 14 * nsc);
     for (unsigned i = 0; i != nports; ++i) {
@@ -1003,6 +1032,8 @@ public:
     auto*    resident = dynamic_cast<rx_softbuffer_hip*>(&softbuffer);
     auto*    d_g    = static_cast<float*>(c->buf(0, host.size() * sizeof(srsran::cf_t)));
     auto*    d_misc = static_cast<uint8_t*>(c->buf(3, 64 + 64 + 128 + data.size() + 64));
+    auto*    d_uci  = static_cast<int8_t*>(c->buf(4, nof_uci_llr + 64));
+    auto*    d_evm  = reinterpret_cast<float*>(d_misc + 56); // [0,52) codeblock CRC flags of a host softbuffer, [56,60) EVM, [64,..) result
     auto*    d_res  = reinterpret_cast<miphy_pusch_result*>(d_misc + 64);
     auto*    d_sc   = reinterpret_cast<float*>(d_misc + 128);
     uint8_t* d_tb   = d_misc + 256;
@@ -1029,9 +1060,17 @@ public:
     }
     c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
     c->h2d(d_tb, data.data(), data.size());
-    context::check(miphy_pusch_process_batch(c->ctx, &p, 1, d_g, d_soft, d_msg, d_crc, d_tb, d_res, d_sc, c->stream), "pusch_process");
+    context::check(miphy_pusch_process_batch_ex(c->ctx, &p, &u, 1, d_g, d_soft, d_msg, d_crc, d_tb, d_res, d_sc, d_uci, enable_evm ? d_evm : nullptr, c->stream),
+                   "pusch_process");
     miphy_pusch_result r;
-    float              sc[20];
+    float              sc[20], evm = 0.F;
+    uci_llr.resize(nof_uci_llr);
+    if (nof_uci_llr) {
+      c->d2h(uci_llr.data(), d_uci, nof_uci_llr);
+    }
+    if (enable_evm) {
+      c->d2h(&evm, d_evm, sizeof(evm));
+    }
     c->d2h(&r, d_res, sizeof(r));
     c->d2h(sc, d_sc, sizeof(sc));
     c->d2h(data.data(), d_tb, data.size());
@@ -1062,8 +1101,40 @@ public:
     csi.rsrp_dB        = srsran::convert_power_to_dB(rsrp / static_cast<float>(nports));
     csi.sinr_dB        = srsran::convert_power_to_dB(snr / static_cast<float>(nports));
     csi.time_alignment = srsran::phy_time_unit::from_seconds(ta / nports);
+    if (enable_evm) {
+      csi.sinr_dB = -20 * log10f(evm) - 3.7F; // pusch_processor_impl.cpp:237-241
+    }
     notifier.on_csi(csi);
+    if (has_uci) { // pusch_processor_impl.cpp:264-286: the three fields through the reference's UCI decoder
+      srsran::uci_decoder::configuration ucfg;
+      ucfg.modulation = pdu.mcs_descr.modulation;
+      srsran::pusch_processor_result_control ru;
+      if (enable_evm) {
+        ru.evm.emplace(evm);
+      }
+      auto field = [&](size_t off, unsigned G, unsigned nof_bits) {
+        srsran::pusch_uci_field f;
+        if (nof_bits == 0) {
+          f.payload.clear();
+          f.status = srsran::uci_status::unknown;
+          return f;
+        }
+        f.payload.resize(nof_bits);
+        f.status = uci_dec->decode(f.payload, srsran::span<const srsran::log_likelihood_ratio>(uci_llr.data() + off, G), ucfg);
+        return f;
+      };
+      ru.harq_ack  = field(u.harq_ack_offset, u.nof_enc_harq_ack_bits, pdu.uci.nof_harq_ack);
+      ru.csi_part1 = field(u.csi_part1_offset, u.nof_enc_csi_part1_bits, pdu.uci.nof_csi_part1);
+      ru.csi_part2 = field(u.csi_part2_offset, u.nof_enc_csi_part2_bits, pdu.uci.nof_csi_part2);
+      notifier.on_uci(ru);
+    }
+    if (!pdu.codeword.has_value()) {
+      return;
+    }
     srsran::pusch_processor_result_data result;
+    if (enable_evm) {
+      result.evm.emplace(evm);
+    }
     result.data.tb_crc_ok            = r.tb_crc_ok != 0;
     result.data.nof_codeblocks_total = r.nof_codeblocks_total;
     result.data.ldpc_decoder_stats.reset();
@@ -1083,7 +1154,10 @@ private:
   std::shared_ptr<context>  c;
   unsigned                  dec_nof_iterations;
   bool                      dec_enable_early_stop;
-  std::vector<srsran::cf_t> host;
+  std::unique_ptr<srsran::uci_decoder>      uci_dec;
+  bool                                      enable_evm;
+  std::vector<srsran::cf_t>                 host;
+  std::vector<srsran::log_likelihood_ratio> uci_llr;
 };
 
 /// Replaces create_pusch_processor_factory_sw(config) (channel_processor_factories.h): only the decoder settings of the
@@ -1091,17 +1165,28 @@ private:
 class pusch_processor_factory_hip : public srsran::pusch_processor_factory
 {
 public:
-  pusch_processor_factory_hip(std::shared_ptr<context> c, unsigned nof_iterations, bool early_stop) :
-    c(std::move(c)), nof_iterations(nof_iterations), early_stop(early_stop)
+  /// \c uci_dec_factory: the reference's create_uci_decoder_factory_sw(...) for PDUs with multiplexed UCI (nullptr: such PDUs are
+  /// rejected by the validator); \c enable_evm as in create_pusch_demodulator_factory_sw.
+  pusch_processor_factory_hip(std::shared_ptr<context>                     c,
+                              unsigned                                     nof_iterations,
+                              bool                                         early_stop,
+                              std::shared_ptr<srsran::uci_decoder_factory> uci_dec_factory = nullptr,
+                              bool                                         enable_evm      = false) :
+    c(std::move(c)), nof_iterations(nof_iterations), early_stop(early_stop), uci_dec_factory(std::move(uci_dec_factory)), enable_evm(enable_evm)
   {
   }
-  std::unique_ptr<srsran::pusch_processor> create() override { return std::make_unique<pusch_processor_hip>(c, nof_iterations, early_stop); }
+  std::unique_ptr<srsran::pusch_processor> create() override
+  {
+    return std::make_unique<pusch_processor_hip>(c, nof_iterations, early_stop, uci_dec_factory ? uci_dec_factory->create() : nullptr, enable_evm);
+  }
   std::unique_ptr<srsran::pusch_pdu_validator> create_validator() override; // defined at the end of this header
 
 private:
-  std::shared_ptr<context> c;
-  unsigned                 nof_iterations;
-  bool                     early_stop;
+  std::shared_ptr<context>                     c;
+  unsigned                                     nof_iterations;
+  bool                                         early_stop;
+  std::shared_ptr<srsran::uci_decoder_factory> uci_dec_factory;
+  bool                                         enable_evm;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- uplink processor
@@ -2409,19 +2494,22 @@ inline std::shared_ptr<srsran::crc_calculator_factory> create_crc_calculator_fac
 class pusch_pdu_validator_hip : public srsran::pusch_pdu_validator
 {
 public:
-  explicit pusch_pdu_validator_hip(std::unique_ptr<srsran::pusch_pdu_validator> ref) : ref(std::move(ref)) {}
+  pusch_pdu_validator_hip(std::unique_ptr<srsran::pusch_pdu_validator> ref, bool uci_supported) : ref(std::move(ref)), uci_supported(uci_supported) {}
   bool is_valid(const srsran::pusch_processor::pdu_t& pdu) const override
   {
     if (!ref->is_valid(pdu)) {
       return false;
     }
-    // device path: a transport block without multiplexed UCI, one layer, at most four receive ports, normal cyclic prefix
-    return pdu.codeword.has_value() && pdu.uci.nof_harq_ack == 0 && pdu.uci.nof_csi_part1 == 0 && pdu.uci.nof_csi_part2 == 0 && pdu.nof_tx_layers == 1 &&
-           pdu.rx_ports.size() >= 1 && pdu.rx_ports.size() <= 4 && pdu.cp == srsran::cyclic_prefix::NORMAL && pdu.mcs_descr.modulation != srsran::modulation_scheme::BPSK;
+    const bool has_uci = pdu.uci.nof_harq_ack != 0 || pdu.uci.nof_csi_part1 != 0 || pdu.uci.nof_csi_part2 != 0;
+    // device path: multiplexed UCI only with a UCI decoder behind it, a codeword or UCI present, one layer, at most four receive
+    // ports, normal cyclic prefix
+    return (pdu.codeword.has_value() || has_uci) && (!has_uci || uci_supported) && pdu.nof_tx_layers == 1 && pdu.rx_ports.size() >= 1 &&
+           pdu.rx_ports.size() <= 4 && pdu.cp == srsran::cyclic_prefix::NORMAL && pdu.mcs_descr.modulation != srsran::modulation_scheme::BPSK;
   }
 
 private:
   std::unique_ptr<srsran::pusch_pdu_validator> ref;
+  bool                                         uci_supported;
 };
 
 class pdsch_pdu_validator_hip : public srsran::pdsch_pdu_validator
@@ -2458,7 +2546,7 @@ inline std::unique_ptr<srsran::pusch_pdu_validator> pusch_processor_factory_hip:
   pc.ch_estimate_dimensions.nof_tx_layers = 1;
   pc.dec_nof_iterations                   = nof_iterations;
   pc.dec_enable_early_stop                = early_stop;
-  return std::make_unique<pusch_pdu_validator_hip>(srsran::create_pusch_processor_factory_sw(pc)->create_validator());
+  return std::make_unique<pusch_pdu_validator_hip>(srsran::create_pusch_processor_factory_sw(pc)->create_validator(), uci_dec_factory != nullptr);
 }
 
 inline std::unique_ptr<srsran::pdsch_pdu_validator> pdsch_processor_factory_hip::create_validator()
