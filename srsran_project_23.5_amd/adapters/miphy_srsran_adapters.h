@@ -45,7 +45,11 @@
 #include <cstring>
 #include <hip/hip_runtime_api.h>
 #include <memory>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace miphy {
@@ -1203,26 +1207,51 @@ private:
 class uplink_processor_hip : public srsran::uplink_processor
 {
 public:
-  uplink_processor_hip(std::shared_ptr<context>                 c,
-                       std::unique_ptr<srsran::prach_detector>  prach,
-                       std::unique_ptr<srsran::pucch_processor> pucch,
-                       unsigned                                 grid_nof_ports,
-                       unsigned                                 grid_nof_prb,
-                       unsigned                                 dec_nof_iterations,
-                       bool                                     dec_enable_early_stop,
-                       unsigned                                 max_batch = 64) :
+  /// \c linger_us > 0 (default): asynchronous delivery. process_pusch() returns at once; a delivery thread submits the PDUs of a slot
+  /// as one device batch as soon as no further PDU has arrived for \c linger_us microseconds (or the batch is full / a PDU of another
+  /// slot arrives) and calls the notifier from that thread -- the reference notifies from its executor threads as well. No end-of-slot
+  /// call is needed, so the unmodified caller (upper_phy_rx_symbol_handler_impl.cpp:92-105) works. \c linger_us == 0: synchronous
+  /// mode, results are delivered by flush() (or by the next PDU of another slot / the destructor).
+  /// \c uci_dec_factory / \c enable_evm: for PDUs with multiplexed UCI, which take the per-PDU path (pusch_processor_hip).
+  uplink_processor_hip(std::shared_ptr<context>                     c,
+                       std::unique_ptr<srsran::prach_detector>      prach,
+                       std::unique_ptr<srsran::pucch_processor>     pucch,
+                       unsigned                                     grid_nof_ports,
+                       unsigned                                     grid_nof_prb,
+                       unsigned                                     dec_nof_iterations,
+                       bool                                         dec_enable_early_stop,
+                       unsigned                                     max_batch       = 64,
+                       unsigned                                     linger_us       = 100,
+                       std::shared_ptr<srsran::uci_decoder_factory> uci_dec_factory = nullptr,
+                       bool                                         enable_evm      = false) :
     c(std::move(c)),
     prach(std::move(prach)),
     pucch(std::move(pucch)),
-    single(this->c, dec_nof_iterations, dec_enable_early_stop),
+    single(this->c, dec_nof_iterations, dec_enable_early_stop, uci_dec_factory ? uci_dec_factory->create() : nullptr, enable_evm),
     nports(grid_nof_ports),
     nprb(grid_nof_prb),
     nof_iterations(dec_nof_iterations),
     early_stop(dec_enable_early_stop),
-    max_batch(max_batch)
+    max_batch(max_batch),
+    linger(std::chrono::microseconds(linger_us))
   {
+    if (linger_us != 0) {
+      wc     = std::make_shared<context>(device_of(*this->c)); // the delivery thread drives the device through its own context
+      worker = std::thread([this]() { deliver_loop(); });
+    }
   }
-  ~uplink_processor_hip() override { flush(); }
+  ~uplink_processor_hip() override
+  {
+    flush();
+    if (worker.joinable()) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+      }
+      cv.notify_all();
+      worker.join();
+    }
+  }
 
   void process_prach(srsran::upper_phy_rx_results_notifier& notifier, const srsran::prach_buffer& buffer, const srsran::prach_buffer_context& context) override
   {
@@ -1268,8 +1297,10 @@ public:
                      const srsran::resource_grid_reader&    grid,
                      const pusch_pdu&                       pdu) override
   {
-    auto* resident = dynamic_cast<rx_softbuffer_hip*>(&softbuffer.get());
-    if (resident == nullptr) { // not a device softbuffer: per-PDU path, like uplink_processor_impl::process_pusch
+    auto*      resident = dynamic_cast<rx_softbuffer_hip*>(&softbuffer.get());
+    const bool has_uci  = pdu.pdu.uci.nof_harq_ack != 0 || pdu.pdu.uci.nof_csi_part1 != 0 || pdu.pdu.uci.nof_csi_part2 != 0;
+    if (resident == nullptr || has_uci || !pdu.pdu.codeword.has_value()) {
+      // not a device softbuffer, or UCI to decode on the host: per-PDU path at once, like uplink_processor_impl::process_pusch
       notifier_adaptor n(notifier, pdu, data);
       single.process(data, softbuffer.get(), n, grid, pdu.pdu);
       if (n.tb_crc_ok) {
@@ -1277,26 +1308,103 @@ public:
       }
       return;
     }
-    if (!queue.empty() && (queue.front().pdu.pdu.slot != pdu.pdu.slot || queue_grid != &grid || queue.size() >= max_batch)) {
-      flush();
+    std::unique_lock<std::mutex> lk(mu);
+    if (!open.entries.empty() && (open.entries.front().pdu.pdu.slot != pdu.pdu.slot || open.grid != &grid || open.entries.size() >= max_batch)) {
+      close_open_batch(lk);
     }
-    queue_grid = &grid;
-    queue.emplace_back(entry{data, std::move(softbuffer), resident, &notifier, pdu});
+    if (open.entries.empty()) {
+      // The samples of the slot are copied NOW: the resource-grid pool may hand the grid to another slot before the batch is
+      // submitted, and a late submission must be slow rather than wrong.
+      const unsigned nsc = nprb * 12;
+      open.grid          = &grid;
+      open.samples.resize(static_cast<size_t>(nports) * 14 * nsc);
+      for (unsigned p = 0; p != nports; ++p) {
+        for (unsigned l = 0; l != 14; ++l) {
+          grid.get(srsran::span<srsran::cf_t>(open.samples.data() + (static_cast<size_t>(p) * 14 + l) * nsc, nsc), p, l, 0);
+        }
+      }
+    }
+    open.entries.emplace_back(entry{data, std::move(softbuffer), resident, &notifier, pdu});
+    last_push = std::chrono::steady_clock::now();
+    lk.unlock();
+    cv.notify_all();
   }
 
-  /// Submits the queued PUSCH PDUs as one batch and delivers their results.
+  /// Submits what is queued and returns when every result has been delivered (asynchronous mode: waits for the delivery thread).
   void flush()
   {
+    std::unique_lock<std::mutex> lk(mu);
+    if (!open.entries.empty()) {
+      close_open_batch(lk);
+    }
+    if (worker.joinable()) {
+      cv.notify_all();
+      cv_done.wait(lk, [this]() { return ready.empty() && !busy; });
+    }
+  }
+
+private:
+  struct entry;
+  struct batch;
+  static int device_of(const context&)
+  {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+  }
+  // Moves the open batch to the ready list (asynchronous mode) or runs it in place (synchronous mode). Called with the lock held.
+  void close_open_batch(std::unique_lock<std::mutex>& lk)
+  {
+    batch b = std::move(open);
+    open    = batch{};
+    if (worker.joinable()) {
+      ready.emplace_back(std::move(b));
+      return;
+    }
+    lk.unlock();
+    run_batch(b, *c);
+    lk.lock();
+  }
+  void deliver_loop()
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      if (ready.empty() && !open.entries.empty()) {
+        // wait for the linger time of the open batch, then close it
+        if (!cv.wait_until(lk, last_push + linger, [this]() { return stop || !ready.empty() || std::chrono::steady_clock::now() >= last_push + linger; })) {
+          continue;
+        }
+        if (ready.empty() && !open.entries.empty() && std::chrono::steady_clock::now() >= last_push + linger) {
+          ready.emplace_back(std::move(open));
+          open = batch{};
+        }
+      } else if (ready.empty()) {
+        if (stop) {
+          return;
+        }
+        cv.wait(lk, [this]() { return stop || !ready.empty() || !open.entries.empty(); });
+        continue;
+      }
+      while (!ready.empty()) {
+        batch b = std::move(ready.front());
+        ready.pop_front();
+        busy = true;
+        lk.unlock();
+        run_batch(b, *wc);
+        lk.lock();
+        busy = false;
+      }
+      cv_done.notify_all();
+    }
+  }
+  void run_batch(batch& bt, context& dc)
+  {
+    std::vector<entry>& queue = bt.entries;
     if (queue.empty()) {
       return;
     }
-    const unsigned n = queue.size(), nsc = nprb * 12;
-    host.resize(static_cast<size_t>(nports) * 14 * nsc);
-    for (unsigned p = 0; p != nports; ++p) {
-      for (unsigned l = 0; l != 14; ++l) {
-        queue_grid->get(srsran::span<srsran::cf_t>(host.data() + (static_cast<size_t>(p) * 14 + l) * nsc, nsc), p, l, 0);
-      }
-    }
+    const unsigned n = queue.size();
+    std::vector<srsran::cf_t>& host = bt.samples;
     std::vector<miphy_pusch_pdu> pdus(n);
     size_t                       tb_bytes = 0;
     int8_t*                      d_soft   = queue.front().resident->softbits();
@@ -1304,13 +1412,11 @@ public:
     for (unsigned i = 0; i != n; ++i) {
       entry&                                  e   = queue[i];
       const srsran::pusch_processor::pdu_t&   pdu = e.pdu.pdu;
-      srsran_assert(e.resident->softbits() == d_soft, "All softbuffers of a batch must belong to the same device pool.");
-      require(pdu.uci.nof_harq_ack == 0 && pdu.uci.nof_csi_part1 == 0 && pdu.uci.nof_csi_part2 == 0 && pdu.codeword.has_value(),
-                    "UCI on PUSCH / PDUs without codeword are not supported.");
+      require(e.resident->softbits() == d_soft, "All softbuffers of a batch must belong to the same device pool.");
       require(pdu.dmrs == srsran::dmrs_type::TYPE1 && pdu.nof_cdm_groups_without_data == 2 && pdu.nof_tx_layers == 1,
-                    "Only DM-RS type 1, two CDM groups without data and one layer are supported.");
+              "Only DM-RS type 1, two CDM groups without data and one layer are supported.");
       const srsran::bounded_bitset<srsran::MAX_RB> rb_mask = pdu.freq_alloc.get_prb_mask(pdu.bwp_start_rb, pdu.bwp_size_rb);
-      srsran_assert(rb_mask.size() <= nprb, "The allocation exceeds the resource grid.");
+      require(rb_mask.size() <= nprb, "The allocation exceeds the resource grid.");
       e.resident->flush();
       miphy_pusch_pdu& p = pdus[i];
       p                  = {};
@@ -1322,7 +1428,7 @@ public:
       p.bg = bg_id(pdu.codeword.value().ldpc_base_graph), p.rv = pdu.codeword.value().rv, p.new_data = pdu.codeword.value().new_data;
       p.use_early_stop = early_stop, p.nof_ldpc_iterations = nof_iterations, p.grid_nof_prb = nprb;
       for (unsigned k = 0; k != pdu.rx_ports.size(); ++k) {
-        srsran_assert(pdu.rx_ports[k] < nports, "Receive port outside the resource grid.");
+        require(pdu.rx_ports[k] < nports, "Receive port outside the resource grid.");
         p.rx_ports[k] = pdu.rx_ports[k];
       }
       for (unsigned l = 0; l != 14 && l != pdu.dmrs_symbol_mask.size(); ++l) {
@@ -1334,20 +1440,20 @@ public:
       p.grid_offset = 0, p.tb_offset = tb_bytes;
       tb_bytes += (e.data.size() + 15) & ~static_cast<size_t>(15);
     }
-    auto*    d_g    = static_cast<float*>(c->buf(0, host.size() * sizeof(srsran::cf_t)));
-    auto*    d_tb   = static_cast<uint8_t*>(c->buf(1, tb_bytes + 16));
-    auto*    d_misc = static_cast<uint8_t*>(c->buf(2, static_cast<size_t>(n) * (sizeof(miphy_pusch_result) + 80) + 64));
+    auto*    d_g    = static_cast<float*>(dc.buf(0, host.size() * sizeof(srsran::cf_t)));
+    auto*    d_tb   = static_cast<uint8_t*>(dc.buf(1, tb_bytes + 16));
+    auto*    d_misc = static_cast<uint8_t*>(dc.buf(2, static_cast<size_t>(n) * (sizeof(miphy_pusch_result) + 80) + 64));
     auto*    d_res  = reinterpret_cast<miphy_pusch_result*>(d_misc);
     auto*    d_sc   = reinterpret_cast<float*>(d_misc + ((static_cast<size_t>(n) * sizeof(miphy_pusch_result) + 63) & ~static_cast<size_t>(63)));
-    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
-    context::check(miphy_pusch_process_batch(c->ctx, pdus.data(), n, d_g, d_soft, d_msg, d_crc, d_tb, d_res, d_sc, c->stream), "pusch_process");
+    dc.h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    context::check(miphy_pusch_process_batch(dc.ctx, pdus.data(), n, d_g, d_soft, d_msg, d_crc, d_tb, d_res, d_sc, dc.stream), "pusch_process");
     std::vector<miphy_pusch_result> res(n);
     std::vector<float>              sc(static_cast<size_t>(n) * 20);
-    tbs.resize(tb_bytes);
-    c->d2h(res.data(), d_res, n * sizeof(miphy_pusch_result));
-    c->d2h(sc.data(), d_sc, sc.size() * sizeof(float));
-    c->d2h(tbs.data(), d_tb, tb_bytes);
-    c->sync();
+    std::vector<uint8_t>            tbs(tb_bytes);
+    dc.d2h(res.data(), d_res, n * sizeof(miphy_pusch_result));
+    dc.d2h(sc.data(), d_sc, sc.size() * sizeof(float));
+    dc.d2h(tbs.data(), d_tb, tb_bytes);
+    dc.sync();
     for (unsigned i = 0; i != n; ++i) {
       entry&                      e = queue[i];
       const miphy_pusch_result&   r = res[i];
@@ -1431,17 +1537,27 @@ private:
     pusch_pdu                              pdu;
   };
 
-  std::shared_ptr<context>                 c;
+  struct batch {
+    std::vector<entry>                  entries;
+    const srsran::resource_grid_reader* grid = nullptr;
+    std::vector<srsran::cf_t>           samples; // the slot's resource grid, copied when the batch was opened
+  };
+
+  std::shared_ptr<context>                 c, wc;
   std::unique_ptr<srsran::prach_detector>  prach;
   std::unique_ptr<srsran::pucch_processor> pucch;
   pusch_processor_hip                      single;
   unsigned                                 nports, nprb, nof_iterations;
   bool                                     early_stop;
   unsigned                                 max_batch;
-  std::vector<entry>                       queue;
-  const srsran::resource_grid_reader*      queue_grid = nullptr;
-  std::vector<srsran::cf_t>                host;
-  std::vector<uint8_t>                     tbs;
+  std::chrono::microseconds                linger;
+  std::mutex                               mu;
+  std::condition_variable                  cv, cv_done;
+  std::thread                              worker;
+  batch                                    open;
+  std::deque<batch>                        ready;
+  std::chrono::steady_clock::time_point    last_push;
+  bool                                     stop = false, busy = false;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- PDSCH modulator / DM-RS
