@@ -432,7 +432,7 @@ def main():
             ctx.ofdm_demodulate_slots(ocfg, ojobs_d[a * 24:b * 24], samples_d, grid_d, st)
             if timed:
                 e[1].record(st)
-            ctx.dmrs_pusch_estimate_batch(cjobs_d[a * 96:b * 96], grid_d, ce_d, sc_d, st)
+            ctx.dmrs_pusch_estimate_batch(cjobs_d[a * 152:b * 152], grid_d, ce_d, sc_d, st)
             if timed:
                 e[2].record(st)
             ctx.pusch_demodulate_batch(djobs_d[a * 120:b * 120], grid_d, ce_d, sc_d, llr_d, st)
@@ -503,7 +503,7 @@ def main():
             if r == 3:
                 ev0.record(stream)
             ctx.ofdm_demodulate_slots(ocfg, ojobs_d[:24], samples_d, grid_d, stream)
-            ctx.dmrs_pusch_estimate_batch(cjobs_d[:96], grid_d, ce_d, sc_d, stream)
+            ctx.dmrs_pusch_estimate_batch(cjobs_d[:152], grid_d, ce_d, sc_d, stream)
             ctx.pusch_demodulate_batch(djobs_d[:120], grid_d, ce_d, sc_d, llr_d, stream)
             p1.run(llr_d, soft_d, msgs_d, crc_d, tb_d, res_d, stream)
         ev1.record(stream)

@@ -270,8 +270,24 @@ typedef struct {
                               only the allocated PRBs of symbols [first_symbol, first_symbol+nof_symbols) are written.
                               With ce_compact: [layer][rx port][grid_nof_prb*12] */
   uint64_t scalars_offset; /* float offset: per (rx port, layer) {rsrp, epre, noise_var, snr, time_alignment_s} */
+  /* port_channel_estimator::configuration beyond what dmrs_pusch_estimator_impl fills in (port_channel_estimator.h:45-107,
+   * port_channel_estimator_average_impl.cpp:97-224): intra-slot frequency hopping and externally generated pilots. */
+  uint64_t rb_mask2[5];    /* layer_dmrs_pattern::rb_mask2: allocation of the second hop (used when hop_symbol != 0) */
+  uint64_t pilots_offset;  /* cf_t offset into `pilots` of miphy_port_channel_estimate_batch: dmrs_symbol_list
+                              [layer][DM-RS symbol][pilot of the allocated PRBs]; ignored by miphy_dmrs_pusch_estimate_batch */
+  uint8_t  hop_symbol;     /* layer_dmrs_pattern::hopping_symbol_index: first OFDM symbol of the second hop, 0 = no hopping */
+  uint8_t  re_odd_mask;    /* with external pilots: bit ly = layer ly has its DM-RS on the odd subcarriers (layer_dmrs_pattern::re_pattern of
+                              DM-RS type 1); the PUSCH estimator derives it from the layer number instead */
+  uint8_t  reserved2[6];
 } miphy_pusch_chest_job;
 
+/* The port estimator on its own: the same kernel with the pilots given by the caller (device, cf_t) instead of generated from
+ * (slot, scrambling_id, n_scid) -- srsran::port_channel_estimator::compute (port_channel_estimator.h:102-106). slot_in_frame,
+ * scrambling_id and n_scid of the jobs are ignored; hop_symbol / rb_mask2 select intra-slot frequency hopping (per-hop least squares,
+ * interpolation and mapping, time alignment averaged over the hops, noise variance = epre / 1000 as the reference forces it with
+ * hopping: port_channel_estimator_average_impl.cpp:118-138). */
+int miphy_port_channel_estimate_batch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int jobs_on_device, uint32_t n, const float* grid /* device cf_t */,
+                                      const float* pilots /* device cf_t */, float* ce /* device cf_t */, float* scalars /* device */, void* stream);
 int miphy_dmrs_pusch_estimate_batch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int jobs_on_device, uint32_t n,
                                     const float* grid /* device cf_t */, float* ce /* device cf_t */, float* scalars /* device */,
                                     void* stream);

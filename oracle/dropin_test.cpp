@@ -1893,6 +1893,103 @@ static void test_pusch_processor_uci(std::shared_ptr<miphy::context> c)
          failures);
 }
 
+// port_channel_estimator: the reference's averaging estimator against port_channel_estimator_hip, pilots given by the caller, one and
+// two layers, and intra-slot frequency hopping (per-hop estimates on different PRBs, port_channel_estimator_average_impl.cpp:97-224).
+static void test_port_channel_estimator(std::shared_ptr<miphy::context> c)
+{
+  auto e_ref = create_port_channel_estimator_factory_sw(std::make_shared<generic_dft_factory>())->create();
+  auto e_hip = miphy::create_port_channel_estimator_factory_hip(c)->create();
+  std::normal_distribution<float>    n(0.F, 0.05F);
+  std::uniform_int_distribution<int> bit(0, 1);
+  struct tc {
+    unsigned nprb_grid, rb0, nrb, rb0_hop, first, nof, hop, nl;
+    std::vector<unsigned> dsyms;
+  };
+  for (const tc& t : {tc{52, 4, 30, 0, 0, 14, 0, 1, {2, 11}}, tc{106, 10, 80, 0, 2, 12, 0, 2, {3}}, tc{52, 2, 20, 28, 0, 14, 7, 1, {2, 9}},
+                      tc{60, 0, 25, 33, 1, 12, 6, 2, {2, 4, 8, 11}}, tc{30, 3, 24, 0, 0, 14, 0, 1, {2, 5, 8, 11}}}) {
+    const unsigned nsc = t.nprb_grid * 12, np = t.nrb * 6, nds = t.dsyms.size();
+    port_channel_estimator::configuration cfg;
+    cfg.scs = subcarrier_spacing::kHz30, cfg.cp = cyclic_prefix::NORMAL, cfg.first_symbol = t.first, cfg.nof_symbols = t.nof, cfg.scaling = 1.4125F;
+    cfg.rx_ports.push_back(0);
+    for (unsigned ly = 0; ly != t.nl; ++ly) {
+      port_channel_estimator::layer_dmrs_pattern p;
+      p.symbols = bounded_bitset<MAX_NSYMB_PER_SLOT>(14);
+      for (unsigned l : t.dsyms) {
+        p.symbols.set(l);
+      }
+      p.rb_mask = bounded_bitset<MAX_RB>(t.nprb_grid);
+      p.rb_mask.fill(t.rb0, t.rb0 + t.nrb, true);
+      p.rb_mask2 = bounded_bitset<MAX_RB>(t.nprb_grid);
+      if (t.hop) {
+        p.rb_mask2.fill(t.rb0_hop, t.rb0_hop + t.nrb, true);
+        p.hopping_symbol_index.emplace(t.hop);
+      }
+      p.re_pattern = bounded_bitset<NRE>(12);
+      for (unsigned k = (ly >= 1 && t.nl == 2 && t.hop == 0) ? 1 : 0; k < 12; k += 2) { // second layer of the non-hopping case on the odd comb
+        p.re_pattern.set(k);
+      }
+      cfg.dmrs_pattern.push_back(p);
+    }
+    dmrs_symbol_list pilots;
+    pilots.resize({np, nds, t.nl});
+    for (unsigned ly = 0; ly != t.nl; ++ly) {
+      for (unsigned d = 0; d != nds; ++d) {
+        span<cf_t> v = pilots.get_symbol(d, ly);
+        for (auto& x : v) {
+          x = cf_t(0.7071F * (1 - 2 * bit(rgen)), 0.7071F * (1 - 2 * bit(rgen)));
+        }
+      }
+    }
+    // grid: pilots through a frequency-selective channel with a delay, plus noise (everywhere, so that EPRE sees it)
+    auto              grid = create_resource_grid(1, 14, nsc);
+    std::vector<cf_t> row(nsc);
+    for (unsigned l = 0; l != 14; ++l) {
+      for (auto& x : row) {
+        x = cf_t(n(rgen), n(rgen));
+      }
+      unsigned d = 0;
+      for (; d != nds && t.dsyms[d] != l; ++d) {
+      }
+      if (d != nds) {
+        const bool     second = t.hop && l >= t.hop;
+        const unsigned rb0    = second ? t.rb0_hop : t.rb0;
+        for (unsigned ly = 0; ly != t.nl; ++ly) {
+          const unsigned   delta = cfg.dmrs_pattern[ly].re_pattern.test(1) ? 1 : 0;
+          span<const cf_t> v     = pilots.get_symbol(d, ly);
+          for (unsigned i = 0; i != np; ++i) {
+            const unsigned k  = (rb0 + i / 6) * 12 + 2 * (i % 6) + delta;
+            const float    ph = -2.0F * 3.14159265F * 9.0F * static_cast<float>(k) / 4096.0F + 0.3F * ly;
+            row[k] += cfg.scaling * v[i] * cf_t(std::cos(ph), std::sin(ph)) * (0.8F + 0.2F * std::cos(k / 50.0F));
+          }
+        }
+      }
+      grid->put(0, l, 0, row);
+    }
+    channel_estimate::channel_estimate_dimensions dims;
+    dims.nof_prb = t.nprb_grid, dims.nof_symbols = 14, dims.nof_rx_ports = 1, dims.nof_tx_layers = t.nl;
+    channel_estimate ce1(dims), ce2(dims);
+    e_ref->compute(ce1, *grid, 0, pilots, cfg);
+    e_hip->compute(ce2, *grid, 0, pilots, cfg);
+    for (unsigned ly = 0; ly != t.nl; ++ly) {
+      for (unsigned l = t.first; l != t.first + t.nof; ++l) {
+        const bool       second = t.hop && l >= t.hop;
+        const unsigned   rb0    = second ? t.rb0_hop : t.rb0;
+        span<const cf_t> a = static_cast<const channel_estimate&>(ce1).get_symbol_ch_estimate(l, 0, ly), b = static_cast<const channel_estimate&>(ce2).get_symbol_ch_estimate(l, 0, ly);
+        const float      e = rel_err(a.subspan(rb0 * 12, t.nrb * 12), b.subspan(rb0 * 12, t.nrb * 12));
+        CHECK(e < 1e-4F, "port_channel_estimator: estimate differs (hop %u layer %u symbol %u): %g", t.hop, ly, l, e);
+      }
+      CHECK(std::abs(ce1.get_rsrp(0, ly) - ce2.get_rsrp(0, ly)) < 1e-4F * ce1.get_rsrp(0, ly) && std::abs(ce1.get_epre(0, ly) - ce2.get_epre(0, ly)) < 1e-4F * ce1.get_epre(0, ly) &&
+                std::abs(ce1.get_noise_variance(0, ly) - ce2.get_noise_variance(0, ly)) < 2e-3F * ce1.get_noise_variance(0, ly) &&
+                std::abs(ce1.get_snr(0, ly) - ce2.get_snr(0, ly)) < 2e-3F * ce1.get_snr(0, ly),
+            "port_channel_estimator: scalars differ (hop %u layer %u): rsrp %g/%g epre %g/%g noise %g/%g", t.hop, ly, ce1.get_rsrp(0, ly), ce2.get_rsrp(0, ly),
+            ce1.get_epre(0, ly), ce2.get_epre(0, ly), ce1.get_noise_variance(0, ly), ce2.get_noise_variance(0, ly));
+      CHECK(std::abs(ce1.get_time_alignment(0, ly).to_seconds() - ce2.get_time_alignment(0, ly).to_seconds()) < 1.1 / (4096 * 30e3),
+            "port_channel_estimator: time alignment differs (hop %u): %g / %g", t.hop, ce1.get_time_alignment(0, ly).to_seconds(), ce2.get_time_alignment(0, ly).to_seconds());
+    }
+  }
+  printf("port_channel_estimator (pilots from the caller, 1-2 layers, intra-slot hopping) done, failures so far %d\n", failures);
+}
+
 static void on_fault(int sig)
 {
   void* frames[64];
@@ -1931,6 +2028,7 @@ int main()
   test_ofdm_symbols(c);
   test_validators(c);
   test_pusch_processor_uci(c);
+  test_port_channel_estimator(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);
     return 1;

@@ -37,6 +37,7 @@
 #include "srsran/phy/upper/uplink_processor.h"
 #include "srsran/phy/upper/upper_phy_rx_results_notifier.h"
 #include "srsran/phy/upper/signal_processors/nzp_csi_rs_generator.h"
+#include "srsran/phy/upper/signal_processors/port_channel_estimator.h"
 #include "srsran/phy/upper/signal_processors/signal_processor_factories.h"
 #include "srsran/support/error_handling.h"
 #include <algorithm>
@@ -2601,6 +2602,107 @@ private:
 inline std::shared_ptr<srsran::crc_calculator_factory> create_crc_calculator_factory_hip(std::shared_ptr<context> c)
 {
   return std::make_shared<crc_calculator_factory_hip>(std::move(c));
+}
+
+// ---------------------------------------------------------------------------------------------------------------- port channel estimator
+/// srsran::port_channel_estimator over miphy_port_channel_estimate_batch (port_channel_estimator.h:102-106): the pilots come from the
+/// caller (PUSCH and PUCCH estimators build them), one receive port per call, all layers, intra-slot frequency hopping included
+/// (port_channel_estimator_average_impl.cpp:97-224). DM-RS on every second subcarrier (type 1 / PUCCH formats 1-4 comb); the layers
+/// share symbols, PRBs and hop, as in every caller of the reference.
+class port_channel_estimator_hip : public srsran::port_channel_estimator
+{
+public:
+  explicit port_channel_estimator_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void compute(srsran::channel_estimate&           estimate,
+               const srsran::resource_grid_reader& grid,
+               unsigned                            port,
+               const srsran::dmrs_symbol_list&     pilots,
+               const configuration&                cfg) override
+  {
+    const unsigned nl = cfg.dmrs_pattern.size();
+    require(nl >= 1 && nl <= 4, "port_channel_estimator_hip: 1 to 4 layers.");
+    const layer_dmrs_pattern& pt   = cfg.dmrs_pattern[0];
+    const unsigned            nprb = pt.rb_mask.size(), nsc = nprb * 12;
+    miphy_pusch_chest_job     j    = {};
+    j.numerology = srsran::to_numerology_value(cfg.scs), j.scaling = cfg.scaling, j.nof_tx_layers = nl, j.nof_rx_ports = 1;
+    j.first_symbol = cfg.first_symbol, j.nof_symbols = cfg.nof_symbols, j.grid_nof_prb = nprb;
+    for (unsigned ly = 0; ly != nl; ++ly) {
+      const layer_dmrs_pattern& q = cfg.dmrs_pattern[ly];
+      require(q.symbols == pt.symbols && q.rb_mask == pt.rb_mask && q.rb_mask2 == pt.rb_mask2 && q.hopping_symbol_index == pt.hopping_symbol_index,
+              "port_channel_estimator_hip: the layers must share symbols, PRBs and hop.");
+      uint16_t re = 0;
+      for (unsigned k = 0; k != 12; ++k) {
+        re |= static_cast<uint16_t>(q.re_pattern.test(k) ? (1U << k) : 0U);
+      }
+      require(re == 0x555 || re == 0xaaa, "port_channel_estimator_hip: DM-RS on every second subcarrier only.");
+      j.re_odd_mask |= static_cast<uint8_t>((re == 0xaaa) ? (1U << ly) : 0U);
+    }
+    for (unsigned l = 0; l != 14 && l != pt.symbols.size(); ++l) {
+      j.symbols_mask |= static_cast<uint16_t>(pt.symbols.test(l) ? (1U << l) : 0U);
+    }
+    pt.rb_mask.for_each(0, nprb, [&j](unsigned r) { j.rb_mask[r >> 6] |= 1ULL << (r & 63); });
+    if (pt.hopping_symbol_index.has_value()) {
+      j.hop_symbol = pt.hopping_symbol_index.value();
+      pt.rb_mask2.for_each(0, pt.rb_mask2.size(), [&j](unsigned r) { j.rb_mask2[r >> 6] |= 1ULL << (r & 63); });
+    }
+    const unsigned nsymb = cfg.first_symbol + cfg.nof_symbols;
+    host.resize(static_cast<size_t>(14) * nsc);
+    for (unsigned l = 0; l != 14; ++l) {
+      grid.get(srsran::span<srsran::cf_t>(host.data() + static_cast<size_t>(l) * nsc, nsc), port, l, 0);
+    }
+    const srsran::re_measurement_dimensions pd = pilots.size();
+    pil.resize(static_cast<size_t>(nl) * pd.nof_symbols * pd.nof_subc);
+    for (unsigned ly = 0; ly != nl; ++ly) {
+      for (unsigned d = 0; d != pd.nof_symbols; ++d) {
+        srsran::span<const srsran::cf_t> v = pilots.get_symbol(d, ly);
+        std::copy(v.begin(), v.end(), pil.begin() + (static_cast<size_t>(ly) * pd.nof_symbols + d) * pd.nof_subc);
+      }
+    }
+    auto* d_g  = static_cast<float*>(c->buf(0, host.size() * sizeof(srsran::cf_t)));
+    auto* d_p  = static_cast<float*>(c->buf(1, pil.size() * sizeof(srsran::cf_t)));
+    auto* d_ce = static_cast<float*>(c->buf(2, static_cast<size_t>(nl) * nsymb * nsc * sizeof(srsran::cf_t)));
+    auto* d_sc = static_cast<float*>(c->buf(3, 5 * 4 * sizeof(float) + 64));
+    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    c->h2d(d_p, pil.data(), pil.size() * sizeof(srsran::cf_t));
+    context::check(miphy_port_channel_estimate_batch(c->ctx, &j, 0, 1, d_g, d_p, d_ce, d_sc, c->stream), "port_channel_estimate");
+    ce.resize(static_cast<size_t>(nl) * nsymb * nsc);
+    float sc[20];
+    c->d2h(ce.data(), d_ce, ce.size() * sizeof(srsran::cf_t));
+    c->d2h(sc, d_sc, sizeof(float) * 5 * nl);
+    c->sync();
+    for (unsigned ly = 0; ly != nl; ++ly) {
+      for (unsigned l = cfg.first_symbol; l != nsymb; ++l) {
+        // only the PRBs of the hop the symbol belongs to carry an estimate (port_channel_estimator_average_impl.cpp:216-224)
+        const srsran::bounded_bitset<srsran::MAX_RB>& m = (pt.hopping_symbol_index.has_value() && l >= pt.hopping_symbol_index.value()) ? pt.rb_mask2 : pt.rb_mask;
+        srsran::span<srsran::cf_t>                    o = estimate.get_symbol_ch_estimate(l, port, ly);
+        const srsran::cf_t*                           v = ce.data() + (static_cast<size_t>(ly) * nsymb + l) * nsc;
+        m.for_each(0, m.size(), [&](unsigned r) { std::copy(v + r * 12, v + r * 12 + 12, o.begin() + r * 12); });
+      }
+      estimate.set_rsrp(sc[5 * ly + 0], port, ly);
+      estimate.set_epre(sc[5 * ly + 1], port, ly);
+      estimate.set_noise_variance(sc[5 * ly + 2], port, ly);
+      estimate.set_snr(sc[5 * ly + 3], port, ly);
+      estimate.set_time_alignment(srsran::phy_time_unit::from_seconds(sc[5 * ly + 4]), port, ly);
+    }
+  }
+
+private:
+  std::shared_ptr<context>  c;
+  std::vector<srsran::cf_t> host, pil, ce;
+};
+
+class port_channel_estimator_factory_hip : public srsran::port_channel_estimator_factory
+{
+public:
+  explicit port_channel_estimator_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  std::unique_ptr<srsran::port_channel_estimator> create() override { return std::make_unique<port_channel_estimator_hip>(c); }
+
+private:
+  std::shared_ptr<context> c;
+};
+inline std::shared_ptr<srsran::port_channel_estimator_factory> create_port_channel_estimator_factory_hip(std::shared_ptr<context> c)
+{
+  return std::make_shared<port_channel_estimator_factory_hip>(std::move(c));
 }
 
 // ---------------------------------------------------------------------------------------------------------------- PDU validators

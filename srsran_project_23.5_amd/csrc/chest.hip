@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
                                                     const cplx* __restrict__ tw,
                                                     const float2* __restrict__ grid,
                                                     float2* __restrict__ ce_out,
-                                                    float* __restrict__ scalars)
+                                                    float* __restrict__ scalars,
+                                                    const float2* __restrict__ ext_pilots) // nullptr: pilots generated from the job (PUSCH DM-RS)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cplx*     fbuf   = reinterpret_cast<cplx*>(smem);                  // 4096 cplx: IDFT buffer, later interpolated response
@@ -91,9 +92,6 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
   // run time would live in scratch memory.
   const miphy_pusch_chest_job& job = jobs[blockIdx.x];
   __shared__ uint64_t rbm[5];
-  if (threadIdx.x < 5)
-    rbm[threadIdx.x] = job.rb_mask[threadIdx.x];
-  __syncthreads();
   const int tid = threadIdx.x, nt = blockDim.x;
   const int port = blockIdx.y % 4, layer = blockIdx.y / 4;
   const int sgrp = blockIdx.z, ngrp = gridDim.z; // symbol group: stores OFDM symbols l with l % ngrp == sgrp; group 0 owns the scalars
@@ -101,15 +99,37 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
     return;
   const int nprb_grid = job.grid_nof_prb, nsc = nprb_grid * 12;
   const int first = job.first_symbol, nsymb_out = first + job.nof_symbols;
-
-  // DM-RS symbol list inside the allocation.
-  int dsym[4], nds = 0;
+  const int hop_symbol = (job.hop_symbol > first && job.hop_symbol < nsymb_out) ? job.hop_symbol : 0;
+  const int nhops      = hop_symbol ? 2 : 1;
+  // DM-RS symbols of the whole allocation (the pilots of the second hop follow those of the first in an external pilot list)
+  int nds_all = 0;
   for (int l = first; l < nsymb_out; ++l)
+    nds_all += (job.symbols_mask >> l) & 1;
+  const int   delta = ext_pilots ? ((job.re_odd_mask >> layer) & 1) : ((layer >> 1) & 1); // RE pattern: even subcarriers for ports 0,1 ; odd for 2,3
+  const float wf1 = (layer & 1) ? -1.f : 1.f;       // frequency weight on odd pilots (layers > 0)
+  const float amp = 0.70710678118654752440f;
+  const float2* g = grid + job.grid_offset + (size_t)(((uint32_t)job.rx_ports[0] | ((uint32_t)job.rx_ports[1] << 8) | ((uint32_t)job.rx_ports[2] << 16) | ((uint32_t)job.rx_ports[3] << 24)) >> (8 * port) & 0xffu) * 14 * nsc;
+  const float   beta = job.scaling;
+  const bool    compact = job.ce_compact != 0;
+  float2*       dst0    = ce_out + job.ce_offset + ((size_t)(layer * job.nof_rx_ports + port) * (compact ? 1 : nsymb_out)) * nsc;
+  // accumulated over the hops (port_channel_estimator_average_impl.cpp:110-124)
+  float epre_tot = 0.f, rsrp_tot = 0.f, noise_tot = 0.f, ta_tot = 0.f;
+  int   np_sym = 0; // pilots per DM-RS symbol (the same in both hops)
+  for (int hop = 0; hop < nhops; ++hop) {
+  const int h_first = (hop == 1) ? hop_symbol : first, h_last = (hop == 0 && hop_symbol) ? hop_symbol : nsymb_out;
+  __syncthreads();
+  if (tid < 5)
+    rbm[tid] = (hop == 1) ? job.rb_mask2[tid] : job.rb_mask[tid];
+  __syncthreads();
+  // DM-RS symbol list inside the hop.
+  int dsym[4], nds = 0;
+  for (int l = h_first; l < h_last; ++l)
     if ((job.symbols_mask >> l) & 1) {
       if (nds < 4)
         dsym[nds] = l;
       ++nds;
     }
+  const int hop_offset = (hop == 1) ? nds_all - nds : 0; // compute_layer_hop: pilots.size().nof_symbols - nof_dmrs_symbols
   // Allocated PRB list (compact): PRB r goes to slot popcount(mask bits below r).
   for (int r = tid; r < nprb_grid; r += nt) {
     const int wd = r >> 6, bt = r & 63;
@@ -126,35 +146,45 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
       c += __popcll(w * 64 < nprb_grid ? (rbm[w] & ((nprb_grid - w * 64 >= 64) ? ~0ull : ((1ull << (nprb_grid - w * 64)) - 1ull))) : 0ull);
     ired[0] = c;
   }
-  // Gold sequences of the DM-RS symbols (dmrs_pusch_estimator_impl.cpp:158-162).
-  uint32_t c_init[4] = {0, 0, 0, 0};
-  for (int q = 0; q < nds && q < 4; ++q) {
-    const uint64_t t = ((uint64_t)(14u * job.slot_in_frame + (uint32_t)dsym[q] + 1u) * (2ull * job.scrambling_id + 1ull)) % (1ull << 31);
-    c_init[q]        = (uint32_t)((t * (1ull << 17) + (2ull * job.scrambling_id + (job.n_scid ? 1u : 0u))) % (1ull << 31));
+  if (!ext_pilots) {
+    // Gold sequences of the DM-RS symbols (dmrs_pusch_estimator_impl.cpp:158-162).
+    uint32_t c_init[4] = {0, 0, 0, 0};
+    for (int q = 0; q < nds && q < 4; ++q) {
+      const uint64_t t = ((uint64_t)(14u * job.slot_in_frame + (uint32_t)dsym[q] + 1u) * (2ull * job.scrambling_id + 1ull)) % (1ull << 31);
+      c_init[q]        = (uint32_t)((t * (1ull << 17) + (2ull * job.scrambling_id + (job.n_scid ? 1u : 0u))) % (1ull << 31));
+    }
+    gold_bits_block(*gj, c_init, min(nds, 4), 12 * nprb_grid, cbits, gtmp, tid, nt);
+  } else {
+    __syncthreads();
   }
-  gold_bits_block(*gj, c_init, min(nds, 4), 12 * nprb_grid, cbits, gtmp, tid, nt);
   const int nprb = ired[0];
   const int np   = nprb * 6;
-  const int delta = (layer >> 1) & 1;             // RE pattern: even subcarriers for ports 0,1 ; odd for 2,3
-  const float wf1 = (layer & 1) ? -1.f : 1.f;     // frequency weight on odd pilots (layers > 0)
-  const float amp = 0.70710678118654752440f;
-  const float2* g = grid + job.grid_offset + (size_t)(((uint32_t)job.rx_ports[0] | ((uint32_t)job.rx_ports[1] << 8) | ((uint32_t)job.rx_ports[2] << 16) | ((uint32_t)job.rx_ports[3] << 24)) >> (8 * port) & 0xffu) * 14 * nsc;
-  const float   beta = job.scaling;
+  np_sym         = np;
+  // pilot of DM-RS symbol d (of this hop), pilot i of the allocation: generated from the Gold sequence counted from PRB 0
+  // (dmrs_helper.h:45-96) with the layer's frequency weight, or read from the caller's list
+  const float2* xp = ext_pilots ? ext_pilots + job.pilots_offset + ((size_t)layer * nds_all + hop_offset) * np : nullptr;
+  auto pilot = [&](int d, int i, int gp) -> cplx {
+    if (xp) {
+      const float2 v = xp[(size_t)d * np + i];
+      return cplx{v.x, v.y};
+    }
+    const uint32_t* cb = cbits + d * 104;
+    const int       b0 = 2 * gp;
+    const float     pr = amp * (1.f - 2.f * (float)((cb[b0 >> 5] >> (b0 & 31)) & 1u));
+    const float     pi = amp * (1.f - 2.f * (float)((cb[(b0 + 1) >> 5] >> ((b0 + 1) & 31)) & 1u));
+    const float     w  = (layer != 0 && (i & 1)) ? wf1 : 1.f;
+    return cplx{pr * w, pi * w};
+  };
 
   // ---- LS estimate, EPRE (port_channel_estimator_average_impl.cpp:180-201)
   float epre_acc = 0.f, rsrp_acc = 0.f;
   for (int i = tid; i < np; i += nt) {
     const int r = prb_of[i / 6], q = i % 6;
-    const int gp = r * 6 + q;                      // pilot index counted from PRB 0 (dmrs_helper.h:45-96)
+    const int gp = r * 6 + q;                      // pilot index counted from PRB 0
     cplx      acc = {0.f, 0.f};
     for (int d = 0; d < nds && d < 4; ++d) {
-      const uint32_t* cb = cbits + d * 104;
-      const int       b0 = 2 * gp;
-      const float     pr = amp * (1.f - 2.f * (float)((cb[b0 >> 5] >> (b0 & 31)) & 1u));
-      const float     pi = amp * (1.f - 2.f * (float)((cb[(b0 + 1) >> 5] >> ((b0 + 1) & 31)) & 1u));
-      const float     w  = (layer != 0 && (i & 1)) ? wf1 : 1.f;
-      const cplx      p  = {pr * w, pi * w};
-      const float2    x  = g[(size_t)dsym[d] * nsc + r * 12 + 2 * q + delta];
+      const cplx   p = pilot(d, i, gp);
+      const float2 x = g[(size_t)dsym[d] * nsc + r * 12 + 2 * q + delta];
       acc.x += x.x * p.x + x.y * p.y; // rx * conj(pilot)
       acc.y += x.y * p.x - x.x * p.y;
       epre_acc += x.x * x.x + x.y * x.y;
@@ -163,8 +193,8 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
     const float ts = 1.0f / ((float)nds * beta);
     lse[i]         = {acc.x * ts, acc.y * ts};
   }
-  const float epre_sum = block_sum(epre_acc, red, tid);
-  const float rsrp_sum = block_sum(rsrp_acc, red, tid) / (float)nds;
+  epre_tot += block_sum(epre_acc, red, tid);
+  rsrp_tot += block_sum(rsrp_acc, red, tid) / (float)nds;
   __syncthreads();
 
   // ---- noise (:271-310): per-PRB mean of the estimates, predicted observation, residual power (symbol group 0 only)
@@ -178,21 +208,15 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
     avg = {avg.x / 6.f * -beta, avg.y / 6.f * -beta};
     const int r = prb_of[i / 6], q = i % 6, gp = r * 6 + q;
     for (int d = 0; d < nds && d < 4; ++d) {
-      const uint32_t* cb = cbits + d * 104;
-      const int       b0 = 2 * gp;
-      const float     pr = amp * (1.f - 2.f * (float)((cb[b0 >> 5] >> (b0 & 31)) & 1u));
-      const float     pi = amp * (1.f - 2.f * (float)((cb[(b0 + 1) >> 5] >> ((b0 + 1) & 31)) & 1u));
-      const float     w  = (layer != 0 && (i & 1)) ? wf1 : 1.f;
-      const cplx      pred = cmul(avg, cplx{pr * w, pi * w});
-      const float2    x    = g[(size_t)dsym[d] * nsc + r * 12 + 2 * q + delta];
-      const float     er = pred.x + x.x, ei = pred.y + x.y;
+      const cplx   pred = cmul(avg, pilot(d, i, gp));
+      const float2 x    = g[(size_t)dsym[d] * nsc + r * 12 + 2 * q + delta];
+      const float  er = pred.x + x.x, ei = pred.y + x.y;
       noise_acc += er * er + ei * ei;
     }
   }
-  const float noise_sum = block_sum(noise_acc, red, tid); // = sum over symbols of |pred|^2 ; x window / np applied below
+  noise_tot += block_sum(noise_acc, red, tid) / (float)np * 6.f; // = sum over symbols of |residual|^2 / np * window (:300-309)
 
   // ---- time alignment (:312-347): zero-padded IDFT of the LS estimates at their RE positions
-  float ta_samples = 0.f;
   if (sgrp == 0) {
   for (int i = tid; i < (int)(fft_lds_bytes(CE_DFT) / 8); i += nt)
     fbuf[i] = {0.f, 0.f};
@@ -241,15 +265,13 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
   const float md = __uint_as_float((unsigned)(keys[0] >> 32)), ma = __uint_as_float((unsigned)(keys[1] >> 32));
   const int   id = (int)(0xffffffffu - (unsigned)(keys[0] & 0xffffffffu));
   const int   ia = (int)(0xffffffffu - (unsigned)(keys[1] & 0xffffffffu)) - HALF_CP;
-  ta_samples = (md >= ma) ? (float)id : -(float)(HALF_CP - ia);
+  ta_tot += (md >= ma) ? (float)id : -(float)(HALF_CP - ia);
   __syncthreads();
   } // sgrp == 0
 
   // ---- linear interpolation over the concatenated allocated PRBs (interpolator_linear_impl.cpp:58-78; offset = delta,
-  // stride 2, edges held) written straight to every OFDM symbol of the allocation (:216-224).
-  const int  nout    = nprb * 12;
-  const bool compact = job.ce_compact != 0;
-  float2*    dst0    = ce_out + job.ce_offset + ((size_t)(layer * job.nof_rx_ports + port) * (compact ? 1 : nsymb_out)) * nsc;
+  // stride 2, edges held) written straight to every OFDM symbol of the hop (:216-224).
+  const int nout = nprb * 12;
   for (int k = tid; k < nout; k += nt) {
     cplx v;
     const int kk = k - delta;
@@ -271,20 +293,21 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
       if (sgrp == 0)
         dst0[col] = make_float2(v.x, v.y);
     } else {
-      for (int l = first; l < nsymb_out; ++l)
+      for (int l = h_first; l < h_last; ++l)
         if (l % ngrp == sgrp)
           dst0[(size_t)l * nsc + col] = make_float2(v.x, v.y);
     }
   }
+  } // hops
 
   // ---- side-band scalars (:118-144)
   if (tid == 0 && sgrp == 0) {
-    const float ndp  = (float)(np * nds);
-    const float rsrp = rsrp_sum / ndp;
-    const float epre = epre_sum / ndp;
-    // noise_energy = sum_sym (sum|pred|^2 / np) * window ; noise_var = noise_energy / (window * nds - 1)
-    float noise_var = (noise_sum / (float)np * 6.f) / (float)(6 * nds - 1);
-    if (nds < 3)
+    const float ndp  = (float)(np_sym * nds_all);
+    const float rsrp = rsrp_tot / ndp;
+    const float epre = epre_tot / ndp;
+    // noise_var = sum over hops and symbols of the residual energy / (window * all DM-RS symbols - 1)
+    float noise_var = noise_tot / (float)(6 * nds_all - 1);
+    if (nds_all < 3 || nhops == 2)
       noise_var = 0.001f * epre; // convert_dB_to_power(-30) * epre
     const float datarp = rsrp / beta / beta;
     const float snr    = (noise_var != 0.f) ? datarp / noise_var : 1000.f;
@@ -294,22 +317,16 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
     sc[1] = epre;
     sc[2] = noise_var;
     sc[3] = snr;
-    sc[4] = ta_samples / ((float)CE_DFT * scs_khz * 1000.0f);
+    sc[4] = (nhops == 2 ? ta_tot / 2.0f : ta_tot) / ((float)CE_DFT * scs_khz * 1000.0f);
   }
 }
 
 } // namespace
 
-extern "C" int miphy_dmrs_pusch_estimate_batch(miphy_ctx*                   ctx,
-                                               const miphy_pusch_chest_job* jobs,
-                                               int                          jobs_on_device,
-                                               uint32_t                     n,
-                                               const float*                 grid,
-                                               float*                       ce,
-                                               float*                       scalars,
-                                               void*                        stream)
+static int chest_launch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int jobs_on_device, uint32_t n, const float* grid, const float* pilots, float* ce,
+                        float* scalars, void* stream, const char* what)
 {
-  MIPHY_REQUIRE(ctx && jobs && grid && ce && scalars, "miphy_dmrs_pusch_estimate_batch: null argument");
+  MIPHY_REQUIRE(ctx && jobs && grid && ce && scalars, "%s: null argument", what);
   if (n == 0)
     return MIPHY_OK;
   unsigned max_ports = 4, max_layers = 4;
@@ -329,6 +346,17 @@ extern "C" int miphy_dmrs_pusch_estimate_batch(miphy_ctx*                   ctx,
       for (unsigned r = 0; r < j.grid_nof_prb; ++r)
         nprb += (unsigned)((j.rb_mask[r >> 6] >> (r & 63)) & 1ull);
       MIPHY_REQUIRE(nds >= 1 && nds <= 4, "pusch_chest: job %u: %u DM-RS symbols (1..4 supported)", i, nds);
+      if (j.hop_symbol != 0) { // intra-slot frequency hopping (port_channel_estimator_average_impl.cpp:118-124,153-163)
+        MIPHY_REQUIRE(j.hop_symbol > j.first_symbol && j.hop_symbol < j.first_symbol + j.nof_symbols, "pusch_chest: job %u: hop symbol outside the allocation", i);
+        MIPHY_REQUIRE(!j.ce_compact, "pusch_chest: job %u: the compact estimate holds one hop only", i);
+        unsigned d0 = 0, d1 = 0, nprb2 = 0;
+        for (unsigned l = j.first_symbol; l < (unsigned)j.first_symbol + j.nof_symbols; ++l)
+          (l < j.hop_symbol ? d0 : d1) += (j.symbols_mask >> l) & 1;
+        for (unsigned r = 0; r < j.grid_nof_prb; ++r)
+          nprb2 += (unsigned)((j.rb_mask2[r >> 6] >> (r & 63)) & 1ull);
+        MIPHY_REQUIRE(d0 >= 1 && d1 >= 1, "pusch_chest: job %u: every hop needs a DM-RS symbol", i);
+        MIPHY_REQUIRE(nprb2 == nprb, "pusch_chest: job %u: the hops have different numbers of PRBs", i);
+      }
       MIPHY_REQUIRE(nprb >= 1, "pusch_chest: job %u: empty allocation", i);
       max_ports  = j.nof_rx_ports > max_ports ? j.nof_rx_ports : max_ports;
       max_layers = j.nof_tx_layers > max_layers ? j.nof_tx_layers : max_layers;
@@ -353,7 +381,20 @@ extern "C" int miphy_dmrs_pusch_estimate_batch(miphy_ctx*                   ctx,
   const int ngrp = 1, cthreads = 512;
   hipLaunchKernelGGL(chest_kernel, dim3(n, 4 * max_layers, ngrp), dim3(cthreads), lds, s, (const miphy_pusch_chest_job*)d_jobs,
                      (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw,
-                     (const float2*)grid, (float2*)ce, scalars);
+                     (const float2*)grid, (float2*)ce, scalars, (const float2*)pilots);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
+}
+
+extern "C" int miphy_dmrs_pusch_estimate_batch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int jobs_on_device, uint32_t n, const float* grid, float* ce,
+                                               float* scalars, void* stream)
+{
+  return chest_launch(ctx, jobs, jobs_on_device, n, grid, nullptr, ce, scalars, stream, "miphy_dmrs_pusch_estimate_batch");
+}
+
+extern "C" int miphy_port_channel_estimate_batch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int jobs_on_device, uint32_t n, const float* grid,
+                                                 const float* pilots, float* ce, float* scalars, void* stream)
+{
+  MIPHY_REQUIRE(pilots, "miphy_port_channel_estimate_batch: null pilots");
+  return chest_launch(ctx, jobs, jobs_on_device, n, grid, pilots, ce, scalars, stream, "miphy_port_channel_estimate_batch");
 }

@@ -43,6 +43,8 @@ def lib():
         l.miphy_ofdm_slot_size.restype = C.c_uint32
         l.miphy_dmrs_pusch_estimate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p]
+        l.miphy_port_channel_estimate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                        C.c_void_p]
         l.miphy_polar_code_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_polar_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_polar_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -136,8 +138,9 @@ PuschChestJob = np.dtype([("numerology", np.uint32), ("slot_in_frame", np.uint32
                           ("n_scid", np.uint8), ("nof_tx_layers", np.uint8), ("nof_rx_ports", np.uint8), ("first_symbol", np.uint8),
                           ("nof_symbols", np.uint8), ("rx_ports", np.uint8, 4), ("ce_compact", np.uint8), ("reserved", np.uint8, 2), ("symbols_mask", np.uint16),
                           ("grid_nof_prb", np.uint16), ("rb_mask", np.uint64, 5), ("grid_offset", np.uint64), ("ce_offset", np.uint64),
-                          ("scalars_offset", np.uint64)], align=True)
-assert PuschChestJob.itemsize == 96, PuschChestJob.itemsize
+                          ("scalars_offset", np.uint64), ("rb_mask2", np.uint64, 5), ("pilots_offset", np.uint64), ("hop_symbol", np.uint8),
+                          ("re_odd_mask", np.uint8), ("reserved2", np.uint8, 6)], align=True)
+assert PuschChestJob.itemsize == 152, PuschChestJob.itemsize
 assert PuschChestJob.fields["rb_mask"][1] == 32 and PuschChestJob.fields["symbols_mask"][1] == 28
 
 
@@ -470,6 +473,11 @@ class Context:
     def dmrs_pusch_estimate_batch(self, jobs, grid, ce, scalars, stream=None):
         jobs, n, ptr, on_dev = self._descs(jobs, PuschChestJob)
         check(lib().miphy_dmrs_pusch_estimate_batch(self.h, ptr, on_dev, n, _dptr(grid), _dptr(ce), _dptr(scalars), _stream_ptr(stream)))
+
+    def port_channel_estimate_batch(self, jobs, grid, pilots, ce, scalars, stream=None):
+        """port_channel_estimator::compute: pilots given by the caller (device complex64), optional intra-slot hopping."""
+        jobs, n, ptr, on_dev = self._descs(jobs, PuschChestJob)
+        check(lib().miphy_port_channel_estimate_batch(self.h, ptr, on_dev, n, _dptr(grid), _dptr(pilots), _dptr(ce), _dptr(scalars), _stream_ptr(stream)))
 
     # ------------------------------------------------------------------ polar chains / PDCCH encoder
     def polar_encode_batch(self, code, n, msg, rm_out, allocated_tap=None, encoded_tap=None, stream=None):
