@@ -343,6 +343,32 @@ int miphy_pusch_demodulate_batch(miphy_ctx* ctx, const miphy_pusch_demod_job* jo
                                  int8_t* llr_out /* device */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Channel equalizer on its own  --  replaces srsran::channel_equalizer::equalize of the zero-forcing equalizer
+ * (include/srsran/phy/upper/equalization/channel_equalizer.h:27-114, lib/phy/upper/equalization/channel_equalizer_zf_impl.cpp:123-162).
+ * Topologies are the reference's: one transmit layer with 1..4 receive ports (equalize_zf_1xn.h:120-158) and two layers on two ports
+ * (equalize_zf_2x2.cpp:30-117); anything else is MIPHY_EINVAL where the reference asserts. The noise variance is the one of the
+ * first receive port, as the reference takes it (channel_equalizer_zf_impl.cpp:141-142). Abnormal elements (zero / non-finite
+ * denominator, non-positive or non-finite noise variance) give symbol 0 and noise variance +inf.
+ * Note: in 23.5 the PUSCH demodulator never calls the equalizer with two layers (pusch_demodulator_impl.h asserts one layer, "layer
+ * demapping is not implemented"), so the 2 x 2 case only exists behind this entry point; miphy_pusch_demodulate_batch fuses the
+ * 1 x N case. Tensors are the reference's re_measurement layouts, resource element fastest. */
+typedef struct {
+  uint32_t nof_re;
+  uint8_t  nof_rx_ports;        /* 1..4 */
+  uint8_t  nof_tx_layers;       /* 1, or 2 with nof_rx_ports == 2 */
+  uint8_t  reserved[2];
+  float    noise_var;           /* noise_var_estimates[0] */
+  float    tx_scaling;          /* > 0 */
+  uint64_t ch_symbols_offset;   /* cf_t offset: [rx port][nof_re] */
+  uint64_t ch_estimates_offset; /* cf_t offset: [tx layer][rx port][nof_re] */
+  uint64_t eq_symbols_offset;   /* cf_t offset: [tx layer][nof_re] */
+  uint64_t eq_noise_vars_offset; /* float offset: [tx layer][nof_re] */
+} miphy_equalizer_job;
+int miphy_channel_equalize_batch(miphy_ctx* ctx, const miphy_equalizer_job* jobs, int jobs_on_device, uint32_t n, const float* ch_symbols /* device cf_t */,
+                                 const float* ch_estimates /* device cf_t */, float* eq_symbols /* device cf_t */, float* eq_noise_vars /* device */,
+                                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * PDSCH modulator and PDSCH DM-RS  --  replace srsran::pdsch_modulator::modulate and srsran::dmrs_pdsch_processor::map
  * (after the encoder, before the OFDM modulator)
  *   include/srsran/phy/upper/channel_processors/pdsch_modulator.h:40-99, lib/.../pdsch_modulator_impl.cpp:30-282

@@ -1999,6 +1999,69 @@ static void on_fault(int sig)
   _exit(128 + sig);
 }
 
+// channel_equalizer: the reference's zero-forcing equalizer against channel_equalizer_hip on the reference's own tensor types: one layer
+// on 1..4 ports (the reference divides with the approximate _mm256_rcp_ps: 4e-4 relative), two layers on two ports (scalar code in the
+// reference, contraction in its build: scaled by the cancellation of the determinant), a dead estimate in both.
+static void test_channel_equalizer(std::shared_ptr<miphy::context> c)
+{
+  auto q_ref = create_channel_equalizer_factory_zf()->create();
+  auto q_hip = miphy::create_channel_equalizer_factory_hip(c)->create();
+  std::normal_distribution<float> n(0.F, 0.7F);
+  struct tc {
+    unsigned npt, nl, nre;
+    float    nvar, txs;
+  };
+  using re_t = dynamic_tensor<2, cf_t, channel_equalizer::re_list::dims>;
+  using nv_t = dynamic_tensor<2, float, channel_equalizer::re_list::dims>;
+  using ch_t = dynamic_tensor<3, cf_t, channel_equalizer::ch_est_list::dims>;
+  for (const tc& t : {tc{1, 1, 301, 0.01F, 1.F}, tc{2, 1, 3276, 0.1F, 0.5F}, tc{4, 1, 1203, 0.05F, 1.F}, tc{2, 2, 3276, 0.02F, 1.F}, tc{2, 2, 77, 0.3F, 0.7071F}}) {
+    re_t y({t.nre, t.npt}), z1({t.nre, t.nl}), z2({t.nre, t.nl});
+    nv_t v1({t.nre, t.nl}), v2({t.nre, t.nl});
+    ch_t h({t.nre, t.npt, t.nl});
+    for (cf_t& x : h.get_data()) {
+      x = cf_t(n(rgen), n(rgen));
+    }
+    for (cf_t& x : y.get_data()) {
+      x = cf_t(n(rgen), n(rgen));
+    }
+    for (unsigned p = 0; p != t.npt; ++p) {
+      for (unsigned l = 0; l != t.nl; ++l) {
+        h[{11, p, l}] = 0; // a dead resource element
+      }
+    }
+    std::vector<float> nvars(t.npt, t.nvar);
+    q_ref->equalize(z1, v1, y, h, nvars, t.txs);
+    q_hip->equalize(z2, v2, y, h, nvars, t.txs);
+    unsigned bad = 0;
+    for (unsigned l = 0; l != t.nl; ++l) {
+      for (unsigned i = 0; i != t.nre; ++i) {
+        const cf_t  a = z1[{i, l}], b = z2[{i, l}];
+        const float va = v1[{i, l}], vb = v2[{i, l}];
+        if (std::isinf(va) || std::isinf(vb)) {
+          bad += (std::isinf(va) != std::isinf(vb)) || a != cf_t(0, 0) || b != cf_t(0, 0);
+          continue;
+        }
+        float tol = 4e-4F;
+        if (t.nl == 2) {
+          float n0 = 0, n1 = 0;
+          cf_t  xi = 0;
+          for (unsigned p = 0; p != 2; ++p) {
+            const cf_t h0 = h[{i, p, 0}], h1 = h[{i, p, 1}];
+            n0 += std::norm(h0), n1 += std::norm(h1), xi += std::conj(h0) * h1;
+          }
+          tol = 2e-6F * n0 * n1 / std::max(n0 * n1 - std::norm(xi), 1e-30F);
+        }
+        bad += std::abs(a - b) > tol * (std::abs(a) + 1.F) || std::abs(va - vb) > tol * va;
+      }
+    }
+    CHECK(bad == 0, "channel equalizer %u x %u: %u of %u elements differ from the reference", t.nl, t.npt, bad, t.nre * t.nl);
+    const float dead_v = v2[{11, 0}];
+    const cf_t  dead_z = z2[{11, 0}];
+    CHECK(std::isinf(dead_v) && dead_z == cf_t(0, 0), "channel equalizer: dead element not flagged");
+  }
+  printf("channel_equalizer: 5 topologies match the reference\n");
+}
+
 int main()
 {
   setvbuf(stdout, nullptr, _IOLBF, 0);
@@ -2029,6 +2092,7 @@ int main()
   test_validators(c);
   test_pusch_processor_uci(c);
   test_port_channel_estimator(c);
+  test_channel_equalizer(c);
   if (failures) {
     printf("DROPIN TEST FAILED: %d failures\n", failures);
     return 1;

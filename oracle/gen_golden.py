@@ -322,3 +322,15 @@ for i, (row, nports, k, cdm, dens, start_rb, nof_rb, l0, slot, scr, amp) in enum
     d["meta_%d" % i] = np.array([slot, scr, amp, start_rb, nof_rb, bes[0], bes[1], bes[2], row, cdm, dens, nports], dtype=np.float64)
 d["n"] = np.array(len(cases))
 save("csi_rs", **d)
+
+# ---------------------------------------------------------------------- zero-forcing equalizer on its own (reference outputs, AVX2 1 x N / scalar 2 x 2)
+d = {}
+erng = np.random.default_rng(5150)
+EQ_CASES = [(1, 1, 300, 1.0), (2, 1, 301, 0.5), (3, 1, 77, 2.0), (4, 1, 1203, 1.0), (2, 2, 300, 1.0), (2, 2, 1201, 0.7071)]
+for i, (npt, nl, nre, txs) in enumerate(EQ_CASES):
+    y, h, nvar, x = O.equalizer_case(erng, nre, npt, nl, dead=(5, nre - 1))
+    z, nv = O.r_channel_equalize(y, h, nvar, txs)
+    d["y_%d" % i], d["h_%d" % i], d["z_%d" % i], d["nv_%d" % i] = y, h, z, nv
+    d["meta_%d" % i] = np.array([nvar, txs], dtype=np.float64)
+d["n"] = np.array(len(EQ_CASES))
+save("channel_equalizer", **d)

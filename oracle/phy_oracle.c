@@ -2410,3 +2410,73 @@ int orc_ulsch_demultiplex(int mod, unsigned nof_layers, unsigned nof_prb, unsign
     *nof_placeholders = n_ph;
   return (int)(n_in * bpr);
 }
+
+/* ------------------------------------------------------------------------------------------------ zero-forcing equalizer (stand-alone block)
+ * channel_equalizer_zf_impl.cpp:123-162 picks the kernel; both kernels below follow the reference's scalar statements one by one
+ * (std::complex products written out: (a+bi)(c+di) = (ac-bd) + (ad+bc)i, no fused multiply-add: this file is built with -ffp-contract=off). */
+static int orc_isnormal_f(float x)
+{
+  return isnormal(x);
+}
+int orc_channel_equalize(unsigned nof_re, unsigned nof_rx_ports, unsigned nof_tx_layers, const float* ch_symbols, const float* ch_estimates,
+                         float noise_var, float tx_scaling, float* eq_symbols, float* eq_noise_vars)
+{
+  const int nv_ok = orc_isnormal_f(noise_var) && noise_var > 0.0f;
+  if (nof_tx_layers == 1 && nof_rx_ports >= 1 && nof_rx_ports <= 4) { /* equalize_zf_1xn.h:120-158 */
+    for (unsigned i = 0; i != nof_re; ++i) {
+      float ch_mod_sq = 0.0f, re = 0.0f, im = 0.0f;
+      for (unsigned p = 0; p != nof_rx_ports; ++p) {
+        const float* y = ch_symbols + 2 * ((size_t)p * nof_re + i);
+        const float* c = ch_estimates + 2 * ((size_t)p * nof_re + i);
+        ch_mod_sq += c[0] * c[0] + c[1] * c[1];
+        re += y[0] * c[0] - y[1] * (-c[1]); /* re_in * conj(ch_est) */
+        im += y[0] * (-c[1]) + y[1] * c[0];
+      }
+      eq_symbols[2 * i] = 0.0f, eq_symbols[2 * i + 1] = 0.0f;
+      eq_noise_vars[i] = INFINITY;
+      const float d_pinv = tx_scaling * ch_mod_sq;
+      if (orc_isnormal_f(d_pinv) && nv_ok) {
+        const float rcp      = 1.0f / d_pinv;
+        eq_symbols[2 * i]     = re * rcp;
+        eq_symbols[2 * i + 1] = im * rcp;
+        eq_noise_vars[i]      = rcp * (noise_var / tx_scaling);
+      }
+    }
+    return 0;
+  }
+  if (nof_tx_layers == 2 && nof_rx_ports == 2) { /* equalize_zf_2x2.cpp:56-116 */
+    const size_t n = nof_re;
+    for (unsigned i = 0; i != nof_re; ++i) {
+      const float *a = ch_estimates + 2 * i, *c = ch_estimates + 2 * (n + i);           /* layer 0: port 0, port 1 */
+      const float *b = ch_estimates + 2 * (2 * n + i), *d = ch_estimates + 2 * (3 * n + i); /* layer 1: port 0, port 1 */
+      const float *r0 = ch_symbols + 2 * i, *r1 = ch_symbols + 2 * (n + i);
+      const float n0 = (a[0] * a[0] + a[1] * a[1]) + (c[0] * c[0] + c[1] * c[1]);
+      const float n1 = (b[0] * b[0] + b[1] * b[1]) + (d[0] * d[0] + d[1] * d[1]);
+      /* xi = conj(a) b + conj(c) d */
+      const float xr = (a[0] * b[0] - (-a[1]) * b[1]) + (c[0] * d[0] - (-c[1]) * d[1]);
+      const float xi = (a[0] * b[1] + (-a[1]) * b[0]) + (c[0] * d[1] + (-c[1]) * d[0]);
+      const float xm = xr * xr + xi * xi;
+      const float m0r = (a[0] * r0[0] - (-a[1]) * r0[1]) + (c[0] * r1[0] - (-c[1]) * r1[1]);
+      const float m0i = (a[0] * r0[1] + (-a[1]) * r0[0]) + (c[0] * r1[1] + (-c[1]) * r1[0]);
+      const float m1r = (b[0] * r0[0] - (-b[1]) * r0[1]) + (d[0] * r1[0] - (-d[1]) * r1[1]);
+      const float m1i = (b[0] * r0[1] + (-b[1]) * r0[0]) + (d[0] * r1[1] + (-d[1]) * r1[0]);
+      const float d_pinv  = tx_scaling * ((n0 * n1) - xm);
+      const float d_nvars = tx_scaling * d_pinv;
+      float*      o0 = eq_symbols + 2 * i;
+      float*      o1 = eq_symbols + 2 * (n + i);
+      o0[0] = o0[1] = o1[0] = o1[1] = 0.0f;
+      eq_noise_vars[i] = eq_noise_vars[n + i] = INFINITY;
+      if (orc_isnormal_f(d_pinv) && nv_ok) {
+        const float rp = 1.0f / d_pinv, rn = 1.0f / d_nvars;
+        o0[0] = (n1 * m0r - (xr * m1r - xi * m1i)) * rp;
+        o0[1] = (n1 * m0i - (xr * m1i + xi * m1r)) * rp;
+        o1[0] = (n0 * m1r - (xr * m0r - (-xi) * m0i)) * rp; /* conj(xi) * m0 */
+        o1[1] = (n0 * m1i - (xr * m0i + (-xi) * m0r)) * rp;
+        eq_noise_vars[i]     = noise_var * n1 * rn;
+        eq_noise_vars[n + i] = noise_var * n0 * rn;
+      }
+    }
+    return 0;
+  }
+  return -1;
+}

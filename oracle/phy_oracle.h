@@ -157,6 +157,13 @@ int orc_pusch_demodulate(unsigned rnti, unsigned n_id, int mod, unsigned start_s
                          unsigned nof_rx_ports, const float* grid, const float* ce, unsigned ce_nof_symbols, float noise_var, int8_t* llr_out,
                          float* eq_out, float* nvar_out);
 
+/* Zero-forcing equalizer on its own (channel_equalizer_zf_impl.cpp:123-162): one layer on 1..4 ports (equalize_zf_1xn.h:120-158, the
+ * scalar path with the exact reciprocal) or two layers on two ports (equalize_zf_2x2.cpp:30-117). Layouts of the reference's tensors:
+ * ch_symbols [port][nof_re], ch_estimates [layer][port][nof_re], eq_symbols / eq_noise_vars [layer][nof_re]; cf_t as float pairs.
+ * Returns 0, or -1 for a topology the reference asserts on. */
+int orc_channel_equalize(unsigned nof_re, unsigned nof_rx_ports, unsigned nof_tx_layers, const float* ch_symbols, const float* ch_estimates,
+                         float noise_var, float tx_scaling, float* eq_symbols, float* eq_noise_vars);
+
 /* ------------------------------------------------------------------------------------------------ PDSCH modulator + DM-RS
  * Modulation mapper: bits one per byte -> cf_t symbols (mod 1 = pi/2-BPSK, 2, 4, 6, 8). */
 void orc_modulate(int mod, unsigned nsym, const uint8_t* bits, float* symbols);

@@ -1558,6 +1558,25 @@ double ref_pusch_decoder_bench(unsigned      nthreads,
   return now_s() - t0;
 }
 
+// ---------------------------------------------------------------- channel equalizer on its own
+// create_channel_equalizer_factory_zf()->create()->equalize() on tensors of the reference's own types.
+int ref_channel_equalize(unsigned nof_re, unsigned nof_rx_ports, unsigned nof_tx_layers, const float* ch_symbols, const float* ch_estimates, float noise_var,
+                         float tx_scaling, float* eq_symbols, float* eq_noise_vars)
+{
+  auto                                                                    eq = create_channel_equalizer_factory_zf()->create();
+  dynamic_tensor<2, cf_t, channel_equalizer::re_list::dims>                y({nof_re, nof_rx_ports}), z({nof_re, nof_tx_layers});
+  dynamic_tensor<2, float, channel_equalizer::re_list::dims>        nv({nof_re, nof_tx_layers});
+  dynamic_tensor<3, cf_t, channel_equalizer::ch_est_list::dims>            h({nof_re, nof_rx_ports, nof_tx_layers});
+  span<cf_t>                                                               yv = y.get_data(), hv = h.get_data();
+  std::memcpy(yv.data(), ch_symbols, sizeof(cf_t) * yv.size());
+  std::memcpy(hv.data(), ch_estimates, sizeof(cf_t) * hv.size());
+  std::vector<float> nvars(nof_rx_ports, noise_var);
+  eq->equalize(z, nv, y, h, nvars, tx_scaling);
+  std::memcpy(eq_symbols, z.get_data().data(), sizeof(cf_t) * z.get_data().size());
+  std::memcpy(eq_noise_vars, nv.get_data().data(), sizeof(float) * nv.get_data().size());
+  return 0;
+}
+
 // ---------------------------------------------------------------- UL-SCH demultiplexer (UCI on PUSCH)
 // ulsch_demultiplex_impl through its factory: demultiplex() and get_placeholders(). Stream lengths: n_sch / G_ack / G_csi1 / G_csi2 LLRs.
 int ref_ulsch_demultiplex(int mod, unsigned nof_layers, unsigned nof_prb, unsigned start_symbol, unsigned nof_symbols, unsigned G_rvd, int dmrs_type2,

@@ -24,6 +24,7 @@
 #include "srsran/phy/support/resource_grid_context.h"
 #include "srsran/phy/upper/channel_processors/channel_processor_factories.h"
 #include "srsran/phy/upper/downlink_processor.h"
+#include "srsran/phy/upper/equalization/equalization_factories.h"
 #include "srsran/phy/upper/resource_grid_mapper.h"
 #include "srsran/phy/upper/upper_phy_rg_gateway.h"
 #include "srsran/ran/csi_rs/csi_rs_pattern.h"
@@ -2703,6 +2704,71 @@ private:
 inline std::shared_ptr<srsran::port_channel_estimator_factory> create_port_channel_estimator_factory_hip(std::shared_ptr<context> c)
 {
   return std::make_shared<port_channel_estimator_factory_hip>(std::move(c));
+}
+
+// ---------------------------------------------------------------------------------------------------------------- channel equalizer
+/// srsran::channel_equalizer over miphy_channel_equalize_batch (channel_equalizer.h:93-100, channel_equalizer_zf_impl.cpp:123-162):
+/// one transmit layer on up to four ports or two layers on two ports. Inside pusch_processor_hip the one-layer case runs fused with
+/// the soft demapper; this class is the block for whoever builds a demodulator of their own around the reference interfaces.
+class channel_equalizer_hip : public srsran::channel_equalizer
+{
+public:
+  explicit channel_equalizer_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  void equalize(re_list&                 eq_symbols,
+                noise_var_list&          eq_noise_vars,
+                const re_list&           ch_symbols,
+                const ch_est_list&       ch_estimates,
+                srsran::span<const float> noise_var_estimates,
+                float                    tx_scaling) override
+  {
+    const unsigned nre = ch_symbols.get_dimension_size(re_list::dims::re);
+    const unsigned npt = ch_estimates.get_dimension_size(ch_est_list::dims::rx_port);
+    const unsigned nl  = ch_estimates.get_dimension_size(ch_est_list::dims::tx_layer);
+    // the checks of channel_equalizer_zf_impl.cpp:27-90
+    require(ch_symbols.get_dimension_size(re_list::dims::slice) == npt, "Number of Rx ports does not match: ch_symbols vs ch_estimates.");
+    require(ch_estimates.get_dimension_size(ch_est_list::dims::re) == nre, "Number of channel estimates does not match the number of Rx symbols.");
+    require(eq_symbols.get_dimension_size(re_list::dims::re) == nre && eq_symbols.get_dimension_size(re_list::dims::slice) == nl,
+            "Equalized symbols do not match the channel dimensions.");
+    require(eq_noise_vars.get_dimension_size(re_list::dims::re) == nre && eq_noise_vars.get_dimension_size(re_list::dims::slice) == nl,
+            "Post-equalization noise variances do not match the channel dimensions.");
+    require(noise_var_estimates.size() == npt, "Number of noise variance estimates does not match the number of Rx ports.");
+    require(tx_scaling > 0, "Tx scaling factor must be positive.");
+    require((nl == 1 && npt >= 1 && npt <= 4) || (nl == 2 && npt == 2), "Invalid channel spatial topology.");
+    if (nre == 0) {
+      return;
+    }
+    miphy_equalizer_job j = {};
+    j.nof_re = nre, j.nof_rx_ports = static_cast<uint8_t>(npt), j.nof_tx_layers = static_cast<uint8_t>(nl);
+    j.noise_var = noise_var_estimates[0], j.tx_scaling = tx_scaling;
+    const size_t ny = static_cast<size_t>(npt) * nre, nh = ny * nl, nz = static_cast<size_t>(nl) * nre;
+    auto*        d_y = static_cast<float*>(c->buf(0, ny * sizeof(srsran::cf_t)));
+    auto*        d_h = static_cast<float*>(c->buf(1, nh * sizeof(srsran::cf_t)));
+    auto*        d_z = static_cast<float*>(c->buf(2, nz * sizeof(srsran::cf_t)));
+    auto*        d_v = static_cast<float*>(c->buf(3, nz * sizeof(float)));
+    c->h2d(d_y, ch_symbols.get_view<2>({}).data(), ny * sizeof(srsran::cf_t));
+    c->h2d(d_h, ch_estimates.get_view<3>({}).data(), nh * sizeof(srsran::cf_t));
+    context::check(miphy_channel_equalize_batch(c->ctx, &j, 0, 1, d_y, d_h, d_z, d_v, c->stream), "channel_equalize");
+    c->d2h(eq_symbols.get_view<2>({}).data(), d_z, nz * sizeof(srsran::cf_t));
+    c->d2h(eq_noise_vars.get_view<2>({}).data(), d_v, nz * sizeof(float));
+    c->sync();
+  }
+
+private:
+  std::shared_ptr<context> c;
+};
+
+class channel_equalizer_factory_hip : public srsran::channel_equalizer_factory
+{
+public:
+  explicit channel_equalizer_factory_hip(std::shared_ptr<context> c) : c(std::move(c)) {}
+  std::unique_ptr<srsran::channel_equalizer> create() override { return std::make_unique<channel_equalizer_hip>(c); }
+
+private:
+  std::shared_ptr<context> c;
+};
+inline std::shared_ptr<srsran::channel_equalizer_factory> create_channel_equalizer_factory_hip(std::shared_ptr<context> c)
+{
+  return std::make_shared<channel_equalizer_factory_hip>(std::move(c));
 }
 
 // ---------------------------------------------------------------------------------------------------------------- PDU validators

@@ -94,6 +94,7 @@ def lib():
         l.miphy_ulsch_demux_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_ulsch_placeholders.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         l.miphy_ulsch_demultiplex_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        l.miphy_channel_equalize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32] + [C.c_void_p] * 5
         l.miphy_polar_block_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         for name in ("miphy_ofdm_demodulate_symbols", "miphy_ofdm_modulate_symbols"):
             getattr(l, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -313,6 +314,12 @@ def ulsch_placeholders(job):
     return out[:n.value].copy()
 
 
+# Mirrors miphy_equalizer_job.
+EqualizerJob = np.dtype([("nof_re", np.uint32), ("nof_rx_ports", np.uint8), ("nof_tx_layers", np.uint8), ("reserved", np.uint8, 2), ("noise_var", np.float32),
+                         ("tx_scaling", np.float32), ("ch_symbols_offset", np.uint64), ("ch_estimates_offset", np.uint64), ("eq_symbols_offset", np.uint64),
+                         ("eq_noise_vars_offset", np.uint64)], align=True)
+assert EqualizerJob.itemsize == 48, EqualizerJob.itemsize
+
 # Mirrors miphy_crc_desc.
 CrcDesc = np.dtype([("bit_offset", np.uint64), ("nbits", np.uint32), ("poly", np.uint32)], align=True)
 assert CrcDesc.itemsize == 16
@@ -506,6 +513,12 @@ class Context:
         jobs = np.ascontiguousarray(jobs)
         check(lib().miphy_ulsch_demultiplex_batch(self.h, C.c_void_p(jobs.ctypes.data), jobs.size, _dptr(llr_in), _dptr(sch), _dptr(harq_ack),
                                                   _dptr(csi1), _dptr(csi2), _stream_ptr(stream)))
+
+    def channel_equalize_batch(self, jobs, ch_symbols, ch_estimates, eq_symbols, eq_noise_vars, stream=None):
+        """channel_equalizer::equalize (zero forcing) for a batch of EqualizerJob records."""
+        jobs, n, ptr, on_dev = self._descs(jobs, EqualizerJob)
+        check(lib().miphy_channel_equalize_batch(self.h, ptr, on_dev, n, _dptr(ch_symbols), _dptr(ch_estimates), _dptr(eq_symbols), _dptr(eq_noise_vars),
+                                                 _stream_ptr(stream)))
 
     def polar_block_batch(self, code, op, param, n, x, out, stream=None):
         check(lib().miphy_polar_block_batch(self.h, C.byref(code) if code is not None else None, op, param, n, _dptr(x), _dptr(out), _stream_ptr(stream)))

@@ -938,3 +938,36 @@ def ulsch_cases(rng, n):
             continue
         out.append(case)
     return out
+
+
+# ---------------------------------------------------------------------------------------------- zero-forcing equalizer on its own
+def _equalize(fn, ch_symbols, ch_estimates, noise_var, tx_scaling):
+    """ch_symbols complex64 [ports][nof_re]; ch_estimates complex64 [layers][ports][nof_re] -> (eq complex64 [layers][nof_re], noise vars)."""
+    y = np.ascontiguousarray(ch_symbols, dtype=np.complex64)
+    h = np.ascontiguousarray(ch_estimates, dtype=np.complex64)
+    nl, npt, nre = h.shape
+    assert y.shape == (npt, nre)
+    z = np.zeros((nl, nre), np.complex64)
+    nv = np.zeros((nl, nre), np.float32)
+    rc = fn(C.c_uint(nre), C.c_uint(npt), C.c_uint(nl), _p(y), _p(h), C.c_float(noise_var), C.c_float(tx_scaling), _p(z), _p(nv))
+    return (z, nv) if rc == 0 else None
+
+
+def o_channel_equalize(ch_symbols, ch_estimates, noise_var, tx_scaling):
+    return _equalize(oracle().orc_channel_equalize, ch_symbols, ch_estimates, noise_var, tx_scaling)
+
+
+def r_channel_equalize(ch_symbols, ch_estimates, noise_var, tx_scaling):
+    return _equalize(ref().ref_channel_equalize, ch_symbols, ch_estimates, noise_var, tx_scaling)
+
+
+def equalizer_case(rng, nre, npt, nl, snr_db=20.0, dead=()):
+    """A random flat-ish channel, QAM-like symbols through it plus noise; `dead` lists resource elements whose estimates are zeroed."""
+    h = (rng.standard_normal((nl, npt, nre)) + 1j * rng.standard_normal((nl, npt, nre))).astype(np.complex64) * np.float32(0.7)
+    x = (rng.integers(0, 4, (nl, nre)) * 2 - 3 + 1j * (rng.integers(0, 4, (nl, nre)) * 2 - 3)).astype(np.complex64) / np.float32(np.sqrt(10))
+    nvar = float(10 ** (-snr_db / 10))
+    y = np.einsum("lpr,lr->pr", h, x).astype(np.complex64)
+    y = y + (np.sqrt(nvar / 2) * (rng.standard_normal((npt, nre)) + 1j * rng.standard_normal((npt, nre)))).astype(np.complex64)
+    for i in dead:
+        h[:, :, i] = 0
+    return y.astype(np.complex64), h, nvar, x

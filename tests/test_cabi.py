@@ -80,6 +80,7 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(miphy_pusch_pdu), sizeof(miphy_pdsch_pdu), sizeof(miphy_harq_pool_config), sizeof(miphy_harq_buffer_info));
   printf("%zu %zu\n", sizeof(miphy_ofh_iq_job), sizeof(miphy_pdcch_pdu));
   printf("%zu %zu\n", sizeof(miphy_ssb_pdu), sizeof(miphy_csi_rs_job));
+  printf("%zu %zu %zu\n", sizeof(miphy_ulsch_demux_job), sizeof(miphy_pusch_uci), sizeof(miphy_equalizer_job));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -93,7 +94,8 @@ int main(void) {
             miphy.PuschTbDesc.itemsize, miphy.PuschResult.itemsize, miphy.PdschTbDesc.itemsize, ctypes.sizeof(miphy.binding.SchSegmentation),
             miphy.PuschDemodJob.itemsize, miphy.RePattern.itemsize, miphy.PdschModJob.itemsize, miphy.DmrsPdschJob.itemsize,
             miphy.PuschPdu.itemsize, miphy.PdschPdu.itemsize, ctypes.sizeof(miphy.HarqPoolConfig), ctypes.sizeof(miphy.HarqBufferInfo),
-            miphy.OfhIqJob.itemsize, miphy.PdcchPdu.itemsize, miphy.SsbPdu.itemsize, miphy.CsiRsJob.itemsize]
+            miphy.OfhIqJob.itemsize, miphy.PdcchPdu.itemsize, miphy.SsbPdu.itemsize, miphy.CsiRsJob.itemsize,
+            miphy.UlschDemuxJob.itemsize, miphy.PuschUci.itemsize, miphy.EqualizerJob.itemsize]
     assert sizes == mine, (sizes, mine)
 
 

@@ -1,0 +1,100 @@
+"""GPU: miphy_channel_equalize_batch (the zero-forcing equalizer as a block of its own, channel_equalizer_zf_impl.cpp:123-162)
+through the C-ABI against the oracle -- bit-exact single precision -- and against the reference-produced fixture
+tests/golden/channel_equalizer.npz within the tolerance stated in tests/test_oracle_golden.py (approximate reciprocal of the
+reference's AVX2 path / contraction in its build)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "channel_equalizer.npz")
+
+
+def run_batch(ctx, cases):
+    """cases: list of (y [ports][nre], h [layers][ports][nre], noise_var, tx_scaling). Returns [(z, nv)] from ONE launch."""
+    import torch
+    import miphy
+    jobs = np.zeros(len(cases), dtype=miphy.EqualizerJob)
+    oy = oh = oz = 0
+    for i, (y, h, nvar, txs) in enumerate(cases):
+        nl, npt, nre = h.shape
+        jobs[i]["nof_re"], jobs[i]["nof_rx_ports"], jobs[i]["nof_tx_layers"] = nre, npt, nl
+        jobs[i]["noise_var"], jobs[i]["tx_scaling"] = nvar, txs
+        jobs[i]["ch_symbols_offset"], jobs[i]["ch_estimates_offset"], jobs[i]["eq_symbols_offset"], jobs[i]["eq_noise_vars_offset"] = oy, oh, oz, oz
+        oy, oh, oz = oy + npt * nre, oh + nl * npt * nre, oz + nl * nre
+    yd = torch.from_numpy(np.concatenate([c[0].reshape(-1) for c in cases]).view(np.float32)).cuda()
+    hd = torch.from_numpy(np.concatenate([c[1].reshape(-1) for c in cases]).view(np.float32)).cuda()
+    zd = torch.full((2 * oz,), 7.0, dtype=torch.float32, device="cuda")
+    vd = torch.full((oz,), 7.0, dtype=torch.float32, device="cuda")
+    ctx.channel_equalize_batch(jobs, yd, hd, zd, vd)
+    torch.cuda.synchronize()
+    z, v = zd.cpu().numpy().view(np.complex64), vd.cpu().numpy()
+    out = []
+    for i, (y, h, _, _) in enumerate(cases):
+        nl, _, nre = h.shape
+        o = int(jobs[i]["eq_symbols_offset"])
+        out.append((z[o:o + nl * nre].reshape(nl, nre), v[o:o + nl * nre].reshape(nl, nre)))
+    return out
+
+
+def test_equalizer_matches_oracle_bit_exact():
+    import miphy
+    ctx = miphy.Context(0)
+    rng = np.random.default_rng(99)
+    cases = []
+    for npt, nl, nre in ((1, 1, 1), (1, 1, 1023), (2, 1, 1024), (3, 1, 1025), (4, 1, 3276 * 13), (2, 2, 5), (2, 2, 3276 * 14), (2, 2, 2049)):
+        y, h, nvar, _ = O.equalizer_case(rng, nre, npt, nl, snr_db=float(rng.uniform(-3, 30)), dead=(0, nre // 2))
+        cases.append((y, h, nvar, float(rng.choice([1.0, 0.5, 1.4142]))))
+    # abnormal parameters: zero / negative / infinite noise variance, infinite and NaN estimates
+    y, h, nvar, _ = O.equalizer_case(rng, 200, 2, 1)
+    cases += [(y, h, 0.0, 1.0), (y, h, -0.5, 1.0), (y, h, float("inf"), 1.0)]
+    y, h, nvar, _ = O.equalizer_case(rng, 200, 2, 2)
+    h = h.copy()
+    h[0, 0, 7] = np.inf
+    h[1, 1, 9] = np.nan
+    cases += [(y, h, nvar, 1.0), (y, h, 0.0, 1.0)]
+    got = run_batch(ctx, cases)
+    for i, ((y, h, nvar, txs), (z, nv)) in enumerate(zip(cases, got)):
+        ez, env = O.o_channel_equalize(y, h, nvar, txs)
+        assert np.array_equal(z.view(np.uint32), ez.view(np.uint32)), "case %d: equalised symbols differ from the oracle" % i
+        assert np.array_equal(nv.view(np.uint32), env.view(np.uint32)), "case %d: noise variances differ from the oracle" % i
+    ctx.close()
+
+
+def test_equalizer_against_reference_fixture():
+    import miphy
+    ctx = miphy.Context(0)
+    d = np.load(GOLD)
+    cases = [(d["y_%d" % i], d["h_%d" % i], float(d["meta_%d" % i][0]), float(d["meta_%d" % i][1])) for i in range(int(d["n"]))]
+    got = run_batch(ctx, cases)
+    for i, ((y, h, nvar, txs), (z, nv)) in enumerate(zip(cases, got)):
+        zr, nvr = d["z_%d" % i], d["nv_%d" % i]
+        assert np.array_equal(np.isinf(nv), np.isinf(nvr)) and np.all(z[np.isinf(nv)] == 0)
+        fin = ~np.isinf(nv)
+        if h.shape[0] == 1:
+            assert np.all(np.abs(z[fin] - zr[fin]) <= 4e-4 * np.abs(zr[fin]) + 1e-7)
+            assert np.all(np.abs(nv[fin] - nvr[fin]) <= 4e-4 * nvr[fin])
+        else:
+            n0, n1 = (np.abs(h[0]) ** 2).sum(0), (np.abs(h[1]) ** 2).sum(0)
+            tol = 2e-6 * (n0 * n1) / np.maximum(n0 * n1 - np.abs((h[0].conj() * h[1]).sum(0)) ** 2, 1e-30)
+            for l in range(2):
+                f = fin[l]
+                assert np.all(np.abs(z[l][f] - zr[l][f]) <= tol[f] * (np.abs(zr[l][f]) + 1.0))
+                assert np.all(np.abs(nv[l][f] - nvr[l][f]) <= tol[f] * nvr[l][f])
+    ctx.close()
+
+
+def test_equalizer_rejects_what_the_reference_asserts():
+    import torch
+    import miphy
+    ctx = miphy.Context(0)
+    t = torch.zeros(64, dtype=torch.float32, device="cuda")
+    for npt, nl, txs in ((3, 2, 1.0), (2, 3, 1.0), (5, 1, 1.0), (2, 1, 0.0)):
+        j = np.zeros(1, dtype=miphy.EqualizerJob)
+        j[0]["nof_re"], j[0]["nof_rx_ports"], j[0]["nof_tx_layers"], j[0]["noise_var"], j[0]["tx_scaling"] = 2, npt, nl, 0.1, txs
+        with pytest.raises(RuntimeError):
+            ctx.channel_equalize_batch(j, t, t, t, t)
+    ctx.close()

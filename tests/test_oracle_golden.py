@@ -168,6 +168,35 @@ def test_pusch_demodulator():
         assert ((got < 0).astype(np.uint8)[nz] == bits[nz]).mean() > (0.999 if mod <= 4 else 0.9)  # 64/256QAM: the stimulus noise flips some LSBs
 
 
+def test_channel_equalizer():
+    """Stand-alone zero-forcing equalizer against reference-produced outputs (create_channel_equalizer_factory_zf). Stated tolerance:
+    one layer -- the reference's AVX2 path divides with the approximate _mm256_rcp_ps (relative error <= 1.5 * 2^-12): 4e-4 relative;
+    two layers on two ports -- scalar code on both sides, the reference build may contract a*b+c into fused multiply-adds: 2e-5 of
+    the largest magnitude. Dead estimates give symbol 0 and noise variance +inf on both sides."""
+    d = load("channel_equalizer")
+    for i in range(int(d["n"])):
+        y, h, zr, nvr = d["y_%d" % i], d["h_%d" % i], d["z_%d" % i], d["nv_%d" % i]
+        nvar, txs = (float(v) for v in d["meta_%d" % i])
+        z, nv = O.o_channel_equalize(y, h, nvar, txs)
+        assert np.array_equal(np.isinf(nv), np.isinf(nvr)) and np.isinf(nv).sum() == 2 * h.shape[0]
+        assert np.all(z[np.isinf(nv)] == 0) and np.all(zr[np.isinf(nvr)] == 0)
+        fin = ~np.isinf(nv)
+        if h.shape[0] == 1:
+            assert np.all(np.abs(z[fin] - zr[fin]) <= 4e-4 * np.abs(zr[fin]) + 1e-7), i
+            assert np.all(np.abs(nv[fin] - nvr[fin]) <= 4e-4 * nvr[fin]), i
+        else:
+            # the 2 x 2 denominator n0 n1 - |xi|^2 cancels: compare in units of what went into the subtraction
+            n0 = (np.abs(h[0]) ** 2).sum(0)
+            n1 = (np.abs(h[1]) ** 2).sum(0)
+            cond = (n0 * n1) / np.maximum(n0 * n1 - np.abs((h[0].conj() * h[1]).sum(0)) ** 2, 1e-30)
+            tol = 2e-6 * cond
+            for l in range(2):
+                f = fin[l]
+                assert np.all(np.abs(z[l][f] - zr[l][f]) <= tol[f] * (np.abs(zr[l][f]) + 1.0)), i
+                assert np.all(np.abs(nv[l][f] - nvr[l][f]) <= tol[f] * nvr[l][f]), i
+    assert O.o_channel_equalize(np.zeros((3, 4), np.complex64), np.zeros((2, 3, 4), np.complex64), 0.1, 1.0) is None  # 2 layers on 3 ports
+
+
 def test_pdsch_modulator_and_dmrs():
     """Modulation mapper, PDSCH modulator (scrambling, mapping around DM-RS and reserved patterns, scaling incl. NaN = none) and PDSCH
     DM-RS mapping against reference-produced grids: bit-exact single-precision values."""

@@ -240,6 +240,42 @@ def test_pusch_demodulator_placeholders_and_evm():
             assert (o2 != o).sum() > 0 and set(np.nonzero(o2 != o)[0] // mod) <= set(int(x) for x in ph)
 
 
+def test_channel_equalizer_standalone():
+    """channel_equalizer_zf_impl through its factory vs the restatement. One layer: the scalar tail of the reference (the last
+    nof_re % 8 elements, equalize_zf_1xn.h:120-158) agrees to a few ulp (its build contracts a*b+c), the AVX2 body within the error
+    of _mm256_rcp_ps; two layers on two ports: scalar on both sides, differences only from contraction, scaled by the cancellation
+    of the determinant. Dead estimates and a zero / negative noise variance give (0, +inf) on both sides."""
+    rng = np.random.default_rng(4242)
+    for npt, nl, nre in ((1, 1, 13), (2, 1, 260), (3, 1, 47), (4, 1, 1000), (2, 2, 9), (2, 2, 777)):
+        for nvar_override in (None, 0.0, -1.0):
+            y, h, nvar, _ = O.equalizer_case(rng, nre, npt, nl, snr_db=float(rng.uniform(0, 30)), dead=(3,))
+            nvar = nvar if nvar_override is None else nvar_override
+            txs = float(rng.choice([1.0, 0.5, 1.4142]))
+            (z, nv), (zr, nvr) = O.o_channel_equalize(y, h, nvar, txs), O.r_channel_equalize(y, h, nvar, txs)
+            assert np.array_equal(np.isinf(nv), np.isinf(nvr))
+            if nvar_override is not None:
+                assert np.all(np.isinf(nv)) and np.all(z == 0) and np.all(zr == 0)
+                continue
+            assert np.isinf(nv[:, 3]).all() and np.all(z[:, 3] == 0) and np.all(zr[:, 3] == 0)
+            fin = ~np.isinf(nv)
+            if nl == 1:
+                tail = np.zeros(nre, bool)
+                tail[nre // 8 * 8:] = True
+                t = fin[0] & tail
+                assert np.all(np.abs(z[0][t] - zr[0][t]) <= 1e-6 * (np.abs(zr[0][t]) + 1.0))
+                assert np.all(np.abs(nv[0][t] - nvr[0][t]) <= 1e-6 * nvr[0][t])
+                assert np.all(np.abs(z[fin] - zr[fin]) <= 4e-4 * np.abs(zr[fin]) + 1e-6)
+                assert np.all(np.abs(nv[fin] - nvr[fin]) <= 4e-4 * nvr[fin])
+            else:
+                n0, n1 = (np.abs(h[0]) ** 2).sum(0), (np.abs(h[1]) ** 2).sum(0)
+                cond = (n0 * n1) / np.maximum(n0 * n1 - np.abs((h[0].conj() * h[1]).sum(0)) ** 2, 1e-30)
+                tol = 2e-6 * cond
+                for l in range(2):
+                    f = fin[l]
+                    assert np.all(np.abs(z[l][f] - zr[l][f]) <= tol[f] * (np.abs(zr[l][f]) + 1.0))
+                    assert np.all(np.abs(nv[l][f] - nvr[l][f]) <= tol[f] * nvr[l][f])
+
+
 def test_pdsch_modulator_and_dmrs():
     """Modulation mapper, pdsch_modulator_impl (one layer, contiguous allocation: what 23.5 can do) and dmrs_pdsch_processor_impl
     against the oracle: bit-exact single-precision grids."""
