@@ -390,7 +390,8 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
                              int                          force_scalar,
                              const miphy_ldpc_rdm_desc*   fuse_rdm,
                              const int8_t*                fuse_in,
-                             const miphy_ldpc_rdm_limits* fuse_rlim)
+                             const miphy_ldpc_rdm_limits* fuse_rlim,
+                             int                          bg_mask)
 {
   MIPHY_REQUIRE(ctx && descs && llr && out_bits && iters, "ldpc_decode: null argument");
   if (n == 0)
@@ -424,8 +425,11 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
     }
   } else if (limits) {
     MIPHY_REQUIRE(limits->max_Z >= 2 && limits->max_Z <= MIPHY_MAX_Z, "ldpc_decode: limits: invalid max_Z");
-    account(1, limits->max_Z, limits->max_in_len); // the base graph of device descriptors is unknown: size for both
-    account(2, limits->max_Z, limits->max_in_len);
+    // the base graph of device descriptors is not visible here: size for those the caller names (bg_mask, default both)
+    if (bg_mask & 1)
+      account(1, limits->max_Z, limits->max_in_len);
+    if (bg_mask & 2)
+      account(2, limits->max_Z, limits->max_in_len);
   } else {
     account(1, MIPHY_MAX_Z, 66 * MIPHY_MAX_Z);
     account(2, MIPHY_MAX_Z, 50 * MIPHY_MAX_Z);

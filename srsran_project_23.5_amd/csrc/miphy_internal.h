@@ -93,7 +93,8 @@ int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t b
 int miphy_ldpc_decode_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* descs, int descs_on_device, uint32_t n, const int8_t* llr,
                              uint8_t* out_bits, int32_t* iters, const miphy_ldpc_dec_limits* limits, const uint32_t* harq_slot,
                              uint8_t* harq_crc_ok, void* stream, int force_scalar = 0, const miphy_ldpc_rdm_desc* fuse_rdm = nullptr,
-                             const int8_t* fuse_in = nullptr, const miphy_ldpc_rdm_limits* fuse_rlim = nullptr);
+                             const int8_t* fuse_in = nullptr, const miphy_ldpc_rdm_limits* fuse_rlim = nullptr,
+                             int bg_mask = 3 /* device descriptors: bit 0 / 1 = base graph 1 / 2 occurs */);
 
 // Returns a device scratch buffer of at least `bytes` (reallocated, after a stream sync, when it has to grow).
 int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out, int which = 0);

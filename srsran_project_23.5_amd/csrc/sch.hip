@@ -343,6 +343,7 @@ struct pusch_decode_build {
   std::vector<uint32_t>            cb_tb; // transport block of each codeblock
   uint32_t                         max_Z = 2, max_nodes = 0, max_E = 0;
   bool                             any_odd_Z = false; // the packed decoder pairs rows l and l + Z/2
+  int                              bg_mask   = 0;     // bit 0 / 1: base graph 1 / 2 occurs (the decoder sizes its LDS per base graph)
   bool                             fusable   = true;  // every codeblock can be rate-dematched by the decoder while it loads
 };
 
@@ -423,6 +424,7 @@ int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_
       b.fusable &= d.new_data && d.rv == 0 && !(d.Nref > 0 && d.Nref < sg.N) && E + sg.nof_filler_bits <= sg.N &&
                    E >= (bgK - 2) * sg.Z - sg.nof_filler_bits && (sg.Z % 16) == 0;
       b.any_odd_Z |= (sg.Z & 1u) != 0;
+      b.bg_mask |= 1 << (d.bg - 1);
       q.flags           = d.use_early_stop ? 0u : 1u;
       q.llr_offset = (uint64_t)slot * HARQ_CB_STRIDE, q.out_offset = (uint64_t)slot * HARQ_MSG_STRIDE;
       b.dec.push_back(q);
@@ -497,7 +499,7 @@ int launch_pusch_decode(miphy_ctx* ctx, const pusch_decode_build& b, const pusch
     if (ev)
       MIPHY_HIP_CHECK(hipEventRecord(ev[1], s));
     if ((rc = miphy_ldpc_decode_launch(ctx, v.dec + c0, 1, c1 - c0, harq_softbits, harq_msgs, v.iters + c0, &lim, v.slots + c0, harq_crc_ok, s,
-                                       b.any_odd_Z ? 1 : 0, b.fusable ? v.rdm + c0 : nullptr, b.fusable ? llrs : nullptr, &rlim)))
+                                       b.any_odd_Z ? 1 : 0, b.fusable ? v.rdm + c0 : nullptr, b.fusable ? llrs : nullptr, &rlim, b.bg_mask)))
       return rc;
     t0 = t1;
   }
