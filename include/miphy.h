@@ -275,7 +275,8 @@ typedef struct {
   uint64_t rb_mask2[5];    /* layer_dmrs_pattern::rb_mask2: allocation of the second hop (used when hop_symbol != 0) */
   uint64_t pilots_offset;  /* cf_t offset into `pilots` of miphy_port_channel_estimate_batch: dmrs_symbol_list
                               [layer][DM-RS symbol][pilot of the allocated PRBs]; ignored by miphy_dmrs_pusch_estimate_batch */
-  uint8_t  hop_symbol;     /* layer_dmrs_pattern::hopping_symbol_index: first OFDM symbol of the second hop, 0 = no hopping */
+  uint8_t  hop_symbol;     /* layer_dmrs_pattern::hopping_symbol_index: first OFDM symbol of the second hop, 0 = no hopping;
+                              honoured by miphy_port_channel_estimate_batch only (the reference's PUSCH estimator never hops) */
   uint8_t  re_odd_mask;    /* with external pilots: bit ly = layer ly has its DM-RS on the odd subcarriers (layer_dmrs_pattern::re_pattern of
                               DM-RS type 1); the PUSCH estimator derives it from the layer number instead */
   uint8_t  reserved2[6];

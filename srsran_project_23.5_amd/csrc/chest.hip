@@ -71,14 +71,18 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid)
 }
 
 
+// GENERAL = false: the PUSCH DM-RS estimator proper (pilots generated from the job, one hop: dmrs_pusch_estimator_impl.cpp never
+// configures hopping); true: pilots from the caller and intra-slot frequency hopping (the port estimator on its own).
+template <bool GENERAL>
 __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job* __restrict__ jobs,
                                                     const gold_jump* __restrict__ gj,
                                                     const cplx* __restrict__ tw,
                                                     const float2* __restrict__ grid,
                                                     float2* __restrict__ ce_out,
                                                     float* __restrict__ scalars,
-                                                    const float2* __restrict__ ext_pilots) // nullptr: pilots generated from the job (PUSCH DM-RS)
+                                                    const float2* __restrict__ ext_pilots_arg)
 {
+  const float2* ext_pilots = GENERAL ? ext_pilots_arg : nullptr;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cplx*     fbuf   = reinterpret_cast<cplx*>(smem);                  // 4096 cplx: IDFT buffer, later interpolated response
   cplx*     lse    = fbuf + fft_lds_bytes(CE_DFT) / 8;                // MAX_PILOTS
@@ -99,7 +103,7 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
     return;
   const int nprb_grid = job.grid_nof_prb, nsc = nprb_grid * 12;
   const int first = job.first_symbol, nsymb_out = first + job.nof_symbols;
-  const int hop_symbol = (job.hop_symbol > first && job.hop_symbol < nsymb_out) ? job.hop_symbol : 0;
+  const int hop_symbol = (GENERAL && job.hop_symbol > first && job.hop_symbol < nsymb_out) ? job.hop_symbol : 0;
   const int nhops      = hop_symbol ? 2 : 1;
   // DM-RS symbols of the whole allocation (the pilots of the second hop follow those of the first in an external pilot list)
   int nds_all = 0;
@@ -346,6 +350,7 @@ static int chest_launch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int j
       for (unsigned r = 0; r < j.grid_nof_prb; ++r)
         nprb += (unsigned)((j.rb_mask[r >> 6] >> (r & 63)) & 1ull);
       MIPHY_REQUIRE(nds >= 1 && nds <= 4, "pusch_chest: job %u: %u DM-RS symbols (1..4 supported)", i, nds);
+      MIPHY_REQUIRE(pilots || j.hop_symbol == 0, "pusch_chest: job %u: intra-slot frequency hopping is served by miphy_port_channel_estimate_batch", i);
       if (j.hop_symbol != 0) { // intra-slot frequency hopping (port_channel_estimator_average_impl.cpp:118-124,153-163)
         MIPHY_REQUIRE(j.hop_symbol > j.first_symbol && j.hop_symbol < j.first_symbol + j.nof_symbols, "pusch_chest: job %u: hop symbol outside the allocation", i);
         MIPHY_REQUIRE(!j.ce_compact, "pusch_chest: job %u: the compact estimate holds one hop only", i);
@@ -379,9 +384,12 @@ static int chest_launch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int j
   // One workgroup of 512 threads per (job, port, layer). (Splitting the broadcast store over symbol groups -- gridDim.z -- was
   // measured and does not pay once the per-workgroup prologue is parallel; 256 threads are slower for the 4096-point IDFT.)
   const int ngrp = 1, cthreads = 512;
-  hipLaunchKernelGGL(chest_kernel, dim3(n, 4 * max_layers, ngrp), dim3(cthreads), lds, s, (const miphy_pusch_chest_job*)d_jobs,
-                     (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw,
-                     (const float2*)grid, (float2*)ce, scalars, (const float2*)pilots);
+  if (pilots)
+    hipLaunchKernelGGL(chest_kernel<true>, dim3(n, 4 * max_layers, ngrp), dim3(cthreads), lds, s, (const miphy_pusch_chest_job*)d_jobs,
+                       (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw, (const float2*)grid, (float2*)ce, scalars, (const float2*)pilots);
+  else
+    hipLaunchKernelGGL(chest_kernel<false>, dim3(n, 4 * max_layers, ngrp), dim3(cthreads), lds, s, (const miphy_pusch_chest_job*)d_jobs,
+                       (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw, (const float2*)grid, (float2*)ce, scalars, (const float2*)nullptr);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

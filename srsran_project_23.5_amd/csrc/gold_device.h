@@ -56,10 +56,12 @@ __device__ __forceinline__ void lfsr_head(uint32_t s, bool is_x2, int head, uint
 // Jump-ahead: the 31-bit window s (bit i = x(n+i)) advances by one position through a linear map M; pow[k] holds the columns
 // of M^(2^k), so any offset costs one matrix-vector product (31 conditional XORs) per set bit of the offset.
 constexpr int GOLD_POW = 26; // offsets below 2^26
+constexpr int GOLD_X1_WORDS = 11584; // x1 of c(0 .. 370687): the longest PUSCH codeword (275 PRB x 12 x 14 symbols x 8 bits) and a window word
 struct gold_tables {
   gold_jump j; // state after the Nc = 1600 warm-up (first member: the estimator only needs this part)
   uint32_t  x1_pow[GOLD_POW][31];
   uint32_t  x2_pow[GOLD_POW][31];
+  uint32_t  x1_seq[GOLD_X1_WORDS]; // x1 does not depend on c_init: its contribution to c(n), bit-packed LSB first from n = 0
 };
 
 __host__ __device__ inline uint32_t gold_mat_apply(const uint32_t* cols, uint32_t v)
@@ -83,6 +85,40 @@ inline void gold_tables_init(gold_tables& t)
       t.x1_pow[k][i] = gold_mat_apply(t.x1_pow[k - 1], t.x1_pow[k - 1][i]);
       t.x2_pow[k][i] = gold_mat_apply(t.x2_pow[k - 1], t.x2_pow[k - 1][i]);
     }
+  uint32_t s1 = t.j.x1_1600; // bit i = x1(1600 + n + i)
+  for (int wd = 0; wd < GOLD_X1_WORDS; ++wd) {
+    uint32_t v = 0;
+    for (int b = 0; b < 32; ++b) {
+      v |= (s1 & 1u) << b;
+      s1 = (s1 >> 1) | ((((s1 >> 3) ^ s1) & 1u) << 30);
+    }
+    t.x1_seq[wd] = v;
+  }
+}
+
+// The x2 half of c(0 .. 32 nwords - 1) in LDS, by a whole workgroup (nt >= 64 threads, a multiple of 64): thread 0 produces the 31-word
+// head 28 bits per step; then the word recurrence w[i] = w[i-28] ^ w[i-29] ^ w[i-30] ^ w[i-31] (the bit recurrence raised to the 32nd
+// power) and its further squares w[i] = w[i-28d] ^ w[i-29d] ^ w[i-30d] ^ w[i-31d], d = 2^k, which need 31 d words of history and
+// yield 28 d independent words per step -- the history doubles until a step fills the workgroup.
+__device__ __forceinline__ void gold_x2_sequence(const gold_jump& j, uint32_t c_init, int nwords, uint32_t* w, int tid, int nt)
+{
+  if (tid == 0) {
+    uint32_t st = 0;
+    for (int k = 0; k < 31; ++k)
+      st ^= ((c_init >> k) & 1u) ? j.x2_col[k] : 0u;
+    lfsr_head(st, true, 31, w);
+  }
+  __syncthreads();
+  int have = 31, k = 0;
+  while (have < nwords) {
+    const int d = 1 << k, step = 28 * d, i = have + tid;
+    if (tid < step && i < nwords)
+      w[i] = w[i - 28 * d] ^ w[i - 29 * d] ^ w[i - 30 * d] ^ w[i - 31 * d];
+    __syncthreads();
+    have += step;
+    while ((56 << k) <= nt && (62 << k) <= have)
+      ++k;
+  }
 }
 
 // 31-bit windows of x1 / x2 at sequence position `offset` of c(n) (i.e. LFSR position 1600 + offset).

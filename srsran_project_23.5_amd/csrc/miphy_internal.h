@@ -53,9 +53,10 @@ struct miphy_ctx {
   void*                d_desc_staging;
   size_t               desc_staging_bytes;
   void*                h_desc_staging; // pinned
-  void*                d_work[4];      // scratch workspaces, grown on demand: [0] the transport-block level entry points, DFT, polar;
-  size_t               work_bytes[4];  // [1] intermediate buffers of miphy_pusch_process_batch, [2] codewords of miphy_pdsch_process_batch,
-                                       // [3] check-to-variable messages of the LDPC decoder when they do not stay in LDS
+  void*                d_work[5];      // scratch workspaces, grown on demand: [0] the transport-block level entry points, DFT, polar;
+  size_t               work_bytes[5];  // [1] intermediate buffers of miphy_pusch_process_batch, [2] codewords of miphy_pdsch_process_batch,
+                                       // [3] check-to-variable messages of the LDPC decoder when they do not stay in LDS,
+                                       // [4] scrambling sequences of the PUSCH demodulator
   int                  num_cus; // compute units of the device (persistent-kernel grid sizing)
   uint32_t*            d_queue; // work-queue counters of the persistent kernels: a ring of MIPHY_NOF_QUEUE_COUNTERS words, one per launch
   uint32_t             queue_next;

@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int MAX_SYM_WORDS = 832; // 275 PRB * 12 RE * 8 bit / 32 = 825 words (+ 1 guard word)
+constexpr int MAX_SYM_WORDS = 832; // 275 PRB * 12 RE * 8 bit / 32 = 825 words + the window word + one for a piece that starts inside a word
 
 // Quantisation of avx2_helpers.h:103-157: scale, clip to +-120, round to nearest even, NaN -> 0.
 __device__ __forceinline__ int demod_quantize(float v, float scale)
@@ -126,6 +126,60 @@ __device__ __forceinline__ void demod_symbol(float re, float im, float nvar, uns
 #undef Q
 }
 
+// The common case in one pass: finite symbol and noise (FAST above), no EVM, no placeholders, MOD >= 2. Descrambling is folded into
+// the quantisation scale (chip b set: scale -> -scale; clip and round-to-nearest-even are symmetric, so the LLR is negated exactly),
+// and rounding + conversion into adding 1.5 * 2^23: the sum is rounded to nearest even at unit spacing and its low mantissa byte is
+// the two's complement int8 of the result. Returns the MOD bytes packed, LLR b in byte b. Same values as demod_symbol<MOD, true>
+// followed by the sign flip.
+__device__ __forceinline__ uint32_t demod_qbyte(float v, float scale, uint32_t chips, int b)
+{
+#pragma clang fp contract(off)
+  const float sc = __uint_as_float(((chips << (31 - b)) & 0x80000000u) | __float_as_uint(scale));
+  return __float_as_uint(__builtin_amdgcn_fmed3f(v * sc, -120.0f, 120.0f) + 12582912.0f);
+}
+__device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+  const uint32_t ab = __builtin_amdgcn_perm(b, a, 0x0c0c0400u), cd = __builtin_amdgcn_perm(d, c, 0x0c0c0400u);
+  return __builtin_amdgcn_perm(cd, ab, 0x05040100u);
+}
+template <int MOD>
+__device__ __forceinline__ uint64_t demod_symbol_packed(float re, float im, float nvar, const float2* tab, uint32_t chips)
+{
+#pragma clang fp contract(off)
+  const float rcp  = (nvar > 0.f) ? 1.0f / nvar : 0.0f;
+  const float x[2] = {re, im};
+  uint32_t    q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    if (MOD == 2) {
+      q[d] = demod_qbyte((NR_DEMOD_QPSK_GAIN * x[d]) * rcp, 120.0f / 24.f, chips, d);
+    } else if (MOD == 4) {
+      const float first  = NR_DEMOD_QAM16_GAIN * x[d];
+      const float second = 2.0f * first - copysignf(0.8f, x[d]);
+      const float l01    = (fabsf(x[d]) > NR_DEMOD_QAM16_THRESHOLD) ? second : first;
+      const float l23    = 0.8f - fabsf(first);
+      q[d]               = demod_qbyte(l01 * rcp, 6.0f, chips, d);
+      q[2 + d]           = demod_qbyte(l23 * rcp, 6.0f, chips, 2 + d);
+    } else if (MOD == 6) {
+      const int i0 = demod_interval_idx(x[d], NR_DEMOD_QAM64_B0_RCP_WIDTH, 8);
+      const int i2 = demod_interval_idx(x[d], NR_DEMOD_QAM64_B2_RCP_WIDTH, 4);
+      q[d]         = demod_qbyte(demod_interval_at(x[d], rcp, tab[i0]), 6.0f, chips, d);
+      q[2 + d]     = demod_qbyte(demod_interval_at(x[d], rcp, tab[16 + i0]), 6.0f, chips, 2 + d);
+      q[4 + d]     = demod_qbyte(demod_interval_at(x[d], rcp, tab[32 + i2]), 6.0f, chips, 4 + d);
+    } else {
+      const int i0 = demod_interval_idx(x[d], NR_DEMOD_QAM256_B0_RCP_WIDTH, 16);
+      const int i3 = demod_interval_idx(x[d], NR_DEMOD_QAM256_B3_RCP_WIDTH, 8);
+      q[d]         = demod_qbyte(demod_interval_at(x[d], rcp, tab[i0]), 6.0f, chips, d);
+      q[2 + d]     = demod_qbyte(demod_interval_at(x[d], rcp, tab[16 + i0]), 6.0f, chips, 2 + d);
+      q[4 + d]     = demod_qbyte(demod_interval_at(x[d], rcp, tab[32 + i0]), 6.0f, chips, 4 + d);
+      q[6 + d]     = demod_qbyte(demod_interval_at(x[d], rcp, tab[48 + i3]), 6.0f, chips, 6 + d);
+    }
+  }
+  const uint32_t lo = pack4(q[0], q[1], q[2], q[3]);
+  const uint32_t hi = MOD > 4 ? pack4(q[4], q[5], q[6], q[7]) : 0u;
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
 // 12-bit mask of the REs of a PRB that carry DM-RS (dmrs_mapping.h:76-92).
 __device__ __forceinline__ unsigned dmrs_prb_mask(int type, unsigned cdm)
 {
@@ -149,7 +203,7 @@ struct demod_args {
 
 template <int MOD>
 __device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* prb_of, const uint8_t* pos, int npp, int n_re, int prefix, int sy,
-                                           const uint32_t* cw, const float2* tab, int tid, int nt)
+                                           const uint32_t* cw, int cw_shift, const float2* tab, int tid, int nt)
 {
 #pragma clang fp contract(off)
   const int   nsc = a.nsc, nports = a.nports;
@@ -166,17 +220,36 @@ __device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* 
   const bool aligned = ((uintptr_t)o % (MOD == 8 ? 8 : MOD == 4 ? 4 : MOD == 1 ? 1 : 2)) == 0;
   const uint32_t npp_magic = (uint32_t)((0x100000000ull + (uint32_t)npp - 1u) / (uint32_t)npp); // r / npp for r < 2^16
   float          evm_acc   = 0.f;
-  for (int r = tid; r < n_re; r += nt) {
+  // The samples and estimates of the NEXT resource element of this thread are requested before the current one is worked on: the
+  // per-element chain load -> equalise -> demap -> store otherwise exposes one memory latency per element.
+  float2 yn[4], cn[4];
+  auto   fetch = [&](int r) {
     const int pi  = (int)__umulhi((uint32_t)r, npp_magic);
     const int prb = prb_of[pi], k = r - pi * npp;
     const int sc  = prb * 12 + pos[k];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (p < nports) {
+        yn[p] = gp[p][sc];
+        cn[p] = hp[p][sc];
+      }
+  };
+  if (tid < n_re)
+    fetch(tid);
+  for (int r = tid; r < n_re; r += nt) {
+    float2 yc[4], cc4[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      yc[p] = yn[p], cc4[p] = cn[p];
+    if (r + nt < n_re)
+      fetch(r + nt);
     // equalize_zf_1xn.h:120-158
     float ch_mod_sq = 0.f, acc_re = 0.f, acc_im = 0.f;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       if (p < nports) {
-        const float2 y = gp[p][sc];
-        const float2 c = hp[p][sc];
+        const float2 y = yc[p];
+        const float2 c = cc4[p];
         const float  t = c.x * c.x, u = c.y * c.y;
         ch_mod_sq      = ch_mod_sq + (t + u);
         const float a = y.x * c.x, b = y.y * c.y, cc = y.y * c.x, d = y.x * c.y;
@@ -196,7 +269,24 @@ __device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* 
     int l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // NaNs can only come from a non-finite symbol or an infinite reciprocal noise variance (0 * inf): rare, exact path.
     const float rcp_chk = (nv > 0.f) ? 1.0f / nv : 0.0f;
-    if (fabsf(z_re) < INFINITY && fabsf(z_im) < INFINITY && rcp_chk < INFINITY)
+    const bool  fast    = fabsf(z_re) < INFINITY && fabsf(z_im) < INFINITY && rcp_chk < INFINITY;
+    int8_t*     q       = o + (size_t)r * MOD;
+    if (MOD >= 2 && fast && aligned && !a.evm && !a.nph) { // the common case: quantise, descramble and pack in one go
+      const int      bi0  = r * MOD + cw_shift;
+      const uint64_t two0 = (uint64_t)cw[bi0 >> 5] | ((uint64_t)cw[(bi0 >> 5) + 1] << 32);
+      const uint64_t w    = demod_symbol_packed<MOD>(z_re, z_im, nv, tab, (uint32_t)(two0 >> (bi0 & 31)));
+      if (MOD == 8)
+        *reinterpret_cast<uint2*>(q) = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+      else if (MOD == 6) {
+        uint16_t* q2 = reinterpret_cast<uint16_t*>(q);
+        q2[0] = (uint16_t)w, q2[1] = (uint16_t)(w >> 16), q2[2] = (uint16_t)(w >> 32);
+      } else if (MOD == 4)
+        *reinterpret_cast<uint32_t*>(q) = (uint32_t)w;
+      else
+        *reinterpret_cast<uint16_t*>(q) = (uint16_t)w;
+      continue;
+    }
+    if (fast)
       demod_symbol<MOD, true>(z_re, z_im, nv, (unsigned)(prefix + r), tab, l);
     else
       demod_symbol<MOD, false>(z_re, z_im, nv, (unsigned)(prefix + r), tab, l);
@@ -210,7 +300,7 @@ __device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* 
       evm_acc += er * er + ei * ei;
     }
     // descramble: bit b of this RE is sequence bit (prefix + r) * MOD + b; cw holds the bits of this OFDM symbol from r = 0
-    const int      bi   = r * MOD;
+    const int      bi   = r * MOD + cw_shift;
     const uint64_t two  = (uint64_t)cw[bi >> 5] | ((uint64_t)cw[(bi >> 5) + 1] << 32);
     uint32_t       bits = (uint32_t)(two >> (bi & 31));
     if (a.nph) { // binary search of this element in the placeholder list (pusch_demodulator_impl.cpp:117-149)
@@ -241,7 +331,6 @@ __device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* 
 #pragma unroll
     for (int b = 0; b < MOD; ++b)
       w |= (uint64_t)(uint8_t)(int8_t)l[b] << (8 * b);
-    int8_t* q = o + (size_t)r * MOD;
     if (aligned) {
       if (MOD == 8)
         *reinterpret_cast<uint2*>(q) = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
@@ -273,12 +362,35 @@ __device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* 
   }
 }
 
+// Scrambling sequence of every transmission, one workgroup each: c(0 .. nof_llr - 1) from c_init = rnti * 2^15 + n_id, x1 from the
+// table, x2 by the doubling word recurrence (gold_device.h). The OFDM symbols of a transmission use consecutive pieces of it, so no
+// jump-ahead is needed; inside the demodulator the generation was a serial chain that held three of four wavefronts of every
+// (transmission, symbol) workgroup at a barrier (0.13 of 0.37 ms per 1024 slots). seq: [transmission][SEQ_STRIDE] words.
+constexpr int SEQ_STRIDE = GOLD_X1_WORDS;
+#ifndef SCR_THREADS
+#define SCR_THREADS 512
+#endif
+__global__ void __launch_bounds__(SCR_THREADS) pusch_scrambling_kernel(const miphy_pusch_demod_job* __restrict__ jobs, const gold_tables* __restrict__ gt,
+                                                                uint32_t* __restrict__ seq)
+{
+  __shared__ uint32_t w[SEQ_STRIDE];
+  const miphy_pusch_demod_job* __restrict__ jp = jobs + blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  int       nwords = (int)((jp->nof_llr + 31u) >> 5) + 2; // + the 64-bit window of the last resource element
+  nwords           = nwords > SEQ_STRIDE ? SEQ_STRIDE : nwords;
+  gold_x2_sequence(gt->j, (jp->rnti << 15) + jp->n_id, nwords, w, tid, nt);
+  uint32_t* o = seq + (size_t)blockIdx.x * SEQ_STRIDE;
+  for (int i = tid; i < nwords; i += nt)
+    o[i] = w[i] ^ gt->x1_seq[i];
+}
+
 __global__ void __launch_bounds__(256) pusch_demod_kernel(const miphy_pusch_demod_job* __restrict__ jobs, const gold_tables* __restrict__ gt,
                                                           const float2* __restrict__ grid, const float2* __restrict__ ce,
                                                           const float* __restrict__ scalars, int8_t* __restrict__ llr,
-                                                          const uint16_t* __restrict__ placeholders, float* __restrict__ evm_sums)
+                                                          const uint16_t* __restrict__ placeholders, float* __restrict__ evm_sums,
+                                                          const uint32_t* __restrict__ seq)
 {
-  __shared__ uint32_t w1[MAX_SYM_WORDS], w2[MAX_SYM_WORDS];
+  __shared__ uint32_t w1[MAX_SYM_WORDS];
   __shared__ uint16_t prb_of[276];
   __shared__ uint8_t  pos[12];
   __shared__ int      nprb_s;
@@ -333,8 +445,16 @@ __global__ void __launch_bounds__(256) pusch_demod_kernel(const miphy_pusch_demo
     prefix += nprb * (((dmrs_syms >> s) & 1) ? per_dm : 12);
   const int n_re   = nprb * npp;
   const int mod    = jp->mod;
-  const int nwords = ((n_re * mod + 31) >> 5) + 1; // + 1: the 64-bit window of the last RE
-  gold_long_block(*gt, (jp->rnti << 15) + jp->n_id, (uint32_t)prefix * (uint32_t)mod, nwords, w1, w2, w1, tid, nt);
+  // the symbol's piece of the scrambling sequence (pusch_scrambling_kernel): it starts at bit prefix * mod of the transmission's
+  const uint32_t bit0 = (uint32_t)prefix * (uint32_t)mod;
+  const int      sh   = (int)(bit0 & 31u);
+  {
+    const uint32_t* sq = seq + (size_t)blockIdx.x * SEQ_STRIDE + (bit0 >> 5);
+    const int       nw = ((n_re * mod + sh + 31) >> 5) + 1;
+    for (int i = tid; i < nw; i += nt)
+      w1[i] = sq[i];
+    __syncthreads();
+  }
   demod_args a;
   a.nsc            = nprb_grid * 12;
   a.nports         = jp->nof_rx_ports;
@@ -351,21 +471,21 @@ __global__ void __launch_bounds__(256) pusch_demod_kernel(const miphy_pusch_demo
     case 8:
       demod_tables_to_lds<8>(tab, tid);
       __syncthreads();
-      demod_body<8>(a, prb_of, pos, npp, n_re, prefix, sy, w1, tab, tid, nt);
+      demod_body<8>(a, prb_of, pos, npp, n_re, prefix, sy, w1, sh, tab, tid, nt);
       break;
     case 6:
       demod_tables_to_lds<6>(tab, tid);
       __syncthreads();
-      demod_body<6>(a, prb_of, pos, npp, n_re, prefix, sy, w1, tab, tid, nt);
+      demod_body<6>(a, prb_of, pos, npp, n_re, prefix, sy, w1, sh, tab, tid, nt);
       break;
     case 4:
-      demod_body<4>(a, prb_of, pos, npp, n_re, prefix, sy, w1, tab, tid, nt);
+      demod_body<4>(a, prb_of, pos, npp, n_re, prefix, sy, w1, sh, tab, tid, nt);
       break;
     case 2:
-      demod_body<2>(a, prb_of, pos, npp, n_re, prefix, sy, w1, tab, tid, nt);
+      demod_body<2>(a, prb_of, pos, npp, n_re, prefix, sy, w1, sh, tab, tid, nt);
       break;
     default:
-      demod_body<1>(a, prb_of, pos, npp, n_re, prefix, sy, w1, tab, tid, nt);
+      demod_body<1>(a, prb_of, pos, npp, n_re, prefix, sy, w1, sh, tab, tid, nt);
       break;
   }
 }
@@ -431,8 +551,12 @@ extern "C" int miphy_pusch_demodulate_batch_ex(miphy_ctx* ctx, const miphy_pusch
   rc                 = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_pusch_demod_job) * (size_t)n, s, &d_jobs);
   if (rc)
     return rc;
+  void* seq = nullptr;
+  if ((rc = miphy_get_workspace(ctx, (size_t)n * SEQ_STRIDE * sizeof(uint32_t), s, &seq, 4)))
+    return rc;
+  hipLaunchKernelGGL(pusch_scrambling_kernel, dim3(n), dim3(SCR_THREADS), 0, s, (const miphy_pusch_demod_job*)d_jobs, gt, (uint32_t*)seq);
   hipLaunchKernelGGL(pusch_demod_kernel, dim3(n, 14), dim3(256), 0, s, (const miphy_pusch_demod_job*)d_jobs, gt, (const float2*)grid, (const float2*)ce,
-                     scalars, llr, placeholders, evm_sums);
+                     scalars, llr, placeholders, evm_sums, (const uint32_t*)seq);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-lib_path = os.path.join(os.path.dirname(_HERE), "libmiphy.so")
+# MIPHY_LIBRARY: another build of the same library (tools/ab_bench.py compares kernel variants this way)
+lib_path = os.environ.get("MIPHY_LIBRARY") or os.path.join(os.path.dirname(_HERE), "libmiphy.so")
 
 CRC24A, CRC24B, CRC24C, CRC16, CRC11 = range(5)
 CRC_NONE = 255
