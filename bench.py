@@ -242,9 +242,11 @@ def sch_leg(ctx, miphy, torch, dev, name, bg, mod, nsym, tb_bytes, n_tb, max_ite
     r = res.cpu().numpy().view(miphy.PuschResult)
     ok = int((r["tb_crc_ok"] != 0).sum())
     same = bool(torch.equal(out.reshape(n_tb, tb_bytes), torch.from_numpy(tb_u).to(dev)[idx])) if ok == n_tb else False
+    fused = plan.info()[1]
     plan.close()
     in_len = min(sg.N, max((22 if bg == 1 else 10) * sg.Z + 2 * sg.Z, -(-(G // C + sg.nof_filler_bits) // sg.Z) * sg.Z))
-    alg = n_tb * C * (in_len + sg.K // 8 + 4)
+    # dematch inside the decoder: rate-matched LLRs in + soft-buffer image (N per codeblock) out, no intermediate re-read
+    alg = n_tb * (G + C * (sg.N + sg.K // 8 + 4)) if fused else n_tb * C * (in_len + sg.K // 8 + 4)
     return {"config": name, "transport_blocks": n_tb, "codeblocks": n_tb * C, "Z": sg.Z, "decoder_in_len": in_len, "ldpc_iterations": max_iter,
             "ms_per_launch": ms, "kernel_ms": tm, "us_per_codeblock": ms * 1e3 / (n_tb * C), "info_bits_per_s": n_tb * tb_bytes * 8 / (ms * 1e-3),
             "ldpc_decode_algorithmic_GBps": alg / (tm["ldpc_decode"] * 1e-3) / 1e9, "ldpc_decode_hbm_frac": alg / (tm["ldpc_decode"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -520,8 +522,12 @@ def main():
     # out per codeblock; OFDM demod = 61440*8 in + 14*3276*8 out per slot-port; estimator = DM-RS REs in (n_dmrs * 13104 B) +
     # 14*3276*8 out per (slot, port, layer); demodulator = 16 B in + mod B out per data RE and port; TB assembly = K/8 per codeblock in
     # + TB bytes out.
-    alg = {"ldpc_decode": S * sum(dec_in_len[c] + K // 8 + 4 for c in range(C)),
-           "rate_dematch": S * (G + C * N),
+    # When the plan dematches inside the decoder (first transmissions, rv 0) the decoder kernel carries the dematcher's figure instead of its own
+    # input read: rate-matched LLRs in + soft-buffer image out (N per codeblock, pusch_decoder_impl.cpp:176-181 keeps it for the next
+    # retransmission) + K/8 + 4 B out; the "rate_dematch" stage is then only the reset of the HARQ flags.
+    dematch_in_decoder = all(p.info()[1] for p in plans)
+    alg = {"ldpc_decode": S * (G + C * (N + K // 8 + 4)) if dematch_in_decoder else S * sum(dec_in_len[c] + K // 8 + 4 for c in range(C)),
+           "rate_dematch": S * C * 4 if dematch_in_decoder else S * (G + C * N),
            "ofdm_demod": S * (slot_samples * 8 + 14 * nsc * 8),
            "dmrs_chest": S * (1 * (nsc // 2) * 8 + nsc * 8),          # DM-RS REs in, one estimate row out (compact form)
            "pusch_demod": S * (w["nsym"] * 8 + nsc * 8 + G),          # data REs + the estimate row in, LLRs out
@@ -584,6 +590,7 @@ def main():
                         "transmitted ones: %s" % (ok_slots, checked, S, all_ok),
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": gbs[dom], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gbs[dom] / HBM_PEAK_GBS, "traffic": traffic.get(dom), "traffic_source": tstamp, "algorithmic_bytes": alg[dom],
+                     "dematch_in_decoder": dematch_in_decoder,
                      "note": "LDPC decode is VALU/LDS-bound (see roofline_valu); the HBM fraction is reported as the contract asks"},
         "kernel_source_sha": kernel_source_sha(),
     }

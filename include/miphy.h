@@ -563,6 +563,10 @@ void miphy_pusch_decode_plan_destroy(miphy_pusch_decode_plan* plan);
  * milliseconds {rate dematch, LDPC decode, TB assembly} and starts a new series. */
 int  miphy_pusch_decode_plan_enable_timing(miphy_pusch_decode_plan* plan, uint32_t max_runs);
 int  miphy_pusch_decode_plan_read_timing(miphy_pusch_decode_plan* plan, float ms_out[3], uint32_t* runs_out);
+/* What the plan will launch: info[0] = codeblocks, info[1] = 1 when every codeblock is rate-dematched while the decoder loads it (one
+ * kernel reads the rate-matched LLRs and writes the soft-buffer image; the "rate dematch" time of _read_timing is then only the HARQ
+ * flag reset), 0 when the dematcher runs as its own launch, info[2] = largest number of variable nodes a codeblock can reach. */
+int  miphy_pusch_decode_plan_info(const miphy_pusch_decode_plan* plan, uint32_t info[3]);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * PUSCH processor  --  replaces srsran::pusch_processor::process for PDUs without UCI

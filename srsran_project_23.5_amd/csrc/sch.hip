@@ -651,6 +651,15 @@ extern "C" int miphy_pusch_decode_plan_read_timing(miphy_pusch_decode_plan* p, f
   return MIPHY_OK;
 }
 
+extern "C" int miphy_pusch_decode_plan_info(const miphy_pusch_decode_plan* p, uint32_t info[3])
+{
+  MIPHY_REQUIRE(p && info, "miphy_pusch_decode_plan_info: null argument");
+  info[0] = p->ncb;
+  info[1] = (p->b.fusable && !p->b.any_odd_Z) ? 1u : 0u;
+  info[2] = p->b.max_nodes;
+  return MIPHY_OK;
+}
+
 extern "C" void miphy_pusch_decode_plan_destroy(miphy_pusch_decode_plan* p)
 {
   if (!p)

@@ -58,6 +58,7 @@ def lib():
         l.miphy_pusch_decode_plan_destroy.restype = None
         l.miphy_pusch_decode_plan_enable_timing.argtypes = [C.c_void_p, C.c_uint32]
         l.miphy_pusch_decode_plan_read_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.miphy_pusch_decode_plan_info.argtypes = [C.c_void_p, C.c_void_p]
         l.miphy_sch_segmentation_info.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         l.miphy_polar_decode_list_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -588,6 +589,12 @@ class PuschDecodePlan:
     def run(self, llrs, harq_softbits, harq_msgs, harq_crc_ok, tb_out, results, stream=None):
         check(lib().miphy_pusch_decode_plan_run(self.h, _dptr(llrs), _dptr(harq_softbits), _dptr(harq_msgs), _dptr(harq_crc_ok), _dptr(tb_out),
                                                 _dptr(results), _stream_ptr(stream)))
+
+    def info(self):
+        """(codeblocks, dematch-inside-the-decoder flag, largest number of variable nodes)."""
+        a = (C.c_uint32 * 3)()
+        check(lib().miphy_pusch_decode_plan_info(self.h, a))
+        return int(a[0]), bool(a[1]), int(a[2])
 
     def enable_timing(self, max_runs=64):
         check(lib().miphy_pusch_decode_plan_enable_timing(self.h, max_runs))
