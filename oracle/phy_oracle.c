@@ -1406,8 +1406,17 @@ int orc_pbch_encode(unsigned N_id, unsigned ssb_idx, unsigned L_max, int hrf, un
   return orc_polar_encode_chain(56, 864, 9, 0, kp, out, 0, 0) > 0 ? 0 : -1;
 }
 
-/* ------------------------------------------------------------------------------------------------ SCL -- PARITY UNPINNED (no reference
- * counterpart; restatement of srsran_project_23.5_amd/csrc/polar_scl.hip for bit-exact checking) */
+/* ------------------------------------------------------------------------------------------------ SCL -- PARITY UNPINNED for L > 1 (the
+ * reference has no list decoder). Written to the literature, not to the kernel: successive-cancellation LIST decoding (Tal, Vardy 2015) with
+ * the LLR path metric (Balatsoukas-Stimming, Parizi, Burg 2015) in the reference's saturating int8 algebra:
+ *   - at an information bit every live path forks into u = 0 and u = 1; the branch that agrees with the hard decision [llr <= 0] keeps its
+ *     metric, the other one adds |llr|; at a frozen bit u = 0 and the metric grows by |llr| when llr < 0;
+ *   - the L candidates with the smallest metrics survive, ties go to the lower candidate index (path p, hard-decision branch first);
+ *   - at the end the surviving path with the smallest metric whose CRC checks is returned (crc_mode 0: the smallest metric).
+ * L = 1 is plain successive cancellation and IS pinned: equal to orc_polar_sc_textbook below, and to the reference's SSC decoder except on
+ * exact zero LLRs at information leaves (tests/test_polar_sc_pinning.py, tests/test_polar_gpu.py). The kernel (csrc/polar.hip) must
+ * reproduce this function bit for bit. An aligned all-frozen block is handled at its own stage (the metric penalty is the sum of the negative
+ * LLRs of that stage, identical to the leaf-by-leaf sum under the min-sum f and exact g). */
 typedef struct {
   int8_t  llr[1024];  /* stage s at offset 2^s, size 2^s (s < n) */
   uint8_t bl[1024];   /* left partial sums of stage s at offset 2^s */
