@@ -102,11 +102,13 @@ inline void gold_tables_init(gold_tables& t)
 // yield 28 d independent words per step -- the history doubles until a step fills the workgroup.
 __device__ __forceinline__ void gold_x2_sequence(const gold_jump& j, uint32_t c_init, int nwords, uint32_t* w, int tid, int nt)
 {
-  if (tid == 0) {
-    uint32_t st = 0;
-    for (int k = 0; k < 31; ++k)
-      st ^= ((c_init >> k) & 1u) ? j.x2_col[k] : 0u;
-    lfsr_head(st, true, 31, w);
+  if (tid < 64) { // state after the warm-up: lane k contributes column k (one parallel load), XOR-reduced over the wavefront
+    uint32_t st = (tid < 31 && ((c_init >> tid) & 1u)) ? j.x2_col[tid] : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+      st ^= __shfl_xor(st, o);
+    if (tid == 0)
+      lfsr_head(st, true, 31, w);
   }
   __syncthreads();
   int have = 31, k = 0;

@@ -135,6 +135,14 @@ class OfdmConfig(C.Structure):
     def slot_size(self, slot_index):
         return int(lib().miphy_ofdm_slot_size(C.byref(self), slot_index))
 
+    def symbol_size(self, symbol_index):
+        """Samples (cyclic prefix included) of OFDM symbol `symbol_index` of the subframe."""
+        return int(lib().miphy_ofdm_symbol_size(C.byref(self), symbol_index))
+
+
+def ofdm_symbol_size(cfg, symbol_index):
+    return cfg.symbol_size(symbol_index)
+
 
 # Mirrors miphy_pusch_chest_job.
 PuschChestJob = np.dtype([("numerology", np.uint32), ("slot_in_frame", np.uint32), ("scrambling_id", np.uint32), ("scaling", np.float32),
@@ -315,6 +323,10 @@ def ulsch_placeholders(job):
     check(lib().miphy_ulsch_placeholders(C.c_void_p(j.ctypes.data), C.c_void_p(out.ctypes.data), out.size, C.byref(n)))
     return out[:n.value].copy()
 
+
+# MIPHY_POLAR_OP_* of miphy_polar_block_batch.
+(POLAR_OP_ALLOCATE, POLAR_OP_ENCODE, POLAR_OP_RATE_MATCH, POLAR_OP_RATE_DEMATCH, POLAR_OP_DECODE, POLAR_OP_DEALLOCATE, POLAR_OP_INTERLEAVE_TX,
+ POLAR_OP_INTERLEAVE_RX) = range(8)
 
 # Mirrors miphy_equalizer_job.
 EqualizerJob = np.dtype([("nof_re", np.uint32), ("nof_rx_ports", np.uint8), ("nof_tx_layers", np.uint8), ("reserved", np.uint8, 2), ("noise_var", np.float32),

@@ -223,6 +223,14 @@ def o_polar_encode_chain(K, E, nMax, ibil, msg):
     return out, alloc[:N], enc[:N]
 
 
+def o_polar_interleave(bits, K, rx):
+    """polar_interleaver::interleave (TX: rx = 0, RX: rx = 1) of K bits."""
+    x = np.ascontiguousarray(bits, dtype=np.uint8)
+    out = np.zeros(K, np.uint8)
+    oracle().orc_polar_interleave(_p(x), _p(out), C.c_uint(K), int(rx))
+    return out
+
+
 def o_polar_decode_chain(K, E, nMax, ibil, llr):
     llr = np.ascontiguousarray(llr, dtype=np.int8)
     msg, dem, u = np.zeros(K, np.uint8), np.zeros(1024, np.int8), np.zeros(1024, np.uint8)

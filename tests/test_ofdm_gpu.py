@@ -119,3 +119,45 @@ def test_ofdm_demodulate_and_modulate(ctx, mu, rb, N, wo, fc):
     torch.cuda.synchronize()
     g2 = g2_d.cpu().numpy().reshape(g.shape)
     assert rel_err(g2, g) < 2e-5
+
+
+@pytest.mark.parametrize("mu,rb,N,wo,fc", [CASES[0], CASES[2], CASES[5]])
+def test_ofdm_symbol_entry_points_equal_the_slot_ones(ctx, mu, rb, N, wo, fc):
+    """miphy_ofdm_{de}modulate_symbols (ofdm_symbol_demodulator / _modulator, ofdm_demodulator.h:55-74): one job per OFDM symbol, in any
+    order, must give the rows / samples the slot entry points give for the same subframe -- bit-identical, it is the same transform."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(N * 3 + rb)
+    nslots = 1 << mu
+    nsc = rb * 12
+    cfg = miphy.OfdmConfig(mu, rb, N, wo, 0.5, 0.0, fc)
+    sizes = [cfg.slot_size(s) for s in range(nslots)]
+    sym = [miphy.ofdm_symbol_size(cfg, i) for i in range(14 * nslots)]
+    assert [sum(sym[14 * s:14 * s + 14]) for s in range(nslots)] == sizes
+    x = ((rng.standard_normal(sum(sizes)) + 1j * rng.standard_normal(sum(sizes))) * 0.7).astype(np.complex64)
+    x_d = torch.from_numpy(x).cuda()
+    sj = np.zeros(nslots, dtype=miphy.OfdmJob)
+    off = 0
+    for s in range(nslots):
+        sj[s] = (off, s * 14 * nsc, s, 0)
+        off += sizes[s]
+    g_slot = torch.zeros(nslots * 14 * nsc, dtype=torch.complex64, device="cuda")
+    ctx.ofdm_demodulate_slots(cfg, sj, x_d, g_slot)
+    order = rng.permutation(14 * nslots)
+    starts = np.concatenate([[0], np.cumsum(sym)[:-1]])
+    yj = np.zeros(14 * nslots, dtype=miphy.OfdmJob)
+    for k, i in enumerate(order):
+        yj[k] = (int(starts[i]), int(i) * nsc, int(i), 0)
+    g_sym = torch.zeros_like(g_slot)
+    ctx.ofdm_demodulate_symbols(cfg, yj, x_d, g_sym)
+    torch.cuda.synchronize()
+    assert torch.equal(g_slot, g_sym)
+    # modulator
+    mcfg = miphy.OfdmConfig(mu, rb, N, 0, 0.01, 0.0, fc)
+    g = (rng.standard_normal(nslots * 14 * nsc) + 1j * rng.standard_normal(nslots * 14 * nsc)).astype(np.complex64)
+    g_d = torch.from_numpy(g).cuda()
+    y_slot, y_sym = torch.zeros_like(x_d), torch.zeros_like(x_d)
+    ctx.ofdm_modulate_slots(mcfg, sj, g_d, y_slot)
+    ctx.ofdm_modulate_symbols(mcfg, yj, g_d, y_sym)
+    torch.cuda.synchronize()
+    assert torch.equal(y_slot, y_sym)

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from oracle_lib import (o_pbch_encode, o_pdcch_encode, o_polar_decode_chain, o_polar_encode_chain, o_polar_scl_decode)
+from oracle_lib import o_polar_interleave as O_interleave
 
 pytestmark = pytest.mark.gpu
 
@@ -220,3 +221,48 @@ def test_scl_list1_is_pinned_to_the_reference_style_decoder(ctx, K, E, nMax, ibi
             assert np.array_equal(scl1[i], ssc[i]), (K, E, i)
         if i < 2:
             assert np.array_equal(scl1[i], msgs[i])
+
+
+@pytest.mark.parametrize("K,E,nMax,ibil", polar_cases()[::3])
+def test_polar_single_blocks_match_the_chain_intermediates(ctx, K, E, nMax, ibil):
+    """miphy_polar_block_batch: every block of the reference's polar chain on its own (allocator, encoder, rate matcher, rate dematcher,
+    decoder, deallocator, interleaver: the classes behind polar_factory, channel_coding_factories.h:107-121) equals the intermediate
+    the oracle chain exposes for the same codeword (which is pinned to the reference block by block, tests/test_oracle_vs_ref.py)."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(K * 11 + E)
+    code = miphy.PolarCode(K, E, nMax, ibil)
+    n_log, N, nPC = code.info()
+    nb = 5
+    msgs = rng.integers(0, 2, (nb, K), dtype=np.uint8)
+    exp = [o_polar_encode_chain(K, E, nMax, ibil, msgs[i]) for i in range(nb)]
+
+    def run(op, param, x, n_out, dtype=torch.uint8):
+        xd = torch.from_numpy(np.ascontiguousarray(x).reshape(-1)).cuda()
+        od = torch.full((nb * n_out,), 9, dtype=dtype, device="cuda")
+        ctx.polar_block_batch(code, op, param, nb, xd, od)
+        torch.cuda.synchronize()
+        return od.cpu().numpy().reshape(nb, n_out)
+
+    OP = miphy.binding
+    alloc = run(OP.POLAR_OP_ALLOCATE, 0, msgs, N)
+    assert np.array_equal(alloc, np.stack([e[1] for e in exp]))
+    enc = run(OP.POLAR_OP_ENCODE, n_log, alloc, N)
+    assert np.array_equal(enc, np.stack([e[2] for e in exp]))
+    rm = run(OP.POLAR_OP_RATE_MATCH, 0, enc, E)
+    assert np.array_equal(rm, np.stack([e[0] for e in exp]))
+    # receive side on noisy LLRs with a few infinities
+    llr = np.clip(np.round((1.0 - 2.0 * rm) * 40 + 25 * rng.standard_normal(rm.shape)), -120, 120).astype(np.int8)
+    llr[rng.random(llr.shape) < 0.02] = 127
+    dexp = [o_polar_decode_chain(K, E, nMax, ibil, llr[i]) for i in range(nb)]
+    dem = run(OP.POLAR_OP_RATE_DEMATCH, 0, llr, N, torch.int8)
+    assert np.array_equal(dem, np.stack([d[1] for d in dexp]))
+    u = run(OP.POLAR_OP_DECODE, 0, dem, N)
+    assert np.array_equal(u, np.stack([d[2] for d in dexp]))
+    out = run(OP.POLAR_OP_DEALLOCATE, 0, u, K)
+    assert np.array_equal(out, np.stack([d[0] for d in dexp]))
+    # interleaver (CRC interleaver of the downlink chains, K <= 164): TX then RX is the identity and TX equals the oracle's pattern
+    if K <= 164:
+        tx = run(OP.POLAR_OP_INTERLEAVE_TX, K, msgs, K)
+        assert np.array_equal(tx, np.stack([O_interleave(msgs[i], K, 0) for i in range(nb)]))
+        assert np.array_equal(run(OP.POLAR_OP_INTERLEAVE_RX, K, tx, K), msgs)
