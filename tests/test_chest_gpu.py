@@ -114,3 +114,92 @@ def test_chest_random_grid_like_benchmark(ctx):
         g = ((rng.standard_normal((nports, 14, 273 * 12)) + 1j * rng.standard_normal((nports, 14, 273 * 12))) * np.sqrt(0.5)).astype(np.complex64)
         cases.append((1, 0, False, 0, 0, 1.0, sm, rb, 0, 14, nl, g))
     run(ctx, cases)
+
+
+def _pilots(rb, l, slot, scr, nscid, nl):
+    """DM-RS type-1 pilots of OFDM symbol l as the PUSCH estimator generates them (dmrs_helper.h:45-96): (nl, 6 * allocated PRBs) complex64."""
+    c_init = (((14 * slot + l + 1) * (2 * scr + 1)) % (1 << 31) * (1 << 17) + 2 * scr + nscid) % (1 << 31)
+    c = o_gold(c_init, 0, 12 * rb.size).astype(np.float32)
+    amp = np.float32(0.70710678118654752440)
+    full = (amp * (np.float32(1) - np.float32(2) * c[0::2])) + 1j * (amp * (np.float32(1) - np.float32(2) * c[1::2]))
+    sel = np.concatenate([np.arange(r * 6, r * 6 + 6) for r in np.nonzero(rb)[0]])
+    p = full[sel].astype(np.complex64)
+    out = np.zeros((nl, p.size), np.complex64)
+    for ly in range(nl):
+        w = np.ones(p.size, np.float32)
+        if ly % 2:
+            w[1::2] = -1
+        out[ly] = p * w
+    return out
+
+
+def test_port_estimator_with_caller_pilots_and_hopping(ctx):
+    """miphy_port_channel_estimate_batch (port_channel_estimator::compute, port_channel_estimator.h:102-106). (1) With the pilots the PUSCH
+    estimator would generate and no hopping it must reproduce miphy_dmrs_pusch_estimate_batch / the oracle. (2) With intra-slot hopping
+    (port_channel_estimator_average_impl.cpp:97-146) every hop is an estimate of its own on its own PRBs: the oracle run per hop gives the
+    coefficients of the hop's symbols; RSRP and EPRE are the DM-RS-symbol-weighted means of the hops, the noise variance is forced to
+    EPRE / 1000 (:118-138), the time alignment is the mean of the hops'. Same tolerances as above."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(2718)
+    for nl, hop, alloc1, alloc2, dsyms, delay in ((1, 0, slice(4, 34), None, [2, 11], 6.0), (2, 0, slice(0, 52), None, [3], -4.0),
+                                                  (1, 7, slice(2, 22), slice(28, 48), [2, 9], 5.0), (2, 6, slice(0, 25), slice(27, 52), [2, 4, 8, 11], -9.0)):
+        nprb, slot, scr, scaling = 52, 5, 321, 1.4125
+        first, nof = (0, 14) if nl == 1 else (1, 12)
+        dsyms = [l for l in dsyms if first <= l < first + nof]
+        hops = [(first, first + nof, alloc1)] if not hop else [(first, hop, alloc1), (hop, first + nof, alloc2)]
+        # the grid: every hop carries its own valid DM-RS (make_case on the hop's PRBs and symbols), added up
+        g = np.zeros((1, 14, nprb * 12), np.complex64)
+        per_hop = []
+        for (a, b, alloc) in hops:
+            ds = [l for l in dsyms if a <= l < b]
+            case = make_case(rng, nprb, alloc, 1, nl, ds, slot=slot, scr=scr, scaling=scaling, delay=delay)
+            gh = case[-1]
+            g[:, a:b, :] = gh[:, a:b, :]
+            per_hop.append((a, b, ds, case[7]))
+        # expected per hop from the oracle on the hop's own allocation
+        exp = []
+        for (a, b, ds, rb) in per_hop:
+            sm = np.zeros(14, np.uint8)
+            sm[ds] = 1
+            ce_h, sc_h = o_dmrs_pusch_estimate(1, slot, False, scr, 0, scaling, sm, rb, a, b - a, nl, g)
+            exp.append((ce_h, sc_h))
+        j = np.zeros(1, dtype=miphy.PuschChestJob)
+        j[0]["numerology"], j[0]["scaling"], j[0]["nof_tx_layers"], j[0]["nof_rx_ports"] = 1, scaling, nl, 1
+        j[0]["first_symbol"], j[0]["nof_symbols"], j[0]["rx_ports"], j[0]["grid_nof_prb"] = first, nof, [0, 1, 2, 3], nprb
+        j[0]["symbols_mask"] = sum(1 << l for l in dsyms)
+        for key, (a, b, ds, rb) in zip(("rb_mask", "rb_mask2"), per_hop):
+            m = [0] * 5
+            for r in np.nonzero(rb)[0]:
+                m[r >> 6] |= 1 << (int(r) & 63)
+            j[0][key] = m
+        j[0]["hop_symbol"] = hop
+        j[0]["re_odd_mask"] = sum(((ly // 2) % 2) << ly for ly in range(nl))
+        # pilots: [layer][DM-RS symbol of the allocation, hop 1 first][pilot]
+        pil = np.concatenate([np.stack([_pilots(rb, l, slot, scr, 0, nl) for l in ds], axis=1) for (a, b, ds, rb) in per_hop], axis=1)
+        nsymb = first + nof
+        g_d, p_d = torch.from_numpy(g.reshape(-1)).cuda(), torch.from_numpy(np.ascontiguousarray(pil).reshape(-1)).cuda()
+        ce_d = torch.ones(nl * nsymb * nprb * 12, dtype=torch.complex64, device="cuda")
+        sc_d = torch.zeros(5 * nl, dtype=torch.float32, device="cuda")
+        ctx.port_channel_estimate_batch(j, g_d, p_d, ce_d, sc_d)
+        torch.cuda.synchronize()
+        ce, sc = ce_d.cpu().numpy().reshape(nl, 1, nsymb, nprb * 12), sc_d.cpu().numpy().reshape(1, nl, 5)
+        nds_all = len(dsyms)
+        for h, ((a, b, ds, rb), (ce_h, sc_h)) in enumerate(zip(per_hop, exp)):
+            mask = np.repeat(rb.astype(bool), 12)
+            got, want = ce[:, :, a:b][..., mask], ce_h[:, :, a:b][..., mask]
+            assert np.abs(got - want).max() / np.abs(want).max() < 1e-4, (nl, hop, h)
+            assert np.all(ce[:, :, a:b][..., ~mask] == 1.0), "only the hop's PRBs are written in the hop's symbols"
+        w = np.array([len(ds) for (_, _, ds, _) in per_hop], np.float64) / nds_all
+        rsrp = sum(wi * e[1][..., 0].astype(np.float64) for wi, e in zip(w, exp))
+        epre = sum(wi * e[1][..., 1].astype(np.float64) for wi, e in zip(w, exp))
+        assert np.all(np.abs(sc[..., 0] - rsrp) <= 1e-4 * rsrp) and np.all(np.abs(sc[..., 1] - epre) <= 1e-4 * epre), (nl, hop)
+        if hop:
+            assert np.all(np.abs(sc[..., 2] - 0.001 * epre) <= 1e-4 * 0.001 * epre)
+            assert np.all(np.abs(sc[..., 3] - rsrp / scaling ** 2 / (0.001 * epre)) <= 2e-4 * sc[..., 3])
+            ta = sum(e[1][..., 4].astype(np.float64) for e in exp) / 2
+        else:
+            for k in (2, 3):
+                assert np.all(np.abs(sc[..., k] - exp[0][1][..., k]) <= 1e-4 * np.abs(exp[0][1][..., k]))
+            ta = exp[0][1][..., 4].astype(np.float64)
+        assert np.abs(sc[..., 4] - ta).max() <= 1.01 / (4096 * 30000.0), (nl, hop, sc[..., 4], ta)
