@@ -64,6 +64,22 @@ __device__ __forceinline__ uint32_t c2v_pack(s16x2 c0, s16x2 c1)
   return __builtin_amdgcn_perm(as_u(c0), as_u(c1), 0x06020400u);
 }
 
+// A descriptor through dword loads: read field by field, its 8- and 16-bit members become vector loads with a wait each (gfx950 has no
+// scalar sub-dword loads); as dwords the whole record arrives in scalar registers with one request and the fields are shifts.
+template <class T>
+__device__ __forceinline__ T load_words(const T* __restrict__ p)
+{
+  static_assert(sizeof(T) % 4 == 0, "dword multiple");
+  uint32_t                     w[sizeof(T) / 4];
+  const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i)
+    w[i] = s[i];
+  T r;
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+
 constexpr int LLR_MAX = 120;
 constexpr int LLR_INF = 127;
 constexpr int INF_MUL = 255; // an infinite soft bit (|s| > 120) becomes a message of magnitude >= 255 + 24
@@ -406,7 +422,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   raw_in16  pre[PK_PRE];
   if (FUSED) {
     if (blockIdx.x < n) {
-      const miphy_ldpc_rdm_desc r0 = rdm[blockIdx.x];
+      const miphy_ldpc_rdm_desc r0 = load_words(rdm + blockIdx.x);
       const int8_t*             in = rm_in_base + r0.in_offset;
       const int                 mb = (int)(((uintptr_t)in) & 3), E = (int)r0.E;
       const int                 nq = (mb == 0) ? (E >> 4) : ((E >= 4) ? ((E - 4) >> 4) : 0);
@@ -424,7 +440,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 #endif
   for (uint32_t cb = blockIdx.x; cb < n;) {
   PROF_T(p_start);
-  const miphy_ldpc_dec_desc dsc = descs[cb];
+  const miphy_ldpc_dec_desc dsc = load_words(descs + cb);
   const int                 Z   = dsc.Z;
   const int                 H   = (Z + 1) >> 1;
   const int                 bgi = (dsc.bg == 1) ? 0 : 1;
@@ -466,7 +482,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   // (re)fills pre[] with the first input vectors of codeblock c
   auto prefetch = [&](uint32_t c) {
     if (c < n) {
-      const miphy_ldpc_rdm_desc rn  = rdm[c];
+      const miphy_ldpc_rdm_desc rn  = load_words(rdm + c);
       const int8_t*             inn = rm_in_base + rn.in_offset;
       const int                 mbn = (int)(((uintptr_t)inn) & 3), En = (int)rn.E;
       const int                 nqn = (mbn == 0) ? (En >> 4) : ((En >= 4) ? ((En - 4) >> 4) : 0);
@@ -482,7 +498,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     // codeblock loop and keep dozens of them alive across the decoder)
     int stid = tid;
     asm volatile("" : "+v"(stid));
-    const miphy_ldpc_rdm_desc rd  = rdm[cb];
+    const miphy_ldpc_rdm_desc rd  = load_words(rdm + cb);
     const int                 E   = (int)rd.E, F = (int)dsc.nof_filler_bits;
     const int8_t*             in  = rm_in_base + rd.in_offset;
     const int                 mb  = (int)(((uintptr_t)in) & 3);
@@ -603,8 +619,17 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   const int nof_layers = cb_len / Z - bgK;
 
   const uint32_t* edges_g   = tab->edge_sb[bgi][zp];
-  const uint16_t* row_start  = tab->row_start[bgi];
-  const uint16_t* pair_start = tab->pair_start[bgi];
+  // Per-layer constants of the base graph, one layer per lane (loaded once per codeblock): first edge (bits 0-9), degree (10-15),
+  // first message pair (16-31). Inside the layer loop they come out with v_readlane instead of three dependent 16-bit loads at the
+  // head of every layer.
+  uint32_t lay_info = 0;
+  {
+    const int ml = tid & 63;
+    if (ml < bgM) {
+      const uint32_t e0 = tab->row_start[bgi][ml];
+      lay_info          = e0 | (((uint32_t)tab->row_start[bgi][ml + 1] - e0) << 10) | ((uint32_t)tab->pair_start[bgi][ml] << 16);
+    }
+  }
   uint32_t        poly = 0, order = 0;
   int             L = 0;
   if (use_crc) {
@@ -622,12 +647,13 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   PROF_ADD(0, p_start, p_loaded);
   for (int it = 0; it < max_iter; ++it) {
     for (int m = 0; m < nof_layers; ++m) {
-      const int       e0    = row_start[m];
-      const int       d     = row_start[m + 1] - e0;
+      const uint32_t  li    = (uint32_t)__builtin_amdgcn_readlane((int)lay_info, m);
+      const int       e0    = (int)(li & 0x3ffu);
+      const int       d     = (int)((li >> 10) & 0x3fu);
       const uint32_t* edges = edges_g + 2 * e0;
       PROF_T(p_l0);
       if (tid < H) {
-        uint32_t* cl = c2v_lane + 64 * pair_start[m];
+        uint32_t* cl = c2v_lane + 64 * (li >> 16);
         if (it == 0)
           update_rows_pk_any<true>(d, soft, cl, edges, tid, H, Z);
         else

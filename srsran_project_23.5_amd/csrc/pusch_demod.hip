@@ -20,8 +20,6 @@
 
 namespace {
 
-constexpr int MAX_SYM_WORDS = 832; // 275 PRB * 12 RE * 8 bit / 32 = 825 words + the window word + one for a piece that starts inside a word
-
 // Quantisation of avx2_helpers.h:103-157: scale, clip to +-120, round to nearest even, NaN -> 0.
 __device__ __forceinline__ int demod_quantize(float v, float scale)
 {
@@ -198,167 +196,207 @@ struct demod_args {
   float         noise_var;
   const uint16_t* ph;  // repetition placeholders of this transmission (sorted RE indices), nph of them
   int             nph;
-  float*          evm; // sum of |hard-decided symbol - equalised symbol|^2 of this OFDM symbol, or nullptr
+  float*          evm_part; // per (OFDM symbol, chunk) partial sums of |hard-decided symbol - equalised symbol|^2 of this transmission, or nullptr
+  const uint32_t* seq;      // the transmission's scrambling sequence (pusch_scrambling_kernel)
+  int             start_symbol, end_symbol, per_dm, nprb;
+  unsigned        dmrs_syms;
 };
 
+constexpr int DEMOD_THREADS = 256;
+constexpr int DEMOD_MAX_CHUNKS = (275 * 12 + DEMOD_THREADS - 1) / DEMOD_THREADS; // 13
+
+// One thread = one allocated subcarrier, walked over the OFDM symbols of the allocation: with the compact estimate (one row per port,
+// valid for every symbol) the channel coefficients, 1 / sum |h|^2, the post-equalisation noise variance and its reciprocal are
+// computed ONCE and stay in registers -- per resource element only the received sample is loaded (the next symbol's is requested
+// before the current one is worked on). The values are those of the per-element computation (same operations, same order).
+// active: the thread owns a subcarrier; a_idx: its index among the allocated subcarriers (= its rank among the data elements of a
+// symbol without DM-RS); r_dm: its rank among the data elements of a DM-RS symbol, -1 when it carries DM-RS there.
 template <int MOD>
-__device__ __forceinline__ void demod_body(const demod_args& a, const uint16_t* prb_of, const uint8_t* pos, int npp, int n_re, int prefix, int sy,
-                                           const uint32_t* cw, int cw_shift, const float2* tab, int tid, int nt)
+__device__ __forceinline__ void demod_columns(const demod_args& a, bool active, int sc, int a_idx, int r_dm, const float2* tab, float* evm_red, int tid)
 {
 #pragma clang fp contract(off)
   const int   nsc = a.nsc, nports = a.nports;
   const float noise_var = a.noise_var;
-  // per-port row pointers of this OFDM symbol
+  const bool  compact   = a.ce_nof_symbols == 1;
   const float2* gp[4];
   const float2* hp[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    gp[p] = a.grid + ((size_t)((a.rxp >> (8 * p)) & 0xffu) * 14 + sy) * nsc;
-    hp[p] = a.ce + ((size_t)p * a.ce_nof_symbols + (a.ce_nof_symbols == 1 ? 0 : sy)) * nsc;
+    gp[p] = a.grid + (size_t)((a.rxp >> (8 * p)) & 0xffu) * 14 * nsc + sc;
+    hp[p] = a.ce + (size_t)p * a.ce_nof_symbols * nsc + sc;
   }
-  int8_t*    o       = a.llr + (size_t)prefix * MOD;
-  const bool aligned = ((uintptr_t)o % (MOD == 8 ? 8 : MOD == 4 ? 4 : MOD == 1 ? 1 : 2)) == 0;
-  const uint32_t npp_magic = (uint32_t)((0x100000000ull + (uint32_t)npp - 1u) / (uint32_t)npp); // r / npp for r < 2^16
-  float          evm_acc   = 0.f;
-  // The samples and estimates of the NEXT resource element of this thread are requested before the current one is worked on: the
-  // per-element chain load -> equalise -> demap -> store otherwise exposes one memory latency per element.
-  float2 yn[4], cn[4];
-  auto   fetch = [&](int r) {
-    const int pi  = (int)__umulhi((uint32_t)r, npp_magic);
-    const int prb = prb_of[pi], k = r - pi * npp;
-    const int sc  = prb * 12 + pos[k];
+  float2 h[4], yn[4];
+  float  ch_mod_sq = 0.f, rcpd = 0.f, nv = INFINITY, rcp_chk = 0.f;
+  auto   channel = [&]() { // equalize_zf_1xn.h:120-158, the part that only depends on the estimate
+    ch_mod_sq = 0.f;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
       if (p < nports) {
-        yn[p] = gp[p][sc];
-        cn[p] = hp[p][sc];
+        const float t = h[p].x * h[p].x, u = h[p].y * h[p].y;
+        ch_mod_sq     = ch_mod_sq + (t + u);
       }
-  };
-  if (tid < n_re)
-    fetch(tid);
-  for (int r = tid; r < n_re; r += nt) {
-    float2 yc[4], cc4[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      yc[p] = yn[p], cc4[p] = cn[p];
-    if (r + nt < n_re)
-      fetch(r + nt);
-    // equalize_zf_1xn.h:120-158
-    float ch_mod_sq = 0.f, acc_re = 0.f, acc_im = 0.f;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      if (p < nports) {
-        const float2 y = yc[p];
-        const float2 c = cc4[p];
-        const float  t = c.x * c.x, u = c.y * c.y;
-        ch_mod_sq      = ch_mod_sq + (t + u);
-        const float a = y.x * c.x, b = y.y * c.y, cc = y.y * c.x, d = y.x * c.y;
-        acc_re        = acc_re + (a + b);
-        acc_im        = acc_im + (cc - d);
-      }
-    }
     const float d_pinv = 1.0f * ch_mod_sq;
-    const float rcpd   = 1.0f / d_pinv;
+    rcpd               = 1.0f / d_pinv;
     const float v      = rcpd * (noise_var / 1.0f);
-    float       z_re = 0.f, z_im = 0.f, nv = INFINITY;
-    if (d_pinv > 0.f && d_pinv < INFINITY && v > 0.f && v < INFINITY) {
-      z_re = acc_re * rcpd;
-      z_im = acc_im * rcpd;
-      nv   = v;
-    }
-    int l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // NaNs can only come from a non-finite symbol or an infinite reciprocal noise variance (0 * inf): rare, exact path.
-    const float rcp_chk = (nv > 0.f) ? 1.0f / nv : 0.0f;
-    const bool  fast    = fabsf(z_re) < INFINITY && fabsf(z_im) < INFINITY && rcp_chk < INFINITY;
-    int8_t*     q       = o + (size_t)r * MOD;
-    if (MOD >= 2 && fast && aligned && !a.evm && !a.nph) { // the common case: quantise, descramble and pack in one go
-      const int      bi0  = r * MOD + cw_shift;
-      const uint64_t two0 = (uint64_t)cw[bi0 >> 5] | ((uint64_t)cw[(bi0 >> 5) + 1] << 32);
-      const uint64_t w    = demod_symbol_packed<MOD>(z_re, z_im, nv, tab, (uint32_t)(two0 >> (bi0 & 31)));
-      if (MOD == 8)
-        *reinterpret_cast<uint2*>(q) = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
-      else if (MOD == 6) {
-        uint16_t* q2 = reinterpret_cast<uint16_t*>(q);
-        q2[0] = (uint16_t)w, q2[1] = (uint16_t)(w >> 16), q2[2] = (uint16_t)(w >> 32);
-      } else if (MOD == 4)
-        *reinterpret_cast<uint32_t*>(q) = (uint32_t)w;
-      else
-        *reinterpret_cast<uint16_t*>(q) = (uint16_t)w;
-      continue;
-    }
-    if (fast)
-      demod_symbol<MOD, true>(z_re, z_im, nv, (unsigned)(prefix + r), tab, l);
-    else
-      demod_symbol<MOD, false>(z_re, z_im, nv, (unsigned)(prefix + r), tab, l);
-    if (a.evm) { // evm_calculator_generic_impl.cpp:31-47 on the soft bits BEFORE descrambling: hard decision, modulation, error power
-      uint32_t hb = 0;
+    nv                 = (d_pinv > 0.f && d_pinv < INFINITY && v > 0.f && v < INFINITY) ? v : INFINITY;
+    rcp_chk            = (nv > 0.f) ? 1.0f / nv : 0.0f;
+  };
 #pragma unroll
-      for (int b = 0; b < MOD; ++b)
-        hb |= (uint32_t)(l[b] <= 0) << b;
-      const float2 id = map_symbol(MOD, hb, (unsigned)(prefix + r));
-      const float  er = id.x - z_re, ei = id.y - z_im;
-      evm_acc += er * er + ei * ei;
-    }
-    // descramble: bit b of this RE is sequence bit (prefix + r) * MOD + b; cw holds the bits of this OFDM symbol from r = 0
-    const int      bi   = r * MOD + cw_shift;
-    const uint64_t two  = (uint64_t)cw[bi >> 5] | ((uint64_t)cw[(bi >> 5) + 1] << 32);
-    uint32_t       bits = (uint32_t)(two >> (bi & 31));
-    if (a.nph) { // binary search of this element in the placeholder list (pusch_demodulator_impl.cpp:117-149)
-      const unsigned re = (unsigned)(prefix + r);
-      int            lo = 0, hi = a.nph - 1;
-      bool           found = false;
-      while (lo <= hi) {
-        const int      mid = (lo + hi) >> 1;
-        const unsigned v   = a.ph[mid];
-        if (v == re) {
-          found = true;
-          break;
-        }
-        if (v < re)
-          lo = mid + 1;
-        else
-          hi = mid - 1;
-      }
-      if (found)
-        bits = (bits & 1u) ? 3u : 0u; // y repeats the chip of bit 0, the x placeholders behind it are not scrambled
-    }
+  for (int p = 0; p < 4; ++p)
+    h[p] = yn[p] = make_float2(0.f, 0.f);
+  // Where symbol sy finds this thread's element in the codeword (rank r among the data elements of the symbol, -1: none).
+  auto rank_in = [&](int sy) { return (((a.dmrs_syms >> sy) & 1) ? (a.per_dm ? r_dm : -1) : a_idx); };
+  auto fetch   = [&](int sy, int prefix, uint64_t& two) { // samples of symbol sy and the 64-bit window of its descrambling chips
 #pragma unroll
-    for (int b = 0; b < MOD; ++b) {
-      const int m = -(int)((bits >> b) & 1u); // 0 / -1
-      l[b]        = (l[b] ^ m) - m;
+    for (int p = 0; p < 4; ++p)
+      if (p < nports)
+        yn[p] = gp[p][(size_t)sy * nsc];
+    const int r = rank_in(sy);
+    if (r >= 0) {
+      const uint32_t bo = (uint32_t)(prefix + r) * (uint32_t)MOD;
+      two               = (uint64_t)a.seq[bo >> 5] | ((uint64_t)a.seq[(bo >> 5) + 1] << 32);
     }
-    uint64_t w = 0;
+  };
+  uint64_t two_n = 0;
+  if (active) {
+    if (compact) {
 #pragma unroll
-    for (int b = 0; b < MOD; ++b)
-      w |= (uint64_t)(uint8_t)(int8_t)l[b] << (8 * b);
-    if (aligned) {
-      if (MOD == 8)
-        *reinterpret_cast<uint2*>(q) = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
-      else if (MOD == 6) {
-        uint16_t* q2 = reinterpret_cast<uint16_t*>(q);
-        q2[0] = (uint16_t)w, q2[1] = (uint16_t)(w >> 16), q2[2] = (uint16_t)(w >> 32);
-      } else if (MOD == 4)
-        *reinterpret_cast<uint32_t*>(q) = (uint32_t)w;
-      else if (MOD == 2)
-        *reinterpret_cast<uint16_t*>(q) = (uint16_t)w;
-      else
-        q[0] = (int8_t)w;
-    } else {
-#pragma unroll
-      for (int b = 0; b < MOD; ++b)
-        q[b] = (int8_t)(w >> (8 * b));
+      for (int p = 0; p < 4; ++p)
+        if (p < nports)
+          h[p] = hp[p][0];
     }
+    fetch(a.start_symbol, 0, two_n);
   }
-  if (a.evm) { // deterministic order: wavefront shuffle tree, then the four wavefronts in sequence
-    __shared__ float evm_red[4];
+  if (compact)
+    channel();
+  int prefix = 0; // data elements of the transmission before the current symbol
+  for (int sy = a.start_symbol; sy < a.end_symbol; ++sy) {
+    const bool is_dmrs = (a.dmrs_syms >> sy) & 1;
+    const int  npp     = is_dmrs ? a.per_dm : 12;
+    float2     y[4];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-      evm_acc += __shfl_xor(evm_acc, off);
-    if ((tid & 63) == 0)
-      evm_red[tid >> 6] = evm_acc;
-    __syncthreads();
-    if (tid == 0)
-      *a.evm = ((evm_red[0] + evm_red[1]) + evm_red[2]) + evm_red[3];
+    for (int p = 0; p < 4; ++p)
+      y[p] = yn[p];
+    const uint64_t two = two_n;
+    if (active && sy + 1 < a.end_symbol)
+      fetch(sy + 1, prefix + a.nprb * npp, two_n);
+    const int  r   = rank_in(sy);
+    const bool has = active && r >= 0;
+    float      evm_acc = 0.f;
+    if (has) {
+      if (!compact) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (p < nports)
+            h[p] = hp[p][(size_t)sy * nsc];
+        channel();
+      }
+      float acc_re = 0.f, acc_im = 0.f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (p < nports) {
+          const float2 c = h[p];
+          const float  aa = y[p].x * c.x, b = y[p].y * c.y, cc = y[p].y * c.x, d = y[p].x * c.y;
+          acc_re         = acc_re + (aa + b);
+          acc_im         = acc_im + (cc - d);
+        }
+      }
+      float z_re = 0.f, z_im = 0.f;
+      if (nv < INFINITY) {
+        z_re = acc_re * rcpd;
+        z_im = acc_im * rcpd;
+      }
+      // NaNs can only come from a non-finite symbol or an infinite reciprocal noise variance (0 * inf): rare, exact path.
+      const bool     fast = fabsf(z_re) < INFINITY && fabsf(z_im) < INFINITY && rcp_chk < INFINITY;
+      const unsigned re   = (unsigned)(prefix + r); // index of the element in the codeword
+      int8_t*        q    = a.llr + (size_t)re * MOD;
+      const bool     aligned = ((uintptr_t)(a.llr + (size_t)prefix * MOD) % (MOD == 8 ? 8 : MOD == 4 ? 4 : MOD == 1 ? 1 : 2)) == 0;
+      // descrambling chips: bit b of this element is sequence bit re * MOD + b (window requested one symbol ahead)
+      uint32_t bits = (uint32_t)(two >> ((re * (uint32_t)MOD) & 31u));
+      if (MOD >= 2 && fast && aligned && !a.evm_part && !a.nph) { // the common case: quantise, descramble and pack in one go
+        const uint64_t w = demod_symbol_packed<MOD>(z_re, z_im, nv, tab, bits);
+        if (MOD == 8)
+          *reinterpret_cast<uint2*>(q) = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+        else if (MOD == 6) {
+          uint16_t* q2 = reinterpret_cast<uint16_t*>(q);
+          q2[0] = (uint16_t)w, q2[1] = (uint16_t)(w >> 16), q2[2] = (uint16_t)(w >> 32);
+        } else if (MOD == 4)
+          *reinterpret_cast<uint32_t*>(q) = (uint32_t)w;
+        else
+          *reinterpret_cast<uint16_t*>(q) = (uint16_t)w;
+      } else {
+        int l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (fast)
+          demod_symbol<MOD, true>(z_re, z_im, nv, re, tab, l);
+        else
+          demod_symbol<MOD, false>(z_re, z_im, nv, re, tab, l);
+        if (a.evm_part) { // evm_calculator_generic_impl.cpp:31-47 on the soft bits BEFORE descrambling: hard decision, modulation, error power
+          uint32_t hb = 0;
+#pragma unroll
+          for (int b = 0; b < MOD; ++b)
+            hb |= (uint32_t)(l[b] <= 0) << b;
+          const float2 id = map_symbol(MOD, hb, re);
+          const float  er = id.x - z_re, ei = id.y - z_im;
+          evm_acc         = er * er + ei * ei;
+        }
+        if (a.nph) { // binary search of this element in the placeholder list (pusch_demodulator_impl.cpp:117-149)
+          int  lo = 0, hi = a.nph - 1;
+          bool found = false;
+          while (lo <= hi) {
+            const int      mid = (lo + hi) >> 1;
+            const unsigned v   = a.ph[mid];
+            if (v == re) {
+              found = true;
+              break;
+            }
+            if (v < re)
+              lo = mid + 1;
+            else
+              hi = mid - 1;
+          }
+          if (found)
+            bits = (bits & 1u) ? 3u : 0u; // y repeats the chip of bit 0, the x placeholders behind it are not scrambled
+        }
+#pragma unroll
+        for (int b = 0; b < MOD; ++b) {
+          const int m = -(int)((bits >> b) & 1u); // 0 / -1
+          l[b]        = (l[b] ^ m) - m;
+        }
+        uint64_t w = 0;
+#pragma unroll
+        for (int b = 0; b < MOD; ++b)
+          w |= (uint64_t)(uint8_t)(int8_t)l[b] << (8 * b);
+        if (aligned) {
+          if (MOD == 8)
+            *reinterpret_cast<uint2*>(q) = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+          else if (MOD == 6) {
+            uint16_t* q2 = reinterpret_cast<uint16_t*>(q);
+            q2[0] = (uint16_t)w, q2[1] = (uint16_t)(w >> 16), q2[2] = (uint16_t)(w >> 32);
+          } else if (MOD == 4)
+            *reinterpret_cast<uint32_t*>(q) = (uint32_t)w;
+          else if (MOD == 2)
+            *reinterpret_cast<uint16_t*>(q) = (uint16_t)w;
+          else
+            q[0] = (int8_t)w;
+        } else {
+#pragma unroll
+          for (int b = 0; b < MOD; ++b)
+            q[b] = (int8_t)(w >> (8 * b));
+        }
+      }
+    }
+    if (a.evm_part && npp != 0) { // deterministic order: wavefront shuffle tree, then the four wavefronts in sequence (uniform branch)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+        evm_acc += __shfl_xor(evm_acc, off);
+      __syncthreads();
+      if ((tid & 63) == 0)
+        evm_red[tid >> 6] = evm_acc;
+      __syncthreads();
+      if (tid == 0)
+        a.evm_part[sy * DEMOD_MAX_CHUNKS + blockIdx.y] = ((evm_red[0] + evm_red[1]) + evm_red[2]) + evm_red[3];
+    }
+    prefix += a.nprb * npp;
   }
 }
 
@@ -384,43 +422,58 @@ __global__ void __launch_bounds__(SCR_THREADS) pusch_scrambling_kernel(const mip
     o[i] = w[i] ^ gt->x1_seq[i];
 }
 
-__global__ void __launch_bounds__(256) pusch_demod_kernel(const miphy_pusch_demod_job* __restrict__ jobs, const gold_tables* __restrict__ gt,
-                                                          const float2* __restrict__ grid, const float2* __restrict__ ce,
-                                                          const float* __restrict__ scalars, int8_t* __restrict__ llr,
-                                                          const uint16_t* __restrict__ placeholders, float* __restrict__ evm_sums,
-                                                          const uint32_t* __restrict__ seq)
+// The descriptor as 30 dwords in scalar registers: its sub-dword fields read one by one become VECTOR byte / short loads with a wait
+// each (there are no scalar sub-dword loads on gfx950) -- several dependent memory round trips at the head of every workgroup.
+// Layout of miphy_pusch_demod_job (include/miphy.h; sizeof = 120 is checked by tests/test_cabi.py).
+struct demod_job_words {
+  uint32_t w[30];
+  __device__ __forceinline__ int      mod() const { return (int)(w[2] & 0xffu); }
+  __device__ __forceinline__ int      nof_rx_ports() const { return (int)((w[2] >> 8) & 0xffu); }
+  __device__ __forceinline__ int      start_symbol() const { return (int)((w[2] >> 16) & 0xffu); }
+  __device__ __forceinline__ int      nof_symbols() const { return (int)(w[2] >> 24); }
+  __device__ __forceinline__ int      dmrs_type() const { return (int)(w[3] & 0xffu); }
+  __device__ __forceinline__ unsigned cdm_groups() const { return (w[3] >> 8) & 0xffu; }
+  __device__ __forceinline__ int      ce_nof_symbols() const { return (int)((w[3] >> 16) & 0xffu); }
+  __device__ __forceinline__ bool     ce_compact() const { return (w[3] >> 24) != 0; }
+  __device__ __forceinline__ uint32_t rx_ports() const { return w[4]; }
+  __device__ __forceinline__ unsigned dmrs_symbols_mask() const { return w[5] & 0xffffu; }
+  __device__ __forceinline__ int      grid_nof_prb() const { return (int)(w[5] >> 16); }
+  __device__ __forceinline__ uint64_t rb_mask(int k) const { return (uint64_t)w[8 + 2 * k] | ((uint64_t)w[9 + 2 * k] << 32); }
+  __device__ __forceinline__ uint64_t grid_offset() const { return (uint64_t)w[18] | ((uint64_t)w[19] << 32); }
+  __device__ __forceinline__ uint64_t ce_offset() const { return (uint64_t)w[20] | ((uint64_t)w[21] << 32); }
+  __device__ __forceinline__ uint64_t scalars_offset() const { return (uint64_t)w[22] | ((uint64_t)w[23] << 32); }
+  __device__ __forceinline__ uint64_t llr_offset() const { return (uint64_t)w[24] | ((uint64_t)w[25] << 32); }
+  __device__ __forceinline__ uint32_t placeholders_offset() const { return w[26]; }
+  __device__ __forceinline__ uint32_t nof_placeholders() const { return w[27]; }
+  __device__ __forceinline__ uint64_t evm_offset() const { return (uint64_t)w[28] | ((uint64_t)w[29] << 32); }
+};
+static_assert(sizeof(miphy_pusch_demod_job) == 120 && offsetof(miphy_pusch_demod_job, rb_mask) == 32 && offsetof(miphy_pusch_demod_job, grid_offset) == 72 &&
+                  offsetof(miphy_pusch_demod_job, placeholders_offset) == 104 && offsetof(miphy_pusch_demod_job, evm_offset) == 112 &&
+                  offsetof(miphy_pusch_demod_job, rx_ports) == 16 && offsetof(miphy_pusch_demod_job, dmrs_symbols_mask) == 20,
+              "demod_job_words follows the layout of miphy_pusch_demod_job");
+__device__ __forceinline__ demod_job_words demod_load_job(const miphy_pusch_demod_job* __restrict__ jp)
 {
-  __shared__ uint32_t w1[MAX_SYM_WORDS];
-  __shared__ uint16_t prb_of[276];
-  __shared__ uint8_t  pos[12];
-  __shared__ int      nprb_s;
-  __shared__ float2   tab[64];
-  __shared__ uint64_t rbm[5];
-  // The descriptor is read field by field (uniform scalar loads) and its arrays go through LDS: a private copy indexed at
-  // run time would live in scratch memory, and every dependent access to it costs a memory round trip.
-  const miphy_pusch_demod_job* __restrict__ jp = jobs + blockIdx.x;
-  const int sy  = blockIdx.y;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int start_symbol = jp->start_symbol, nof_symbols = jp->nof_symbols;
-  float* evm_out = evm_sums ? evm_sums + jp->evm_offset + sy : nullptr;
-  if (evm_out && tid == 0)
-    *evm_out = 0.f; // symbols without data contribute nothing
-  if (sy < start_symbol || sy >= start_symbol + nof_symbols)
-    return;
-  const unsigned dmask     = dmrs_prb_mask(jp->dmrs_type, jp->nof_cdm_groups_without_data);
-  const int      per_dm    = 12 - __popc(dmask);
-  const unsigned dmrs_syms = jp->dmrs_symbols_mask;
-  const bool     is_dmrs   = (dmrs_syms >> sy) & 1;
-  const int      npp       = is_dmrs ? per_dm : 12; // data REs per PRB in this symbol
-  if (npp == 0)
-    return;
-  const int nprb_grid = jp->grid_nof_prb;
-  if (tid < 5)
-    rbm[tid] = jp->rb_mask[tid];
+  const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(jp);
+  demod_job_words j;
+#pragma unroll
+  for (int i = 0; i < 30; ++i)
+    j.w[i] = s[i];
+  return j;
+}
+
+// Allocated PRBs of a job: count and, for the lanes of a workgroup, the compact list prb_of[rank] (LDS). Uniform result.
+__device__ __forceinline__ int demod_prb_list(const demod_job_words& j, uint64_t* rbm, uint16_t* prb_of, int* nprb_s, int tid, int nt)
+{
+  const int nprb_grid = j.grid_nof_prb();
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      rbm[k] = j.rb_mask(k);
+  }
   __syncthreads();
   for (int r = tid; r < nprb_grid; r += nt) {
-    const int wd = r >> 6, bt = r & 63;
-    const uint64_t m = rbm[wd];
+    const int      wd = r >> 6, bt = r & 63;
+    const uint64_t m  = rbm[wd];
     if ((m >> bt) & 1ull) {
       int idx = __popcll(m & ((1ull << bt) - 1ull));
       for (int w = 0; w < wd; ++w)
@@ -428,66 +481,107 @@ __global__ void __launch_bounds__(256) pusch_demod_kernel(const miphy_pusch_demo
       prb_of[idx] = (uint16_t)r;
     }
   }
-  if (tid == 0) {
-    int c = 0;
-    for (int w = 0; w < 5; ++w)
-      c += __popcll(w * 64 < nprb_grid ? (rbm[w] & ((nprb_grid - w * 64 >= 64) ? ~0ull : ((1ull << (nprb_grid - w * 64)) - 1ull))) : 0ull);
-    nprb_s = c;
-    int k  = 0;
-    for (int q = 0; q < 12; ++q)
-      if (!is_dmrs || !((dmask >> q) & 1u))
-        pos[k++] = (uint8_t)q;
+  int c = 0; // uniform: scalar popcounts
+#pragma unroll
+  for (int w = 0; w < 5; ++w) {
+    const int left = nprb_grid - 64 * w;
+    if (left > 0)
+      c += __popcll(j.rb_mask(w) & (left >= 64 ? ~0ull : ((1ull << left) - 1ull)));
   }
+  (void)nprb_s;
   __syncthreads();
-  const int nprb = nprb_s;
-  int       prefix = 0; // data REs of the transmission before this symbol
-  for (int s = start_symbol; s < sy; ++s)
-    prefix += nprb * (((dmrs_syms >> s) & 1) ? per_dm : 12);
-  const int n_re   = nprb * npp;
-  const int mod    = jp->mod;
-  // the symbol's piece of the scrambling sequence (pusch_scrambling_kernel): it starts at bit prefix * mod of the transmission's
-  const uint32_t bit0 = (uint32_t)prefix * (uint32_t)mod;
-  const int      sh   = (int)(bit0 & 31u);
-  {
-    const uint32_t* sq = seq + (size_t)blockIdx.x * SEQ_STRIDE + (bit0 >> 5);
-    const int       nw = ((n_re * mod + sh + 31) >> 5) + 1;
-    for (int i = tid; i < nw; i += nt)
-      w1[i] = sq[i];
-    __syncthreads();
-  }
-  demod_args a;
-  a.nsc            = nprb_grid * 12;
-  a.nports         = jp->nof_rx_ports;
-  a.ce_nof_symbols = jp->ce_compact ? 1 : jp->ce_nof_symbols; // compact estimate: one row per port, valid for every symbol
-  a.rxp            = (uint32_t)jp->rx_ports[0] | ((uint32_t)jp->rx_ports[1] << 8) | ((uint32_t)jp->rx_ports[2] << 16) | ((uint32_t)jp->rx_ports[3] << 24);
-  a.grid           = grid + jp->grid_offset;
-  a.ce             = ce + jp->ce_offset;
-  a.llr            = llr + jp->llr_offset;
-  a.noise_var      = scalars[jp->scalars_offset + 2];
-  a.nph            = placeholders ? (int)jp->nof_placeholders : 0;
-  a.ph             = placeholders ? placeholders + jp->placeholders_offset : nullptr;
-  a.evm            = evm_out;
+  return c;
+}
+
+// grid (transmissions, chunks of 256 allocated subcarriers)
+__global__ void __launch_bounds__(DEMOD_THREADS) pusch_demod_kernel(const miphy_pusch_demod_job* __restrict__ jobs, const float2* __restrict__ grid,
+                                                                    const float2* __restrict__ ce, const float* __restrict__ scalars,
+                                                                    int8_t* __restrict__ llr, const uint16_t* __restrict__ placeholders,
+                                                                    float* __restrict__ evm_part, const uint32_t* __restrict__ seq)
+{
+  __shared__ uint16_t prb_of[276];
+  __shared__ int      nprb_s;
+  __shared__ float2   tab[64];
+  __shared__ uint64_t rbm[5];
+  __shared__ float    evm_red[4];
+  const demod_job_words j    = demod_load_job(jobs + blockIdx.x);
+  const int             tid  = threadIdx.x;
+  const int             nprb = demod_prb_list(j, rbm, prb_of, &nprb_s, tid, DEMOD_THREADS);
+  if ((int)blockIdx.y * DEMOD_THREADS >= nprb * 12)
+    return; // uniform
+  const unsigned dmask = dmrs_prb_mask(j.dmrs_type(), j.cdm_groups());
+  demod_args     a;
+  a.per_dm         = 12 - __popc(dmask);
+  a.dmrs_syms      = j.dmrs_symbols_mask();
+  a.start_symbol   = j.start_symbol();
+  a.end_symbol     = a.start_symbol + j.nof_symbols();
+  a.nprb           = nprb;
+  a.nsc            = j.grid_nof_prb() * 12;
+  a.nports         = j.nof_rx_ports();
+  a.ce_nof_symbols = j.ce_compact() ? 1 : j.ce_nof_symbols(); // compact estimate: one row per port, valid for every symbol
+  a.rxp            = j.rx_ports();
+  a.grid           = grid + j.grid_offset();
+  a.ce             = ce + j.ce_offset();
+  a.llr            = llr + j.llr_offset();
+  a.noise_var      = scalars[j.scalars_offset() + 2];
+  a.nph            = placeholders ? (int)j.nof_placeholders() : 0;
+  a.ph             = placeholders ? placeholders + j.placeholders_offset() : nullptr;
+  a.evm_part       = evm_part ? evm_part + (size_t)blockIdx.x * 14 * DEMOD_MAX_CHUNKS : nullptr;
+  a.seq            = seq + (size_t)blockIdx.x * SEQ_STRIDE;
+  // this thread's subcarrier
+  const int  a_idx  = (int)blockIdx.y * DEMOD_THREADS + tid;
+  const bool active = a_idx < nprb * 12;
+  const int  pr     = a_idx / 12, k = a_idx - 12 * pr;
+  const int  sc     = active ? (int)prb_of[pr] * 12 + k : 0;
+  const int  r_dm   = ((dmask >> k) & 1u) ? -1 : pr * a.per_dm + __popc(~dmask & ((1u << k) - 1u));
+  const int  mod    = j.mod();
   switch (mod) {
     case 8:
       demod_tables_to_lds<8>(tab, tid);
       __syncthreads();
-      demod_body<8>(a, prb_of, pos, npp, n_re, prefix, sy, w1, sh, tab, tid, nt);
+      demod_columns<8>(a, active, sc, a_idx, r_dm, tab, evm_red, tid);
       break;
     case 6:
       demod_tables_to_lds<6>(tab, tid);
       __syncthreads();
-      demod_body<6>(a, prb_of, pos, npp, n_re, prefix, sy, w1, sh, tab, tid, nt);
+      demod_columns<6>(a, active, sc, a_idx, r_dm, tab, evm_red, tid);
       break;
     case 4:
-      demod_body<4>(a, prb_of, pos, npp, n_re, prefix, sy, w1, sh, tab, tid, nt);
+      demod_columns<4>(a, active, sc, a_idx, r_dm, tab, evm_red, tid);
       break;
     case 2:
-      demod_body<2>(a, prb_of, pos, npp, n_re, prefix, sy, w1, sh, tab, tid, nt);
+      demod_columns<2>(a, active, sc, a_idx, r_dm, tab, evm_red, tid);
       break;
     default:
-      demod_body<1>(a, prb_of, pos, npp, n_re, prefix, sy, w1, sh, tab, tid, nt);
+      demod_columns<1>(a, active, sc, a_idx, r_dm, tab, evm_red, tid);
       break;
   }
+}
+
+// Per-symbol EVM sums of a transmission from the per-chunk partials, chunks added in order (deterministic); symbols without data: 0.
+__global__ void __launch_bounds__(64) pusch_evm_reduce_kernel(const miphy_pusch_demod_job* __restrict__ jobs, const float* __restrict__ evm_part,
+                                                              float* __restrict__ evm_sums)
+{
+  const miphy_pusch_demod_job* __restrict__ jp = jobs + blockIdx.x;
+  const int sy = threadIdx.x;
+  if (sy >= 14)
+    return;
+  int nprb = 0;
+  for (int w = 0; w < 5; ++w) {
+    const int left = (int)jp->grid_nof_prb - 64 * w;
+    if (left > 0)
+      nprb += __popcll(jp->rb_mask[w] & (left >= 64 ? ~0ull : ((1ull << left) - 1ull)));
+  }
+  const unsigned dmask = dmrs_prb_mask(jp->dmrs_type, jp->nof_cdm_groups_without_data);
+  const int      npp   = ((jp->dmrs_symbols_mask >> sy) & 1) ? 12 - __popc(dmask) : 12;
+  float          s     = 0.f;
+  if (sy >= jp->start_symbol && sy < jp->start_symbol + jp->nof_symbols && npp != 0) {
+    const int    nch = (nprb * 12 + DEMOD_THREADS - 1) / DEMOD_THREADS;
+    const float* p   = evm_part + ((size_t)blockIdx.x * 14 + sy) * DEMOD_MAX_CHUNKS;
+    for (int c = 0; c < nch; ++c)
+      s += p[c];
+  }
+  evm_sums[jp->evm_offset + sy] = s;
 }
 
 } // namespace
@@ -522,7 +616,16 @@ extern "C" int miphy_pusch_demodulate_batch_ex(miphy_ctx* ctx, const miphy_pusch
   if (n == 0)
     return MIPHY_OK;
   MIPHY_REQUIRE(n <= 65535, "pusch_demodulate: batch too large (max 65535 transmissions per call)");
+  uint32_t max_chunks = DEMOD_MAX_CHUNKS; // device-resident jobs: the widest grid
   if (!jobs_on_device) {
+    uint32_t max_prb = 1;
+    for (uint32_t i = 0; i < n; ++i) {
+      uint32_t np = 0;
+      for (unsigned r = 0; r < jobs[i].grid_nof_prb && r < 275; ++r)
+        np += (uint32_t)((jobs[i].rb_mask[r >> 6] >> (r & 63)) & 1ull);
+      max_prb = np > max_prb ? np : max_prb;
+    }
+    max_chunks = (max_prb * 12 + DEMOD_THREADS - 1) / DEMOD_THREADS;
     for (uint32_t i = 0; i < n; ++i) {
       const miphy_pusch_demod_job& j = jobs[i];
       MIPHY_REQUIRE(j.mod == 1 || j.mod == 2 || j.mod == 4 || j.mod == 6 || j.mod == 8, "pusch_demodulate: job %u: invalid modulation order %u", i, j.mod);
@@ -551,12 +654,18 @@ extern "C" int miphy_pusch_demodulate_batch_ex(miphy_ctx* ctx, const miphy_pusch
   rc                 = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_pusch_demod_job) * (size_t)n, s, &d_jobs);
   if (rc)
     return rc;
-  void* seq = nullptr;
-  if ((rc = miphy_get_workspace(ctx, (size_t)n * SEQ_STRIDE * sizeof(uint32_t), s, &seq, 4)))
+  void*        work      = nullptr;
+  const size_t seq_bytes = (size_t)n * SEQ_STRIDE * sizeof(uint32_t);
+  const size_t evm_bytes = evm_sums ? (size_t)n * 14 * DEMOD_MAX_CHUNKS * sizeof(float) : 0;
+  if ((rc = miphy_get_workspace(ctx, seq_bytes + evm_bytes, s, &work, 4)))
     return rc;
-  hipLaunchKernelGGL(pusch_scrambling_kernel, dim3(n), dim3(SCR_THREADS), 0, s, (const miphy_pusch_demod_job*)d_jobs, gt, (uint32_t*)seq);
-  hipLaunchKernelGGL(pusch_demod_kernel, dim3(n, 14), dim3(256), 0, s, (const miphy_pusch_demod_job*)d_jobs, gt, (const float2*)grid, (const float2*)ce,
-                     scalars, llr, placeholders, evm_sums, (const uint32_t*)seq);
+  uint32_t* seq      = static_cast<uint32_t*>(work);
+  float*    evm_part = evm_sums ? reinterpret_cast<float*>(static_cast<uint8_t*>(work) + seq_bytes) : nullptr;
+  hipLaunchKernelGGL(pusch_scrambling_kernel, dim3(n), dim3(SCR_THREADS), 0, s, (const miphy_pusch_demod_job*)d_jobs, gt, seq);
+  hipLaunchKernelGGL(pusch_demod_kernel, dim3(n, max_chunks), dim3(DEMOD_THREADS), 0, s, (const miphy_pusch_demod_job*)d_jobs, (const float2*)grid,
+                     (const float2*)ce, scalars, llr, placeholders, evm_part, (const uint32_t*)seq);
+  if (evm_sums)
+    hipLaunchKernelGGL(pusch_evm_reduce_kernel, dim3(n), dim3(64), 0, s, (const miphy_pusch_demod_job*)d_jobs, (const float*)evm_part, evm_sums);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }
