@@ -94,7 +94,9 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
 
   // Read field by field (uniform loads); the arrays go through LDS / a packed word: a private copy of the descriptor indexed at
   // run time would live in scratch memory.
-  const miphy_pusch_chest_job& job = jobs[blockIdx.x];
+  // static fields from a dword copy in scalar registers (load_words), the run-time indexed arrays from the record in memory
+  const miphy_pusch_chest_job& jmem = jobs[blockIdx.x];
+  const miphy_pusch_chest_job  job  = load_words(jobs + blockIdx.x);
   __shared__ uint64_t rbm[5];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int port = blockIdx.y % 4, layer = blockIdx.y / 4;
@@ -123,7 +125,7 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
   const int h_first = (hop == 1) ? hop_symbol : first, h_last = (hop == 0 && hop_symbol) ? hop_symbol : nsymb_out;
   __syncthreads();
   if (tid < 5)
-    rbm[tid] = (hop == 1) ? job.rb_mask2[tid] : job.rb_mask[tid];
+    rbm[tid] = (hop == 1) ? jmem.rb_mask2[tid] : jmem.rb_mask[tid];
   __syncthreads();
   // DM-RS symbol list inside the hop.
   int dsym[4], nds = 0;

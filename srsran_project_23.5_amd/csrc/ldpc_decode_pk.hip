@@ -64,22 +64,6 @@ __device__ __forceinline__ uint32_t c2v_pack(s16x2 c0, s16x2 c1)
   return __builtin_amdgcn_perm(as_u(c0), as_u(c1), 0x06020400u);
 }
 
-// A descriptor through dword loads: read field by field, its 8- and 16-bit members become vector loads with a wait each (gfx950 has no
-// scalar sub-dword loads); as dwords the whole record arrives in scalar registers with one request and the fields are shifts.
-template <class T>
-__device__ __forceinline__ T load_words(const T* __restrict__ p)
-{
-  static_assert(sizeof(T) % 4 == 0, "dword multiple");
-  uint32_t                     w[sizeof(T) / 4];
-  const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(p);
-#pragma unroll
-  for (unsigned i = 0; i < sizeof(T) / 4; ++i)
-    w[i] = s[i];
-  T r;
-  __builtin_memcpy(&r, w, sizeof(T));
-  return r;
-}
-
 constexpr int LLR_MAX = 120;
 constexpr int LLR_INF = 127;
 constexpr int INF_MUL = 255; // an infinite soft bit (|s| > 120) becomes a message of magnitude >= 255 + 24
@@ -275,15 +259,10 @@ __device__ __forceinline__ bool block_crc_is_zero(const int8_t* soft, const miph
       }
       w &= valid;
     }
-    const uint4* m = reinterpret_cast<const uint4*>(tab->crc_zmask[zi][nw - 1 - t]);
+    const uint32_t* m = &tab->crc_zmask[zi][0][nw - 1 - t]; // lanes: consecutive words, coalesced
 #pragma unroll
-    for (int g = 0; g < 6; ++g) {
-      const uint4 mk = m[g];
-      acc[4 * g + 0] += __builtin_popcount(w & mk.x);
-      acc[4 * g + 1] += __builtin_popcount(w & mk.y);
-      acc[4 * g + 2] += __builtin_popcount(w & mk.z);
-      acc[4 * g + 3] += __builtin_popcount(w & mk.w);
-    }
+    for (int k = 0; k < 24; ++k)
+      acc[k] += __builtin_popcount(w & m[k * MIPHY_CRC_ZMASK_WORDS]);
   }
   uint32_t par = 0;
 #pragma unroll
@@ -685,11 +664,16 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   PROF_T(p_crc);
   PROF_ADD(3, p_dec, p_crc);
 
+  const bool out_aligned = ((uintptr_t)out & 3u) == 0;
   for (int t = tid; t < kwords; t += nt) {
     const uint32_t w      = hard_word(soft, t, K);
     const int      nbytes = min(4, (K - 32 * t + 7) / 8);
-    for (int q = 0; q < nbytes; ++q)
-      out[4 * t + q] = (uint8_t)(w >> (24 - 8 * q));
+    if (nbytes == 4 && out_aligned) {
+      reinterpret_cast<uint32_t*>(out)[t] = __builtin_bswap32(w); // MSB-first bytes
+    } else {
+      for (int q = 0; q < nbytes; ++q)
+        out[4 * t + q] = (uint8_t)(w >> (24 - 8 * q));
+    }
   }
   if (tid == 0) {
     iters_out[cb] = result_iters;

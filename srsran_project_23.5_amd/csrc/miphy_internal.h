@@ -28,14 +28,16 @@ struct miphy_graph_tables {
   uint32_t crc_poly[5];
   uint32_t crc_order[5];
   // Zero test of a codeblock CRC by masks (LDPC decoders): for the polynomials a codeblock can carry (index 0 = CRC24A, 1 = CRC24B,
-  // 2 = CRC16) and word u counted from the END of the message padded with zeros to a multiple of 32 bits, crc_zmask[.][u][k] selects
+  // 2 = CRC16) and word u counted from the END of the message padded with zeros to a multiple of 32 bits, crc_zmask[.][k][u] selects
   // the bits of that word whose weight x^(distance to the end + order) mod P has bit k set; bit k of the checksum of the padded
   // message is the parity of the sum over u of popcount(word & mask). (M(x) x^r mod P == 0 <=> M(x) mod P == 0, so the padding
   // does not change the verdict.) Word layout: bit (q + 8 b) of a word is message bit 4 q + b of its group of 32 (see hard_flags()).
-  uint32_t crc_zmask[3][MIPHY_CRC_ZMASK_WORDS][24];
+  // Stored [k][u]: the lanes of a wavefront take consecutive words u, so the 24 mask loads of a lane are coalesced across the wavefront
+  // (as [u][k] every lane walked its own 96-byte row: 64 cache lines per load instruction).
+  uint32_t crc_zmask[3][24][MIPHY_CRC_ZMASK_WORDS];
   // The same for CRC24A over PACKED message bytes read as little-endian dwords (transport-block assembly): bit 8 k + 7 - j of a
   // word is message bit 8 k + j of its group of 32.
-  uint32_t crc_zmask_packed24a[MIPHY_CRC_ZMASK_WORDS][24];
+  uint32_t crc_zmask_packed24a[24][MIPHY_CRC_ZMASK_WORDS];
 };
 // index into crc_zmask for a MIPHY_CRC_* id, -1 if the polynomial has no mask table
 static inline __host__ __device__ int miphy_crc_zmask_index(int crc_id)
@@ -81,6 +83,24 @@ void miphy_set_error(const char* fmt, ...);
       return MIPHY_EINVAL;                \
     }                                     \
   } while (0)
+
+#ifdef __HIPCC__
+// A descriptor through dword loads: read field by field, its 8- and 16-bit members become vector loads with a wait each (gfx950 has no
+// scalar sub-dword loads); as dwords the whole record arrives in scalar registers with one request and the fields are shifts.
+template <class T>
+__device__ __forceinline__ T load_words(const T* __restrict__ p)
+{
+  static_assert(sizeof(T) % 4 == 0, "dword multiple");
+  uint32_t                     w[sizeof(T) / 4];
+  const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i)
+    w[i] = s[i];
+  T r;
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+#endif
 
 // Ensures the descriptor array is on the device; returns the device pointer through *out.
 int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t bytes, hipStream_t s, const void** out);

@@ -87,15 +87,22 @@ __global__ void harq_reset_kernel(const uint32_t* __restrict__ slots, uint32_t n
 // codeblock's bits as if the message ended with them), which one lane then weights with the bits that follow in TB + CRC24A.
 // The XOR of the parts is zero exactly when CRC24A passes (all parts carry the same invertible factor x^24, see below).
 // Then: decoder statistics, result record, CRC flags reset on a TB CRC failure.
+// The mask / popcount form of the checksum parts applies to multi-codeblock transport blocks with byte-aligned payloads.
+__host__ __device__ inline bool tb_mask_crc(const tb_asm_desc& d)
+{
+  return d.nof_cbs > 1 && d.nof_data_bits <= 32u * MIPHY_CRC_ZMASK_WORDS && (d.nof_data_bits & 7u) == 0;
+}
+
 __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_desc* __restrict__ descs,
                                                                 const miphy_graph_tables* __restrict__ tab,
                                                                 const int32_t* __restrict__ iters,
                                                                 const uint8_t* __restrict__ harq_msgs,
                                                                 uint8_t* __restrict__ harq_crc_ok,
                                                                 uint8_t* __restrict__ tb_out,
-                                                                miphy_pusch_result* __restrict__ results)
+                                                                miphy_pusch_result* __restrict__ results,
+                                                                const uint32_t* __restrict__ cbw)
 {
-  __shared__ uint32_t wpart[16];
+  __shared__ uint32_t cbpar[64]; // checksum part of every codeblock (at most 52), before its weight
   __shared__ int      all_ok;
   const tb_asm_desc d    = descs[blockIdx.x];
   const int         tid  = threadIdx.x;
@@ -132,33 +139,43 @@ __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_de
       results[blockIdx.x]    = r;
     }
   }
-  if (tid < 16)
-    wpart[tid] = 0;
+  if (tid < 64)
+    cbpar[tid] = 0;
   __syncthreads();
   if (!all_ok)
     return; // nothing is copied, flags stay as they are (multiple codeblocks) / tb_crc_ok = false (single codeblock)
   const uint32_t tb_bits = d.tb_bytes * 8;
-  const bool     mask_crc = d.nof_cbs > 1 && d.nof_data_bits <= 32u * MIPHY_CRC_ZMASK_WORDS && (d.nof_data_bits & 7u) == 0;
-  uint32_t       acc_wave = 0;
+  const bool     mask_crc = tb_mask_crc(d);
   for (uint32_t c = wave; c < d.nof_cbs; c += nwaves) {
     const uint8_t* msg   = harq_msgs + (size_t)(d.harq_cb_index + c) * HARQ_MSG_STRIDE;
     const uint32_t bit0  = c * d.nof_data_bits; // first TB(+CRC) bit of this codeblock
     const uint32_t nbits = min(d.nof_data_bits, d.tb_and_crc_bits - min(bit0, d.tb_and_crc_bits));
-    const uint32_t after = d.tb_and_crc_bits - (bit0 + nbits);
     // ---- copy: whole bytes (codeblock payloads are byte aligned for every TS 38.214 transport block size; a single codeblock
     // starts at bit 0, only its last byte can be partial and is masked)
     const uint32_t o0 = bit0 >> 3;
     const uint32_t e0 = (min(bit0 + nbits, tb_bits) + 7) >> 3; // end byte in the transport block
-    for (uint32_t b = o0 + lane; b < e0; b += 64) {
-      uint32_t       v    = msg[b - o0];
-      const uint32_t last = tb_bits - 8 * b; // bits of this byte that belong to the transport block
-      if (last < 8)
-        v &= 0xffu << (8 - last);
-      tb_out[d.tb_offset + b] = (uint8_t)v;
+    // (tb_bits is a whole number of bytes, so no byte is partial.) The destination has any alignment, the source slot is dword
+    // aligned: head bytes up to the destination's dword boundary, then aligned dword stores fed by a funnel shift of two source
+    // dwords (the slot is HARQ_MSG_STRIDE = 1056 bytes, the dword behind the last payload byte is inside it), then tail bytes.
+    {
+      uint8_t*        dst  = tb_out + d.tb_offset + o0;
+      const uint32_t  nb   = e0 > o0 ? e0 - o0 : 0;
+      const uint32_t  head = min(nb, (uint32_t)((4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u));
+      const uint32_t  ndw  = (nb - head) >> 2;
+      const uint32_t* s32  = reinterpret_cast<const uint32_t*>(msg);
+      uint32_t*       d32  = reinterpret_cast<uint32_t*>(dst + head);
+      if ((uint32_t)lane < head)
+        dst[lane] = msg[lane];
+      for (uint32_t i = lane; i < ndw; i += 64) {
+        const uint32_t lo = s32[i], hi = s32[i + 1];
+        d32[i]            = head ? __builtin_amdgcn_alignbyte(hi, lo, head) : lo;
+      }
+      for (uint32_t b = head + 4 * ndw + lane; b < nb; b += 64)
+        dst[b] = msg[b];
     }
     // ---- checksum part
     if (mask_crc) {
-      const uint32_t  nw = (nbits + 31) >> 5, r = 32 * nw - nbits; // zero bits the mask table assumes behind the message
+      const uint32_t  nw = (nbits + 31) >> 5; // the mask table assumes the message padded with zeros to whole words (folded into cbw)
       const uint32_t* mw = reinterpret_cast<const uint32_t*>(msg); // slots are 1056 B apart: dword aligned
       uint32_t        acc[24];
 #pragma unroll
@@ -170,15 +187,10 @@ __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_de
           const uint32_t nb = (nbits - 32 * t) >> 3;
           w &= (nb >= 4) ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
         }
-        const uint4* m = reinterpret_cast<const uint4*>(tab->crc_zmask_packed24a[nw - 1 - t]);
+        const uint32_t* m = &tab->crc_zmask_packed24a[0][nw - 1 - t]; // lanes: consecutive words, coalesced
 #pragma unroll
-        for (int g = 0; g < 6; ++g) {
-          const uint4 mk = m[g];
-          acc[4 * g + 0] += __builtin_popcount(w & mk.x);
-          acc[4 * g + 1] += __builtin_popcount(w & mk.y);
-          acc[4 * g + 2] += __builtin_popcount(w & mk.z);
-          acc[4 * g + 3] += __builtin_popcount(w & mk.w);
-        }
+        for (int k = 0; k < 24; ++k)
+          acc[k] += __builtin_popcount(w & m[k * MIPHY_CRC_ZMASK_WORDS]);
       }
       uint32_t par = 0;
 #pragma unroll
@@ -187,37 +199,32 @@ __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_de
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1)
         par ^= __shfl_xor(par, off);
-      // par = D(x) x^(r + 24) mod P. Every part is brought to the common factor x^24: times x^(after + 24 - r), r <= 24.
-      const uint32_t poly = tab->crc_poly[MIPHY_CRC24A], order = 24, top = 1u << 24;
-      const uint32_t sh   = after + 24 - r;
-      par                 = crc_gf2_mulmod(par, crc_pow32(tab, MIPHY_CRC24A, sh >> 5, poly, order), poly, order);
-      for (uint32_t b = 0; b < (sh & 31u); ++b) {
-        par <<= 1;
-        par ^= (par & top) ? poly : 0u;
-      }
-      acc_wave ^= par;
+      // par = D(x) x^(r + 24) mod P; its weight x^(after + 24 - r) (cbw, from the host) brings it to the common factor x^24 below.
+      if (lane == 0)
+        cbpar[c] = par;
     } else if (d.nof_cbs > 1) {
       uint32_t par = crc_partial(tab, MIPHY_CRC24A, msg, 0, nbits, lane, 64);
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1)
         par ^= __shfl_xor(par, off);
-      const uint32_t poly = tab->crc_poly[MIPHY_CRC24A], order = 24, top = 1u << 24;
-      const uint32_t sh   = after + 24; // the same common factor as the mask form
-      par                 = crc_gf2_mulmod(par, crc_pow32(tab, MIPHY_CRC24A, sh >> 5, poly, order), poly, order);
-      for (uint32_t b = 0; b < (sh & 31u); ++b) {
-        par <<= 1;
-        par ^= (par & top) ? poly : 0u;
-      }
-      acc_wave ^= par;
+      if (lane == 0)
+        cbpar[c] = par; // weight x^(after + 24): the same common factor as the mask form
     }
   }
-  if (lane == 0)
-    wpart[wave] = acc_wave;
+  __syncthreads();
+  if (tid < 64) { // one lane per codeblock: part x weight, XOR over the codeblocks (all parts carry the invertible factor x^24)
+    uint32_t v = 0;
+    if ((uint32_t)tid < d.nof_cbs && d.nof_cbs > 1)
+      v = crc_gf2_mulmod(cbpar[tid], cbw[d.first_desc + tid], tab->crc_poly[MIPHY_CRC24A], 24);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+      v ^= __shfl_xor(v, off);
+    if (tid == 0)
+      cbpar[0] = v;
+  }
   __syncthreads();
   if (tid == 0) {
-    uint32_t rem = 0;
-    for (int w = 0; w < nwaves; ++w)
-      rem ^= wpart[w];
+    const uint32_t rem = cbpar[0];
     const int tb_ok               = (d.nof_cbs == 1) || (rem == 0);
     results[blockIdx.x].tb_crc_ok = tb_ok;
     all_ok                        = tb_ok;
@@ -341,6 +348,7 @@ struct pusch_decode_build {
   std::vector<uint32_t>            slots, reset_slots;
   std::vector<tb_asm_desc>         asmd;
   std::vector<uint32_t>            cb_tb; // transport block of each codeblock
+  std::vector<uint32_t>            cbw;   // per codeblock: x^sh mod CRC24A, the weight of its checksum part in the transport block's (tb assembly)
   uint32_t                         max_Z = 2, max_nodes = 0, max_E = 0;
   bool                             any_odd_Z = false; // the packed decoder pairs rows l and l + Z/2
   int                              bg_mask   = 0;     // bit 0 / 1: base graph 1 / 2 occurs (the decoder sizes its LDS per base graph)
@@ -355,11 +363,34 @@ struct pusch_decode_dev {
   const uint32_t*            reset;
   const tb_asm_desc*         asmd;
   const uint32_t*            cb_tb;
+  const uint32_t*            cbw;
   int32_t*                   iters;
   uint32_t*                  part; // per codeblock: its part of the TB checksum
   size_t                     staged; // bytes to copy host -> device
   size_t                     total;  // bytes of the whole buffer
 };
+
+// x^e mod the CRC24A polynomial (host, square and multiply).
+static uint32_t crc24a_mulmod(uint32_t a, uint32_t b)
+{
+  uint32_t r = 0;
+  for (int k = 23; k >= 0; --k) {
+    r <<= 1;
+    r ^= (r & (1u << 24)) ? 0x1864CFBu : 0u;
+    r ^= ((b >> k) & 1u) ? a : 0u;
+  }
+  return r;
+}
+static uint32_t crc24a_x_pow(uint64_t e)
+{
+  uint32_t r = 1, base = 2;
+  for (; e; e >>= 1) {
+    if (e & 1u)
+      r = crc24a_mulmod(r, base);
+    base = crc24a_mulmod(base, base);
+  }
+  return r;
+}
 
 int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_build& b)
 {
@@ -388,7 +419,15 @@ int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_
     a.max_iter         = d.nof_ldpc_iterations;
     a.tb_offset        = d.tb_offset;
     uint32_t cw_off = 0, tb_nodes = 0;
+    const bool mask_crc = tb_mask_crc(a);
     for (uint32_t c = 0; c < sg.nof_cbs; ++c) {
+      { // weight of this codeblock's checksum part (pusch_tb_assemble_kernel): every part is brought to the common factor x^24
+        const uint32_t bit0  = c * a.nof_data_bits;
+        const uint32_t nbits = std::min(a.nof_data_bits, a.tb_and_crc_bits - std::min(bit0, a.tb_and_crc_bits));
+        const uint32_t after = a.tb_and_crc_bits - (bit0 + nbits);
+        const uint32_t r     = mask_crc ? 32 * ((nbits + 31) >> 5) - nbits : 0; // zero bits the mask table assumes behind the message
+        b.cbw.push_back(crc24a_x_pow((uint64_t)after + 24 - r));
+      }
       const uint32_t      E    = rm_length(sg, c, d.mod, d.nof_layers, d.nof_ch_symbols);
       const uint32_t      slot = d.harq_cb_index + c;
       miphy_ldpc_rdm_desc r    = {};
@@ -445,7 +484,7 @@ int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_
 size_t pusch_decode_bytes(const pusch_decode_build& b)
 {
   return 64 + b.rdm.size() * sizeof(b.rdm[0]) + b.dec.size() * sizeof(b.dec[0]) + (b.slots.size() + b.reset_slots.size()) * 4 +
-         b.asmd.size() * sizeof(b.asmd[0]) + b.cb_tb.size() * 4 + b.dec.size() * 8 + 16 * 8;
+         b.asmd.size() * sizeof(b.asmd[0]) + (b.cb_tb.size() + b.cbw.size()) * 4 + b.dec.size() * 8 + 16 * 9;
 }
 
 // Lays the build out in a host image `h` of the device buffer `dv` (same offsets) and returns the device pointers.
@@ -459,6 +498,7 @@ pusch_decode_dev layout_pusch_decode(const pusch_decode_build& b, uint8_t* h, ui
   v.reset   = stage_vec(h, dv, b.reset_slots, off);
   v.asmd    = stage_vec(h, dv, b.asmd, off);
   v.cb_tb   = stage_vec(h, dv, b.cb_tb, off);
+  v.cbw     = stage_vec(h, dv, b.cbw, off);
   v.staged  = off;
   off       = (off + 15) & ~(size_t)15;
   v.iters   = reinterpret_cast<int32_t*>(dv + off);
@@ -505,7 +545,7 @@ int launch_pusch_decode(miphy_ctx* ctx, const pusch_decode_build& b, const pusch
   }
   if (ev)
     MIPHY_HIP_CHECK(hipEventRecord(ev[2], s));
-  hipLaunchKernelGGL(pusch_tb_assemble_kernel, dim3(n), dim3(1024), 0, s, v.asmd, ctx->d_tables, v.iters, harq_msgs, harq_crc_ok, tb_out, results);
+  hipLaunchKernelGGL(pusch_tb_assemble_kernel, dim3(n), dim3(1024), 0, s, v.asmd, ctx->d_tables, v.iters, harq_msgs, harq_crc_ok, tb_out, results, v.cbw);
   if (ev)
     MIPHY_HIP_CHECK(hipEventRecord(ev[3], s));
   MIPHY_HIP_CHECK(hipGetLastError());
