@@ -17,7 +17,7 @@ and are resident in HBM before timing starts.
 `value` = LDPC information bits / s over the whole step (all ranks). Extra keys: per-kernel HIP-event times and
 algorithmic GB/s, `roofline` of the dominant kernel, `roofline_valu` (the decoder is a VALU kernel), `cpu_baseline` (the
 reference's own receive chain on all host cores; `cpu_baseline_t1`, `cpu_baseline_decoder_only`), `pcie_inclusive`, the other
-codeblock configurations (`legs`: 16QAM R=658, BG1 Z=384 R=1/3, polar AL 1-16) and, with N > 1, `ingest_scatter` (one ingest
+codeblock configurations (`legs`: 16QAM R=658, BG1 Z=384 R=1/3, polar AL 1-16) and, with --ingest scatter, `ingest_scatter` (one ingest
 GPU scatters LLR slabs over RCCL, every rank decodes, results gathered).
 """
 import argparse
@@ -58,8 +58,9 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-slot latency leg (keeps profiles to the timed step only)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (other MCS / rates, polar, PCIe-inclusive)")
-    ap.add_argument("--ingest", choices=["local", "scatter"], default=None,
-                    help="scatter: add the single-ingest leg (default with N > 1); local: never")
+    ap.add_argument("--ingest", choices=["local", "scatter"], default="local",
+                    help="scatter: add the separately timed single-ingest leg (rank 0 scatters the LLR slabs over RCCL, results all-gathered); "
+                         "local (default): every rank owns its slots, no collective in the data path")
     ap.add_argument("--ingest-slots", type=int, default=128, help="slots per rank in the scatter leg")
     return ap.parse_args()
 
@@ -601,7 +602,7 @@ def main():
     # ---- single-ingest leg ("RCCL only for the batch scatter/gather"): rank 0 holds the codeword LLRs of world x S_in
     # slots, scatters them (grouped point-to-point sends, one per xGMI peer), every rank runs rate-dematch + LDPC decode + TB assembly
     # on its share, the result records are all-gathered. Timed separately; the no-collective weak-scaling number stays `value`.
-    if world > 1 and args.ingest != "local" or (args.ingest == "scatter" and world == 1):
+    if args.ingest == "scatter":
         S_in = max(1, min(args.ingest_slots, S))
         units = world * S_in
         payload = llr_d.reshape(S, G)[torch.arange(units, device=dev) % S].contiguous() if rank == 0 else None
