@@ -259,10 +259,15 @@ __device__ __forceinline__ bool block_crc_is_zero(const int8_t* soft, const miph
       }
       w &= valid;
     }
-    const uint32_t* m = &tab->crc_zmask[zi][0][nw - 1 - t]; // lanes: consecutive words, coalesced
+    const uint4* m = reinterpret_cast<const uint4*>(tab->crc_zmask[zi][nw - 1 - t]);
 #pragma unroll
-    for (int k = 0; k < 24; ++k)
-      acc[k] += __builtin_popcount(w & m[k * MIPHY_CRC_ZMASK_WORDS]);
+    for (int g = 0; g < 6; ++g) {
+      const uint4 mk = m[g];
+      acc[4 * g + 0] += __builtin_popcount(w & mk.x);
+      acc[4 * g + 1] += __builtin_popcount(w & mk.y);
+      acc[4 * g + 2] += __builtin_popcount(w & mk.z);
+      acc[4 * g + 3] += __builtin_popcount(w & mk.w);
+    }
   }
   uint32_t par = 0;
 #pragma unroll

@@ -130,9 +130,9 @@ static void build_tables(miphy_graph_tables* t)
           const int i_local = 31 - jl, q = i_local >> 2, b = i_local & 3;
           for (unsigned k = 0; k < ORDER[p]; ++k)
             if ((c >> k) & 1u) {
-              t->crc_zmask[zi][k][u] |= 1u << (q + 8 * b);
+              t->crc_zmask[zi][u][k] |= 1u << (q + 8 * b);
               if (p == 0)
-                t->crc_zmask_packed24a[k][u] |= 1u << (8 * (i_local >> 3) + 7 - (i_local & 7));
+                t->crc_zmask_packed24a[u][k] |= 1u << (8 * (i_local >> 3) + 7 - (i_local & 7));
             }
           c <<= 1;
           if (c & top)

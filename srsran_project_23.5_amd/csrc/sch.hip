@@ -187,10 +187,15 @@ __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_de
           const uint32_t nb = (nbits - 32 * t) >> 3;
           w &= (nb >= 4) ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
         }
-        const uint32_t* m = &tab->crc_zmask_packed24a[0][nw - 1 - t]; // lanes: consecutive words, coalesced
+        const uint4* m = reinterpret_cast<const uint4*>(tab->crc_zmask_packed24a[nw - 1 - t]);
 #pragma unroll
-        for (int k = 0; k < 24; ++k)
-          acc[k] += __builtin_popcount(w & m[k * MIPHY_CRC_ZMASK_WORDS]);
+        for (int g = 0; g < 6; ++g) {
+          const uint4 mk = m[g];
+          acc[4 * g + 0] += __builtin_popcount(w & mk.x);
+          acc[4 * g + 1] += __builtin_popcount(w & mk.y);
+          acc[4 * g + 2] += __builtin_popcount(w & mk.z);
+          acc[4 * g + 3] += __builtin_popcount(w & mk.w);
+        }
       }
       uint32_t par = 0;
 #pragma unroll
