@@ -47,3 +47,31 @@ for lay in [int(a) for a in sys.argv[1:] if a.isdigit()] or [4, 15, 46]:
     print("BG1 Z=384 %d layers, %d codeblocks, %.3f ms (%.3f us/CB amortised); %d codeblocks stamped" % (lay, m, a.elapsed_time(b), a.elapsed_time(b) * 1e3 / m, cnt))
     for k, nm in enumerate(names):
         print("   %-46s %9.0f cycles per codeblock  (%5.1f %%)" % (nm, buf[k] / cnt, 100.0 * buf[k] / max(1, buf[5])))
+
+# ---- the headline plan (dematch inside the decoder): 1024 transport blocks of 273 PRB / 256QAM / 38 codeblocks, random LLRs
+if "--fused" in sys.argv:
+    S, NCB, G, tb_bytes = 1024, 38, 273 * 156 * 8, 319784 // 8
+    td = np.zeros(S, dtype=miphy.PuschTbDesc)
+    for s_ in range(S):
+        td[s_] = (1, 0, 8, 1, 1, 0, 6, 0, 273 * 156, tb_bytes, s_ * NCB, s_ * G, s_ * tb_bytes)
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    llr = (torch.randn(S * G, device="cuda", generator=g) * 8 + 10).clamp(-120, 120).to(torch.int8)
+    soft = torch.zeros(S * NCB * 66 * 384, dtype=torch.int8, device="cuda")
+    msgs = torch.zeros(S * NCB * 1056, dtype=torch.uint8, device="cuda")
+    crc = torch.zeros(S * NCB, dtype=torch.uint8, device="cuda")
+    tb = torch.zeros(S * tb_bytes, dtype=torch.uint8, device="cuda")
+    res = torch.zeros(S * miphy.PuschResult.itemsize, dtype=torch.uint8, device="cuda")
+    plan = ctx.pusch_decode_plan(td)
+    print("plan info (codeblocks, dematch in decoder, nodes):", plan.info())
+    for rep in range(2):
+        buf = (C.c_ulonglong * 8)()
+        lib.miphy_debug_ldpc_profile(buf, 1)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        plan.run(llr, soft, msgs, crc, tb, res)
+        b.record(); torch.cuda.synchronize()
+        lib.miphy_debug_ldpc_profile(buf, 0)
+    cnt = max(1, buf[7])
+    print("FUSED plan: %d codeblocks, %.3f ms whole plan; %d codeblocks stamped" % (S * NCB, a.elapsed_time(b), cnt))
+    for k, nm in enumerate(names):
+        print("   %-46s %9.0f cycles per codeblock  (%5.1f %%)" % (nm, buf[k] / cnt, 100.0 * buf[k] / max(1, buf[5])))
