@@ -11,7 +11,8 @@ import pytest
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 DEFAULT = ["tests/test_ldpc_decode_gpu.py", "tests/test_ldpc_chain_gpu.py", "tests/test_sch_gpu.py", "tests/test_pusch_demod_gpu.py", "tests/test_pdsch_mod_gpu.py",
            "tests/test_pdsch_proc_gpu.py", "tests/test_polar_gpu.py", "tests/test_ofh_iq_gpu.py", "tests/test_harq_pool_gpu.py", "tests/test_chest_gpu.py",
-           "tests/test_ofdm_gpu.py", "tests/test_pusch_proc_gpu.py", "tests/test_pdcch_proc_gpu.py", "tests/test_ssb_proc_gpu.py", "tests/test_csi_rs_gpu.py"]
+           "tests/test_ofdm_gpu.py", "tests/test_pusch_proc_gpu.py", "tests/test_pdcch_proc_gpu.py", "tests/test_ssb_proc_gpu.py", "tests/test_csi_rs_gpu.py",
+           "tests/test_equalizer_gpu.py", "tests/test_ulsch_demux_gpu.py", "tests/test_pusch_uci_gpu.py"]
 
 
 # Scenario tests: besides their parity assertions they assert a particular outcome of a borderline transmission (first attempt fails,
