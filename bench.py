@@ -153,6 +153,105 @@ def ev_ms(torch, f, reps, stream=None):
     return a.elapsed_time(b) / reps
 
 
+def ports_leg(ctx, miphy, torch, dev, w, grids_tx, tbs_u, nports, S, max_iter, snr_db, seed):
+    """The headline slot received on `nports` antenna ports (maximum-ratio combining in the demodulator): every port sees the transmitted slot
+    through its own flat complex gain plus independent AWGN. OFDM demodulation of S x nports slot-ports, one channel estimate row per
+    port, nports-port equalise / demap / descramble, then the same decode plan. Per-stage HIP-event times; every transport block must
+    come back CRC-ok and equal to the transmitted one."""
+    sg = miphy.sch_segmentation(w["tbs"] // 8, w["bg"])
+    C, G, nsc, tb_bytes, n_unique = sg.nof_cbs, w["nsym"] * w["mod"], w["nprb"] * 12, w["tbs"] // 8, len(tbs_u)
+    mcfg = miphy.OfdmConfig(1, w["nprb"], 4096, 0, 1.0 / 64, 0.0, 3.5e9)
+    ocfg = miphy.OfdmConfig(1, w["nprb"], 4096, 144, 1.0 / 64, 0.0, 3.5e9)
+    ss = ocfg.slot_size(0)
+    st = torch.cuda.current_stream()
+    # transmit once per slot, then one copy per port with its own gain and noise
+    tj = np.zeros(S, dtype=miphy.OfdmJob)
+    for s_ in range(S):
+        tj[s_] = (s_ * ss, s_ * 14 * nsc, s_ % 2, 0)
+    x = torch.zeros(S * ss, dtype=torch.complex64, device=dev)
+    ctx.ofdm_modulate_slots(mcfg, tj, grids_tx.reshape(20, -1)[torch.arange(S, device=dev) % 20].reshape(-1).contiguous(), x, st)
+    gains = torch.tensor([0.9 * np.exp(1j * (0.7 * p_ + 0.3)) for p_ in range(nports)], dtype=torch.complex64, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    sigma = float(10.0 ** (-snr_db / 20.0)) * 0.70710678
+    samples = (x.reshape(S, 1, ss) * gains.reshape(1, nports, 1)).contiguous()
+    samples += torch.view_as_complex(torch.randn(S, nports, ss, 2, device=dev, generator=gen) * sigma)
+    samples = samples.reshape(-1)
+    del x
+    oj = np.zeros(S * nports, dtype=miphy.OfdmJob)
+    cj = np.zeros(S, dtype=miphy.PuschChestJob)
+    dj = np.zeros(S, dtype=miphy.PuschDemodJob)
+    rb_words = [0xFFFFFFFFFFFFFFFF] * 4 + [(1 << (w["nprb"] - 256)) - 1]
+    for s_ in range(S):
+        for p_ in range(nports):
+            oj[s_ * nports + p_] = ((s_ * nports + p_) * ss, (s_ * nports + p_) * 14 * nsc, s_ % 2, 0)
+        j = cj[s_]
+        j["numerology"], j["slot_in_frame"], j["scrambling_id"], j["scaling"] = 1, s_ % 20, DMRS_SCR_ID, DMRS_SCALING
+        j["nof_tx_layers"], j["nof_rx_ports"], j["first_symbol"], j["nof_symbols"], j["rx_ports"] = 1, nports, 0, 14, [0, 1, 2, 3]
+        j["symbols_mask"], j["grid_nof_prb"], j["ce_compact"], j["rb_mask"] = 1 << 2, w["nprb"], 1, rb_words
+        j["grid_offset"], j["ce_offset"], j["scalars_offset"] = s_ * nports * 14 * nsc, s_ * nports * nsc, s_ * nports * 5
+        q = dj[s_]
+        q["rnti"], q["n_id"], q["mod"], q["nof_rx_ports"], q["start_symbol"], q["nof_symbols"] = RNTI, N_ID, w["mod"], nports, 0, 14
+        q["dmrs_type"], q["nof_cdm_groups_without_data"], q["ce_nof_symbols"], q["ce_compact"], q["rx_ports"] = 1, 2, 14, 1, [0, 1, 2, 3]
+        q["dmrs_symbols_mask"], q["grid_nof_prb"], q["nof_llr"], q["rb_mask"] = 1 << 2, w["nprb"], G, rb_words
+        q["grid_offset"], q["ce_offset"], q["scalars_offset"], q["llr_offset"] = s_ * nports * 14 * nsc, s_ * nports * nsc, s_ * nports * 5, s_ * G
+    oj_d, cj_d, dj_d = (torch.from_numpy(a.view(np.uint8)).to(dev) for a in (oj, cj, dj))
+    grid = torch.zeros(S * nports * 14 * nsc, dtype=torch.complex64, device=dev)
+    ce = torch.zeros(S * nports * nsc, dtype=torch.complex64, device=dev)
+    sc = torch.zeros(S * nports * 5, dtype=torch.float32, device=dev)
+    llr = torch.zeros(S * G, dtype=torch.int8, device=dev)
+    soft = torch.zeros(S * C * miphy.HARQ_CB_STRIDE, dtype=torch.int8, device=dev)
+    msgs = torch.zeros(S * C * miphy.HARQ_MSG_STRIDE, dtype=torch.uint8, device=dev)
+    crc = torch.zeros(S * C, dtype=torch.uint8, device=dev)
+    tb = torch.zeros(S * tb_bytes, dtype=torch.uint8, device=dev)
+    res = torch.zeros(S * miphy.PuschResult.itemsize, dtype=torch.uint8, device=dev)
+    td = np.zeros(S, dtype=miphy.PuschTbDesc)
+    for s_ in range(S):
+        td[s_] = (w["bg"], w["rv"], w["mod"], w["nof_layers"], 1, 0, max_iter, w["Nref"], w["nsym"], tb_bytes, s_ * C, s_ * G, s_ * tb_bytes)
+    plan = ctx.pusch_decode_plan(td)
+    plan.enable_timing(16)
+    names = ["ofdm_demod", "dmrs_chest", "pusch_demod"]
+    acc = {k: [] for k in names}
+
+    def step(timed):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+        if timed:
+            e[0].record(st)
+        ctx.ofdm_demodulate_slots(ocfg, oj_d, samples, grid, st)
+        if timed:
+            e[1].record(st)
+        ctx.dmrs_pusch_estimate_batch(cj_d, grid, ce, sc, st)
+        if timed:
+            e[2].record(st)
+        ctx.pusch_demodulate_batch(dj_d, grid, ce, sc, llr, st)
+        if timed:
+            e[3].record(st)
+            for i, k in enumerate(names):
+                acc[k].append((e[i], e[i + 1]))
+        plan.run(llr, soft, msgs, crc, tb, res, st)
+
+    for _ in range(2):
+        step(False)
+    torch.cuda.synchronize()
+    plan.read_timing()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step(True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    kms = {k: float(np.mean([a.elapsed_time(b) for a, b in acc[k]])) for k in names}
+    kms.update(plan.read_timing())
+    r = res.cpu().numpy().view(miphy.PuschResult)
+    ok = int((r["tb_crc_ok"] != 0).sum())
+    idx = torch.from_numpy((np.arange(S) % 20) % n_unique).to(dev)
+    same = bool(torch.equal(tb.reshape(S, tb_bytes), torch.from_numpy(np.stack(tbs_u)).to(dev)[idx])) if ok == S else False
+    plan.close()
+    return {"config": "headline slot on %d rx ports (flat gain per port, %g dB per port), MRC in the demodulator" % (nports, snr_db), "slots": S, "rx_ports": nports,
+            "ms_per_step": dt * 1e3, "kernel_ms": kms, "slots_per_s": S / dt, "info_bits_per_s": S * w["tbs"] / dt,
+            "ofdm_slot_ports_per_s": S * nports / (kms["ofdm_demod"] * 1e-3), "tb_crc_ok": ok, "transport_blocks_recovered": same}
+
+
 # ------------------------------------------------------------------------------------------------ CPU baseline legs
 def cpu_legs(w, samples4, llr4, ocfg_args, max_iter, early_stop, seconds):
     """The reference's receive chain on the host cores (oracle/_ref, the reference compiled in place), driven like its
@@ -648,6 +747,7 @@ def main():
         legs["bg1_z384_rate_one_third"] = sch_leg(ctx, miphy, torch, dev, "BASELINE configs[0]: single codeblock BG1 Z=384, K=8448, full length N=25344 "
                                                   "(rate 1/3, 46 layers)", 1, 2, 12672, 1050, 8192, args.max_iter, 0.7, 8)
         legs["polar_pdcch"] = polar_leg(ctx, miphy, torch, dev)
+        legs["pusch_4_rx_ports"] = ports_leg(ctx, miphy, torch, dev, w, grids_tx, tbs_u, 4, min(S, 256), args.max_iter, 27.0, 4321)
         out["legs"] = legs
         # PCIe-inclusive rate (never `value`): the S slots of time-domain samples from pinned host memory, the step, the transport
         # blocks back to pinned host memory, back to back on one stream.
