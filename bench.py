@@ -409,9 +409,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != max(1, args.gpus):
-        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-        sys.exit(2)
+    if world != max(1, args.gpus):  # under a launcher the launcher's world size is the truth
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: running %d ranks" % (args.gpus, world, world), file=sys.stderr)
     # Rehearsal on a machine with fewer GPUs than ranks: every rank on cuda:0, gloo for the barrier, the MAX reduction and the
     # scatter / gather (RCCL refuses two ranks on one device). Measured multi-GPU runs never set it; the line carries the flag.
     rehearsal = os.environ.get("MIPHY_BENCH_REHEARSAL") == "1"
