@@ -550,7 +550,10 @@ int launch_pusch_decode(miphy_ctx* ctx, const pusch_decode_build& b, const pusch
   }
   if (ev)
     MIPHY_HIP_CHECK(hipEventRecord(ev[2], s));
-  hipLaunchKernelGGL(pusch_tb_assemble_kernel, dim3(n), dim3(1024), 0, s, v.asmd, ctx->d_tables, v.iters, harq_msgs, harq_crc_ok, tb_out, results, v.cbw);
+  #ifndef TBA_THREADS
+#define TBA_THREADS 512
+#endif
+  hipLaunchKernelGGL(pusch_tb_assemble_kernel, dim3(n), dim3(TBA_THREADS), 0, s, v.asmd, ctx->d_tables, v.iters, harq_msgs, harq_crc_ok, tb_out, results, v.cbw);
   if (ev)
     MIPHY_HIP_CHECK(hipEventRecord(ev[3], s));
   MIPHY_HIP_CHECK(hipGetLastError());
