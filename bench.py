@@ -220,7 +220,7 @@ def ports_leg(ctx, miphy, torch, dev, w, grids_tx, tbs_u, nports, S, max_iter, s
         ctx.ofdm_demodulate_slots(ocfg, oj_d, samples, grid, st)
         if timed:
             e[1].record(st)
-        ctx.dmrs_pusch_estimate_batch(cj_d, grid, ce, sc, st)
+        ctx.dmrs_pusch_estimate_batch(cj_d, grid, ce, sc, st, max_ports=nports, max_layers=1)
         if timed:
             e[2].record(st)
         ctx.pusch_demodulate_batch(dj_d, grid, ce, sc, llr, st)
@@ -533,7 +533,7 @@ def main():
             ctx.ofdm_demodulate_slots(ocfg, ojobs_d[a * 24:b * 24], samples_d, grid_d, st)
             if timed:
                 e[1].record(st)
-            ctx.dmrs_pusch_estimate_batch(cjobs_d[a * 152:b * 152], grid_d, ce_d, sc_d, st)
+            ctx.dmrs_pusch_estimate_batch(cjobs_d[a * 152:b * 152], grid_d, ce_d, sc_d, st, max_ports=1, max_layers=1)
             if timed:
                 e[2].record(st)
             ctx.pusch_demodulate_batch(djobs_d[a * 120:b * 120], grid_d, ce_d, sc_d, llr_d, st)

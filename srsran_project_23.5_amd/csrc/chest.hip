@@ -80,7 +80,8 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
                                                     const float2* __restrict__ grid,
                                                     float2* __restrict__ ce_out,
                                                     float* __restrict__ scalars,
-                                                    const float2* __restrict__ ext_pilots_arg)
+                                                    const float2* __restrict__ ext_pilots_arg,
+                                                    int ports_dim) // blockIdx.y = layer * ports_dim + port
 {
   const float2* ext_pilots = GENERAL ? ext_pilots_arg : nullptr;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
   const miphy_pusch_chest_job  job  = load_words(jobs + blockIdx.x);
   __shared__ uint64_t rbm[5];
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int port = blockIdx.y % 4, layer = blockIdx.y / 4;
+  const int port = blockIdx.y % ports_dim, layer = blockIdx.y / ports_dim;
   const int sgrp = blockIdx.z, ngrp = gridDim.z; // symbol group: stores OFDM symbols l with l % ngrp == sgrp; group 0 owns the scalars
   if (port >= job.nof_rx_ports || layer >= job.nof_tx_layers)
     return;
@@ -335,7 +336,12 @@ static int chest_launch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int j
   MIPHY_REQUIRE(ctx && jobs && grid && ce && scalars, "%s: null argument", what);
   if (n == 0)
     return MIPHY_OK;
-  unsigned max_ports = 4, max_layers = 4;
+  // Device-resident jobs cannot be inspected here: bits 8-11 / 12-15 of jobs_on_device may carry the largest nof_rx_ports / nof_tx_layers
+  // of the batch (0 = unknown: the grid is sized for 4 x 4 and the surplus workgroups exit at once).
+  const unsigned hint_ports = ((unsigned)jobs_on_device >> 8) & 0xfu, hint_layers = ((unsigned)jobs_on_device >> 12) & 0xfu;
+  jobs_on_device &= 0xff;
+  MIPHY_REQUIRE(hint_ports <= 4 && hint_layers <= 4, "%s: invalid port / layer hint", what);
+  unsigned max_ports = hint_ports ? hint_ports : 4, max_layers = hint_layers ? hint_layers : 4;
   if (!jobs_on_device) {
     max_ports = max_layers = 1;
     for (uint32_t i = 0; i < n; ++i) {
@@ -387,11 +393,11 @@ static int chest_launch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int j
   // measured and does not pay once the per-workgroup prologue is parallel; 256 threads are slower for the 4096-point IDFT.)
   const int ngrp = 1, cthreads = 512;
   if (pilots)
-    hipLaunchKernelGGL(chest_kernel<true>, dim3(n, 4 * max_layers, ngrp), dim3(cthreads), lds, s, (const miphy_pusch_chest_job*)d_jobs,
-                       (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw, (const float2*)grid, (float2*)ce, scalars, (const float2*)pilots);
+    hipLaunchKernelGGL(chest_kernel<true>, dim3(n, max_ports * max_layers, ngrp), dim3(cthreads), lds, s, (const miphy_pusch_chest_job*)d_jobs,
+                       (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw, (const float2*)grid, (float2*)ce, scalars, (const float2*)pilots, (int)max_ports);
   else
-    hipLaunchKernelGGL(chest_kernel<false>, dim3(n, 4 * max_layers, ngrp), dim3(cthreads), lds, s, (const miphy_pusch_chest_job*)d_jobs,
-                       (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw, (const float2*)grid, (float2*)ce, scalars, (const float2*)nullptr);
+    hipLaunchKernelGGL(chest_kernel<false>, dim3(n, max_ports * max_layers, ngrp), dim3(cthreads), lds, s, (const miphy_pusch_chest_job*)d_jobs,
+                       (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw, (const float2*)grid, (float2*)ce, scalars, (const float2*)nullptr, (int)max_ports);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

@@ -491,8 +491,11 @@ class Context:
         check(lib().miphy_pusch_demodulate_batch(self.h, ptr, on_dev, n, _dptr(grid), _dptr(ce), _dptr(scalars), _dptr(llr), _stream_ptr(stream)))
 
     # ------------------------------------------------------------------ DM-RS PUSCH channel estimator
-    def dmrs_pusch_estimate_batch(self, jobs, grid, ce, scalars, stream=None):
+    def dmrs_pusch_estimate_batch(self, jobs, grid, ce, scalars, stream=None, max_ports=0, max_layers=0):
+        """max_ports / max_layers: optional bound for device-resident jobs (sizes the launch; 0 = unknown)."""
         jobs, n, ptr, on_dev = self._descs(jobs, PuschChestJob)
+        if on_dev:
+            on_dev |= (int(max_ports) << 8) | (int(max_layers) << 12)
         check(lib().miphy_dmrs_pusch_estimate_batch(self.h, ptr, on_dev, n, _dptr(grid), _dptr(ce), _dptr(scalars), _stream_ptr(stream)))
 
     def port_channel_estimate_batch(self, jobs, grid, pilots, ce, scalars, stream=None):
