@@ -347,10 +347,15 @@ __device__ unsigned long long g_ldpc_prof[2048 * 8]; // per workgroup: 7 phase s
 #endif
 
 // Wavefronts per SIMD the register allocation is held to: 4 (128 registers, five 3-wavefront codeblocks per CU with the messages in
-// global memory) measured 11 % faster for the plain decoder; the variant that dematches while loading needs 168 registers to stay
-// out of scratch memory in its layer loop and is faster at 3 (4.05 vs 4.21 ms per 38 912 codeblocks).
+// global memory) measured 11 % faster for the plain decoder. The variant that dematches while loading runs at 3: its load phase is a
+// function of its own (pk_fused_load) and the prefetch registers are reassigned unconditionally, which leaves the kernel at 160
+// registers without a single spill (3.89 ms per 38 912 codeblocks; 3.95 with the load phase inlined and 20 spills); at 4 wavefronts the
+// launcher moves the messages to global memory for a fifth codeblock per CU, and that traffic next to the soft-buffer image stream
+// costs more than the occupancy gives (4.63 ms).
 #define LDPC_PK_MIN_WAVES_PLAIN 4
+#ifndef LDPC_PK_MIN_WAVES_FUSED
 #define LDPC_PK_MIN_WAVES_FUSED 3
+#endif
 // Raw form of load_in16(): the dword-aligned 16 bytes and the following dword of input vector v, not yet funnel-shifted, so that a
 // prefetch keeps them in flight (the shift happens where the vector is consumed).
 struct raw_in16 {
@@ -383,6 +388,84 @@ constexpr int PK_PRE = 3; // rate-matched input vectors per lane fetched one cod
 // [wave][edge pair][64 lanes] dwords, `gmsg_pairs` pairs per wave): a lane only ever touches its own messages, one coalesced dword
 // per two edges and layer visit, re-read an iteration later out of L2 / Infinity Cache. Low-rate codeblocks (many layers) then
 // need LDS for their soft bits only, so that four of them stay resident per CU instead of one.
+// The load phase of the variant that dematches while loading, as a function of its own (never inlined): its staging needs far more
+// registers than the layer loop, and inlined it decides the register allocation of the whole kernel; out of line the kernel holds
+// LDPC_PK_MIN_WAVES_FUSED wavefronts per SIMD with a layer loop free of scratch accesses, and only this phase pays for its spills.
+// Returns this lane's candidate for the position behind the last non-zero soft bit.
+__device__ __attribute__((noinline)) int pk_fused_load(int8_t* __restrict__ soft, int8_t* __restrict__ llr_img, const int8_t* __restrict__ in, int E, int F, int mod,
+                                                       int Z, int bgK, int bgi, int in_len, int soft_bytes, raw_in16 p0, raw_in16 p1, raw_in16 p2, int tid,
+                                                       int nt)
+{
+  static_assert(PK_PRE == 3, "three prefetched vectors are passed by value");
+  int last = 0;
+    // ---- rate dematching into the LDS image soft[2Z + j] = buffer position j
+    // (the lane index is made opaque here: the compiler would otherwise hoist every per-lane staging address out of the
+    // codeblock loop and keep dozens of them alive across the decoder)
+    int stid = tid;
+    asm volatile("" : "+v"(stid));
+    const int                 mb  = (int)(((uintptr_t)in) & 3);
+    const int                 nq  = (mb == 0) ? (E >> 4) : ((E >= 4) ? ((E - 4) >> 4) : 0);
+    int8_t*                   img = soft + 2 * Z;
+    rm_geom                   g;
+    g.r0 = 0, g.f1 = (bgK - 2) * Z, g.f0 = g.f1 - F, g.F = F, g.E = E, g.mod = mod, g.Kq = E / mod;
+    image_access ia;
+    ia.jbase = 0;
+    {
+      uint4* z4 = reinterpret_cast<uint4*>(soft);
+      for (int k = stid; k < (2 * Z) >> 4; k += nt) // the two punctured nodes (Z is a multiple of 16 for every Z >= 128)
+        z4[k] = make_uint4(0, 0, 0, 0);
+      for (int k = g.f0 + stid; k < g.f1; k += nt)
+        img[k] = 127; // fillers
+      for (int k = 2 * Z + E + F + stid; k < soft_bytes; k += nt)
+        soft[k] = 0; // never transmitted
+    }
+    switch (mod) {
+#define PK_STAGE(MOD)                                                                         \
+  case MOD:                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < PK_PRE; ++k) if (stid + k * nt < nq)                 \
+        stage_vector<MOD>(ia, img, g, F, stid + k * nt, shift_in16(k == 0 ? p0 : (k == 1 ? p1 : p2), mb));               \
+    for (int v = stid + PK_PRE * nt; v < nq; v += nt)                                          \
+      stage_vector<MOD>(ia, img, g, F, v, load_in16(in, mb, v));                              \
+    break;
+      PK_STAGE(8)
+      PK_STAGE(6)
+      PK_STAGE(4)
+      PK_STAGE(2)
+      default:
+        PK_STAGE(1)
+#undef PK_STAGE
+    }
+    for (int k = (nq << 4) + stid; k < E; k += nt) {
+      const int p = k / (int)mod, q = k - p * (int)mod;
+      const int r = q * g.Kq + p;
+      img[r + ((r >= g.f0) ? F : 0)] = in[k];
+    }
+    __syncthreads();
+    // ---- the image goes to the HARQ soft buffer (what the reference's dematcher leaves there) while the last non-zero soft bit
+    // is found (ldpc_decoder_impl.cpp:86-99)
+    {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      u32x4*       dst  = reinterpret_cast<u32x4*>(llr_img);
+      const uint4* src  = reinterpret_cast<const uint4*>(img);
+      const int    nimg = in_len >> 4, nall = (((bgi ? 50 : 66) * Z) >> 4);
+      for (int q = tid; q < nimg; q += nt) {
+        const uint4 v = src[q];
+        const u32x4 o = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(o, dst + q);
+        int hi = -1;
+        hi     = v.x ? 3 - (__clz((int)v.x) >> 3) : hi;
+        hi     = v.y ? 7 - (__clz((int)v.y) >> 3) : hi;
+        hi     = v.z ? 11 - (__clz((int)v.z) >> 3) : hi;
+        hi     = v.w ? 15 - (__clz((int)v.w) >> 3) : hi;
+        last   = (hi >= 0) ? 16 * q + hi + 1 : last;
+      }
+      const u32x4 zero = {0, 0, 0, 0};
+      for (int q = nimg + tid; q < nall; q += nt)
+        __builtin_nontemporal_store(zero, dst + q);
+    }
+  return last;
+}
+
 template <bool FUSED, bool GMSG>
 __global__ void __launch_bounds__(192, FUSED ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN)
 ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
@@ -411,9 +494,11 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       const int                 mb = (int)(((uintptr_t)in) & 3), E = (int)r0.E;
       const int                 nq = (mb == 0) ? (E >> 4) : ((E >= 4) ? ((E - 4) >> 4) : 0);
 #pragma unroll
-      for (int k = 0; k < PK_PRE; ++k)
+      for (int k = 0; k < PK_PRE; ++k) {
+        pre[k] = raw_in16{0, 0, 0, 0, 0}; // always assigned: an old value must not stay live across the decode of a codeblock
         if (tid + k * nt < nq)
           pre[k] = load_in16_raw(in, mb, tid + k * nt);
+      }
     }
   }
   // Persistent workgroups: the grid is what the chip holds at once; a workgroup decodes codeblock blockIdx.x first and then takes
@@ -465,86 +550,26 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   int last = 0;
   // (re)fills pre[] with the first input vectors of codeblock c
   auto prefetch = [&](uint32_t c) {
+#pragma unroll
+    for (int k = 0; k < PK_PRE; ++k)
+      pre[k] = raw_in16{0, 0, 0, 0, 0};
     if (c < n) {
       const miphy_ldpc_rdm_desc rn  = load_words(rdm + c);
       const int8_t*             inn = rm_in_base + rn.in_offset;
       const int                 mbn = (int)(((uintptr_t)inn) & 3), En = (int)rn.E;
       const int                 nqn = (mbn == 0) ? (En >> 4) : ((En >= 4) ? ((En - 4) >> 4) : 0);
 #pragma unroll
-      for (int k = 0; k < PK_PRE; ++k)
+      for (int k = 0; k < PK_PRE; ++k) {
+        pre[k] = raw_in16{0, 0, 0, 0, 0};
         if (tid + k * nt < nqn)
           pre[k] = load_in16_raw(inn, mbn, tid + k * nt);
+      }
     }
   };
   if (FUSED) {
-    // ---- rate dematching into the LDS image soft[2Z + j] = buffer position j
-    // (the lane index is made opaque here: the compiler would otherwise hoist every per-lane staging address out of the
-    // codeblock loop and keep dozens of them alive across the decoder)
-    int stid = tid;
-    asm volatile("" : "+v"(stid));
-    const miphy_ldpc_rdm_desc rd  = load_words(rdm + cb);
-    const int                 E   = (int)rd.E, F = (int)dsc.nof_filler_bits;
-    const int8_t*             in  = rm_in_base + rd.in_offset;
-    const int                 mb  = (int)(((uintptr_t)in) & 3);
-    const int                 nq  = (mb == 0) ? (E >> 4) : ((E >= 4) ? ((E - 4) >> 4) : 0);
-    int8_t*                   img = soft + 2 * Z;
-    rm_geom                   g;
-    g.r0 = 0, g.f1 = (bgK - 2) * Z, g.f0 = g.f1 - F, g.F = F, g.E = E, g.mod = rd.mod, g.Kq = E / rd.mod;
-    image_access ia;
-    ia.jbase = 0;
-    {
-      uint4* z4 = reinterpret_cast<uint4*>(soft);
-      for (int k = stid; k < (2 * Z) >> 4; k += nt) // the two punctured nodes (Z is a multiple of 16 for every Z >= 128)
-        z4[k] = make_uint4(0, 0, 0, 0);
-      for (int k = g.f0 + stid; k < g.f1; k += nt)
-        img[k] = 127; // fillers
-      for (int k = 2 * Z + E + F + stid; k < soft_bytes; k += nt)
-        soft[k] = 0; // never transmitted
-    }
-    switch (rd.mod) {
-#define PK_STAGE(MOD)                                                                         \
-  case MOD:                                                                                   \
-    _Pragma("unroll") for (int k = 0; k < PK_PRE; ++k) if (stid + k * nt < nq)                 \
-        stage_vector<MOD>(ia, img, g, F, stid + k * nt, shift_in16(pre[k], mb));               \
-    for (int v = stid + PK_PRE * nt; v < nq; v += nt)                                          \
-      stage_vector<MOD>(ia, img, g, F, v, load_in16(in, mb, v));                              \
-    break;
-      PK_STAGE(8)
-      PK_STAGE(6)
-      PK_STAGE(4)
-      PK_STAGE(2)
-      default:
-        PK_STAGE(1)
-#undef PK_STAGE
-    }
-    for (int k = (nq << 4) + stid; k < E; k += nt) {
-      const int p = k / (int)rd.mod, q = k - p * (int)rd.mod;
-      const int r = q * g.Kq + p;
-      img[r + ((r >= g.f0) ? F : 0)] = in[k];
-    }
-    __syncthreads();
-    // ---- the image goes to the HARQ soft buffer (what the reference's dematcher leaves there) while the last non-zero soft bit
-    // is found (ldpc_decoder_impl.cpp:86-99)
-    {
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      u32x4*       dst  = reinterpret_cast<u32x4*>(const_cast<int8_t*>(llr));
-      const uint4* src  = reinterpret_cast<const uint4*>(img);
-      const int    nimg = in_len >> 4, nall = (((bgi ? 50 : 66) * Z) >> 4);
-      for (int q = tid; q < nimg; q += nt) {
-        const uint4 v = src[q];
-        const u32x4 o = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(o, dst + q);
-        int hi = -1;
-        hi     = v.x ? 3 - (__clz((int)v.x) >> 3) : hi;
-        hi     = v.y ? 7 - (__clz((int)v.y) >> 3) : hi;
-        hi     = v.z ? 11 - (__clz((int)v.z) >> 3) : hi;
-        hi     = v.w ? 15 - (__clz((int)v.w) >> 3) : hi;
-        last   = (hi >= 0) ? 16 * q + hi + 1 : last;
-      }
-      const u32x4 zero = {0, 0, 0, 0};
-      for (int q = nimg + tid; q < nall; q += nt)
-        __builtin_nontemporal_store(zero, dst + q);
-    }
+    const miphy_ldpc_rdm_desc rd = load_words(rdm + cb);
+    last = pk_fused_load(soft, const_cast<int8_t*>(llr), rm_in_base + rd.in_offset, (int)rd.E, (int)dsc.nof_filler_bits, (int)rd.mod, Z, bgK, bgi, in_len,
+                         soft_bytes, pre[0], pre[1], pre[2], tid, nt);
   } else {
   for (int k = tid; k < 2 * Z; k += nt)
     soft[k] = 0;
