@@ -1103,7 +1103,10 @@ static void test_downlink_processor(std::shared_ptr<miphy::context> c)
       dl.process_nzp_csi_rs(cc);
     }
     CHECK(gw.count == round, "downlink_processor: grid sent before finish_processing_pdus()");
-    dl.finish_processing_pdus();
+    dl.finish_processing_pdus(); // returns at once; the processor stays reserved until its completion thread has sent the grid
+    for (unsigned spin = 0; dl.is_reserved() && spin != 20000; ++spin) {
+      std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
     CHECK(gw.count == round + 1 && gw.sent == g2.get() && gw.slot == ctx.slot && gw.sector == 3, "downlink_processor: gateway call (count %u)", gw.count);
     CHECK(!dl.is_reserved(), "downlink_processor: still reserved after the grid was sent");
     std::vector<cf_t> a(nsc), b(nsc);

@@ -43,6 +43,7 @@
 #include "srsran/support/error_handling.h"
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <hip/hip_runtime_api.h>
@@ -2009,8 +2010,11 @@ private:
 /// batches the PDSCH PDUs of a slot: process_pdsch() queues, finish_processing_pdus() -- the reference's own end-of-slot call --
 /// runs miphy_pdsch_process_batch over all of them (transport blocks up once, written REs down once), puts the REs into the grid
 /// and sends it through the gateway. PDCCH, SSB and CSI-RS go to the CPU processors given at construction, at once. Same
-/// observable behaviour as the reference processor with a synchronous executor: nothing happens without a configured grid, the
-/// grid is zeroed on configuration and sent exactly once, after finish_processing_pdus().
+/// observable behaviour as the reference processor with its executor: nothing happens without a configured grid, the grid is zeroed
+/// on configuration and sent exactly once, after finish_processing_pdus(). Like the reference (downlink_processor_single_executor_impl
+/// hands every PDU to an executor and sends the grid from there when the last one is done) the call returns at once: a completion
+/// thread owned by the processor runs the batch, writes the resource elements and calls the gateway; is_reserved() stays true until
+/// the grid has been sent, which is what the processor pool looks at before it hands the processor out again.
 class downlink_processor_hip : public srsran::downlink_processor
 {
 public:
@@ -2023,6 +2027,10 @@ public:
                          unsigned                                      grid_nof_prb) :
     c(std::move(c)), gateway(gateway), pdcch(std::move(pdcch)), ssb(std::move(ssb)), csi_rs(std::move(csi_rs)), nports(grid_nof_ports), nprb(grid_nof_prb)
   {
+    int dev = 0;
+    (void)hipGetDevice(&dev); // the device the caller's context was created on is the current one
+    wc     = std::make_shared<context>(dev); // the completion thread drives the device through its own context and stream
+    worker = std::thread([this] { completion_loop(); });
   }
 
   void process_pdcch(const srsran::pdcch_processor::pdu_t& pdu) override
@@ -2066,23 +2074,65 @@ public:
   }
   void configure_resource_grid(const srsran::resource_grid_context& context, srsran::resource_grid& grid_) override
   {
-    srsran_assert(queue.empty(), "Reusing downlink processor that it is still processing PDUs.");
+    require(!reserved.load(std::memory_order_acquire) && queue.empty(), "Reusing downlink processor that it is still processing PDUs.");
     rg_context = context;
     grid       = &grid_;
     grid->set_all_zero();
+    reserved.store(true, std::memory_order_release);
   }
   void finish_processing_pdus() override
   {
     if (grid == nullptr) {
       return;
     }
-    run_pdsch_batch();
-    gateway.send(rg_context, *grid);
-    grid = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mtx);
+      pending = true; // the completion thread takes the queue, the grid and the context from here
+    }
+    cv.notify_all();
   }
-  bool is_reserved() const override { return grid != nullptr; }
+  /// True from configure_resource_grid() until the completion thread has sent the grid.
+  bool is_reserved() const override { return reserved.load(std::memory_order_acquire); }
+  /// Blocks until the grid of the last finish_processing_pdus() has been sent (tests, shutdown).
+  void wait_sent()
+  {
+    std::unique_lock<std::mutex> lk(mtx);
+    cv.wait(lk, [this] { return !pending; });
+  }
+  ~downlink_processor_hip() override
+  {
+    {
+      std::lock_guard<std::mutex> lk(mtx);
+      stop = true;
+    }
+    cv.notify_all();
+    if (worker.joinable()) {
+      worker.join();
+    }
+  }
 
 private:
+  void completion_loop()
+  {
+    std::unique_lock<std::mutex> lk(mtx);
+    for (;;) {
+      cv.wait(lk, [this] { return pending || stop; });
+      if (pending) {
+        lk.unlock();
+        run_pdsch_batch();
+        gateway.send(rg_context, *grid);
+        grid = nullptr;
+        reserved.store(false, std::memory_order_release);
+        lk.lock();
+        pending = false;
+        cv.notify_all();
+        continue;
+      }
+      if (stop) {
+        return;
+      }
+    }
+  }
   void run_pdsch_batch()
   {
     if (queue.empty()) {
@@ -2120,13 +2170,13 @@ private:
       std::memcpy(&tbs[pdus[i].tb_offset], queue[i].data.data(), queue[i].data.size());
     }
     host.assign(static_cast<size_t>(nports) * 14 * nsc, srsran::cf_t(NAN, NAN)); // NaN marks "not written by the kernels"
-    auto* d_tb = static_cast<uint8_t*>(c->buf(0, tbs.size()));
-    auto* d_g  = static_cast<float*>(c->buf(1, host.size() * sizeof(srsran::cf_t)));
-    c->h2d(d_tb, tbs.data(), tbs.size());
-    c->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
-    context::check(miphy_pdsch_process_batch(c->ctx, pdus.data(), n, d_tb, d_g, c->stream), "pdsch_process");
-    c->d2h(host.data(), d_g, host.size() * sizeof(srsran::cf_t));
-    c->sync();
+    auto* d_tb = static_cast<uint8_t*>(wc->buf(0, tbs.size()));
+    auto* d_g  = static_cast<float*>(wc->buf(1, host.size() * sizeof(srsran::cf_t)));
+    wc->h2d(d_tb, tbs.data(), tbs.size());
+    wc->h2d(d_g, host.data(), host.size() * sizeof(srsran::cf_t));
+    context::check(miphy_pdsch_process_batch(wc->ctx, pdus.data(), n, d_tb, d_g, wc->stream), "pdsch_process");
+    wc->d2h(host.data(), d_g, host.size() * sizeof(srsran::cf_t));
+    wc->sync();
     for (unsigned p = 0; p != nports; ++p) {
       put_written_res(*grid, p, nsc, host.data() + static_cast<size_t>(p) * 14 * nsc);
     }
@@ -2148,6 +2198,12 @@ private:
   std::vector<entry>                            queue;
   std::vector<uint8_t>                          tbs;
   std::vector<srsran::cf_t>                     host;
+  std::atomic<bool>                             reserved{false};
+  std::mutex                                    mtx;
+  std::condition_variable                       cv;
+  bool                                          pending = false, stop = false;
+  std::shared_ptr<context>                      wc;
+  std::thread                                   worker; // started at the end of the constructor
 };
 
 /// A downlink processor whose four PDU types all run on the device: PDSCH batched per slot, PDCCH / SSB / CSI-RS through the
