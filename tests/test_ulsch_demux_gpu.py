@@ -38,3 +38,32 @@ def test_demultiplex_batch_matches_oracle(ctx):
     for i, (o0, streams) in enumerate(exp):
         for k in range(4):
             assert np.array_equal(got[k][o0[k]:o0[k] + streams[k].size], streams[k]), (i, cases[i], k)
+
+
+def test_demultiplex_full_size_allocation(ctx):
+    """The largest allocation of the path (273 PRB, 14 symbols, 256QAM, HARQ-ACK on reserved elements + both CSI parts) against the oracle,
+    and the size-independent property: every input LLR lands in exactly one stream (or is punctured), so the multiset of non-zero
+    inputs equals the multiset of non-zero outputs."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(615)
+    mod, nprb = 8, 273
+    re_sym = nprb * 12
+    # (mod, layers, nprb, start, nof, G_rvd, dmrs_type, dmrs_mask, cdm, (G_ack, G_csi1, G_csi2), (O_ack, O_csi1, O_csi2))
+    case = (mod, 1, nprb, 0, 14, mod * 700, 1, (1 << 2) | (1 << 11), 2, (mod * 650, mod * 900, mod * 1500), (2, 20, 40))
+    n_in, n_sch, _, _ = O.o_ulsch_demultiplex(*case)
+    assert n_in == re_sym * 12 * mod
+    llr = rng.integers(1, 121, n_in).astype(np.int8) * rng.choice(np.array([-1, 1], np.int8), n_in)
+    _, _, streams, _ = O.o_ulsch_demultiplex(*case, llr=llr)
+    job = np.zeros(1, dtype=miphy.UlschDemuxJob)
+    job[0] = _job(miphy, case)
+    outs = [torch.full((max(s.size, 1),), 77, dtype=torch.int8, device="cuda") for s in streams]
+    ctx.ulsch_demultiplex_batch(job, torch.from_numpy(llr).cuda(), *outs)
+    torch.cuda.synchronize()
+    got = [o.cpu().numpy()[:s.size] for o, s in zip(outs, streams)]
+    for k in range(4):
+        assert np.array_equal(got[k], streams[k]), k
+    allout = np.concatenate(got)
+    assert np.array_equal(np.sort(allout[allout != 0]), np.sort(llr))  # no LLR lost or duplicated (inputs are all non-zero)
+    # HARQ-ACK sits on reserved elements: each of its LLRs leaves an all-zero LLR in the stream it punctures (SCH or CSI part 2)
+    assert (allout == 0).sum() == case[9][0] and (got[0] == 0).sum() + (got[3] == 0).sum() == case[9][0]
