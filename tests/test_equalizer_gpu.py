@@ -98,3 +98,25 @@ def test_equalizer_rejects_what_the_reference_asserts():
         with pytest.raises(RuntimeError):
             ctx.channel_equalize_batch(j, t, t, t, t)
     ctx.close()
+
+
+def test_equalizer_inverts_the_channel_at_full_size():
+    """Size-independent property at the largest slot (273 PRB x 14 symbols): without noise the zero-forcing equalizer returns the
+    transmitted symbols -- H x in, x out -- for one layer on four ports and for two layers on two ports (relative error of single
+    precision times the conditioning of the channel), and the post-equalisation noise variance is nv / (scaling^2 * sum |h|^2) with one layer."""
+    import miphy
+    ctx = miphy.Context(0)
+    rng = np.random.default_rng(123)
+    nre = 273 * 12 * 14
+    for npt, nl in ((4, 1), (2, 2)):
+        y, h, nvar, x = O.equalizer_case(rng, nre, npt, nl, snr_db=300.0)  # 300 dB: the additive noise vanishes below single precision
+        (z, nv), = run_batch(ctx, [(y, h, 0.01, 1.0)])
+        if nl == 1:
+            assert np.abs(z - x).max() < 2e-5
+            assert np.allclose(nv[0], 0.01 / (np.abs(h[0]) ** 2).sum(0), rtol=1e-5)
+        else:
+            n0, n1 = (np.abs(h[0]) ** 2).sum(0), (np.abs(h[1]) ** 2).sum(0)
+            cond = (n0 * n1) / np.maximum(n0 * n1 - np.abs((h[0].conj() * h[1]).sum(0)) ** 2, 1e-30)
+            ok = cond < 1e3  # well-conditioned elements
+            assert ok.mean() > 0.95 and np.abs(z - x)[:, ok].max() < 1e-3
+    ctx.close()
