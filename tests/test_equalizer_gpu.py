@@ -112,11 +112,11 @@ def test_equalizer_inverts_the_channel_at_full_size():
         y, h, nvar, x = O.equalizer_case(rng, nre, npt, nl, snr_db=300.0)  # 300 dB: the additive noise vanishes below single precision
         (z, nv), = run_batch(ctx, [(y, h, 0.01, 1.0)])
         if nl == 1:
-            assert np.abs(z - x).max() < 2e-5
+            assert np.abs(z - x).max() < 5e-5
             assert np.allclose(nv[0], 0.01 / (np.abs(h[0]) ** 2).sum(0), rtol=1e-5)
         else:
             n0, n1 = (np.abs(h[0]) ** 2).sum(0), (np.abs(h[1]) ** 2).sum(0)
             cond = (n0 * n1) / np.maximum(n0 * n1 - np.abs((h[0].conj() * h[1]).sum(0)) ** 2, 1e-30)
-            ok = cond < 1e3  # well-conditioned elements
-            assert ok.mean() > 0.95 and np.abs(z - x)[:, ok].max() < 1e-3
+            ok = cond < 1e3  # well-conditioned elements; the error grows with the cancellation in the determinant
+            assert ok.mean() > 0.95 and np.all(np.abs(z - x)[:, ok] <= 4e-6 * cond[ok] + 2e-5)
     ctx.close()
