@@ -289,6 +289,9 @@ typedef struct {
  * hopping: port_channel_estimator_average_impl.cpp:118-138). */
 /* jobs_on_device: 0 = host array (validated), 1 = device array; with a device array bits 8-11 / 12-15 may carry the largest nof_rx_ports /
  * nof_tx_layers of the batch (0 = unknown: workgroups for 4 x 4 are launched and the surplus ones exit at once). */
+#define MIPHY_JOBS_ON_HOST 0
+#define MIPHY_JOBS_ON_DEVICE 1
+#define MIPHY_JOBS_ON_DEVICE_HINT(max_ports, max_layers) (1 | ((int)(max_ports) << 8) | ((int)(max_layers) << 12))
 int miphy_port_channel_estimate_batch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int jobs_on_device, uint32_t n, const float* grid /* device cf_t */,
                                       const float* pilots /* device cf_t */, float* ce /* device cf_t */, float* scalars /* device */, void* stream);
 int miphy_dmrs_pusch_estimate_batch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int jobs_on_device, uint32_t n,
