@@ -71,9 +71,10 @@ def pusch_workload():
 
 
 def kernel_source_sha():
-    """Hash of the kernel sources: profiles collected on another build must not be quoted."""
+    """Hash of the kernel sources and their build recipe: profiles collected on another build must not be quoted."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "srsran_project_23.5_amd", "csrc")
+    h.update(open(os.path.join(ROOT, "srsran_project_23.5_amd", "Makefile"), "rb").read())
     for dirpath, _, files in sorted(os.walk(d)):
         for f in sorted(files):
             if f.endswith((".hip", ".h")):

@@ -391,13 +391,14 @@ constexpr int PK_PRE = 3; // rate-matched input vectors per lane fetched one cod
 // The load phase of the variant that dematches while loading, as a function of its own (never inlined): its staging needs far more
 // registers than the layer loop, and inlined it decides the register allocation of the whole kernel; out of line the kernel holds
 // LDPC_PK_MIN_WAVES_FUSED wavefronts per SIMD with a layer loop free of scratch accesses, and only this phase pays for its spills.
-// Returns this lane's candidate for the position behind the last non-zero soft bit.
-__device__ __attribute__((noinline)) int pk_fused_load(int8_t* __restrict__ soft, int8_t* __restrict__ llr_img, const int8_t* __restrict__ in, int E, int F, int mod,
-                                                       int Z, int bgK, int bgi, int in_len, int soft_bytes, raw_in16 p0, raw_in16 p1, raw_in16 p2, int tid,
-                                                       int nt)
+// A plain pointer argument of a function that is not inlined is a generic one (flat_load: both wait counters, aperture test); the
+// rate-matched input is global memory, and a parameter that says so gives global_load.
+typedef __attribute__((address_space(1))) const int8_t* global_ci8;
+__device__ __attribute__((noinline)) void pk_fused_load(int8_t* __restrict__ soft, global_ci8 in_global, int E, int F, int mod, int Z, int bgK, int soft_bytes,
+                                                        raw_in16 p0, raw_in16 p1, raw_in16 p2, int tid, int nt)
 {
   static_assert(PK_PRE == 3, "three prefetched vectors are passed by value");
-  int last = 0;
+  const int8_t* __restrict__ in = (const int8_t*)in_global;
     // ---- rate dematching into the LDS image soft[2Z + j] = buffer position j
     // (the lane index is made opaque here: the compiler would otherwise hoist every per-lane staging address out of the
     // codeblock loop and keep dozens of them alive across the decoder)
@@ -441,28 +442,33 @@ __device__ __attribute__((noinline)) int pk_fused_load(int8_t* __restrict__ soft
       img[r + ((r >= g.f0) ? F : 0)] = in[k];
     }
     __syncthreads();
-    // ---- the image goes to the HARQ soft buffer (what the reference's dematcher leaves there) while the last non-zero soft bit
-    // is found (ldpc_decoder_impl.cpp:86-99)
-    {
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      u32x4*       dst  = reinterpret_cast<u32x4*>(llr_img);
-      const uint4* src  = reinterpret_cast<const uint4*>(img);
-      const int    nimg = in_len >> 4, nall = (((bgi ? 50 : 66) * Z) >> 4);
-      for (int q = tid; q < nimg; q += nt) {
-        const uint4 v = src[q];
-        const u32x4 o = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(o, dst + q);
-        int hi = -1;
-        hi     = v.x ? 3 - (__clz((int)v.x) >> 3) : hi;
-        hi     = v.y ? 7 - (__clz((int)v.y) >> 3) : hi;
-        hi     = v.z ? 11 - (__clz((int)v.z) >> 3) : hi;
-        hi     = v.w ? 15 - (__clz((int)v.w) >> 3) : hi;
-        last   = (hi >= 0) ? 16 * q + hi + 1 : last;
-      }
-      const u32x4 zero = {0, 0, 0, 0};
-      for (int q = nimg + tid; q < nall; q += nt)
-        __builtin_nontemporal_store(zero, dst + q);
-    }
+}
+
+// The image goes to the HARQ soft buffer (what the reference's dematcher leaves there) while the last non-zero soft bit is found
+// (ldpc_decoder_impl.cpp:86-99). Inlined into the kernel: a function has to wait for its stores before it returns (25 KB per
+// codeblock on their way to HBM), here they drain under the first layers. Returns this lane's candidate for the position behind the
+// last non-zero soft bit.
+__device__ __forceinline__ int pk_fused_image_out(const int8_t* __restrict__ soft, int8_t* __restrict__ llr_img, int Z, int bgi, int in_len, int tid, int nt)
+{
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  int          last = 0;
+  u32x4*       dst  = reinterpret_cast<u32x4*>(llr_img);
+  const uint4* src  = reinterpret_cast<const uint4*>(soft + 2 * Z);
+  const int    nimg = in_len >> 4, nall = (((bgi ? 50 : 66) * Z) >> 4);
+  for (int q = tid; q < nimg; q += nt) {
+    const uint4 v = src[q];
+    const u32x4 o = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(o, dst + q);
+    int hi = -1;
+    hi     = v.x ? 3 - (__clz((int)v.x) >> 3) : hi;
+    hi     = v.y ? 7 - (__clz((int)v.y) >> 3) : hi;
+    hi     = v.z ? 11 - (__clz((int)v.z) >> 3) : hi;
+    hi     = v.w ? 15 - (__clz((int)v.w) >> 3) : hi;
+    last   = (hi >= 0) ? 16 * q + hi + 1 : last;
+  }
+  const u32x4 zero = {0, 0, 0, 0};
+  for (int q = nimg + tid; q < nall; q += nt)
+    __builtin_nontemporal_store(zero, dst + q);
   return last;
 }
 
@@ -568,8 +574,8 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   };
   if (FUSED) {
     const miphy_ldpc_rdm_desc rd = load_words(rdm + cb);
-    last = pk_fused_load(soft, const_cast<int8_t*>(llr), rm_in_base + rd.in_offset, (int)rd.E, (int)dsc.nof_filler_bits, (int)rd.mod, Z, bgK, bgi, in_len,
-                         soft_bytes, pre[0], pre[1], pre[2], tid, nt);
+    pk_fused_load(soft, (global_ci8)(rm_in_base + rd.in_offset), (int)rd.E, (int)dsc.nof_filler_bits, (int)rd.mod, Z, bgK, soft_bytes, pre[0], pre[1], pre[2], tid, nt);
+    last = pk_fused_image_out(soft, const_cast<int8_t*>(llr), Z, bgi, in_len, tid, nt);
   } else {
   for (int k = tid; k < 2 * Z; k += nt)
     soft[k] = 0;

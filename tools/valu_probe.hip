@@ -39,10 +39,40 @@
       cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;                            \
   }
 
+// the same instruction as ONE dependent chain (every instruction reads the result of the one before it) and as two interleaved chains
+#define DEP8(ASM)                                         \
+  asm volatile(ASM "\n" ASM "\n" ASM "\n" ASM "\n" ASM "\n" ASM "\n" ASM "\n" ASM "\n" : "+v"(r[0]) : "v"(a), "v"(b));
+#define DEP8x2(ASM)                                       \
+  asm volatile(ASM "\n" : "+v"(r[0]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[1]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[0]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[1]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[0]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[1]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[0]) : "v"(a), "v"(b)); \
+  asm volatile(ASM "\n" : "+v"(r[1]) : "v"(a), "v"(b));
+#define DEPN(ASM, I) asm volatile(ASM "\n" : "+v"(r[I]) : "v"(a), "v"(b));
+#define DEP12x3(ASM) DEPN(ASM, 0) DEPN(ASM, 1) DEPN(ASM, 2) DEPN(ASM, 0) DEPN(ASM, 1) DEPN(ASM, 2) DEPN(ASM, 0) DEPN(ASM, 1) DEPN(ASM, 2) DEPN(ASM, 0) DEPN(ASM, 1) DEPN(ASM, 2)
+#define DEP8x4(ASM) DEPN(ASM, 0) DEPN(ASM, 1) DEPN(ASM, 2) DEPN(ASM, 3) DEPN(ASM, 0) DEPN(ASM, 1) DEPN(ASM, 2) DEPN(ASM, 3)
+#define DEP12x6(ASM) DEPN(ASM, 0) DEPN(ASM, 1) DEPN(ASM, 2) DEPN(ASM, 3) DEPN(ASM, 4) DEPN(ASM, 5) DEPN(ASM, 0) DEPN(ASM, 1) DEPN(ASM, 2) DEPN(ASM, 3) DEPN(ASM, 4) DEPN(ASM, 5)
+#define D120x3(ASM) DEP12x3(ASM) DEP12x3(ASM) DEP12x3(ASM) DEP12x3(ASM) DEP12x3(ASM) DEP12x3(ASM) DEP12x3(ASM) DEP12x3(ASM) DEP12x3(ASM) DEP12x3(ASM)
+#define D120x6(ASM) DEP12x6(ASM) DEP12x6(ASM) DEP12x6(ASM) DEP12x6(ASM) DEP12x6(ASM) DEP12x6(ASM) DEP12x6(ASM) DEP12x6(ASM) DEP12x6(ASM) DEP12x6(ASM)
+#define D128x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM) DEP8x4(ASM)
+#define D128(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM) DEP8(ASM)
+#define D128x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM) DEP8x2(ASM)
 #define B32(ASM) BODY8(ASM) BODY8(ASM) BODY8(ASM) BODY8(ASM)
 #define B128(ASM) B32(ASM) B32(ASM) B32(ASM) B32(ASM)
 // 128 instructions per loop iteration in the single-instruction kernels (loop overhead < 3 %), 32 in the mix
 DEF_KERNEL(k_add32, B128("v_add_u32 %0, %1, %0"))
+DEF_KERNEL(k_add32_dep, D128("v_add_u32 %0, %1, %0"))
+DEF_KERNEL(k_add32_dep2, D128x2("v_add_u32 %0, %1, %0"))
+DEF_KERNEL(k_pk_add_dep, D128("v_pk_add_u16 %0, %1, %0"))
+DEF_KERNEL(k_pk_add_dep2, D128x2("v_pk_add_u16 %0, %1, %0"))
+DEF_KERNEL(k_pk_add_dep3, D120x3("v_pk_add_u16 %0, %1, %0"))
+DEF_KERNEL(k_pk_add_dep4, D128x4("v_pk_add_u16 %0, %1, %0"))
+DEF_KERNEL(k_pk_add_dep6, D120x6("v_pk_add_u16 %0, %1, %0"))
+DEF_KERNEL(k_add32_dep3, D120x3("v_add_u32 %0, %1, %0"))
+DEF_KERNEL(k_add32_dep4, D128x4("v_add_u32 %0, %1, %0"))
 DEF_KERNEL(k_add32_e64, B128("v_add_u32_e64 %0, %1, %0"))
 DEF_KERNEL(k_xor, B128("v_xor_b32 %0, %1, %0"))
 DEF_KERNEL(k_mov, B128("v_mov_b32 %0, %1"))
@@ -81,7 +111,7 @@ DEF_KERNEL(k_mix, BODY8("v_pk_add_u16 %0, %1, %0") BODY8("v_pk_min_i16 %0, %1, %
 template <typename K>
 void run(const char* name, K kern, unsigned long long* d_cyc, unsigned* d_sink, int instr_per_iter)
 {
-  const int iters = instr_per_iter >= 128 ? 500 : 2000;
+  const int iters = instr_per_iter >= 120 ? 500 : 2000;
   printf("%-26s", name);
   for (int W : {1, 2, 3, 4, 8}) {
     // W workgroups of 4 waves per CU -> W waves per SIMD (256 CUs)
@@ -139,5 +169,14 @@ int main()
   run("v_sad_u8 (VOP3)", k_sad_u8, d_cyc, d_sink, 128);
   run("v_dot4_i32_i8 (VOP3P)", k_dot4, d_cyc, d_sink, 128);
   run("decoder mix 16pk/4perm/12i32", k_mix, d_cyc, d_sink, 32);
+  run("v_add_u32, ONE dependent chain", k_add32_dep, d_cyc, d_sink, 128);
+  run("v_add_u32, two chains", k_add32_dep2, d_cyc, d_sink, 128);
+  run("v_pk_add_u16, ONE dep. chain", k_pk_add_dep, d_cyc, d_sink, 128);
+  run("v_pk_add_u16, two chains", k_pk_add_dep2, d_cyc, d_sink, 128);
+  run("v_pk_add_u16, three chains", k_pk_add_dep3, d_cyc, d_sink, 120);
+  run("v_pk_add_u16, four chains", k_pk_add_dep4, d_cyc, d_sink, 128);
+  run("v_pk_add_u16, six chains", k_pk_add_dep6, d_cyc, d_sink, 120);
+  run("v_add_u32, three chains", k_add32_dep3, d_cyc, d_sink, 120);
+  run("v_add_u32, four chains", k_add32_dep4, d_cyc, d_sink, 128);
   return 0;
 }
