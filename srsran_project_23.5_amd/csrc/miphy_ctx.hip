@@ -161,7 +161,8 @@ extern "C" int miphy_create(int device, miphy_ctx** out)
   build_tables(c->h_tables);
   MIPHY_HIP_CHECK(hipMalloc((void**)&c->d_tables, sizeof(miphy_graph_tables)));
   MIPHY_HIP_CHECK(hipMemcpy(c->d_tables, c->h_tables, sizeof(miphy_graph_tables), hipMemcpyHostToDevice));
-  c->desc_staging_bytes = 4u << 20;
+  c->desc_staging_bytes = 8u << 20;
+  c->staging_head       = 0;
   MIPHY_HIP_CHECK(hipMalloc(&c->d_desc_staging, c->desc_staging_bytes));
   MIPHY_HIP_CHECK(hipHostMalloc(&c->h_desc_staging, c->desc_staging_bytes, hipHostMallocDefault));
   MIPHY_HIP_CHECK(hipMalloc((void**)&c->d_queue, MIPHY_NOF_QUEUE_COUNTERS * sizeof(uint32_t)));
@@ -198,6 +199,21 @@ int miphy_next_queue_counter(miphy_ctx* ctx, hipStream_t s, uint32_t** out)
   return MIPHY_OK;
 }
 
+// Front-to-back allocation in the staging ring. Regions handed out since the last wrap are never overwritten; on a wrap every
+// consumer of the old regions must be done, whatever stream it ran on, hence the device-wide synchronisation (once per
+// desc_staging_bytes of descriptors, not once per call).
+static int staging_take(miphy_ctx* ctx, size_t bytes, size_t* off)
+{
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (ctx->staging_head + need > ctx->desc_staging_bytes) {
+    MIPHY_HIP_CHECK(hipDeviceSynchronize());
+    ctx->staging_head = 0;
+  }
+  *off = ctx->staging_head;
+  ctx->staging_head += need;
+  return MIPHY_OK;
+}
+
 int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t bytes, hipStream_t s, const void** out)
 {
   if (on_device) {
@@ -205,11 +221,34 @@ int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t b
     return MIPHY_OK;
   }
   MIPHY_REQUIRE(bytes <= ctx->desc_staging_bytes, "descriptor batch too large (%zu bytes > %zu)", bytes, ctx->desc_staging_bytes);
-  // The staging buffers are reused by the next call on this context: wait for the stream before overwriting.
-  MIPHY_HIP_CHECK(hipStreamSynchronize(s));
-  memcpy(ctx->h_desc_staging, descs, bytes);
-  MIPHY_HIP_CHECK(hipMemcpyAsync(ctx->d_desc_staging, ctx->h_desc_staging, bytes, hipMemcpyHostToDevice, s));
-  *out = ctx->d_desc_staging;
+  size_t off = 0;
+  int    rc  = staging_take(ctx, bytes, &off);
+  if (rc)
+    return rc;
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_desc_staging) + off;
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_desc_staging) + off;
+  memcpy(h, descs, bytes);
+  MIPHY_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+  *out = d;
+  return MIPHY_OK;
+}
+
+int miphy_upload(miphy_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s)
+{
+  if (bytes == 0)
+    return MIPHY_OK;
+  if (bytes > ctx->desc_staging_bytes / 2) {
+    MIPHY_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    MIPHY_HIP_CHECK(hipStreamSynchronize(s)); // `src` may be pageable or about to go out of scope
+    return MIPHY_OK;
+  }
+  size_t off = 0;
+  int    rc  = staging_take(ctx, bytes, &off);
+  if (rc)
+    return rc;
+  uint8_t* h = static_cast<uint8_t*>(ctx->h_desc_staging) + off;
+  memcpy(h, src, bytes);
+  MIPHY_HIP_CHECK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, s));
   return MIPHY_OK;
 }
 

@@ -52,9 +52,10 @@ struct miphy_ctx {
   miphy_ctx_ext*       ext;
   miphy_graph_tables*  d_tables; // device copy
   miphy_graph_tables*  h_tables; // host copy
-  void*                d_desc_staging;
-  size_t               desc_staging_bytes;
-  void*                h_desc_staging; // pinned
+  void*                d_desc_staging; // descriptor staging: a RING of desc_staging_bytes on the device and the same in pinned host memory,
+  size_t               desc_staging_bytes; // handed out front to back (miphy_stage_descs, miphy_upload); the device is synchronised only when
+  void*                h_desc_staging; // pinned    // the ring wraps, so a call with host descriptors never waits for the stream
+  size_t               staging_head;
   void*                d_work[5];      // scratch workspaces, grown on demand: [0] the transport-block level entry points, DFT, polar;
   size_t               work_bytes[5];  // [1] intermediate buffers of miphy_pusch_process_batch, [2] codewords of miphy_pdsch_process_batch,
                                        // [3] check-to-variable messages of the LDPC decoder when they do not stay in LDS,
@@ -102,8 +103,14 @@ __device__ __forceinline__ T load_words(const T* __restrict__ p)
 }
 #endif
 
-// Ensures the descriptor array is on the device; returns the device pointer through *out.
+// Ensures the descriptor array is on the device; returns the device pointer through *out. Host descriptors are copied into the
+// context's staging ring (pinned host -> device, asynchronous on `s`): the call does not wait for the stream, and the caller's array
+// can be reused as soon as it returns.
 int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t bytes, hipStream_t s, const void** out);
+// Asynchronous upload of a host buffer of any kind (pageable, a local vector) to device memory `dst`, ordered on `s`: the bytes travel
+// through the pinned ring, so `src` can be released when the call returns and the stream is not waited for. (Buffers larger than half
+// the ring are copied directly and the stream is synchronised, as every upload was before.)
+int miphy_upload(miphy_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s);
 
 // Decoder launch shared by miphy_ldpc_decode_batch and the transport-block level PUSCH decoder.
 // force_scalar: the batch holds odd lifting sizes the packed kernel cannot take (device descriptors hide them from the launcher).

@@ -1053,8 +1053,8 @@ extern "C" int miphy_pbch_encode_batch(miphy_ctx* ctx, const miphy_pbch_msg* msg
   void*       ws = nullptr;
   if ((rc = miphy_get_workspace(ctx, ap.size(), s, &ws)))
     return rc;
-  MIPHY_HIP_CHECK(hipMemcpyAsync(ws, ap.data(), ap.size(), hipMemcpyHostToDevice, s));
-  MIPHY_HIP_CHECK(hipStreamSynchronize(s)); // `ap` is a local buffer
+  if ((rc = miphy_upload(ctx, ws, ap.data(), ap.size(), s))) // `ap` is a local buffer
+    return rc;
   hipLaunchKernelGGL(pdcch_encode_kernel, dim3(n), dim3(64), 0, s, *p, 32u, (const uint8_t*)ws, (const uint16_t*)nullptr, out, 0);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;

@@ -153,12 +153,10 @@ extern "C" int miphy_pusch_process_batch_ex(miphy_ctx* ctx, const miphy_pusch_pd
   float*    d_evm = reinterpret_cast<float*>(d_llr + llr_bytes + sch_bytes);
   uint16_t* d_ph  = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(d_evm) + evm_bytes);
   uint32_t* d_nre = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(d_ph) + ph_bytes);
-  if (!ph.empty())
-    MIPHY_HIP_CHECK(hipMemcpyAsync(d_ph, ph.data(), ph.size() * 2, hipMemcpyHostToDevice, s));
-  if (evm_out)
-    MIPHY_HIP_CHECK(hipMemcpyAsync(d_nre, nof_re.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-  if (!ph.empty() || evm_out)
-    MIPHY_HIP_CHECK(hipStreamSynchronize(s)); // pageable host vectors
+  if (!ph.empty() && (rc = miphy_upload(ctx, d_ph, ph.data(), ph.size() * 2, s)))
+    return rc;
+  if (evm_out && (rc = miphy_upload(ctx, d_nre, nof_re.data(), (size_t)n * 4, s)))
+    return rc;
   if ((rc = miphy_dmrs_pusch_estimate_batch(ctx, cj.data(), 0, n, grid, d_ce, scalars_out, s)))
     return rc;
   if ((rc = miphy_pusch_demodulate_batch_ex(ctx, dj.data(), 0, n, grid, d_ce, scalars_out, d_llr, ph.empty() ? nullptr : d_ph, evm_out ? d_evm : nullptr, s)))

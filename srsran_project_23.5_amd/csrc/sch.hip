@@ -587,9 +587,8 @@ extern "C" int miphy_pusch_decode_batch(miphy_ctx*                 ctx,
   if ((rc = miphy_get_workspace(ctx, bytes, s, &wsv)))
     return rc;
   const pusch_decode_dev v = layout_pusch_decode(b, host.data(), (uint8_t*)wsv);
-  // The staging copy is synchronous with respect to the host vector (pageable memory): it completes before returning.
-  MIPHY_HIP_CHECK(hipMemcpyAsync(wsv, host.data(), v.staged, hipMemcpyHostToDevice, s));
-  MIPHY_HIP_CHECK(hipStreamSynchronize(s));
+  if ((rc = miphy_upload(ctx, wsv, host.data(), v.staged, s))) // through the pinned ring: the stream is not waited for
+    return rc;
   return launch_pusch_decode(ctx, b, v, n, llrs, harq_softbits, harq_msgs, harq_crc_ok, tb_out, results, s);
 }
 
@@ -806,8 +805,8 @@ extern "C" int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_des
   uint8_t* d_msg = dv + off;
   off += msg_bytes;
   uint8_t* d_cb = dv + off;
-  MIPHY_HIP_CHECK(hipMemcpyAsync(dv, h, staged, hipMemcpyHostToDevice, s));
-  MIPHY_HIP_CHECK(hipStreamSynchronize(s));
+  if ((rc = miphy_upload(ctx, dv, h, staged, s)))
+    return rc;
   if ((rc = miphy_crc_batch(ctx, d_crcd, 1, n, tb_in, d_tbcrc, s)))
     return rc;
   hipLaunchKernelGGL(pdsch_cb_prepare_kernel, dim3(ncb), dim3(256), 0, s, d_prep, ctx->d_tables, tb_in, d_tbcrc, d_msg);

@@ -193,9 +193,8 @@ extern "C" int miphy_ulsch_demultiplex_batch(miphy_ctx* ctx, const miphy_ulsch_d
     return rc;
   auto* d_plans = static_cast<ulsch_plan*>(ws);
   auto* d_jobs  = reinterpret_cast<demux_dev_job*>(d_plans + n);
-  MIPHY_HIP_CHECK(hipMemcpyAsync(d_plans, plans.data(), n * sizeof(ulsch_plan), hipMemcpyHostToDevice, s));
-  MIPHY_HIP_CHECK(hipMemcpyAsync(d_jobs, dj.data(), n * sizeof(demux_dev_job), hipMemcpyHostToDevice, s));
-  MIPHY_HIP_CHECK(hipStreamSynchronize(s)); // the host vectors go out of scope
+  if ((rc = miphy_upload(ctx, d_plans, plans.data(), n * sizeof(ulsch_plan), s)) || (rc = miphy_upload(ctx, d_jobs, dj.data(), n * sizeof(demux_dev_job), s)))
+    return rc; // (the host vectors go out of scope: the bytes travel through the pinned ring)
   hipLaunchKernelGGL(ulsch_demux_kernel, dim3(n, 14), dim3(256), 0, s, d_plans, d_jobs, llr_in, sch_out, harq_ack_out, csi_part1_out, csi_part2_out);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
