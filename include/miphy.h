@@ -43,7 +43,12 @@ typedef struct miphy_ctx miphy_ctx;
 
 /* Creates a context on HIP device `device`: uploads the TS 38.212 graph tables, CRC tables and polar tables and
  * allocates the scratch workspace.  One context per host thread (the reference's processors are single-threaded
- * objects, one per worker: lib/phy/upper/uplink_processor_concurrent.h:41-54). */
+ * objects, one per worker: lib/phy/upper/uplink_processor_concurrent.h:41-54).
+ * Execution model of every *_batch entry point: the work is ENQUEUED on `stream` and the call returns; nothing waits for the
+ * stream. Descriptor arrays in host memory are copied when the call is made (pinned staging ring of the context: the array can be
+ * reused at once; the device is synchronised only when the 8 MB ring wraps) -- or pass descriptors that already live on the device
+ * (`*_on_device` = 1). Scratch workspaces belong to the context and are reused by its next call in stream order: use one stream
+ * at a time per context. */
 int         miphy_create(int device, miphy_ctx** ctx);
 void        miphy_destroy(miphy_ctx* ctx);
 const char* miphy_last_error(void);
