@@ -104,6 +104,10 @@ __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_de
 {
   __shared__ uint32_t cbpar[64]; // checksum part of every codeblock (at most 52), before its weight
   __shared__ int      all_ok;
+  // The checksum masks of the word positions of one codeblock (rows counted from the END of the message, so a shorter last
+  // codeblock uses the leading rows of the same copy): fetched once per transport block instead of 96 bytes per word and codeblock
+  // out of L2 -- that stream was 1 GB per launch of 1024 transport blocks and half of this kernel's time.
+  __shared__ __attribute__((aligned(16))) uint32_t zmask[MIPHY_CRC_ZMASK_WORDS * 24];
   const tb_asm_desc d    = descs[blockIdx.x];
   const int         tid  = threadIdx.x;
   const int         lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -146,6 +150,14 @@ __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_de
     return; // nothing is copied, flags stay as they are (multiple codeblocks) / tb_crc_ok = false (single codeblock)
   const uint32_t tb_bits = d.tb_bytes * 8;
   const bool     mask_crc = tb_mask_crc(d);
+  if (mask_crc) {
+    const uint32_t nrows = (d.nof_data_bits + 31) >> 5;
+    const uint4*   src   = reinterpret_cast<const uint4*>(tab->crc_zmask_packed24a[0]);
+    uint4*         dst   = reinterpret_cast<uint4*>(zmask);
+    for (uint32_t q = tid; q < nrows * 6; q += blockDim.x)
+      dst[q] = src[q];
+    __syncthreads();
+  }
   for (uint32_t c = wave; c < d.nof_cbs; c += nwaves) {
     const uint8_t* msg   = harq_msgs + (size_t)(d.harq_cb_index + c) * HARQ_MSG_STRIDE;
     const uint32_t bit0  = c * d.nof_data_bits; // first TB(+CRC) bit of this codeblock
@@ -157,44 +169,60 @@ __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_de
     // (tb_bits is a whole number of bytes, so no byte is partial.) The destination has any alignment, the source slot is dword
     // aligned: head bytes up to the destination's dword boundary, then aligned dword stores fed by a funnel shift of two source
     // dwords (the slot is HARQ_MSG_STRIDE = 1056 bytes, the dword behind the last payload byte is inside it), then tail bytes.
+    // All source words of the codeblock are requested before the first store (a slot is 264 dwords: at most five per lane), and the
+    // checksum below works on the same registers.
+    constexpr int   KW   = (HARQ_MSG_STRIDE / 4 + 63) / 64;
+    const uint32_t* s32  = reinterpret_cast<const uint32_t*>(msg);
+    const uint32_t  nw   = (nbits + 31) >> 5; // words the checksum covers
+    uint32_t        lo[KW], hi[KW];
+    uint8_t*        dst  = tb_out + d.tb_offset + o0;
+    const uint32_t  nb   = e0 > o0 ? e0 - o0 : 0;
+    const uint32_t  head = min(nb, (uint32_t)((4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u));
+    const uint32_t  ndw  = (nb - head) >> 2;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const uint32_t i = (uint32_t)lane + 64u * k;
+      lo[k]            = (i < ndw || i < nw) ? s32[i] : 0u;
+      hi[k]            = (i < ndw && head) ? s32[i + 1] : 0u;
+    }
     {
-      uint8_t*        dst  = tb_out + d.tb_offset + o0;
-      const uint32_t  nb   = e0 > o0 ? e0 - o0 : 0;
-      const uint32_t  head = min(nb, (uint32_t)((4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u));
-      const uint32_t  ndw  = (nb - head) >> 2;
-      const uint32_t* s32  = reinterpret_cast<const uint32_t*>(msg);
-      uint32_t*       d32  = reinterpret_cast<uint32_t*>(dst + head);
+      uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
       if ((uint32_t)lane < head)
         dst[lane] = msg[lane];
-      for (uint32_t i = lane; i < ndw; i += 64) {
-        const uint32_t lo = s32[i], hi = s32[i + 1];
-        d32[i]            = head ? __builtin_amdgcn_alignbyte(hi, lo, head) : lo;
+#pragma unroll
+      for (int k = 0; k < KW; ++k) {
+        const uint32_t i = (uint32_t)lane + 64u * k;
+        if (i < ndw)
+          d32[i] = head ? __builtin_amdgcn_alignbyte(hi[k], lo[k], head) : lo[k];
       }
       for (uint32_t b = head + 4 * ndw + lane; b < nb; b += 64)
         dst[b] = msg[b];
     }
     // ---- checksum part
     if (mask_crc) {
-      const uint32_t  nw = (nbits + 31) >> 5; // the mask table assumes the message padded with zeros to whole words (folded into cbw)
-      const uint32_t* mw = reinterpret_cast<const uint32_t*>(msg); // slots are 1056 B apart: dword aligned
-      uint32_t        acc[24];
+      // (the mask table assumes the message padded with zeros to whole words: folded into cbw)
+      uint32_t acc[24];
 #pragma unroll
       for (int k = 0; k < 24; ++k)
         acc[k] = 0;
-      for (uint32_t t = lane; t < nw; t += 64) {
-        uint32_t w = mw[t];
-        if (32 * t + 32 > nbits) { // last word: keep the first nbits - 32 t message bits = the leading bytes (byte aligned)
-          const uint32_t nb = (nbits - 32 * t) >> 3;
-          w &= (nb >= 4) ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
-        }
-        const uint4* m = reinterpret_cast<const uint4*>(tab->crc_zmask_packed24a[nw - 1 - t]);
 #pragma unroll
-        for (int g = 0; g < 6; ++g) {
-          const uint4 mk = m[g];
-          acc[4 * g + 0] += __builtin_popcount(w & mk.x);
-          acc[4 * g + 1] += __builtin_popcount(w & mk.y);
-          acc[4 * g + 2] += __builtin_popcount(w & mk.z);
-          acc[4 * g + 3] += __builtin_popcount(w & mk.w);
+      for (int k = 0; k < KW; ++k) {
+        const uint32_t t = (uint32_t)lane + 64u * k;
+        if (t < nw) {
+          uint32_t w = lo[k];
+          if (32 * t + 32 > nbits) { // last word: keep the first nbits - 32 t message bits = the leading bytes (byte aligned)
+            const uint32_t nbl = (nbits - 32 * t) >> 3;
+            w &= (nbl >= 4) ? 0xffffffffu : ((1u << (8 * nbl)) - 1u);
+          }
+          const uint4* m = reinterpret_cast<const uint4*>(zmask + (nw - 1 - t) * 24);
+#pragma unroll
+          for (int g = 0; g < 6; ++g) {
+            const uint4 mk = m[g];
+            acc[4 * g + 0] += __builtin_popcount(w & mk.x);
+            acc[4 * g + 1] += __builtin_popcount(w & mk.y);
+            acc[4 * g + 2] += __builtin_popcount(w & mk.z);
+            acc[4 * g + 3] += __builtin_popcount(w & mk.w);
+          }
         }
       }
       uint32_t par = 0;
