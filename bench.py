@@ -834,6 +834,38 @@ def main():
         out.update(cpu_legs(w, samples4, llr_h[:4], ofdm_args, args.max_iter, bool(args.early_stop), args.cpu_seconds))
         if "cpu_baseline_t1" in out:
             out["cpu_baseline_all_cores"] = out["cpu_baseline"]
+    def graph_latency():
+        """The eight launches of one slot captured once in a HIP graph and replayed (the library only enqueues: nothing in the calls
+        waits for the stream, so they can be captured as they are). Runs LAST: a failed capture must not disturb the measurements."""
+        reps, ev0, ev1 = 20, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        try:
+            td1 = np.zeros(1, dtype=miphy.PuschTbDesc)
+            td1[0] = (w["bg"], w["rv"], w["mod"], w["nof_layers"], 1, args.early_stop, args.max_iter, w["Nref"], w["nsym"], tb_bytes, 0, 0, 0)
+            pg = ctx.pusch_decode_plan(td1)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                cs = torch.cuda.current_stream()
+                ctx.ofdm_demodulate_slots(ocfg, ojobs_d[:24], samples_d, grid_d, cs)
+                ctx.dmrs_pusch_estimate_batch(cjobs_d[:152], grid_d, ce_d, sc_d, cs)
+                ctx.pusch_demodulate_batch(djobs_d[:120], grid_d, ce_d, sc_d, llr_d, cs)
+                pg.run(llr_d, soft_d, msgs_d, crc_d, tb_d, res_d, cs)
+            tb_d[:tb_bytes].zero_()
+            for r in range(reps + 3):
+                if r == 3:
+                    ev0.record(stream)
+                graph.replay()
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            us = ev0.elapsed_time(ev1) / reps * 1e3
+            ok = np.array_equal(tb_d[:tb_bytes].cpu().numpy(), tbs_u[slot_src[0]])  # the replayed graph must deliver the transport block
+            pg.close()
+            return us if ok else None
+        except Exception as e:  # capture is an extra: the line is printed without it
+            print("bench.py: HIP graph capture of the single-slot pipeline failed: %s" % e, file=sys.stderr)
+            return None
+
+    if rank == 0 and world == 1 and not args.no_latency:
+        out["single_slot_latency_hip_graph_us"] = graph_latency()
     if rank == 0:
         print(json.dumps(out))
     if ok_slots != checked:

@@ -135,3 +135,30 @@ def test_crc_batch(ctx):
     out = out_d.cpu().numpy().astype(np.uint32)
     for i, (off, nbits, poly) in enumerate(cases):
         assert int(out[i]) == o_crc_bits(poly, bits[off:off + nbits]), cases[i]
+
+
+def test_host_descriptors_queued_without_synchronisation_across_the_staging_ring(ctx):
+    """Host descriptor arrays are copied at the call into the context's pinned staging ring and the call returns without waiting for
+    the stream (miphy.h, execution model). 2600 calls queued back to back, each with its own descriptors (reused host array, 200
+    descriptors = 3.2 KB (one 3.25 KB ring slot) per call: 8.7 MB in all, the 8 MB ring wraps inside the run), one synchronisation at the end: every call
+    must have seen ITS descriptors."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(77)
+    data = rng.integers(0, 256, 4096, dtype=np.uint8)
+    bits = np.unpackbits(data)
+    d_d = torch.from_numpy(np.concatenate([data, np.zeros(16, dtype=np.uint8)])).cuda()
+    ncall, per = 2600, 200
+    out_d = torch.zeros(ncall * per, dtype=torch.int32, device="cuda")
+    descs = np.zeros(per, dtype=miphy.CrcDesc)  # ONE host array, overwritten for every call
+    offs = rng.integers(0, 4096 * 8 - 64, (ncall, per))
+    lens = rng.integers(1, 64, (ncall, per))
+    for c in range(ncall):
+        descs["bit_offset"], descs["nbits"], descs["poly"] = offs[c], lens[c], miphy.CRC16
+        ctx.crc_batch(descs, d_d, out_d[c * per:(c + 1) * per])
+    torch.cuda.synchronize()
+    out = out_d.cpu().numpy().astype(np.uint32).reshape(ncall, per)
+    for c in list(range(0, ncall, 97)) + [ncall - 1]:
+        for i in range(0, per, 13):
+            o, n = int(offs[c, i]), int(lens[c, i])
+            assert int(out[c, i]) == o_crc_bits(miphy.CRC16, bits[o:o + n]), (c, i)
