@@ -99,7 +99,8 @@ inline void gold_tables_init(gold_tables& t)
 // The x2 half of c(0 .. 32 nwords - 1) in LDS, by a whole workgroup (nt >= 64 threads, a multiple of 64): thread 0 produces the 31-word
 // head 28 bits per step; then the word recurrence w[i] = w[i-28] ^ w[i-29] ^ w[i-30] ^ w[i-31] (the bit recurrence raised to the 32nd
 // power) and its further squares w[i] = w[i-28d] ^ w[i-29d] ^ w[i-30d] ^ w[i-31d], d = 2^k, which need 31 d words of history and
-// yield 28 d independent words per step -- the history doubles until a step fills the workgroup.
+// yield 28 d independent words per step -- the history doubles with every step (a step larger than the workgroup is a short loop), so
+// a sequence of n words takes about log2(n / 31) + 4 barriers.
 __device__ __forceinline__ void gold_x2_sequence(const gold_jump& j, uint32_t c_init, int nwords, uint32_t* w, int tid, int nt)
 {
   if (tid < 64) { // state after the warm-up: lane k contributes column k (one parallel load), XOR-reduced over the wavefront
@@ -113,12 +114,12 @@ __device__ __forceinline__ void gold_x2_sequence(const gold_jump& j, uint32_t c_
   __syncthreads();
   int have = 31, k = 0;
   while (have < nwords) {
-    const int d = 1 << k, step = 28 * d, i = have + tid;
-    if (tid < step && i < nwords)
+    const int d = 1 << k, step = 28 * d, end = min(have + step, nwords);
+    for (int i = have + tid; i < end; i += nt)
       w[i] = w[i - 28 * d] ^ w[i - 29 * d] ^ w[i - 30 * d] ^ w[i - 31 * d];
     __syncthreads();
     have += step;
-    while ((56 << k) <= nt && (62 << k) <= have)
+    while ((62 << k) <= have) // 31 * 2d words of history allow the next square
       ++k;
   }
 }
