@@ -660,6 +660,13 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   const int max_iter     = dsc.max_iter;
   PROF_T(p_loaded);
   PROF_ADD(0, p_start, p_loaded);
+  // The two wrap constants of the address computations live in VECTOR registers: a VOP2 add / sub with a scalar operand issues at
+  // the rate of the three-operand encodings (2.88 instead of 1.93 cycles at three waves per SIMD, tools/valu_probe), and three of
+  // the eight address instructions per edge only have Z or Z/2 as their second operand.
+  int Zv = Z, Hv = H;
+#ifndef LDPC_PK_SCALAR_WRAP
+  asm volatile("" : "+v"(Zv), "+v"(Hv));
+#endif
   for (int it = 0; it < max_iter; ++it) {
     for (int m = 0; m < nof_layers; ++m) {
       const uint32_t  li    = (uint32_t)__builtin_amdgcn_readlane((int)lay_info, m);
@@ -670,9 +677,9 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       if (tid < H) {
         uint32_t* cl = c2v_lane + 64 * (li >> 16);
         if (it == 0)
-          update_rows_pk_any<true>(d, soft, cl, edges, tid, H, Z);
+          update_rows_pk_any<true>(d, soft, cl, edges, tid, Hv, Zv);
         else
-          update_rows_pk_any<false>(d, soft, cl, edges, tid, H, Z);
+          update_rows_pk_any<false>(d, soft, cl, edges, tid, Hv, Zv);
       }
       PROF_T(p_l1);
       __syncthreads();

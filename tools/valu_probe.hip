@@ -73,6 +73,13 @@ DEF_KERNEL(k_pk_add_dep4, D128x4("v_pk_add_u16 %0, %1, %0"))
 DEF_KERNEL(k_pk_add_dep6, D120x6("v_pk_add_u16 %0, %1, %0"))
 DEF_KERNEL(k_add32_dep3, D120x3("v_add_u32 %0, %1, %0"))
 DEF_KERNEL(k_add32_dep4, D128x4("v_add_u32 %0, %1, %0"))
+// operands from scalar registers (the decoder's shifts and column offsets are SGPRs) and the condition-code forms
+DEF_KERNEL(k_add32_sgpr, B128("v_add_u32 %0, s20, %0"))
+DEF_KERNEL(k_pk_add_sgpr, B128("v_pk_add_u16 %0, s20, %0"))
+DEF_KERNEL(k_min_u32_sgpr, B128("v_min_u32 %0, s20, %0"))
+DEF_KERNEL(k_cndmask_sgpr, B128("v_cndmask_b32_e64 %0, %1, %0, s[22:23]"))
+DEF_KERNEL(k_cmp_cnd, B128("v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %0, %1, %0, vcc"))
+DEF_KERNEL(k_add32_lit, B128("v_add_u32 %0, 0x12345, %0"))
 DEF_KERNEL(k_add32_e64, B128("v_add_u32_e64 %0, %1, %0"))
 DEF_KERNEL(k_xor, B128("v_xor_b32 %0, %1, %0"))
 DEF_KERNEL(k_mov, B128("v_mov_b32 %0, %1"))
@@ -169,6 +176,12 @@ int main()
   run("v_sad_u8 (VOP3)", k_sad_u8, d_cyc, d_sink, 128);
   run("v_dot4_i32_i8 (VOP3P)", k_dot4, d_cyc, d_sink, 128);
   run("decoder mix 16pk/4perm/12i32", k_mix, d_cyc, d_sink, 32);
+  run("v_add_u32 v, SGPR, v", k_add32_sgpr, d_cyc, d_sink, 128);
+  run("v_add_u32 v, literal, v", k_add32_lit, d_cyc, d_sink, 128);
+  run("v_pk_add_u16 v, SGPR, v", k_pk_add_sgpr, d_cyc, d_sink, 128);
+  run("v_min_u32 v, SGPR, v", k_min_u32_sgpr, d_cyc, d_sink, 128);
+  run("v_cndmask_b32 e64, SGPR pair", k_cndmask_sgpr, d_cyc, d_sink, 128);
+  run("v_cmp + v_cndmask (per PAIR)", k_cmp_cnd, d_cyc, d_sink, 128);
   run("v_add_u32, ONE dependent chain", k_add32_dep, d_cyc, d_sink, 128);
   run("v_add_u32, two chains", k_add32_dep2, d_cyc, d_sink, 128);
   run("v_pk_add_u16, ONE dep. chain", k_pk_add_dep, d_cyc, d_sink, 128);
