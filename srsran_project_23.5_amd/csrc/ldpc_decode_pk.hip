@@ -64,6 +64,21 @@ __device__ __forceinline__ uint32_t c2v_pack(s16x2 c0, s16x2 c1)
   return __builtin_amdgcn_perm(as_u(c0), as_u(c1), 0x06020400u);
 }
 
+// p mod Z for p < 2 Z: min(p, p - Z) on the LOW HALVES. The 16-bit VOP2 minimum issues at the fast rate (1.93 cycles at three waves
+// per SIMD, where v_min_u32 takes 2.88: tools/valu_probe) and clears the upper half of its destination (tools/min16_probe), so the
+// result is the address term itself. Positions are below 2 * 384.
+__device__ __forceinline__ uint32_t wrap_z(uint32_t p, uint32_t Z)
+{
+#ifdef LDPC_PK_MIN32
+  return min(p, p - Z);
+#else
+  const uint32_t t = p - Z;
+  uint32_t       r;
+  asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(p), "v"(t));
+  return r;
+#endif
+}
+
 constexpr int LLR_MAX = 120;
 constexpr int LLR_INF = 127;
 constexpr int INF_MUL = 255; // an infinite soft bit (|s| > 120) becomes a message of magnitude >= 255 + 24
@@ -84,10 +99,8 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
   // messages): the latency of the LDS pipe is paid once per layer instead of once per group of edges.
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    uint32_t pA = (uint32_t)l + edges[2 * j];
-    pA          = min(pA, pA - (uint32_t)Z);
-    uint32_t pB = pA + (uint32_t)H;
-    pB          = min(pB, pB - (uint32_t)Z);
+    const uint32_t pA = wrap_z((uint32_t)l + edges[2 * j], (uint32_t)Z);
+    const uint32_t pB = wrap_z(pA + (uint32_t)H, (uint32_t)Z);
     adrA[j]     = edges[2 * j + 1] + pA;
     adrB[j]     = edges[2 * j + 1] + pB;
   }

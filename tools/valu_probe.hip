@@ -79,6 +79,9 @@ DEF_KERNEL(k_pk_add_sgpr, B128("v_pk_add_u16 %0, s20, %0"))
 DEF_KERNEL(k_min_u32_sgpr, B128("v_min_u32 %0, s20, %0"))
 DEF_KERNEL(k_cndmask_sgpr, B128("v_cndmask_b32_e64 %0, %1, %0, s[22:23]"))
 DEF_KERNEL(k_cmp_cnd, B128("v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %0, %1, %0, vcc"))
+DEF_KERNEL(k_min_u16, B128("v_min_u16 %0, %1, %0"))
+DEF_KERNEL(k_sub_u16, B128("v_sub_u16 %0, %1, %0"))
+DEF_KERNEL(k_min_u32, B128("v_min_u32 %0, %1, %0"))
 DEF_KERNEL(k_add32_lit, B128("v_add_u32 %0, 0x12345, %0"))
 DEF_KERNEL(k_add32_e64, B128("v_add_u32_e64 %0, %1, %0"))
 DEF_KERNEL(k_xor, B128("v_xor_b32 %0, %1, %0"))
@@ -182,6 +185,9 @@ int main()
   run("v_min_u32 v, SGPR, v", k_min_u32_sgpr, d_cyc, d_sink, 128);
   run("v_cndmask_b32 e64, SGPR pair", k_cndmask_sgpr, d_cyc, d_sink, 128);
   run("v_cmp + v_cndmask (per PAIR)", k_cmp_cnd, d_cyc, d_sink, 128);
+  run("v_min_u32 (VOP2)", k_min_u32, d_cyc, d_sink, 128);
+  run("v_min_u16 (VOP2)", k_min_u16, d_cyc, d_sink, 128);
+  run("v_sub_u16 (VOP2)", k_sub_u16, d_cyc, d_sink, 128);
   run("v_add_u32, ONE dependent chain", k_add32_dep, d_cyc, d_sink, 128);
   run("v_add_u32, two chains", k_add32_dep2, d_cyc, d_sink, 128);
   run("v_pk_add_u16, ONE dep. chain", k_pk_add_dep, d_cyc, d_sink, 128);
