@@ -118,5 +118,6 @@ def test_equalizer_inverts_the_channel_at_full_size():
             n0, n1 = (np.abs(h[0]) ** 2).sum(0), (np.abs(h[1]) ** 2).sum(0)
             cond = (n0 * n1) / np.maximum(n0 * n1 - np.abs((h[0].conj() * h[1]).sum(0)) ** 2, 1e-30)
             ok = cond < 1e3  # well-conditioned elements; the error grows with the cancellation in the determinant
-            assert ok.mean() > 0.95 and np.all(np.abs(z - x)[:, ok] <= 4e-6 * cond[ok] + 2e-5)
+            # 100 eps x conditioning: the worst of 45 864 elements reaches 49 eps x cond over the seeds tried (oracle arithmetic, tools/fuzz_seeds)
+            assert ok.mean() > 0.95 and np.all(np.abs(z - x)[:, ok] <= 1.2e-5 * cond[ok] + 2e-5)
     ctx.close()
