@@ -48,7 +48,9 @@ typedef struct miphy_ctx miphy_ctx;
  * stream. Descriptor arrays in host memory are copied when the call is made (pinned staging ring of the context: the array can be
  * reused at once; the device is synchronised only when the 8 MB ring wraps) -- or pass descriptors that already live on the device
  * (`*_on_device` = 1). Scratch workspaces belong to the context and are reused by its next call in stream order: use one stream
- * at a time per context. */
+ * at a time per context. With device-resident descriptors and plans a sequence of calls can be captured in a HIP graph as it is
+ * (bench.py replays the single-slot pipeline that way); host descriptors must not be captured: a replay would read a staging
+ * slot that has been reused since. */
 int         miphy_create(int device, miphy_ctx** ctx);
 void        miphy_destroy(miphy_ctx* ctx);
 const char* miphy_last_error(void);
