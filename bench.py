@@ -632,10 +632,10 @@ def main():
     # + TB bytes out.
     # When the plan dematches inside the decoder (first transmissions, rv 0) the decoder kernel carries the dematcher's figure instead of its own
     # input read: rate-matched LLRs in + soft-buffer image out (N per codeblock, pusch_decoder_impl.cpp:176-181 keeps it for the next
-    # retransmission) + K/8 + 4 B out; the "rate_dematch" stage is then only the reset of the HARQ flags.
+    # retransmission) + K/8 + 4 B out; the "rate_dematch" stage is then EMPTY (no launch: the decoder also writes the codeblock CRC flags).
     dematch_in_decoder = all(p.info()[1] for p in plans)
     alg = {"ldpc_decode": S * (G + C * (N + K // 8 + 4)) if dematch_in_decoder else S * sum(dec_in_len[c] + K // 8 + 4 for c in range(C)),
-           "rate_dematch": S * C * 4 if dematch_in_decoder else S * (G + C * N),
+           "rate_dematch": 0 if dematch_in_decoder else S * (G + C * N),
            "ofdm_demod": S * (slot_samples * 8 + 14 * nsc * 8),
            "dmrs_chest": S * (1 * (nsc // 2) * 8 + nsc * 8),          # DM-RS REs in, one estimate row out (compact form)
            "pusch_demod": S * (w["nsym"] * 8 + nsc * 8 + G),          # data REs + the estimate row in, LLRs out

@@ -376,6 +376,14 @@ extern "C" void miphy_debug_force_ldpc_kernel(int mode)
   g_force_kernel = mode;
 }
 
+// pusch_decoder_impl.cpp:146-149: the codeblock CRC flags of a new transmission start cleared.
+__global__ void harq_flags_reset_kernel(const uint32_t* __restrict__ slots, uint32_t n, uint8_t* __restrict__ harq_crc_ok)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    harq_crc_ok[slots[i]] = 0;
+}
+
 int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
                              const miphy_ldpc_dec_desc*   descs,
                              int                          descs_on_device,
@@ -391,7 +399,9 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
                              const miphy_ldpc_rdm_desc*   fuse_rdm,
                              const int8_t*                fuse_in,
                              const miphy_ldpc_rdm_limits* fuse_rlim,
-                             int                          bg_mask)
+                             int                          bg_mask,
+                             const uint32_t*              reset_slots,
+                             uint32_t                     nof_reset_slots)
 {
   MIPHY_REQUIRE(ctx && descs && llr && out_bits && iters, "ldpc_decode: null argument");
   if (n == 0)
@@ -499,6 +509,10 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
     use_pk = pk_ok;
   // The fused form needs 16-byte aligned soft buffers (its write-back is vectorised); otherwise the dematcher runs on its own.
   const bool fuse = fuse_rdm && use_pk && ((uintptr_t)llr & 15) == 0;
+  if (!fuse && reset_slots && nof_reset_slots && harq_crc_ok) {
+    hipLaunchKernelGGL(harq_flags_reset_kernel, dim3((nof_reset_slots + 255) / 256), dim3(256), 0, s, reset_slots, nof_reset_slots, harq_crc_ok);
+    MIPHY_HIP_CHECK(hipGetLastError());
+  }
   if (fuse_rdm && !fuse) {
     if ((rc = miphy_ldpc_rate_dematch_batch(ctx, fuse_rdm, 1, n, fuse_in, const_cast<int8_t*>(llr), fuse_rlim, s)))
       return rc;

@@ -551,8 +551,15 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 
   // Next codeblock of this workgroup (taken now so that the queue round trip is off the critical path).
   __syncthreads(); // the previous codeblock's readers of red[] / soft[] are done
-  if (tid == 0)
-    red[15] = gridDim.x + atomicAdd(queue, 1u);
+  if (tid == 0) {
+    // One ticket per codeblock processed: the launch draws exactly n tickets (0 .. n - 1), so the workgroup that draws the last one
+    // knows nobody else will touch the counter and leaves it at zero for the next launch (no clearing memset per launch, and a
+    // captured launch can be replayed).
+    const uint32_t ticket = atomicAdd(queue, 1u);
+    if (ticket == n - 1u)
+      *queue = 0u;
+    red[15] = gridDim.x + ticket;
+  }
   if (!FUSED && harq_crc_ok && harq_crc_ok[harq_slot[cb]]) {
     if (tid == 0)
       iters_out[cb] = -1;
@@ -635,8 +642,11 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
         out[b]        = (rem >= 8) ? 0xff : (uint8_t)(0xff << (8 - rem));
       }
     }
-    if (tid == 0)
+    if (tid == 0) {
       iters_out[cb] = 0;
+      if (FUSED && harq_crc_ok)
+        harq_crc_ok[harq_slot[cb]] = 0;
+    }
     if (FUSED)
       prefetch(red[15]);
     cb = red[15];
@@ -733,8 +743,10 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   }
   if (tid == 0) {
     iters_out[cb] = result_iters;
-    if (harq_crc_ok && result_iters > 0)
-      harq_crc_ok[harq_slot[cb]] = 1;
+    // A codeblock that is dematched here is a first transmission: its flag is written either way, which is the reset the caller
+    // would otherwise launch before the decoder (pusch_decoder_impl.cpp:146-149).
+    if (harq_crc_ok && (FUSED || result_iters > 0))
+      harq_crc_ok[harq_slot[cb]] = result_iters > 0;
   }
   PROF_T(p_end);
   PROF_ADD(4, p_crc, p_end);
@@ -799,7 +811,7 @@ int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uin
   per_cu           = std::max(per_cu, 1);
   const uint32_t grid = std::min<uint32_t>(n, (uint32_t)(ctx->num_cus * per_cu));
   uint32_t*      queue = nullptr;
-  int            rc    = miphy_next_queue_counter(ctx, s, &queue);
+  int            rc    = miphy_next_queue_counter(ctx, &queue);
   if (rc)
     return rc;
   void* gmsg = nullptr;

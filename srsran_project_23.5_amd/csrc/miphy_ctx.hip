@@ -166,6 +166,7 @@ extern "C" int miphy_create(int device, miphy_ctx** out)
   MIPHY_HIP_CHECK(hipMalloc(&c->d_desc_staging, c->desc_staging_bytes));
   MIPHY_HIP_CHECK(hipHostMalloc(&c->h_desc_staging, c->desc_staging_bytes, hipHostMallocDefault));
   MIPHY_HIP_CHECK(hipMalloc((void**)&c->d_queue, MIPHY_NOF_QUEUE_COUNTERS * sizeof(uint32_t)));
+  MIPHY_HIP_CHECK(hipMemset(c->d_queue, 0, MIPHY_NOF_QUEUE_COUNTERS * sizeof(uint32_t)));
   c->queue_next = 0;
   *out = c;
   return MIPHY_OK;
@@ -189,13 +190,11 @@ extern "C" void miphy_destroy(miphy_ctx* c)
   delete c;
 }
 
-int miphy_next_queue_counter(miphy_ctx* ctx, hipStream_t s, uint32_t** out)
+int miphy_next_queue_counter(miphy_ctx* ctx, uint32_t** out)
 {
-  // A launch owns its counter until MIPHY_NOF_QUEUE_COUNTERS later launches of this context have been enqueued; the zeroing is
-  // ordered on the launch's own stream.
-  uint32_t* c = ctx->d_queue + (ctx->queue_next++ % MIPHY_NOF_QUEUE_COUNTERS);
-  MIPHY_HIP_CHECK(hipMemsetAsync(c, 0, sizeof(uint32_t), s));
-  *out = c;
+  // A launch owns its counter until MIPHY_NOF_QUEUE_COUNTERS later launches of this context have been enqueued. The counters are
+  // zero when the context is created and every launch leaves its counter at zero (the workgroup that draws the last ticket).
+  *out = ctx->d_queue + (ctx->queue_next++ % MIPHY_NOF_QUEUE_COUNTERS);
   return MIPHY_OK;
 }
 

@@ -122,7 +122,9 @@ int miphy_ldpc_decode_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* descs, i
                              uint8_t* out_bits, int32_t* iters, const miphy_ldpc_dec_limits* limits, const uint32_t* harq_slot,
                              uint8_t* harq_crc_ok, void* stream, int force_scalar = 0, const miphy_ldpc_rdm_desc* fuse_rdm = nullptr,
                              const int8_t* fuse_in = nullptr, const miphy_ldpc_rdm_limits* fuse_rlim = nullptr,
-                             int bg_mask = 3 /* device descriptors: bit 0 / 1 = base graph 1 / 2 occurs */);
+                             int bg_mask = 3 /* device descriptors: bit 0 / 1 = base graph 1 / 2 occurs */,
+                             const uint32_t* reset_slots = nullptr, uint32_t nof_reset_slots = 0 /* CRC flags to clear before decoding (device
+                             array): new transmissions. Skipped when the decoder dematches itself -- it then writes every flag either way */);
 
 // Returns a device scratch buffer of at least `bytes` (reallocated, after a stream sync, when it has to grow).
 int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out, int which = 0);
@@ -133,5 +135,5 @@ int    miphy_ldpc_pk_waves_per_cu(bool fused);
 int    miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                             uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
                             const miphy_ldpc_rdm_desc* d_rdm = nullptr, const int8_t* rm_in = nullptr, int gmsg_pairs = 0);
-// Zeroes (on the stream) and returns the next work-queue counter of the context.
-int miphy_next_queue_counter(miphy_ctx* ctx, hipStream_t s, uint32_t** out);
+// The next work-queue counter of the context (zero: every launch leaves its counter cleared).
+int miphy_next_queue_counter(miphy_ctx* ctx, uint32_t** out);

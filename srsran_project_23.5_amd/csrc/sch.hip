@@ -74,13 +74,6 @@ struct tb_asm_desc { // per transport block, consumed by pusch_tb_part_kernel / 
   uint64_t tb_offset;
 };
 
-__global__ void harq_reset_kernel(const uint32_t* __restrict__ slots, uint32_t n, uint8_t* __restrict__ harq_crc_ok)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n)
-    harq_crc_ok[slots[i]] = 0; // pusch_decoder_impl.cpp:146-149
-}
-
 // Transport-block assembly (pusch_decoder_impl.cpp:198-222): one workgroup per transport block, one WAVEFRONT per codeblock
 // (round robin). When every codeblock passed its CRC, a wavefront copies the data bits of its codeblock to their place in the
 // transport block and computes their part of the TB checksum by masks and popcounts (crc_zmask_packed24a: the remainder of the
@@ -550,8 +543,6 @@ int launch_pusch_decode(miphy_ctx* ctx, const pusch_decode_build& b, const pusch
                         hipEvent_t* ev = nullptr /* optional: 4 events around dematch / decode / assembly (single-launch batches) */)
 {
   int rc;
-  if (!b.reset_slots.empty())
-    hipLaunchKernelGGL(harq_reset_kernel, dim3((unsigned)(b.reset_slots.size() + 255) / 256), dim3(256), 0, s, v.reset, (uint32_t)b.reset_slots.size(), harq_crc_ok);
   miphy_ldpc_rdm_limits rlim = {b.max_E};
   // The decoder derives its LDS size from (max_Z, max_in_len) as ceil((max_in_len + 2 max_Z) / max_Z) nodes: hand it the node
   // bound of the batch expressed in units of the largest lifting size (codeblocks with a smaller Z reach more nodes per LLR).
@@ -572,7 +563,10 @@ int launch_pusch_decode(miphy_ctx* ctx, const pusch_decode_build& b, const pusch
     if (ev)
       MIPHY_HIP_CHECK(hipEventRecord(ev[1], s));
     if ((rc = miphy_ldpc_decode_launch(ctx, v.dec + c0, 1, c1 - c0, harq_softbits, harq_msgs, v.iters + c0, &lim, v.slots + c0, harq_crc_ok, s,
-                                       b.any_odd_Z ? 1 : 0, b.fusable ? v.rdm + c0 : nullptr, b.fusable ? llrs : nullptr, &rlim, b.bg_mask)))
+                                       b.any_odd_Z ? 1 : 0, b.fusable ? v.rdm + c0 : nullptr, b.fusable ? llrs : nullptr, &rlim, b.bg_mask,
+                                       // the flags of every new transmission of the CALL, cleared before its first launch (a decoder that
+                                       // dematches itself writes the flags of its own codeblocks instead)
+                                       t0 == 0 ? v.reset : nullptr, t0 == 0 ? (uint32_t)b.reset_slots.size() : 0u)))
       return rc;
     t0 = t1;
   }
