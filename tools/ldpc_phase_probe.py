@@ -9,7 +9,8 @@ sys.path.insert(0, PKG)
 so = os.path.join(ROOT, "tools", "_prof", "libmiphy.so")
 if not os.path.exists(so) or "--rebuild" in sys.argv:
     os.makedirs(os.path.dirname(so), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-DLDPC_PK_PROFILE", "-shared"] + [a for a in sys.argv[1:] if a.startswith("-D")] + [
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-DLDPC_PK_PROFILE", "-mllvm", "-enable-post-misched=false", "-shared"]  # the decoder is built without post-RA scheduling (Makefile)
+                           + [a for a in sys.argv[1:] if a.startswith("-D")] + [
                            "-o", so] + sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip"))))
 if "--build-only" in sys.argv:
     sys.exit(0)
