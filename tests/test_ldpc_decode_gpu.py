@@ -191,3 +191,44 @@ def test_device_descriptors_any_base_graph(ctx, bg, Z, use_limits):
     out, its = out_d.cpu().numpy().reshape(n, -1), it_d.cpu().numpy()
     for i in range(n):
         assert its[i] == exp[i][0] and np.array_equal(out[i], exp[i][1]), (bg, Z, i)
+
+
+def test_many_launches_queued_back_to_back(ctx, ldpc_kernel):
+    """The packed decoder hands out codeblocks through a work-queue counter that the launch itself leaves at zero (the workgroup that
+    draws the last ticket clears it); the context cycles through 256 counters. 600 launches of 1 to 5 codeblocks queued without any
+    synchronisation in between -- every counter reused -- must each decode their own codeblocks like the oracle."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(4242)
+    bg, Z = 1, 128
+    K, N = BG_K[bg] * Z, BG_NS[bg] * Z
+    in_len = 26 * Z
+    pool = []
+    for k in range(6):
+        msg, cw = make_codeword(bg, Z, rng)
+        llr = noisy_llr(cw[:in_len], 0.45, rng)
+        it, packed = o_ldpc_decode(bg, Z, llr, 0, CRC24B, 6)
+        pool.append((llr, packed, it))
+    llr_d = torch.from_numpy(np.concatenate([p[0] for p in pool])).cuda()
+    nb = K // 8
+    launches = 600
+    sizes = rng.integers(1, 6, launches)
+    picks = [rng.integers(0, len(pool), s) for s in sizes]
+    out_d = torch.zeros(int(sizes.sum()) * nb, dtype=torch.uint8, device="cuda")
+    it_d = torch.full((int(sizes.sum()),), -7, dtype=torch.int32, device="cuda")
+    base = 0
+    for l in range(launches):
+        d = np.zeros(int(sizes[l]), dtype=miphy.LdpcDecDesc)
+        for i, k in enumerate(picks[l]):
+            d[i] = (bg, miphy.CRC24B, Z, 6, 0, in_len, 0, int(k) * in_len, (base + i) * nb)
+        ctx.ldpc_decode_batch(d, llr_d, out_d, it_d[base:base + int(sizes[l])])
+        base += int(sizes[l])
+    torch.cuda.synchronize()
+    out, its = out_d.cpu().numpy().reshape(-1, nb), it_d.cpu().numpy()
+    base = 0
+    for l in range(launches):
+        for i, k in enumerate(picks[l]):
+            _, packed, it = pool[int(k)]
+            assert its[base + i] == it, (l, i)
+            assert np.array_equal(out[base + i], packed[:nb]), (l, i)
+        base += int(sizes[l])
