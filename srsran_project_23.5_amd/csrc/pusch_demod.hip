@@ -199,6 +199,7 @@ struct demod_args {
   float*          evm_part; // per (OFDM symbol, chunk) partial sums of |hard-decided symbol - equalised symbol|^2 of this transmission, or nullptr
   const uint32_t* seq;      // the transmission's scrambling sequence (pusch_scrambling_kernel)
   int             start_symbol, end_symbol, per_dm, nprb;
+  int             prefix0; // data elements of the transmission before start_symbol (a workgroup may own a part of the symbols)
   unsigned        dmrs_syms;
 };
 
@@ -265,11 +266,11 @@ __device__ __forceinline__ void demod_columns(const demod_args& a, bool active, 
         if (p < nports)
           h[p] = hp[p][0];
     }
-    fetch(a.start_symbol, 0, two_n);
+    fetch(a.start_symbol, a.prefix0, two_n);
   }
   if (compact)
     channel();
-  int prefix = 0; // data elements of the transmission before the current symbol
+  int prefix = a.prefix0; // data elements of the transmission before the current symbol
   for (int sy = a.start_symbol; sy < a.end_symbol; ++sy) {
     const bool is_dmrs = (a.dmrs_syms >> sy) & 1;
     const int  npp     = is_dmrs ? a.per_dm : 12;
@@ -493,7 +494,9 @@ __device__ __forceinline__ int demod_prb_list(const demod_job_words& j, uint64_t
   return c;
 }
 
-// grid (transmissions, chunks of 256 allocated subcarriers)
+// grid (transmissions, chunks of 256 allocated subcarriers, parts of the OFDM symbols): a batch that fills the chip walks all symbols of a
+// chunk in one workgroup (the channel row is set up once); a small one (a single slot: 13 chunks) is cut along the symbols as well, which
+// shortens the dependent walk of every thread.
 __global__ void __launch_bounds__(DEMOD_THREADS) pusch_demod_kernel(const miphy_pusch_demod_job* __restrict__ jobs, const float2* __restrict__ grid,
                                                                     const float2* __restrict__ ce, const float* __restrict__ scalars,
                                                                     int8_t* __restrict__ llr, const uint16_t* __restrict__ placeholders,
@@ -516,6 +519,17 @@ __global__ void __launch_bounds__(DEMOD_THREADS) pusch_demod_kernel(const miphy_
   a.start_symbol   = j.start_symbol();
   a.end_symbol     = a.start_symbol + j.nof_symbols();
   a.nprb           = nprb;
+  a.prefix0        = 0;
+  if (gridDim.z > 1) { // uniform
+    const int per = (a.end_symbol - a.start_symbol + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int f = a.start_symbol + (int)blockIdx.z * per, l = min(a.end_symbol, f + per);
+    if (f >= l)
+      return;
+    for (int sy = a.start_symbol; sy < f; ++sy)
+      a.prefix0 += nprb * (((a.dmrs_syms >> sy) & 1u) ? a.per_dm : 12);
+    a.start_symbol = f;
+    a.end_symbol   = l;
+  }
   a.nsc            = j.grid_nof_prb() * 12;
   a.nports         = j.nof_rx_ports();
   a.ce_nof_symbols = j.ce_compact() ? 1 : j.ce_nof_symbols(); // compact estimate: one row per port, valid for every symbol
@@ -662,7 +676,8 @@ extern "C" int miphy_pusch_demodulate_batch_ex(miphy_ctx* ctx, const miphy_pusch
   uint32_t* seq      = static_cast<uint32_t*>(work);
   float*    evm_part = evm_sums ? reinterpret_cast<float*>(static_cast<uint8_t*>(work) + seq_bytes) : nullptr;
   hipLaunchKernelGGL(pusch_scrambling_kernel, dim3(n), dim3(SCR_THREADS), 0, s, (const miphy_pusch_demod_job*)d_jobs, gt, seq);
-  hipLaunchKernelGGL(pusch_demod_kernel, dim3(n, max_chunks), dim3(DEMOD_THREADS), 0, s, (const miphy_pusch_demod_job*)d_jobs, (const float2*)grid,
+  const uint32_t sym_parts = std::max(1u, std::min(4u, (uint32_t)ctx->num_cus / (n * max_chunks)));
+  hipLaunchKernelGGL(pusch_demod_kernel, dim3(n, max_chunks, sym_parts), dim3(DEMOD_THREADS), 0, s, (const miphy_pusch_demod_job*)d_jobs, (const float2*)grid,
                      (const float2*)ce, scalars, llr, placeholders, evm_part, (const uint32_t*)seq);
   if (evm_sums)
     hipLaunchKernelGGL(pusch_evm_reduce_kernel, dim3(n), dim3(64), 0, s, (const miphy_pusch_demod_job*)d_jobs, (const float*)evm_part, evm_sums);
