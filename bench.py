@@ -604,7 +604,7 @@ def main():
         ok_slots = -1
 
     # ---- single-slot latency of the same pipeline (one slot = 38 codeblocks: the real-time unit of work), not part of `value`
-    lat_us = None
+    lat_us = lat_stage_us = None
     if rank == 0 and not args.no_latency:
         p1 = make_plans([(0, 1)])[0]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -619,6 +619,22 @@ def main():
         ev1.record(stream)
         torch.cuda.synchronize()
         lat_us = ev0.elapsed_time(ev1) / reps * 1e3
+        # the same pipeline once more with an event after every stage (the events cost a few microseconds themselves: the total above is
+        # measured without them)
+        marks = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(reps)]
+        for r in range(reps):
+            marks[r][0].record(stream)
+            ctx.ofdm_demodulate_slots(ocfg, ojobs_d[:24], samples_d, grid_d, stream)
+            marks[r][1].record(stream)
+            ctx.dmrs_pusch_estimate_batch(cjobs_d[:152], grid_d, ce_d, sc_d, stream)
+            marks[r][2].record(stream)
+            ctx.pusch_demodulate_batch(djobs_d[:120], grid_d, ce_d, sc_d, llr_d, stream)
+            marks[r][3].record(stream)
+            p1.run(llr_d, soft_d, msgs_d, crc_d, tb_d, res_d, stream)
+            marks[r][4].record(stream)
+        torch.cuda.synchronize()
+        lat_stage_us = {k: float(np.mean([m[i].elapsed_time(m[i + 1]) for m in marks])) * 1e3
+                        for i, k in enumerate(["ofdm_demod", "dmrs_chest", "scrambling_and_demod", "decode_and_tb_assembly"])}
         p1.close()
 
     # ---- per-launch durations (HIP events on the launching stream); a step has G_ch launches of each kernel
@@ -694,6 +710,7 @@ def main():
                           "frac": gbs["ofdm_demod"] / HBM_PEAK_GBS, "traffic": traffic.get("ofdm_demod")},
         "roofline_valu": valu,
         "single_slot_latency_us": lat_us,
+        "single_slot_stage_us": lat_stage_us,
         "parity_check": "%d/%d slots: LLRs, codeblocks and CRC verdict identical to the oracle; all %d transport blocks of the last step CRC-ok and equal to the "
                         "transmitted ones: %s" % (ok_slots, checked, S, all_ok),
         "transport_blocks_recovered": nof_tb_good,
