@@ -789,6 +789,34 @@ def main():
             for q in plans:
                 q.close()
             plans[:] = saved
+        # One PDU per call through the HOST-descriptor entry point (what the srsRAN adapters issue per PUSCH PDU): the composed
+        # miphy_pusch_process_batch on slot 0's grid -- estimator, demodulator, decode, assembly; the calls only enqueue.
+        pdu = np.zeros(1, dtype=miphy.PuschPdu)
+        q = pdu[0]
+        q["numerology"], q["slot_in_frame"], q["rnti"], q["n_id"], q["dmrs_scrambling_id"] = 1, 0, RNTI, N_ID, DMRS_SCR_ID
+        q["tb_bytes"], q["harq_cb_index"], q["mod"], q["nof_rx_ports"], q["start_symbol"], q["nof_symbols"] = tb_bytes, 0, w["mod"], 1, 0, 14
+        q["bg"], q["rv"], q["new_data"], q["rx_ports"], q["use_early_stop"], q["nof_ldpc_iterations"] = w["bg"], 0, 1, [0, 1, 2, 3], args.early_stop, args.max_iter
+        q["dmrs_symbols_mask"], q["grid_nof_prb"], q["rb_mask"], q["grid_offset"], q["tb_offset"] = 1 << 2, w["nprb"], rb_words, 0, 0
+        sc1 = torch.zeros(20, dtype=torch.float32, device=dev)
+        one = lambda: ctx.pusch_process_batch(pdu, grid_d, soft_d, msgs_d, crc_d, tb_d, res_d, sc1, stream)
+        tb_d[:tb_bytes].zero_()
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        ok1 = bool(np.array_equal(tb_d[:tb_bytes].cpu().numpy(), tbs_u[slot_src[0]]))
+        t1 = time.perf_counter()
+        for _ in range(50):
+            one()
+        torch.cuda.synchronize()
+        queued_us = (time.perf_counter() - t1) / 50 * 1e6
+        t1 = time.perf_counter()
+        for _ in range(50):
+            one()
+            torch.cuda.synchronize()
+        synced_us = (time.perf_counter() - t1) / 50 * 1e6
+        legs["host_descriptor_api_one_pdu"] = {"config": "miphy_pusch_process_batch, one 273-PRB PDU per call, host descriptors (the adapters' path)",
+                                               "us_per_call_queued_back_to_back": queued_us, "us_per_call_with_synchronise": synced_us,
+                                               "transport_block_recovered": ok1}
         out["legs"] = legs
         # PCIe-inclusive rate (never `value`): the S slots of time-domain samples from pinned host memory, the step, the transport
         # blocks back to pinned host memory, back to back on one stream.
