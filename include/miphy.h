@@ -81,7 +81,10 @@ typedef struct {
  * and input length in the batch. NULL = worst case (Z = 384, full-length codeblocks: one workgroup per CU).
  * The library sizes its on-chip buffers for ceil((max_in_len + 2 max_Z) / max_Z) variable nodes. When the batch mixes lifting
  * sizes, a codeblock with a smaller Z reaches more nodes per LLR: pass max_in_len = (n_max - 2) * max_Z with
- * n_max = max over codeblocks of ceil((in_len + 2 Z) / Z). A bound that is too small corrupts the result. */
+ * n_max = max over codeblocks of ceil((in_len + 2 Z) / Z). A bound that is too small corrupts the result.
+ * Any mix of lifting sizes up to max_Z, odd ones included, is legal in one batch. Device-resident descriptors are decoded by ONE
+ * launch sized for max_Z (a codeblock with a small Z then leaves most lanes of its workgroup idle); hand the descriptors over in host
+ * memory, or use the transport-block level entry points, to have the batch sorted into per-lifting-size launch classes. */
 typedef struct {
   uint32_t max_Z;
   uint32_t max_in_len;
@@ -96,9 +99,17 @@ int miphy_ldpc_decode_batch(miphy_ctx*                 ctx,
                             int32_t*                   iters,    /* device, n entries */
                             const miphy_ldpc_dec_limits* limits, /* may be NULL */
                             void*                      stream);
-/* Test / A-B knob: 0 = automatic choice, 1 = one-row-per-lane kernel, 2 = packed two-rows-per-lane kernel (even Z only).
- * Both kernels produce identical results. */
+/* Test / A-B knob: 0 = automatic choice (host descriptors: sorted into launch classes by lifting size and code rate, one launch per
+ * class; device descriptors: one launch), 1 = one-row-per-lane kernel, 2 = packed two-rows-per-lane kernel as one launch,
+ * 3 = class-sorted launches. All kernels produce identical results. */
 void miphy_debug_force_ldpc_kernel(int mode);
+/* Which decoder kernels have been launched since the last reset (tests assert that a forced choice really ran): */
+#define MIPHY_LDPC_KERNEL_SCALAR 1u /* one check row per lane */
+#define MIPHY_LDPC_KERNEL_PACKED 2u /* two check rows per lane, one codeblock per workgroup */
+#define MIPHY_LDPC_KERNEL_FUSED  4u /* ... that rate-dematches while it loads */
+#define MIPHY_LDPC_KERNEL_GMSG   8u /* ... with the check-to-variable messages in global memory */
+#define MIPHY_LDPC_KERNEL_WAVE  16u /* several small codeblocks per wavefront (Z <= 64) */
+unsigned miphy_debug_ldpc_kernels_used(int reset);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * LDPC rate dematcher  --  replaces srsran::ldpc_rate_dematcher::rate_dematch

@@ -17,6 +17,7 @@
 #include "miphy_internal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -217,10 +218,12 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                    int32_t* __restrict__ iters_out,
                    int max_nodes, // host bound on ceil((in_len + 2Z) / Z) over the batch
                    const uint32_t* __restrict__ harq_slot, // optional: per-descriptor codeblock slot in harq_crc_ok
-                   uint8_t* __restrict__ harq_crc_ok)       // optional: skip codeblocks already decoded, flag new successes
+                   uint8_t* __restrict__ harq_crc_ok,      // optional: skip codeblocks already decoded, flag new successes
+                   const uint32_t* __restrict__ cb_order)     // optional: workgroup b decodes codeblock order[b] of the arrays
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const miphy_ldpc_dec_desc dsc = descs[blockIdx.x];
+  const uint32_t            cbx = cb_order ? cb_order[blockIdx.x] : blockIdx.x;
+  const miphy_ldpc_dec_desc dsc = descs[cbx];
   const int                 tid = threadIdx.x;
   const int                 nt  = blockDim.x;
   const int                 Z   = dsc.Z;
@@ -242,9 +245,9 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   uint8_t*      out = out_base + dsc.out_offset;
   const int     in_len = (int)dsc.in_len;
 
-  if (harq_crc_ok && harq_crc_ok[harq_slot[blockIdx.x]]) { // pusch_decoder_impl.cpp:184: CRC already OK, keep the message
+  if (harq_crc_ok && harq_crc_ok[harq_slot[cbx]]) { // pusch_decoder_impl.cpp:184: CRC already OK, keep the message
     if (tid == 0)
-      iters_out[blockIdx.x] = -1;
+      iters_out[cbx] = -1;
     return;
   }
   if (tid < 16)
@@ -298,7 +301,7 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       }
     }
     if (tid == 0)
-      iters_out[blockIdx.x] = 0;
+      iters_out[cbx] = 0;
     return;
   }
 
@@ -361,19 +364,34 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       out[4 * tid + q] = (uint8_t)(w >> (24 - 8 * q));
   }
   if (tid == 0) {
-    iters_out[blockIdx.x] = result_iters;
+    iters_out[cbx] = result_iters;
     if (harq_crc_ok && result_iters > 0)
-      harq_crc_ok[harq_slot[blockIdx.x]] = 1;
+      harq_crc_ok[harq_slot[cbx]] = 1;
   }
 }
 
 } // namespace
 
-static int g_force_kernel = 0; // 0 auto, 1 scalar, 2 packed (miphy_debug_force_ldpc_kernel)
+
+static int      g_force_kernel = 0; // 0 auto, 1 one-row-per-lane kernel, 2 packed kernel as ONE launch, 3 class-sorted launches (miphy_debug_force_ldpc_kernel)
+static unsigned g_kernels_used = 0; // MIPHY_LDPC_KERNEL_* of every decoder launch since the last reset (miphy_debug_ldpc_kernels_used)
 
 extern "C" void miphy_debug_force_ldpc_kernel(int mode)
 {
   g_force_kernel = mode;
+}
+
+bool miphy_ldpc_scalar_forced()
+{
+  return g_force_kernel == 1;
+}
+
+extern "C" unsigned miphy_debug_ldpc_kernels_used(int reset)
+{
+  const unsigned m = g_kernels_used;
+  if (reset)
+    g_kernels_used = 0;
+  return m;
 }
 
 // pusch_decoder_impl.cpp:146-149: the codeblock CRC flags of a new transmission start cleared.
@@ -384,6 +402,143 @@ __global__ void harq_flags_reset_kernel(const uint32_t* __restrict__ slots, uint
     harq_crc_ok[slots[i]] = 0;
 }
 
+int miphy_ldpc_flags_reset(const uint32_t* d_slots, uint32_t n, uint8_t* harq_crc_ok, hipStream_t s)
+{
+  if (!n || !d_slots || !harq_crc_ok)
+    return MIPHY_OK;
+  hipLaunchKernelGGL(harq_flags_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_slots, n, harq_crc_ok);
+  MIPHY_HIP_CHECK(hipGetLastError());
+  return MIPHY_OK;
+}
+
+// ---- class-sorted launches ------------------------------------------------------------------------------------------------------
+// The reference decoder scales its work with the lifting size of each codeblock (ldpc_decoder_avx2.cpp:59-64). A launch has ONE
+// workgroup size and ONE LDS size, so a batch that mixes lifting sizes and code rates is sorted on the host into classes that share
+// both, and every class gets a launch of its own:
+//   * kind 0: Z <= 64 -- the wave kernel (ldpc_decode_pkw.hip), several codeblocks of one (base graph, Z) per wavefront;
+//   * kind 1..3: the packed kernel with 1, 2 or 3 wavefronts per codeblock (Z <= 128 / 256 / 384);
+//   * per base graph and per bucket of reachable layers (LDS per codeblock, hence codeblocks per CU, follows the layers);
+//   * codeblocks the decoder can rate-dematch while it loads (first transmissions, see sch.hip) apart from those it cannot.
+static int layer_bucket(int lay)
+{
+  static const int bound[6] = {4, 6, 10, 16, 26, 46};
+  int              b        = 0;
+  while (lay > bound[b])
+    ++b;
+  return b;
+}
+
+void miphy_ldpc_build_classes(const miphy_ldpc_dec_desc* descs, uint32_t n, const uint8_t* fusable, miphy_ldpc_classes& C)
+{
+  struct item {
+    uint64_t key;
+    uint32_t idx;
+  };
+  std::vector<item> it(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const miphy_ldpc_dec_desc& d   = descs[i];
+    const int                  bgi = d.bg == 1 ? 0 : 1, bgK = bgi ? 10 : 22, bgM = bgi ? 42 : 46;
+    const int                  nodes = (int)((d.in_len + 2u * d.Z + d.Z - 1u) / d.Z);
+    const int                  lay   = std::min(bgM, std::max(4, nodes - bgK));
+    const int                  H     = (d.Z + 1) / 2;
+    const int                  kind  = d.Z <= 64 ? 0 : (H + 63) / 64;
+    const bool                 fus   = fusable && fusable[i] && kind != 0;
+    // class: fused | kind | base graph | layer bucket; below it the fields a bundle of the wave kernel must share; then the layer bound
+    uint64_t key = ((uint64_t)(fus ? 1 : 0) << 63) | ((uint64_t)kind << 61) | ((uint64_t)bgi << 60) | ((uint64_t)layer_bucket(lay) << 57);
+    if (kind == 0)
+      key |= ((uint64_t)d.Z << 40) | ((uint64_t)(d.crc_poly & 0xff) << 32) | ((uint64_t)(d.flags & 1u) << 31) | ((uint64_t)d.max_iter << 8);
+    key |= (uint64_t)lay; // 6 bits, read back below
+    it[i].key = key, it[i].idx = i;
+  }
+  std::stable_sort(it.begin(), it.end(), [](const item& a, const item& b) { return (a.key >> 8) < (b.key >> 8); });
+  C.order.resize(n);
+  C.bundles.clear();
+  C.classes.clear();
+  C.nof_unfused = 0;
+  C.identity    = true;
+  const uint64_t class_mask = ~(uint64_t)0 << 57;
+  for (uint32_t p = 0; p < n;) {
+    uint32_t q = p;
+    while (q < n && (it[q].key & class_mask) == (it[p].key & class_mask))
+      ++q;
+    miphy_ldpc_class c = {};
+    c.fused            = (uint8_t)(it[p].key >> 63);
+    c.kind             = (uint8_t)((it[p].key >> 61) & 3);
+    c.bgi              = (uint8_t)((it[p].key >> 60) & 1);
+    c.first = p, c.count = q - p;
+    c.bundle_first = (uint32_t)C.bundles.size() / 2;
+    const int bgK  = c.bgi ? 10 : 22;
+    for (uint32_t k = p; k < q; ++k) {
+      const miphy_ldpc_dec_desc& d = descs[it[k].idx];
+      c.lay                        = std::max<uint8_t>(c.lay, (uint8_t)(it[k].key & 63));
+      c.max_Z                      = std::max<uint16_t>(c.max_Z, d.Z);
+      C.order[k]                   = it[k].idx;
+      C.identity &= it[k].idx == k;
+    }
+    if (!c.fused)
+      C.nof_unfused += c.count;
+    if (c.kind == 0) {
+      for (uint32_t k = p; k < q;) { // bundles: runs of identical (Z, CRC, mode, iterations), G codeblocks at most
+        const miphy_ldpc_dec_desc& d = descs[it[k].idx];
+        const uint32_t             G = 64u / ((d.Z + 1u) / 2u);
+        uint32_t                   e = k;
+        while (e < q && e - k < G && ((it[e].key ^ it[k].key) >> 8) == 0)
+          ++e;
+        C.bundles.push_back(k);
+        C.bundles.push_back(e - k);
+        const uint32_t sstride = (((uint32_t)(bgK + c.lay) * d.Z) + 15u) & ~15u;
+        c.soft_total           = std::max(c.soft_total, G * sstride);
+        k                      = e;
+      }
+    }
+    c.bundle_count = (uint32_t)C.bundles.size() / 2 - c.bundle_first;
+    C.classes.push_back(c);
+    p = q;
+  }
+}
+
+int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, const miphy_ldpc_classes& C, const uint32_t* d_order,
+                                     const uint32_t* d_bundles, const int8_t* llr, uint8_t* out_bits, int32_t* iters, const uint32_t* harq_slot,
+                                     uint8_t* harq_crc_ok, hipStream_t s, const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in, bool allow_fuse)
+{
+  for (const miphy_ldpc_class& c : C.classes) {
+    int rc;
+    if (g_force_kernel == 1) { // A-B knob: the one-row-per-lane kernel on every class (the caller has dematched: allow_fuse is false then)
+      const int    bgK = c.bgi ? 10 : 22, threads = ((c.max_Z + 63) / 64) * 64;
+      const size_t lds = ((((size_t)bgK + c.lay) * threads + 15) & ~(size_t)15) + (size_t)(c.lay + 4) * threads * 4 + 64;
+      if (lds > 48 * 1024)
+        MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(ldpc_decode_kernel, dim3(c.count), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, bgK + c.lay, harq_slot,
+                         harq_crc_ok, d_order + c.first);
+      MIPHY_HIP_CHECK(hipGetLastError());
+      g_kernels_used |= MIPHY_LDPC_KERNEL_SCALAR;
+      continue;
+    }
+    if (c.kind == 0) {
+      int gm = 0;
+      if ((rc = miphy_ldpc_pkw_launch(ctx, d_descs, d_order, d_bundles + 2 * (size_t)c.bundle_first, c.bundle_count, c.bgi, c.lay, c.soft_total, llr, out_bits,
+                                      iters, harq_slot, harq_crc_ok, s, &gm)))
+        return rc;
+      g_kernels_used |= MIPHY_LDPC_KERNEL_WAVE | (gm ? MIPHY_LDPC_KERNEL_GMSG : 0u);
+      continue;
+    }
+    const int    bgK = c.bgi ? 10 : 22, threads = 64 * c.kind, waves = c.kind;
+    const int    pairs = ctx->h_tables->pair_start[c.bgi][c.lay];
+    const bool   fuse  = c.fused && allow_fuse && d_rdm;
+    const size_t lds_l = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, pairs), lds_g = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, 0);
+    // messages in LDS while that keeps as many codeblocks resident per CU as the registers allow; otherwise in global memory
+    auto       per_cu = [&](size_t lds) { return std::max(1, std::min((int)((size_t)160 * 1024 / lds), miphy_ldpc_pk_waves_per_cu(fuse) / waves)); };
+    const bool gm     = per_cu(lds_g) > per_cu(lds_l);
+    if ((rc = miphy_ldpc_pk_launch(ctx, d_descs, c.count, threads, gm ? lds_g : lds_l, llr, out_bits, iters, bgK + c.lay, harq_slot, harq_crc_ok, s,
+                                   fuse ? d_rdm : nullptr, fuse ? rm_in : nullptr, gm ? pairs : 0,
+                                   (C.identity && C.classes.size() == 1) ? nullptr : d_order + c.first)))
+      return rc;
+    g_kernels_used |= MIPHY_LDPC_KERNEL_PACKED | (fuse ? MIPHY_LDPC_KERNEL_FUSED : 0u) | (gm ? MIPHY_LDPC_KERNEL_GMSG : 0u);
+  }
+  return MIPHY_OK;
+}
+
+// ---- one launch for the whole batch (device-resident descriptors, which the host cannot sort; forced kernels of the A-B knob) -------
 int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
                              const miphy_ldpc_dec_desc*   descs,
                              int                          descs_on_device,
@@ -395,7 +550,6 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
                              const uint32_t*              harq_slot,
                              uint8_t*                     harq_crc_ok,
                              void*                        stream,
-                             int                          force_scalar,
                              const miphy_ldpc_rdm_desc*   fuse_rdm,
                              const int8_t*                fuse_in,
                              const miphy_ldpc_rdm_limits* fuse_rlim,
@@ -412,10 +566,8 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   // (the reference asserts the same conditions, ldpc_decoder_impl.cpp:66-84); for device descriptors the caller
   // vouches for validity and may pass `limits` (worst case assumed otherwise).
   int    max_threads = 64;
-  bool   all_even     = true;   // the packed kernel pairs rows l and l + Z/2
   int    max_nodes[2] = {0, 0}; // per base graph: largest ceil((in_len + 2Z) / Z)
   auto   account      = [&](unsigned bg, unsigned Z, unsigned in_len) {
-    all_even &= (Z % 2 == 0);
     const int nodes   = (int)((in_len + 2 * Z + Z - 1) / Z);
     const int threads = ((Z + 63) / 64) * 64;
     max_threads       = threads > max_threads ? threads : max_threads;
@@ -432,6 +584,24 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
       MIPHY_REQUIRE(d.crc_poly == MIPHY_CRC_NONE || d.crc_poly <= MIPHY_CRC11, "ldpc_decode: desc %u: invalid CRC", i);
       MIPHY_REQUIRE(d.nof_filler_bits < bgK * d.Z, "ldpc_decode: desc %u: invalid number of filler bits", i);
       account(d.bg, d.Z, d.in_len);
+    }
+    if (g_force_kernel == 0 || g_force_kernel == 3) {
+      // host descriptors: sorted into launch classes (nothing is dematched by the decoder on this path: fuse_rdm comes with device
+      // descriptors only)
+      miphy_ldpc_classes C;
+      miphy_ldpc_build_classes(descs, n, nullptr, C);
+      const void *d_descs = nullptr, *d_order = nullptr, *d_bundles = nullptr;
+      int         rc;
+      if ((rc = miphy_stage_descs(ctx, descs, 0, sizeof(miphy_ldpc_dec_desc) * (size_t)n, s, &d_descs)))
+        return rc;
+      if ((rc = miphy_stage_descs(ctx, C.order.data(), 0, sizeof(uint32_t) * (size_t)n, s, &d_order)))
+        return rc;
+      if (!C.bundles.empty() && (rc = miphy_stage_descs(ctx, C.bundles.data(), 0, sizeof(uint32_t) * C.bundles.size(), s, &d_bundles)))
+        return rc;
+      if ((rc = miphy_ldpc_flags_reset(reset_slots, nof_reset_slots, harq_crc_ok, s)))
+        return rc;
+      return miphy_ldpc_decode_classes_launch(ctx, (const miphy_ldpc_dec_desc*)d_descs, C, (const uint32_t*)d_order, (const uint32_t*)d_bundles, llr, out_bits,
+                                              iters, harq_slot, harq_crc_ok, s, nullptr, nullptr, false);
     }
   } else if (limits) {
     MIPHY_REQUIRE(limits->max_Z >= 2 && limits->max_Z <= MIPHY_MAX_Z, "ldpc_decode: limits: invalid max_Z");
@@ -466,7 +636,8 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   // one-row-per-lane kernel (compressed messages, twice the wavefronts) wins. Both are scored by the check rows a CU holds in
   // flight (workgroups per CU limited by LDS, wavefront slots and registers), the packed one weighted by its instruction advantage;
   // measured crossovers: tools/ldpc_rate_sweep.py. miphy_debug_force_ldpc_kernel() overrides (parity tests run both kernels).
-  const bool         pk_ok = max_threads >= 128 && all_even && (!descs_on_device || limits);
+  // Any lifting size is legal in the packed kernel (an odd one folds its unpaired last row onto itself, ldpc_decode_pk.hip).
+  const bool         pk_ok = !descs_on_device || limits;
   const int          pk_threads = ((max_threads / 2 + 63) / 64) * 64; // max_threads >= max Z, a multiple of 64
   size_t             pk_lds     = 0, pk_lds_g = 0;                    // with the messages in LDS / in global memory
   int                pk_pairs   = 0;
@@ -503,29 +674,31 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
     return wgs * threads * rows_per_lane;
   };
   bool use_pk = pk_ok && 1.6 * rows_in_flight(pk_lds, pk_threads, 4, 2) >= 1.0 * rows_in_flight(max_lds, max_threads, 8, 1);
-  if (g_force_kernel == 1 || force_scalar)
+  if (g_force_kernel == 1)
     use_pk = false;
-  if (g_force_kernel == 2 && !force_scalar)
+  if (g_force_kernel == 2 || g_force_kernel == 3)
     use_pk = pk_ok;
-  // The fused form needs 16-byte aligned soft buffers (its write-back is vectorised); otherwise the dematcher runs on its own.
+  // The fused form needs 16-byte aligned soft buffers (its write-back is vectorised) and lifting sizes that are multiples of 16 (the
+  // caller vouches for that when it passes fuse_rdm); otherwise the dematcher runs on its own.
   const bool fuse = fuse_rdm && use_pk && ((uintptr_t)llr & 15) == 0;
-  if (!fuse && reset_slots && nof_reset_slots && harq_crc_ok) {
-    hipLaunchKernelGGL(harq_flags_reset_kernel, dim3((nof_reset_slots + 255) / 256), dim3(256), 0, s, reset_slots, nof_reset_slots, harq_crc_ok);
-    MIPHY_HIP_CHECK(hipGetLastError());
-  }
+  if (!fuse && (rc = miphy_ldpc_flags_reset(reset_slots, nof_reset_slots, harq_crc_ok, s)))
+    return rc;
   if (fuse_rdm && !fuse) {
     if ((rc = miphy_ldpc_rate_dematch_batch(ctx, fuse_rdm, 1, n, fuse_in, const_cast<int8_t*>(llr), fuse_rlim, s)))
       return rc;
   }
-  if (use_pk)
+  if (use_pk) {
+    g_kernels_used |= MIPHY_LDPC_KERNEL_PACKED | (fuse ? MIPHY_LDPC_KERNEL_FUSED : 0u) | (pk_gmsg ? MIPHY_LDPC_KERNEL_GMSG : 0u);
     return miphy_ldpc_pk_launch(ctx, (const miphy_ldpc_dec_desc*)d_descs, n, pk_threads, pk_lds, llr, out_bits, iters, nodes_all, harq_slot,
                                 harq_crc_ok, s, fuse ? fuse_rdm : nullptr, fuse ? fuse_in : nullptr, pk_gmsg ? pk_pairs : 0);
+  }
   // Above the default 64 KB of dynamic LDS the limit has to be raised; it is a per-device attribute of the kernel, so it is set on
   // every such launch (a cache per thread would be wrong for a thread that drives several devices).
   if (max_lds > 48 * 1024) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
   }
-  hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n), dim3(max_threads), max_lds, s, (const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot, harq_crc_ok);
+  g_kernels_used |= MIPHY_LDPC_KERNEL_SCALAR;
+  hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n), dim3(max_threads), max_lds, s, (const miphy_ldpc_dec_desc*)d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot, harq_crc_ok, (const uint32_t*)nullptr);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

@@ -11,244 +11,11 @@
 // gfx950: a DS write costs ~5 cycles of the CU's LDS pipe whatever its width, a read ~2.8 -- tools/lds_probe.hip).
 #include "miphy_internal.h"
 #include "rdm_device.h"
+#include "ldpc_pk_device.h"
 #include <algorithm>
 #include <cstdlib>
 
 namespace {
-
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ s16x2 as_s2(uint32_t x)
-{
-  return __builtin_bit_cast(s16x2, x);
-}
-__device__ __forceinline__ uint32_t as_u(s16x2 x)
-{
-  return __builtin_bit_cast(uint32_t, x);
-}
-__device__ __forceinline__ s16x2 splat(int c)
-{
-  return s16x2{(short)c, (short)c};
-}
-__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b)
-{
-  return __builtin_elementwise_min(a, b);
-}
-__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b)
-{
-  return __builtin_elementwise_max(a, b);
-}
-__device__ __forceinline__ s16x2 pk_ashr15(s16x2 a)
-{
-  return a >> splat(15);
-}
-// two sign-extended bytes -> one register with two int16 (bytes 1:0 of each source)
-__device__ __forceinline__ s16x2 pk_pair(int lo, int hi)
-{
-  return as_s2(__builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u));
-}
-// Message dword {A1, A0, B1, B0} (bytes 0..3) -> edge 0 = (sext A0, sext B0), edge 1 = (sext A1, sext B1).
-// v_perm_b32 selectors 8 / 9 replicate the sign of byte 1 / 3 of the low source (10 / 11: of the high source).
-__device__ __forceinline__ s16x2 c2v_even(uint32_t w)
-{
-  return as_s2(__builtin_amdgcn_perm(w, w, 0x09030801u));
-}
-__device__ __forceinline__ s16x2 c2v_odd(uint32_t w)
-{
-  const uint32_t h = w << 8; // bytes {0, A1, A0, B1}: A1 -> byte 1, B1 -> byte 3
-  return as_s2(__builtin_amdgcn_perm(h, h, 0x09030801u));
-}
-__device__ __forceinline__ uint32_t c2v_pack(s16x2 c0, s16x2 c1)
-{
-  // {S0 = c0 -> bytes 4..7, S1 = c1 -> bytes 0..3}: out = {c1.A, c0.A, c1.B, c0.B}
-  return __builtin_amdgcn_perm(as_u(c0), as_u(c1), 0x06020400u);
-}
-
-// p mod Z for p < 2 Z: min(p, p - Z) on the LOW HALVES. The 16-bit VOP2 minimum issues at the fast rate (1.93 cycles at three waves
-// per SIMD, where v_min_u32 takes 2.88: tools/valu_probe) and clears the upper half of its destination (tools/min16_probe), so the
-// result is the address term itself. Positions are below 2 * 384.
-__device__ __forceinline__ uint32_t wrap_z(uint32_t p, uint32_t Z)
-{
-#ifdef LDPC_PK_MIN32
-  return min(p, p - Z);
-#else
-  const uint32_t t = p - Z;
-  uint32_t       r;
-  asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(p), "v"(t));
-  return r;
-#endif
-}
-
-constexpr int LLR_MAX = 120;
-constexpr int LLR_INF = 127;
-constexpr int INF_MUL = 255; // an infinite soft bit (|s| > 120) becomes a message of magnitude >= 255 + 24
-
-template <int D, bool FIRST>
-__device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
-                                               uint32_t* __restrict__ c2v, // this lane's message dword of edges 0,1 of the layer
-                                               const uint32_t* __restrict__ edges, // {shift, column*Z} per edge
-                                               int l,
-                                               int H,
-                                               int Z)
-{
-  s16x2    v2c[D], mabs[D];
-  uint32_t adrA[D], adrB[D];
-  int      rawA[D], rawB[D];
-  uint32_t cw[(D + 1) / 2];
-  // Stage A: every address of the layer, then every LDS read of the layer in one go (2 soft bits per edge + the old
-  // messages): the latency of the LDS pipe is paid once per layer instead of once per group of edges.
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const uint32_t pA = wrap_z((uint32_t)l + edges[2 * j], (uint32_t)Z);
-    const uint32_t pB = wrap_z(pA + (uint32_t)H, (uint32_t)Z);
-    adrA[j]     = edges[2 * j + 1] + pA;
-    adrB[j]     = edges[2 * j + 1] + pB;
-  }
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    rawA[j] = soft[adrA[j]];
-    rawB[j] = soft[adrB[j]];
-  }
-  if (!FIRST) {
-#pragma unroll
-    for (int jj = 0; jj < (D + 1) / 2; ++jj)
-      cw[jj] = c2v[64 * jj];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  s16x2    mag1 = splat(LLR_MAX), mag2 = splat(LLR_MAX);
-  uint32_t spx  = 0;
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const s16x2 s = pk_pair(rawA[j], rawB[j]);
-    // |s| > 120: infinite soft bit -> "infinite" message with the same sign: d != 0 only then, and 255 * d dominates.
-    const s16x2 sc = pk_min(pk_max(s, splat(-LLR_MAX)), splat(LLR_MAX));
-    const s16x2 d  = s - sc;
-    s16x2       t  = sc;
-    if (!FIRST) {
-      const uint32_t w = cw[j >> 1];
-      const s16x2    c = (j & 1) ? c2v_odd(w) : c2v_even(w);
-      t                = pk_min(pk_max(sc - c, splat(-LLR_MAX)), splat(LLR_MAX));
-    }
-    const s16x2 v = d * splat(INF_MUL) + t;
-    v2c[j]        = v;
-    spx ^= as_u(v);
-    const s16x2 av   = pk_max(v, -v);
-    mabs[j]          = av;
-    const s16x2 help = pk_max(mag1, av);
-    mag1             = pk_min(mag1, av);
-    mag2             = pk_min(mag2, help);
-  }
-  // Scaling by 0.8 = floor(x * 52428 / 65536), per row (avx2_support.h:65-106).
-  const uint32_t s1A = ((uint32_t)(uint16_t)mag1.x * 52428u) >> 16, s1B = ((uint32_t)(uint16_t)mag1.y * 52428u) >> 16;
-  const uint32_t s2A = ((uint32_t)(uint16_t)mag2.x * 52428u) >> 16, s2B = ((uint32_t)(uint16_t)mag2.y * 52428u) >> 16;
-  // The product of ALL signs is folded into the two candidate magnitudes once per layer; an edge then only applies its own sign.
-  const s16x2 pm  = pk_ashr15(as_s2(spx));
-  const s16x2 s2u = as_s2(s2A | (s2B << 16));
-  const s16x2 s1u = as_s2(s1A | (s1B << 16));
-  const s16x2 s2p = as_s2(as_u(s2u) ^ as_u(pm)) - pm;
-  const s16x2 dsp = (as_s2(as_u(s1u) ^ as_u(pm)) - pm) - s2p; // +-(min1 - min2), scaled
-  s16x2 cprev = splat(0);
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const s16x2 v = v2c[j];
-    // x = 0 where |v| == min1 (this edge provided the minimum, or ties it: then min1 == min2), 1 elsewhere
-    const s16x2 x   = pk_min(mabs[j] - mag1, splat(1));
-    const s16x2 mag = x * dsp + s2p;
-    const s16x2 m   = pk_ashr15(v); // -1 where this edge's own message is negative
-    const s16x2 c   = as_s2(as_u(mag) ^ as_u(m)) - m;
-    if (j & 1)
-      c2v[64 * (j >> 1)] = c2v_pack(cprev, c);
-    else if (j == D - 1)
-      c2v[64 * (j >> 1)] = c2v_pack(c, c);
-    cprev = c;
-    const uint32_t r = as_u(pk_min(pk_max(c + v, splat(-LLR_INF)), splat(LLR_INF)));
-    soft[adrA[j]]    = (int8_t)r;
-    soft[adrB[j]]    = (int8_t)(r >> 16);
-  }
-}
-
-template <bool FIRST>
-__device__ __forceinline__ void update_rows_pk_any(int d, int8_t* soft, uint32_t* c2v, const uint32_t* edges, int l, int H, int Z)
-{
-  switch (d) {
-    case 19:
-      update_rows_pk<19, FIRST>(soft, c2v, edges, l, H, Z);
-      break;
-    case 10:
-      update_rows_pk<10, FIRST>(soft, c2v, edges, l, H, Z);
-      break;
-    case 9:
-      update_rows_pk<9, FIRST>(soft, c2v, edges, l, H, Z);
-      break;
-    case 8:
-      update_rows_pk<8, FIRST>(soft, c2v, edges, l, H, Z);
-      break;
-    case 7:
-      update_rows_pk<7, FIRST>(soft, c2v, edges, l, H, Z);
-      break;
-    case 6:
-      update_rows_pk<6, FIRST>(soft, c2v, edges, l, H, Z);
-      break;
-    case 5:
-      update_rows_pk<5, FIRST>(soft, c2v, edges, l, H, Z);
-      break;
-    case 4:
-      update_rows_pk<4, FIRST>(soft, c2v, edges, l, H, Z);
-      break;
-    default:
-      update_rows_pk<3, FIRST>(soft, c2v, edges, l, H, Z);
-      break;
-  }
-}
-
-__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b, uint32_t poly, uint32_t order)
-{
-  uint32_t       r   = 0;
-  const uint32_t top = 1u << order;
-  for (int k = (int)order - 1; k >= 0; --k) {
-    r <<= 1;
-    r ^= (r & top) ? poly : 0u;
-    r ^= ((b >> k) & 1u) ? a : 0u;
-  }
-  return r;
-}
-
-__device__ __forceinline__ uint32_t hard_word(const int8_t* soft, int t, int K)
-{
-  const uint32_t* p = reinterpret_cast<const uint32_t*>(soft) + 8 * t;
-  uint32_t        w = 0;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const uint32_t x = p[q];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int v = (int8_t)(x >> (8 * b));
-      w |= (uint32_t)(v <= 0) << (31 - (4 * q + b));
-    }
-  }
-  const int rem = K - 32 * t;
-  if (rem < 32)
-    w &= (rem <= 0) ? 0u : (0xffffffffu << (32 - rem));
-  return w;
-}
-
-// Hard-decision flags of the 32 soft bits of group t in the layout of crc_zmask: bit (q + 8 b) = (soft[32 t + 4 q + b] <= 0).
-// Per dword of four soft bytes: bit 7 of a byte of ((x & 0x7f..) + 0x7f..) says "low seven bits non-zero"; the byte is <= 0 when
-// its sign bit is set or that bit is clear.
-__device__ __forceinline__ uint32_t hard_flags(const int8_t* soft, int t)
-{
-  const uint4* p  = reinterpret_cast<const uint4*>(soft) + 2 * t;
-  const uint4  lo = p[0], hi = p[1];
-  const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  uint32_t       w    = 0;
-#pragma unroll
-  for (int q = 7; q >= 0; --q) {
-    const uint32_t nz  = (x[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu;
-    const uint32_t le0 = (x[q] | ~nz) & 0x80808080u;
-    w                  = (w << 1) | (le0 >> 7);
-  }
-  return w;
-}
 
 // Is the checksum of the first L hard bits zero? Mask / popcount form (crc_zmask in miphy_internal.h): no bit-serial division, no
 // position weights. zi = table index of the polynomial, order = its degree.
@@ -500,7 +267,8 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                       const miphy_ldpc_rdm_desc* __restrict__ rdm,
                       const int8_t* __restrict__ rm_in_base,
                       uint32_t* __restrict__ gmsg,
-                      int gmsg_pairs)
+                      int gmsg_pairs,
+                      const uint32_t* __restrict__ cb_order) // optional: the launch decodes codeblocks order[0 .. n) of the arrays (one class of a sorted batch)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -508,7 +276,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   raw_in16  pre[PK_PRE];
   if (FUSED) {
     if (blockIdx.x < n) {
-      const miphy_ldpc_rdm_desc r0 = load_words(rdm + blockIdx.x);
+      const miphy_ldpc_rdm_desc r0 = load_words(rdm + (cb_order ? cb_order[blockIdx.x] : blockIdx.x));
       const int8_t*             in = rm_in_base + r0.in_offset;
       const int                 mb = (int)(((uintptr_t)in) & 3), E = (int)r0.E;
       const int                 nq = (mb == 0) ? (E >> 4) : ((E >= 4) ? ((E - 4) >> 4) : 0);
@@ -526,8 +294,9 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 #ifdef LDPC_PK_PROFILE
   unsigned long long prof_acc[7] = {};
 #endif
-  for (uint32_t cb = blockIdx.x; cb < n;) {
+  for (uint32_t q = blockIdx.x; q < n;) {
   PROF_T(p_start);
+  const uint32_t cb = cb_order ? cb_order[q] : q;
   const miphy_ldpc_dec_desc dsc = load_words(descs + cb);
   const int                 Z   = dsc.Z;
   const int                 H   = (Z + 1) >> 1;
@@ -564,7 +333,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     if (tid == 0)
       iters_out[cb] = -1;
     __syncthreads();
-    cb = red[15];
+    q = red[15];
     continue;
   }
   const int8_t* llr    = llr_base + dsc.llr_offset;
@@ -580,7 +349,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     for (int k = 0; k < PK_PRE; ++k)
       pre[k] = raw_in16{0, 0, 0, 0, 0};
     if (c < n) {
-      const miphy_ldpc_rdm_desc rn  = load_words(rdm + c);
+      const miphy_ldpc_rdm_desc rn  = load_words(rdm + (cb_order ? cb_order[c] : c));
       const int8_t*             inn = rm_in_base + rn.in_offset;
       const int                 mbn = (int)(((uintptr_t)inn) & 3), En = (int)rn.E;
       const int                 nqn = (mbn == 0) ? (En >> 4) : ((En >= 4) ? ((En - 4) >> 4) : 0);
@@ -649,7 +418,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     }
     if (FUSED)
       prefetch(red[15]);
-    cb = red[15];
+    q = red[15];
     continue;
   }
   int cb_len = max(last + 2 * Z, K + 4 * Z);
@@ -686,7 +455,10 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   // The two wrap constants of the address computations live in VECTOR registers: a VOP2 add / sub with a scalar operand issues at
   // the rate of the three-operand encodings (2.88 instead of 1.93 cycles at three waves per SIMD, tools/valu_probe), and three of
   // the eight address instructions per edge only have Z or Z/2 as their second operand.
-  int Zv = Z, Hv = H;
+  // Odd lifting size: the last lane would own rows H - 1 and Z (= row 0 again, a lane's second row is l + H). Its distance to the
+  // second row is set to zero instead: both halves of its packed registers then carry row H - 1, read the same soft bits, compute
+  // the same values and store them to the same addresses -- no row is visited twice and no instruction is added.
+  int Zv = Z, Hv = (tid + H < Z) ? H : 0;
 #ifndef LDPC_PK_SCALAR_WRAP
   asm volatile("" : "+v"(Zv), "+v"(Hv));
 #endif
@@ -752,7 +524,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   PROF_ADD(4, p_crc, p_end);
   PROF_ADD(5, p_start, p_end);
   PROF_COUNT();
-  cb = red[15];
+  q = red[15];
   } // codeblock loop
 }
 
@@ -794,7 +566,7 @@ size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all)
 
 int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                          uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
-                         const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in, int gmsg_pairs)
+                         const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in, int gmsg_pairs, const uint32_t* d_order)
 {
   const bool  fused = d_rdm != nullptr, gm = gmsg_pairs > 0;
   const void* kern  = fused ? (gm ? (const void*)ldpc_decode_pk_kernel<true, true> : (const void*)ldpc_decode_pk_kernel<true, false>)
@@ -819,7 +591,7 @@ int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uin
     return rc;
 #define PK_LAUNCH(F, G)                                                                                                                              \
   hipLaunchKernelGGL((ldpc_decode_pk_kernel<F, G>), dim3(grid), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot, \
-                     harq_crc_ok, n, queue, d_rdm, rm_in, (uint32_t*)gmsg, gmsg_pairs)
+                     harq_crc_ok, n, queue, d_rdm, rm_in, (uint32_t*)gmsg, gmsg_pairs, d_order)
   if (fused && gm)
     PK_LAUNCH(true, true);
   else if (fused)

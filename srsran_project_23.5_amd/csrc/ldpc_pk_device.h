@@ -1,0 +1,245 @@
+// Device code shared by the packed LDPC decoder kernels (ldpc_decode_pk.hip: one codeblock per workgroup; ldpc_decode_pkw.hip:
+// several small codeblocks per wavefront). Arithmetic contract: ldpc_decoder_impl.cpp:60-146 + ldpc_decoder_avx2.cpp:66-243,
+// avx2_support.h:65-106 of the reference; every kernel built from these functions is bit-identical to it.
+#pragma once
+#include "miphy_internal.h"
+
+namespace {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s16x2 as_s2(uint32_t x)
+{
+  return __builtin_bit_cast(s16x2, x);
+}
+__device__ __forceinline__ uint32_t as_u(s16x2 x)
+{
+  return __builtin_bit_cast(uint32_t, x);
+}
+__device__ __forceinline__ s16x2 splat(int c)
+{
+  return s16x2{(short)c, (short)c};
+}
+__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b)
+{
+  return __builtin_elementwise_min(a, b);
+}
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b)
+{
+  return __builtin_elementwise_max(a, b);
+}
+__device__ __forceinline__ s16x2 pk_ashr15(s16x2 a)
+{
+  return a >> splat(15);
+}
+// two sign-extended bytes -> one register with two int16 (bytes 1:0 of each source)
+__device__ __forceinline__ s16x2 pk_pair(int lo, int hi)
+{
+  return as_s2(__builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u));
+}
+// Message dword {A1, A0, B1, B0} (bytes 0..3) -> edge 0 = (sext A0, sext B0), edge 1 = (sext A1, sext B1).
+// v_perm_b32 selectors 8 / 9 replicate the sign of byte 1 / 3 of the low source (10 / 11: of the high source).
+__device__ __forceinline__ s16x2 c2v_even(uint32_t w)
+{
+  return as_s2(__builtin_amdgcn_perm(w, w, 0x09030801u));
+}
+__device__ __forceinline__ s16x2 c2v_odd(uint32_t w)
+{
+  const uint32_t h = w << 8; // bytes {0, A1, A0, B1}: A1 -> byte 1, B1 -> byte 3
+  return as_s2(__builtin_amdgcn_perm(h, h, 0x09030801u));
+}
+__device__ __forceinline__ uint32_t c2v_pack(s16x2 c0, s16x2 c1)
+{
+  // {S0 = c0 -> bytes 4..7, S1 = c1 -> bytes 0..3}: out = {c1.A, c0.A, c1.B, c0.B}
+  return __builtin_amdgcn_perm(as_u(c0), as_u(c1), 0x06020400u);
+}
+
+// p mod Z for p < 2 Z: min(p, p - Z) on the LOW HALVES. The 16-bit VOP2 minimum issues at the fast rate (1.93 cycles at three waves
+// per SIMD, where v_min_u32 takes 2.88: tools/valu_probe) and clears the upper half of its destination (tools/min16_probe), so the
+// result is the address term itself. Positions are below 2 * 384.
+__device__ __forceinline__ uint32_t wrap_z(uint32_t p, uint32_t Z)
+{
+#ifdef LDPC_PK_MIN32
+  return min(p, p - Z);
+#else
+  const uint32_t t = p - Z;
+  uint32_t       r;
+  asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(p), "v"(t));
+  return r;
+#endif
+}
+
+constexpr int LLR_MAX = 120;
+constexpr int LLR_INF = 127;
+constexpr int INF_MUL = 255; // an infinite soft bit (|s| > 120) becomes a message of magnitude >= 255 + 24
+
+// `base` = LDS byte offset of the codeblock's soft bits (0 where a workgroup holds one codeblock: the term then folds away).
+template <int D, bool FIRST>
+__device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
+                                               uint32_t* __restrict__ c2v, // this lane's message dword of edges 0,1 of the layer
+                                               const uint32_t* __restrict__ edges, // {shift, column*Z} per edge
+                                               int l,
+                                               int H,
+                                               int Z,
+                                               uint32_t base = 0)
+{
+  s16x2    v2c[D], mabs[D];
+  uint32_t adrA[D], adrB[D];
+  int      rawA[D], rawB[D];
+  uint32_t cw[(D + 1) / 2];
+  // Stage A: every address of the layer, then every LDS read of the layer in one go (2 soft bits per edge + the old
+  // messages): the latency of the LDS pipe is paid once per layer instead of once per group of edges.
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const uint32_t pA = wrap_z((uint32_t)l + edges[2 * j], (uint32_t)Z);
+    const uint32_t pB = wrap_z(pA + (uint32_t)H, (uint32_t)Z);
+    adrA[j]     = edges[2 * j + 1] + pA + base;
+    adrB[j]     = edges[2 * j + 1] + pB + base;
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    rawA[j] = soft[adrA[j]];
+    rawB[j] = soft[adrB[j]];
+  }
+  if (!FIRST) {
+#pragma unroll
+    for (int jj = 0; jj < (D + 1) / 2; ++jj)
+      cw[jj] = c2v[64 * jj];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  s16x2    mag1 = splat(LLR_MAX), mag2 = splat(LLR_MAX);
+  uint32_t spx  = 0;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const s16x2 s = pk_pair(rawA[j], rawB[j]);
+    // |s| > 120: infinite soft bit -> "infinite" message with the same sign: d != 0 only then, and 255 * d dominates.
+    const s16x2 sc = pk_min(pk_max(s, splat(-LLR_MAX)), splat(LLR_MAX));
+    const s16x2 d  = s - sc;
+    s16x2       t  = sc;
+    if (!FIRST) {
+      const uint32_t w = cw[j >> 1];
+      const s16x2    c = (j & 1) ? c2v_odd(w) : c2v_even(w);
+      t                = pk_min(pk_max(sc - c, splat(-LLR_MAX)), splat(LLR_MAX));
+    }
+    const s16x2 v = d * splat(INF_MUL) + t;
+    v2c[j]        = v;
+    spx ^= as_u(v);
+    const s16x2 av   = pk_max(v, -v);
+    mabs[j]          = av;
+    const s16x2 help = pk_max(mag1, av);
+    mag1             = pk_min(mag1, av);
+    mag2             = pk_min(mag2, help);
+  }
+  // Scaling by 0.8 = floor(x * 52428 / 65536), per row (avx2_support.h:65-106).
+  const uint32_t s1A = ((uint32_t)(uint16_t)mag1.x * 52428u) >> 16, s1B = ((uint32_t)(uint16_t)mag1.y * 52428u) >> 16;
+  const uint32_t s2A = ((uint32_t)(uint16_t)mag2.x * 52428u) >> 16, s2B = ((uint32_t)(uint16_t)mag2.y * 52428u) >> 16;
+  // The product of ALL signs is folded into the two candidate magnitudes once per layer; an edge then only applies its own sign.
+  const s16x2 pm  = pk_ashr15(as_s2(spx));
+  const s16x2 s2u = as_s2(s2A | (s2B << 16));
+  const s16x2 s1u = as_s2(s1A | (s1B << 16));
+  const s16x2 s2p = as_s2(as_u(s2u) ^ as_u(pm)) - pm;
+  const s16x2 dsp = (as_s2(as_u(s1u) ^ as_u(pm)) - pm) - s2p; // +-(min1 - min2), scaled
+  s16x2 cprev = splat(0);
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const s16x2 v = v2c[j];
+    // x = 0 where |v| == min1 (this edge provided the minimum, or ties it: then min1 == min2), 1 elsewhere
+    const s16x2 x   = pk_min(mabs[j] - mag1, splat(1));
+    const s16x2 mag = x * dsp + s2p;
+    const s16x2 m   = pk_ashr15(v); // -1 where this edge's own message is negative
+    const s16x2 c   = as_s2(as_u(mag) ^ as_u(m)) - m;
+    if (j & 1)
+      c2v[64 * (j >> 1)] = c2v_pack(cprev, c);
+    else if (j == D - 1)
+      c2v[64 * (j >> 1)] = c2v_pack(c, c);
+    cprev = c;
+    const uint32_t r = as_u(pk_min(pk_max(c + v, splat(-LLR_INF)), splat(LLR_INF)));
+    soft[adrA[j]]    = (int8_t)r;
+    soft[adrB[j]]    = (int8_t)(r >> 16);
+  }
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void update_rows_pk_any(int d, int8_t* soft, uint32_t* c2v, const uint32_t* edges, int l, int H, int Z, uint32_t base = 0)
+{
+  switch (d) {
+    case 19:
+      update_rows_pk<19, FIRST>(soft, c2v, edges, l, H, Z, base);
+      break;
+    case 10:
+      update_rows_pk<10, FIRST>(soft, c2v, edges, l, H, Z, base);
+      break;
+    case 9:
+      update_rows_pk<9, FIRST>(soft, c2v, edges, l, H, Z, base);
+      break;
+    case 8:
+      update_rows_pk<8, FIRST>(soft, c2v, edges, l, H, Z, base);
+      break;
+    case 7:
+      update_rows_pk<7, FIRST>(soft, c2v, edges, l, H, Z, base);
+      break;
+    case 6:
+      update_rows_pk<6, FIRST>(soft, c2v, edges, l, H, Z, base);
+      break;
+    case 5:
+      update_rows_pk<5, FIRST>(soft, c2v, edges, l, H, Z, base);
+      break;
+    case 4:
+      update_rows_pk<4, FIRST>(soft, c2v, edges, l, H, Z, base);
+      break;
+    default:
+      update_rows_pk<3, FIRST>(soft, c2v, edges, l, H, Z, base);
+      break;
+  }
+}
+
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b, uint32_t poly, uint32_t order)
+{
+  uint32_t       r   = 0;
+  const uint32_t top = 1u << order;
+  for (int k = (int)order - 1; k >= 0; --k) {
+    r <<= 1;
+    r ^= (r & top) ? poly : 0u;
+    r ^= ((b >> k) & 1u) ? a : 0u;
+  }
+  return r;
+}
+
+__device__ __forceinline__ uint32_t hard_word(const int8_t* soft, int t, int K)
+{
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(soft) + 8 * t;
+  uint32_t        w = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const uint32_t x = p[q];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int v = (int8_t)(x >> (8 * b));
+      w |= (uint32_t)(v <= 0) << (31 - (4 * q + b));
+    }
+  }
+  const int rem = K - 32 * t;
+  if (rem < 32)
+    w &= (rem <= 0) ? 0u : (0xffffffffu << (32 - rem));
+  return w;
+}
+
+// Hard-decision flags of the 32 soft bits of group t in the layout of crc_zmask: bit (q + 8 b) = (soft[32 t + 4 q + b] <= 0).
+// Per dword of four soft bytes: bit 7 of a byte of ((x & 0x7f..) + 0x7f..) says "low seven bits non-zero"; the byte is <= 0 when
+// its sign bit is set or that bit is clear.
+__device__ __forceinline__ uint32_t hard_flags(const int8_t* soft, int t)
+{
+  const uint4* p  = reinterpret_cast<const uint4*>(soft) + 2 * t;
+  const uint4  lo = p[0], hi = p[1];
+  const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uint32_t       w    = 0;
+#pragma unroll
+  for (int q = 7; q >= 0; --q) {
+    const uint32_t nz  = (x[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    const uint32_t le0 = (x[q] | ~nz) & 0x80808080u;
+    w                  = (w << 1) | (le0 >> 7);
+  }
+  return w;
+}
+
+} // namespace

@@ -112,19 +112,55 @@ int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t b
 // the ring are copied directly and the stream is synchronised, as every upload was before.)
 int miphy_upload(miphy_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s);
 
-// Decoder launch shared by miphy_ldpc_decode_batch and the transport-block level PUSCH decoder.
-// force_scalar: the batch holds odd lifting sizes the packed kernel cannot take (device descriptors hide them from the launcher).
+// Decoder launch, ONE kernel launch for the whole batch: device-resident descriptors (which the host cannot sort) and the forced kernels
+// of miphy_debug_force_ldpc_kernel. Host descriptors are sorted into launch classes instead (below) unless a kernel is forced.
 // fuse_rdm / fuse_in / fuse_rlim (device descriptors with the same index as descs): every codeblock is a first transmission that
-// can be rate-dematched while the decoder loads it (conditions in ldpc_decode_pk.hip); `llr` is then the HARQ soft-buffer array the
-// dematched codeblocks are written to. When the packed kernel is not the one selected, the rate dematcher runs as its own launch
-// first -- the result is the same either way.
+// can be rate-dematched while the decoder loads it (conditions in ldpc_decode_pk.hip; sch.hip checks them); `llr` is then the HARQ
+// soft-buffer array the dematched codeblocks are written to. When the packed kernel is not the one selected, the rate dematcher runs
+// as its own launch first -- the result is the same either way.
 int miphy_ldpc_decode_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* descs, int descs_on_device, uint32_t n, const int8_t* llr,
                              uint8_t* out_bits, int32_t* iters, const miphy_ldpc_dec_limits* limits, const uint32_t* harq_slot,
-                             uint8_t* harq_crc_ok, void* stream, int force_scalar = 0, const miphy_ldpc_rdm_desc* fuse_rdm = nullptr,
+                             uint8_t* harq_crc_ok, void* stream, const miphy_ldpc_rdm_desc* fuse_rdm = nullptr,
                              const int8_t* fuse_in = nullptr, const miphy_ldpc_rdm_limits* fuse_rlim = nullptr,
                              int bg_mask = 3 /* device descriptors: bit 0 / 1 = base graph 1 / 2 occurs */,
                              const uint32_t* reset_slots = nullptr, uint32_t nof_reset_slots = 0 /* CRC flags to clear before decoding (device
                              array): new transmissions. Skipped when the decoder dematches itself -- it then writes every flag either way */);
+
+#ifdef __cplusplus
+#include <vector>
+// Launch classes of a batch whose descriptors the host can see (ldpc_decode.hip): codeblocks sorted so that each class shares a
+// workgroup size and an LDS size.
+struct miphy_ldpc_class {
+  uint8_t  kind;  // 0 = wave kernel (Z <= 64, several codeblocks per wavefront); 1..3 = packed kernel with that many wavefronts per codeblock
+  uint8_t  bgi;   // base graph - 1
+  uint8_t  fused; // every codeblock can be rate-dematched by the decoder while it loads
+  uint8_t  lay;   // layers a codeblock of the class can reach at most
+  uint16_t max_Z;
+  uint32_t first, count;               // the class's range of `order`
+  uint32_t bundle_first, bundle_count; // kind 0: its range of `bundles` (pairs of words)
+  uint32_t soft_total;                 // kind 0: LDS bytes for the soft bits of a bundle
+};
+struct miphy_ldpc_classes {
+  std::vector<uint32_t>         order;   // codeblock indices, class after class; classes that are not fused come first
+  std::vector<uint32_t>         bundles; // wave kernel: {first position in order, count} per bundle
+  std::vector<miphy_ldpc_class> classes;
+  uint32_t                      nof_unfused = 0; // order[0 .. nof_unfused) need the rate dematcher as a launch of its own
+  bool                          identity    = true;
+};
+// fusable: optional flag per codeblock ("the decoder may dematch it"); descriptors must be valid (validated by the caller).
+void miphy_ldpc_build_classes(const miphy_ldpc_dec_desc* descs, uint32_t n, const uint8_t* fusable, miphy_ldpc_classes& C);
+// One launch per class. d_order / d_bundles = device copies of C.order / C.bundles. d_rdm / rm_in: rate-dematcher descriptors (same
+// index as d_descs) and rate-matched input for the fused classes; allow_fuse = false runs them unfused (the caller has dematched).
+int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, const miphy_ldpc_classes& C, const uint32_t* d_order,
+                                     const uint32_t* d_bundles, const int8_t* llr, uint8_t* out_bits, int32_t* iters, const uint32_t* harq_slot,
+                                     uint8_t* harq_crc_ok, hipStream_t s, const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in, bool allow_fuse);
+bool miphy_ldpc_scalar_forced(); // miphy_debug_force_ldpc_kernel(1): nothing is dematched inside the decoder then
+int miphy_ldpc_flags_reset(const uint32_t* d_slots, uint32_t n, uint8_t* harq_crc_ok, hipStream_t s);
+// Wave kernel (ldpc_decode_pkw.hip).
+int miphy_ldpc_pkw_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, const uint32_t* d_order, const uint32_t* d_bundles, uint32_t nof_bundles,
+                          int bgi, int lay, size_t soft_total, const int8_t* llr, uint8_t* out_bits, int32_t* iters, const uint32_t* harq_slot,
+                          uint8_t* harq_crc_ok, hipStream_t s, int* used_gmsg);
+#endif
 
 // Returns a device scratch buffer of at least `bytes` (reallocated, after a stream sync, when it has to grow).
 int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out, int which = 0);
@@ -134,6 +170,7 @@ size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all); // p
 int    miphy_ldpc_pk_waves_per_cu(bool fused);
 int    miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                             uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
-                            const miphy_ldpc_rdm_desc* d_rdm = nullptr, const int8_t* rm_in = nullptr, int gmsg_pairs = 0);
+                            const miphy_ldpc_rdm_desc* d_rdm = nullptr, const int8_t* rm_in = nullptr, int gmsg_pairs = 0,
+                            const uint32_t* d_order = nullptr /* the launch decodes codeblocks d_order[0 .. n) of the arrays */);
 // The next work-queue counter of the context (zero: every launch leaves its counter cleared).
 int miphy_next_queue_counter(miphy_ctx* ctx, uint32_t** out);

@@ -376,14 +376,27 @@ struct pusch_decode_build {
   std::vector<uint32_t>            cb_tb; // transport block of each codeblock
   std::vector<uint32_t>            cbw;   // per codeblock: x^sh mod CRC24A, the weight of its checksum part in the transport block's (tb assembly)
   uint32_t                         max_Z = 2, max_nodes = 0, max_E = 0;
-  bool                             any_odd_Z = false; // the packed decoder pairs rows l and l + Z/2
   int                              bg_mask   = 0;     // bit 0 / 1: base graph 1 / 2 occurs (the decoder sizes its LDS per base graph)
-  bool                             fusable   = true;  // every codeblock can be rate-dematched by the decoder while it loads
+  std::vector<uint8_t>             fusable;           // per codeblock: it can be rate-dematched by the decoder while it loads
+  // Launches: chunks of at most 65535 codeblocks (whole transport blocks), each sorted into the decoder's launch classes
+  // (miphy_ldpc_build_classes: by lifting size, base graph, reachable layers, dematch-while-loading or not).
+  struct chunk {
+    uint32_t           t0, t1, c0, c1;
+    miphy_ldpc_classes cls;
+    uint32_t           order_off, bundle_off, rdm_nf_off; // positions in the concatenated `order` / `bundles` / `rdm_nf` arrays
+  };
+  std::vector<chunk>               chunks;
+  std::vector<uint32_t>            order, bundles;    // all chunks, indices relative to the chunk's first codeblock
+  std::vector<miphy_ldpc_rdm_desc> rdm_nf;            // dematcher descriptors of the codeblocks of classes that are not fused, chunk after chunk
+  bool                             all_fused = true;  // every class of every chunk dematches in the decoder
 };
 
 // Device-side view of a staged build (pointers into one buffer).
 struct pusch_decode_dev {
   const miphy_ldpc_rdm_desc* rdm;
+  const miphy_ldpc_rdm_desc* rdm_nf;
+  const uint32_t*            order;
+  const uint32_t*            bundles;
   const miphy_ldpc_dec_desc* dec;
   const uint32_t*            slots;
   const uint32_t*            reset;
@@ -486,9 +499,8 @@ int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_
       }
       // Dematching while the decoder loads: first transmission at redundancy version 0 into the full circular buffer, the E bits
       // neither wrap around it nor stop inside the systematic part, soft-buffer slots 16-byte aligned (HARQ_CB_STRIDE is).
-      b.fusable &= d.new_data && d.rv == 0 && !(d.Nref > 0 && d.Nref < sg.N) && E + sg.nof_filler_bits <= sg.N &&
-                   E >= (bgK - 2) * sg.Z - sg.nof_filler_bits && (sg.Z % 16) == 0;
-      b.any_odd_Z |= (sg.Z & 1u) != 0;
+      b.fusable.push_back(d.new_data && d.rv == 0 && !(d.Nref > 0 && d.Nref < sg.N) && E + sg.nof_filler_bits <= sg.N &&
+                          E >= (bgK - 2) * sg.Z - sg.nof_filler_bits && (sg.Z % 16) == 0);
       b.bg_mask |= 1 << (d.bg - 1);
       q.flags           = d.use_early_stop ? 0u : 1u;
       q.llr_offset = (uint64_t)slot * HARQ_CB_STRIDE, q.out_offset = (uint64_t)slot * HARQ_MSG_STRIDE;
@@ -504,13 +516,34 @@ int build_pusch_decode(const miphy_pusch_tb_desc* tbs, uint32_t n, pusch_decode_
     b.max_Z     = sg.Z > b.max_Z ? sg.Z : b.max_Z;
     b.max_nodes = tb_nodes > b.max_nodes ? tb_nodes : b.max_nodes;
   }
+  // chunks of whole transport blocks, each with its launch classes
+  for (uint32_t t0 = 0; t0 < n;) {
+    pusch_decode_build::chunk ch;
+    ch.t0 = t0, ch.t1 = t0, ch.c0 = b.asmd[t0].first_desc, ch.c1 = ch.c0;
+    while (ch.t1 < n && ch.c1 + b.asmd[ch.t1].nof_cbs - ch.c0 <= 65535) {
+      ch.c1 += b.asmd[ch.t1].nof_cbs;
+      ++ch.t1;
+    }
+    MIPHY_REQUIRE(ch.t1 > ch.t0, "pusch_decode: TB %u has more than 65535 codeblocks", t0);
+    miphy_ldpc_build_classes(b.dec.data() + ch.c0, ch.c1 - ch.c0, b.fusable.data() + ch.c0, ch.cls);
+    ch.order_off = (uint32_t)b.order.size(), ch.bundle_off = (uint32_t)b.bundles.size(), ch.rdm_nf_off = (uint32_t)b.rdm_nf.size();
+    b.order.insert(b.order.end(), ch.cls.order.begin(), ch.cls.order.end());
+    b.bundles.insert(b.bundles.end(), ch.cls.bundles.begin(), ch.cls.bundles.end());
+    for (uint32_t k = 0; k < ch.cls.nof_unfused; ++k)
+      b.rdm_nf.push_back(b.rdm[ch.c0 + ch.cls.order[k]]);
+    b.all_fused &= ch.cls.nof_unfused == 0;
+    std::vector<uint32_t>().swap(ch.cls.order); // kept in b.order
+    std::vector<uint32_t>().swap(ch.cls.bundles);
+    t0 = ch.t1;
+    b.chunks.push_back(std::move(ch));
+  }
   return MIPHY_OK;
 }
 
 size_t pusch_decode_bytes(const pusch_decode_build& b)
 {
-  return 64 + b.rdm.size() * sizeof(b.rdm[0]) + b.dec.size() * sizeof(b.dec[0]) + (b.slots.size() + b.reset_slots.size()) * 4 +
-         b.asmd.size() * sizeof(b.asmd[0]) + (b.cb_tb.size() + b.cbw.size()) * 4 + b.dec.size() * 8 + 16 * 9;
+  return 64 + (b.rdm.size() + b.rdm_nf.size()) * sizeof(b.rdm[0]) + b.dec.size() * sizeof(b.dec[0]) + (b.slots.size() + b.reset_slots.size()) * 4 +
+         b.asmd.size() * sizeof(b.asmd[0]) + (b.cb_tb.size() + b.cbw.size() + b.order.size() + b.bundles.size()) * 4 + b.dec.size() * 8 + 16 * 12;
 }
 
 // Lays the build out in a host image `h` of the device buffer `dv` (same offsets) and returns the device pointers.
@@ -519,6 +552,9 @@ pusch_decode_dev layout_pusch_decode(const pusch_decode_build& b, uint8_t* h, ui
   pusch_decode_dev v;
   size_t           off = 0;
   v.rdm     = stage_vec(h, dv, b.rdm, off);
+  v.rdm_nf  = stage_vec(h, dv, b.rdm_nf, off);
+  v.order   = stage_vec(h, dv, b.order, off);
+  v.bundles = stage_vec(h, dv, b.bundles, off);
   v.dec     = stage_vec(h, dv, b.dec, off);
   v.slots   = stage_vec(h, dv, b.slots, off);
   v.reset   = stage_vec(h, dv, b.reset_slots, off);
@@ -544,31 +580,27 @@ int launch_pusch_decode(miphy_ctx* ctx, const pusch_decode_build& b, const pusch
 {
   int rc;
   miphy_ldpc_rdm_limits rlim = {b.max_E};
-  // The decoder derives its LDS size from (max_Z, max_in_len) as ceil((max_in_len + 2 max_Z) / max_Z) nodes: hand it the node
-  // bound of the batch expressed in units of the largest lifting size (codeblocks with a smaller Z reach more nodes per LLR).
-  miphy_ldpc_dec_limits lim = {b.max_Z, (b.max_nodes - 2) * b.max_Z};
-  uint32_t              t0  = 0;
-  while (t0 < n) {
-    uint32_t t1 = t0, c0 = b.asmd[t0].first_desc, c1 = c0;
-    while (t1 < n && c1 + b.asmd[t1].nof_cbs - c0 <= 65535) {
-      c1 += b.asmd[t1].nof_cbs;
-      ++t1;
-    }
-    if (ev)
-      MIPHY_HIP_CHECK(hipEventRecord(ev[0], s));
-    if (!b.fusable) {
-      if ((rc = miphy_ldpc_rate_dematch_batch(ctx, v.rdm + c0, 1, c1 - c0, llrs, harq_softbits, &rlim, s)))
-        return rc;
-    }
-    if (ev)
-      MIPHY_HIP_CHECK(hipEventRecord(ev[1], s));
-    if ((rc = miphy_ldpc_decode_launch(ctx, v.dec + c0, 1, c1 - c0, harq_softbits, harq_msgs, v.iters + c0, &lim, v.slots + c0, harq_crc_ok, s,
-                                       b.any_odd_Z ? 1 : 0, b.fusable ? v.rdm + c0 : nullptr, b.fusable ? llrs : nullptr, &rlim, b.bg_mask,
-                                       // the flags of every new transmission of the CALL, cleared before its first launch (a decoder that
-                                       // dematches itself writes the flags of its own codeblocks instead)
-                                       t0 == 0 ? v.reset : nullptr, t0 == 0 ? (uint32_t)b.reset_slots.size() : 0u)))
+  // Dematching inside the decoder needs 16-byte aligned soft buffers (its write-back is vectorised; HARQ_CB_STRIDE keeps the slots so)
+  const bool allow_fuse = ((uintptr_t)harq_softbits & 15) == 0 && !miphy_ldpc_scalar_forced();
+  if (ev)
+    MIPHY_HIP_CHECK(hipEventRecord(ev[0], s));
+  // the CRC flags of the new transmissions of the call (a decoder that dematches itself writes the flags of its codeblocks either way)
+  if (!(b.all_fused && allow_fuse) && (rc = miphy_ldpc_flags_reset(v.reset, (uint32_t)b.reset_slots.size(), harq_crc_ok, s)))
+    return rc;
+  for (const pusch_decode_build::chunk& ch : b.chunks) { // rate dematching as launches of its own where the decoder does not do it
+    if (!allow_fuse)
+      rc = miphy_ldpc_rate_dematch_batch(ctx, v.rdm + ch.c0, 1, ch.c1 - ch.c0, llrs, harq_softbits, &rlim, s);
+    else
+      rc = ch.cls.nof_unfused ? miphy_ldpc_rate_dematch_batch(ctx, v.rdm_nf + ch.rdm_nf_off, 1, ch.cls.nof_unfused, llrs, harq_softbits, &rlim, s) : MIPHY_OK;
+    if (rc)
       return rc;
-    t0 = t1;
+  }
+  if (ev)
+    MIPHY_HIP_CHECK(hipEventRecord(ev[1], s));
+  for (const pusch_decode_build::chunk& ch : b.chunks) {
+    if ((rc = miphy_ldpc_decode_classes_launch(ctx, v.dec + ch.c0, ch.cls, v.order + ch.order_off, v.bundles + ch.bundle_off, harq_softbits, harq_msgs,
+                                               v.iters + ch.c0, v.slots + ch.c0, harq_crc_ok, s, v.rdm + ch.c0, llrs, allow_fuse)))
+      return rc;
   }
   if (ev)
     MIPHY_HIP_CHECK(hipEventRecord(ev[2], s));
@@ -659,9 +691,13 @@ extern "C" int miphy_pusch_decode_plan_create(miphy_ctx* ctx, const miphy_pusch_
   }
   // only sizes and limits are needed from here on
   std::vector<miphy_ldpc_rdm_desc>().swap(p->b.rdm);
+  std::vector<miphy_ldpc_rdm_desc>().swap(p->b.rdm_nf);
   std::vector<miphy_ldpc_dec_desc>().swap(p->b.dec);
   std::vector<uint32_t>().swap(p->b.slots);
   std::vector<uint32_t>().swap(p->b.cb_tb);
+  std::vector<uint32_t>().swap(p->b.order);
+  std::vector<uint32_t>().swap(p->b.bundles);
+  std::vector<uint8_t>().swap(p->b.fusable);
   *out = p;
   return MIPHY_OK;
 }
@@ -727,7 +763,7 @@ extern "C" int miphy_pusch_decode_plan_info(const miphy_pusch_decode_plan* p, ui
 {
   MIPHY_REQUIRE(p && info, "miphy_pusch_decode_plan_info: null argument");
   info[0] = p->ncb;
-  info[1] = (p->b.fusable && !p->b.any_odd_Z) ? 1u : 0u;
+  info[1] = p->b.all_fused ? 1u : 0u;
   info[2] = p->b.max_nodes;
   return MIPHY_OK;
 }

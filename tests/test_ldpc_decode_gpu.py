@@ -7,13 +7,37 @@ from oracle_lib import (ALL_Z, BG_K, BG_NS, CRC16, CRC24A, CRC24B, o_crc_bits, o
 pytestmark = pytest.mark.gpu
 
 
+SCALAR, PACKED, FUSED, GMSG, WAVE = 1, 2, 4, 8, 16  # MIPHY_LDPC_KERNEL_* (include/miphy.h)
+
+
 @pytest.fixture(params=["auto", "scalar", "packed"], autouse=True)
 def ldpc_kernel(request):
-    """Every test of this file runs with the automatic kernel choice and with each of the two decoder kernels forced."""
+    """Every test of this file runs with the automatic choice (host descriptors: class-sorted launches -- the wave kernel for Z <= 64,
+    the packed kernel above; device descriptors: one launch), with the one-row-per-lane kernel forced and with the packed kernel
+    forced as ONE launch for the whole batch. `kernels_used()` tells which kernels really ran; the tests assert it."""
     import miphy
     miphy.lib().miphy_debug_force_ldpc_kernel({"auto": 0, "scalar": 1, "packed": 2}[request.param])
+    miphy.lib().miphy_debug_ldpc_kernels_used(1)
     yield request.param
     miphy.lib().miphy_debug_force_ldpc_kernel(0)
+
+
+def kernels_used():
+    import miphy
+    return int(miphy.lib().miphy_debug_ldpc_kernels_used(1))
+
+
+def check_kernels(mode, used, cases):
+    """The forced kernel is the one that ran; the automatic choice never takes the one-row-per-lane kernel for host descriptors, runs the
+    wave kernel exactly when the batch holds Z <= 64 and the packed kernel exactly when it holds Z > 64."""
+    if mode == "scalar":
+        assert used == SCALAR, used
+    elif mode == "packed":
+        assert used & PACKED and not used & (SCALAR | WAVE), used
+    else:
+        assert not used & SCALAR, used
+        assert bool(used & WAVE) == any(c["Z"] <= 64 for c in cases), used
+        assert bool(used & PACKED) == any(c["Z"] > 64 for c in cases), used
 
 
 def noisy_llr(cw, sigma, rng):
@@ -32,8 +56,9 @@ def make_codeword(bg, Z, rng, nof_filler=0, poly=CRC24B):
     return msg, o_ldpc_encode(bg, Z, msg, BG_NS[bg] * Z)
 
 
-def run_batch(ctx, cases):
-    """cases: list of dict(bg,Z,llr,crc,max_iter,nf). Runs them as ONE heterogeneous batch."""
+def run_batch(ctx, cases, mode=None, pad=0):
+    """cases: list of dict(bg,Z,llr,crc,max_iter,nf). Runs them as ONE batch with host descriptors; `pad` LLRs of garbage in front of
+    every codeblock (unaligned inputs). Returns the mismatches against the oracle."""
     import torch
     import miphy
     n = len(cases)
@@ -42,7 +67,10 @@ def run_batch(ctx, cases):
     llrs, exp = [], []
     for i, c in enumerate(cases):
         K = BG_K[c["bg"]] * c["Z"]
-        descs[i] = (c["bg"], c["crc"] if c["crc"] >= 0 else miphy.CRC_NONE, c["Z"], c["max_iter"], c["nf"], c["llr"].size, 0,
+        if pad:
+            llrs.append(np.full(pad, 77, np.int8))
+            llr_off += pad
+        descs[i] = (c["bg"], c["crc"] if c["crc"] >= 0 else miphy.CRC_NONE, c["Z"], c["max_iter"], c["nf"], c["llr"].size, c.get("flags", 0),
                     llr_off, out_off)
         llrs.append(c["llr"])
         llr_off += c["llr"].size
@@ -50,15 +78,26 @@ def run_batch(ctx, cases):
     llr_d = torch.from_numpy(np.concatenate(llrs)).cuda()
     out_d = torch.full((out_off,), 0x5A, dtype=torch.uint8, device="cuda")
     it_d = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    kernels_used()
     ctx.ldpc_decode_batch(descs, llr_d, out_d, it_d)
     torch.cuda.synchronize()
+    if mode is not None:
+        check_kernels(mode, kernels_used(), cases)
     out, its = out_d.cpu().numpy(), it_d.cpu().numpy()
     bad = []
     for i, c in enumerate(cases):
         K = BG_K[c["bg"]] * c["Z"]
         nb = (K + 7) // 8
         init = np.full(nb, 0x5A, dtype=np.uint8)
-        ito, oo = o_ldpc_decode(c["bg"], c["Z"], c["llr"], c["nf"], c["crc"], c["max_iter"], out_init=init)
+        if c.get("flags", 0) & 1:  # CRC checked once after the last iteration (pusch_decoder_impl.cpp:105-118)
+            _, oo = o_ldpc_decode(c["bg"], c["Z"], c["llr"], c["nf"], -1, c["max_iter"], out_init=init)
+            if not np.any(c["llr"]):
+                ito, oo = 0, init  # all-zero input with a CRC: nullopt, output untouched
+            else:
+                L = K - c["nf"]
+                ito = c["max_iter"] if o_crc_bits(c["crc"], np.unpackbits(oo)[:L]) == 0 else 0
+        else:
+            ito, oo = o_ldpc_decode(c["bg"], c["Z"], c["llr"], c["nf"], c["crc"], c["max_iter"], out_init=init)
         o0 = int(descs[i]["out_offset"])
         if ito != its[i] or not np.array_equal(oo, out[o0:o0 + nb]):
             bad.append((i, c["bg"], c["Z"], c["crc"], c["max_iter"], c["nf"], c["llr"].size, ito, int(its[i]),
@@ -66,13 +105,20 @@ def run_batch(ctx, cases):
     return bad
 
 
-def test_all_graphs_noisy(ctx):
-    """Every base graph x lifting size (the 102 cases of ldpc_enc_dec_test.cpp:226-320), three input lengths,
-    with/without CRC early stop."""
-    rng = np.random.default_rng(11)
+def run_per_size(ctx, cases, mode):
+    """One batch per (base graph, lifting size): the packed kernel then runs with the workgroup size of that lifting size (1, 2 or 3
+    wavefronts) and the message placement (LDS / global memory) its code rates select, instead of the geometry of the batch's largest."""
+    bad, used = [], 0
+    for key in sorted({(c["bg"], c["Z"]) for c in cases}):
+        sub = [c for c in cases if (c["bg"], c["Z"]) == key]
+        bad += run_batch(ctx, sub, mode)
+    return bad
+
+
+def graph_cases(rng, sizes):
     cases = []
     for bg in (1, 2):
-        for Z in ALL_Z:
+        for Z in sizes:
             K = BG_K[bg] * Z
             for trial in range(3):
                 nf = int(rng.integers(0, max(1, Z // 2))) if trial == 1 else 0
@@ -87,16 +133,53 @@ def test_all_graphs_noisy(ctx):
                 for crc in (poly, -1):
                     for mi in (1, 6):
                         cases.append(dict(bg=bg, Z=Z, llr=llr, crc=crc, max_iter=mi, nf=nf))
-    bad = run_batch(ctx, cases)
+                cases.append(dict(bg=bg, Z=Z, llr=llr, crc=poly, max_iter=4, nf=nf, flags=1))  # CRC after the last iteration only
+    return cases
+
+
+def test_all_graphs_noisy(ctx, ldpc_kernel):
+    """Every base graph x lifting size (the 102 cases of ldpc_enc_dec_test.cpp:226-320), three input lengths (full, shortest, between),
+    fillers, CRC early stop / no CRC / CRC after the last iteration -- as ONE heterogeneous batch (sizes 2 ... 384 side by side, odd ones
+    included: the packed kernel then runs with most lanes of a small codeblock idle) and as one batch per lifting size."""
+    rng = np.random.default_rng(11)
+    cases = graph_cases(rng, ALL_Z)
+    bad = run_batch(ctx, cases, ldpc_kernel)
+    assert not bad, bad[:10]
+    bad = run_per_size(ctx, cases, ldpc_kernel)
+    assert not bad, bad[:10]
+    bad = run_batch(ctx, cases[::7], ldpc_kernel, pad=5)  # codeblocks that start at any byte alignment
     assert not bad, bad[:10]
 
 
-def test_plus_minus_ten_and_zero(ctx):
-    """ldpc_enc_dec_test.cpp: +-10 LLRs from the encoded bits decode in one iteration; all-zero LLRs give nullopt and
-    all-ones output (only without a CRC)."""
-    rng = np.random.default_rng(12)
+def test_message_placement_of_the_packed_kernel(ctx, ldpc_kernel):
+    """The packed kernel keeps its check-to-variable messages in LDS at high code rates and in global memory (GMSG instance) where that
+    keeps more codeblocks per CU: both instances must be reached and agree with the oracle."""
+    if ldpc_kernel == "scalar":
+        return  # nothing to place: the one-row-per-lane kernel keeps compressed check-node state
+    rng = np.random.default_rng(17)
+    seen = set()
+    for bg, Z, nodes in ((2, 384, 12), (1, 384, 24), (1, 384, 66), (2, 384, 50), (1, 256, 66), (2, 128, 50), (1, 128, 24), (1, 72, 66)):
+        cases = []
+        for t in range(5):
+            msg, cw = make_codeword(bg, Z, rng)
+            llr = noisy_llr(cw[:nodes * Z], 0.55, rng)
+            cases.append(dict(bg=bg, Z=Z, llr=llr, crc=CRC24B, max_iter=6, nf=0))
+        kernels_used()
+        bad = run_batch(ctx, cases)
+        used = kernels_used()
+        assert not bad, (bg, Z, nodes, bad[:5])
+        assert used & PACKED
+        seen.add(used & GMSG)
+        if (bg, Z, nodes) == (2, 384, 12):
+            assert not used & GMSG  # 19 KB of LDS per codeblock: more fit a CU than the register file takes
+        if Z == 384 and nodes > 24:
+            assert used & GMSG
+    assert seen == {0, GMSG}
+
+
+def corner_cases(rng, sizes):
     cases = []
-    for bg, Z in ((1, 384), (1, 2), (2, 3), (2, 208), (1, 15), (2, 384), (1, 96)):
+    for bg, Z in sizes:
         K = BG_K[bg] * Z
         poly = CRC24B if K > 60 else CRC16
         msg, cw = make_codeword(bg, Z, rng, 0, poly)
@@ -104,31 +187,135 @@ def test_plus_minus_ten_and_zero(ctx):
         cases.append(dict(bg=bg, Z=Z, llr=llr, crc=poly, max_iter=1, nf=0))
         cases.append(dict(bg=bg, Z=Z, llr=np.zeros_like(llr), crc=-1, max_iter=6, nf=0))
         cases.append(dict(bg=bg, Z=Z, llr=np.zeros_like(llr), crc=poly, max_iter=6, nf=0))
-        # trailing zeros shorten the number of processed layers
-        l2 = llr.copy()
-        l2[K + 3 * Z + Z // 2:] = 0
-        cases.append(dict(bg=bg, Z=Z, llr=l2, crc=poly, max_iter=3, nf=0))
-    bad = run_batch(ctx, cases)
+        cases.append(dict(bg=bg, Z=Z, llr=np.zeros_like(llr), crc=poly, max_iter=6, nf=0, flags=1))
+        # trailing zeros shorten the number of processed layers (ldpc_decoder_impl.cpp:86-114)
+        for cut in (K + 3 * Z + Z // 2, K + 9 * Z + 1, BG_NS[bg] * Z - 1):
+            l2 = llr.copy()
+            l2[cut:] = 0
+            cases.append(dict(bg=bg, Z=Z, llr=l2, crc=poly, max_iter=3, nf=0))
+        # +-infinity: saturated inputs (every soft bit infinite), and a codeword whose systematic part is infinite
+        cases.append(dict(bg=bg, Z=Z, llr=(127 - 254 * (cw & 1).astype(np.int16)).astype(np.int8), crc=poly, max_iter=2, nf=0))
+        l3 = noisy_llr(cw, 0.8, rng)
+        l3[:K - 2 * Z] = (127 - 254 * (cw[:K - 2 * Z] & 1).astype(np.int16)).astype(np.int8)
+        cases.append(dict(bg=bg, Z=Z, llr=l3, crc=poly, max_iter=4, nf=0))
+        l4 = noisy_llr(cw, 0.5, rng)
+        l4[rng.random(l4.size) < 0.2] = -127  # wrong-signed infinities: sticky through every iteration
+        cases.append(dict(bg=bg, Z=Z, llr=l4, crc=poly, max_iter=5, nf=0))
+    return cases
+
+
+EVEN_LARGE = [(1, 384), (2, 384), (1, 352), (2, 320), (1, 288), (2, 256), (1, 240), (2, 208), (1, 192), (2, 176), (1, 160), (2, 144), (1, 128),
+              (2, 112), (1, 96), (2, 80), (1, 72)]
+SMALL_AND_ODD = [(1, 2), (2, 2), (2, 3), (1, 3), (1, 5), (2, 7), (1, 9), (2, 11), (1, 13), (1, 15), (2, 15), (1, 16), (2, 22), (1, 30), (2, 36),
+                 (1, 44), (2, 52), (1, 60), (2, 64), (1, 64)]
+
+
+@pytest.mark.parametrize("sizes", ["even_large", "small_and_odd"])
+def test_plus_minus_ten_zero_tail_and_infinities(ctx, ldpc_kernel, sizes):
+    """ldpc_enc_dec_test.cpp: +-10 LLRs from the encoded bits decode in one iteration; all-zero LLRs give nullopt and all-ones output
+    (only without a CRC); zero tails cut the layer loop (ldpc_decoder_impl.cpp:86-114); +-127 inputs run the infinity rule of
+    ldpc_decoder_avx2.cpp:85-105,205-243. Every even lifting size above 64 -- the packed kernel's domain -- and the small / odd ones
+    (wave kernel), per lifting size and as one batch."""
+    rng = np.random.default_rng(12)
+    cases = corner_cases(rng, EVEN_LARGE if sizes == "even_large" else SMALL_AND_ODD)
+    bad = run_per_size(ctx, cases, ldpc_kernel)
+    assert not bad, bad[:10]
+    bad = run_batch(ctx, cases, ldpc_kernel)
     assert not bad, bad[:10]
 
 
-def test_full_range_random_llrs(ctx):
+@pytest.mark.parametrize("sizes", ["even_large", "small_and_odd"])
+def test_full_range_random_llrs(ctx, ldpc_kernel, sizes):
     """Arbitrary int8 inputs in [-127,127] including +-infinity: exercises clamp / promotion / infinity stickiness."""
     rng = np.random.default_rng(13)
     cases = []
-    for bg, Z in ((1, 384), (2, 384), (1, 352), (2, 64), (1, 36), (2, 7), (1, 5)):
+    for bg, Z in (EVEN_LARGE[:10] if sizes == "even_large" else SMALL_AND_ODD):
         for t in range(4):
-            n = BG_NS[bg] * Z
+            n = BG_NS[bg] * Z if t != 2 else (BG_K[bg] + 7) * Z
             r = rng.integers(-127, 128, n).astype(np.int8)
             r[rng.random(n) < 0.05] = 127
             r[rng.random(n) < 0.05] = -127
             r[rng.random(n) < 0.1] = 0
-            cases.append(dict(bg=bg, Z=Z, llr=r, crc=[-1, CRC24A, CRC16, CRC24B][t], max_iter=[2, 4, 6, 10][t], nf=0))
-    bad = run_batch(ctx, cases)
+            K = BG_K[bg] * Z
+            crc = [-1, CRC24A, CRC16, CRC24B][t] if K > 60 else [-1, CRC16, CRC16, -1][t]
+            cases.append(dict(bg=bg, Z=Z, llr=r, crc=crc, max_iter=[2, 4, 6, 10][t], nf=0))
+    bad = run_per_size(ctx, cases, ldpc_kernel)
+    assert not bad, bad[:10]
+    bad = run_batch(ctx, cases, ldpc_kernel)
     assert not bad, bad[:10]
 
 
-def test_large_uniform_batch_device_descs(ctx):
+def test_wave_kernel_full_bundles(ctx, ldpc_kernel):
+    """Z <= 64: a wavefront decodes a bundle of floor(64 / ceil(Z / 2)) codeblocks of one lifting size. Many codeblocks per size (full
+    bundles and a ragged last one) that differ in input length, fillers, noise (so their early stops fall in different iterations),
+    with all-zero and saturated inputs among them."""
+    rng = np.random.default_rng(19)
+    cases = []
+    for bg, Z, count in ((1, 2, 150), (2, 3, 70), (1, 5, 45), (2, 7, 40), (1, 15, 27), (2, 16, 27), (1, 22, 14), (2, 30, 14), (1, 32, 11),
+                         (2, 36, 11), (1, 44, 7), (2, 52, 7), (1, 60, 5), (2, 64, 5)):
+        K = BG_K[bg] * Z
+        poly = CRC24B if K > 60 else CRC16
+        for i in range(count):
+            nf = int(rng.integers(0, Z // 2 + 1)) if (i % 3 == 1 and K - Z // 2 > 30) else 0
+            msg, cw = make_codeword(bg, Z, rng, nf, poly)
+            nodes = int(rng.integers(BG_K[bg] + 2, BG_NS[bg] + 1))
+            llr = noisy_llr(cw[:nodes * Z], float(rng.choice([0.2, 0.5, 0.8, 1.1])), rng)
+            if nf:
+                llr[K - 2 * Z - nf:K - 2 * Z] = 127
+            if i % 11 == 5:
+                llr[:] = 0
+            if i % 13 == 7:
+                llr = (127 - 254 * (cw[:nodes * Z] & 1).astype(np.int16)).astype(np.int8)
+            cases.append(dict(bg=bg, Z=Z, llr=llr, crc=poly, max_iter=6, nf=nf))
+    bad = run_batch(ctx, cases, ldpc_kernel, pad=1)
+    assert not bad, bad[:10]
+    rng.shuffle(cases)
+    for c in cases[::3]:
+        c["flags"] = 1
+    bad = run_batch(ctx, cases[:200], ldpc_kernel)
+    assert not bad, bad[:10]
+
+
+def test_mixed_odd_and_even_device_descriptors(ctx, ldpc_kernel):
+    """Device-resident descriptors that mix odd lifting sizes (small transport blocks) with Z = 384 under limits that only name the
+    largest one: ONE launch of the packed kernel, in which an odd-Z codeblock folds its unpaired last row onto itself."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(23)
+    cases = []
+    for bg, Z in ((1, 384), (2, 3), (1, 5), (2, 7), (1, 9), (2, 11), (1, 13), (2, 15), (1, 15), (2, 384), (1, 3), (2, 208)):
+        K = BG_K[bg] * Z
+        poly = CRC24B if K > 60 else CRC16
+        for t in range(2):
+            msg, cw = make_codeword(bg, Z, rng, 0, poly)
+            nodes = BG_NS[bg] if t == 0 else BG_K[bg] + 4
+            cases.append(dict(bg=bg, Z=Z, llr=noisy_llr(cw[:nodes * Z], 0.6, rng), crc=poly if t == 0 else -1, max_iter=5, nf=0))
+    n = len(cases)
+    descs = np.zeros(n, dtype=miphy.LdpcDecDesc)
+    llr_off, out_off = 0, 0
+    for i, c in enumerate(cases):
+        descs[i] = (c["bg"], c["crc"] if c["crc"] >= 0 else miphy.CRC_NONE, c["Z"], c["max_iter"], 0, c["llr"].size, 0, llr_off, out_off)
+        llr_off += c["llr"].size
+        out_off += (BG_K[c["bg"]] * c["Z"] + 7) // 8
+    d_descs = torch.from_numpy(descs.view(np.uint8)).cuda()
+    llr_d = torch.from_numpy(np.concatenate([c["llr"] for c in cases])).cuda()
+    out_d = torch.full((out_off,), 0x5A, dtype=torch.uint8, device="cuda")
+    it_d = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    n_max = max((c["llr"].size + 2 * c["Z"] + c["Z"] - 1) // c["Z"] for c in cases)
+    kernels_used()
+    ctx.ldpc_decode_batch(d_descs, llr_d, out_d, it_d, limits=(384, (n_max - 2) * 384))
+    torch.cuda.synchronize()
+    used = kernels_used()
+    assert used == (SCALAR if ldpc_kernel == "scalar" else PACKED | (used & GMSG)), used
+    out, its = out_d.cpu().numpy(), it_d.cpu().numpy()
+    for i, c in enumerate(cases):
+        nb = (BG_K[c["bg"]] * c["Z"] + 7) // 8
+        ito, oo = o_ldpc_decode(c["bg"], c["Z"], c["llr"], 0, c["crc"], c["max_iter"], out_init=np.full(nb, 0x5A, np.uint8))
+        o0 = int(descs[i]["out_offset"])
+        assert ito == its[i] and np.array_equal(oo, out[o0:o0 + nb]), (i, c["bg"], c["Z"], ito, int(its[i]))
+
+
+def test_large_uniform_batch_device_descs(ctx, ldpc_kernel):
     """BASELINE config: BG1 Z=384 rate ~0.88 codeblocks (4 layers), 6 iterations, device-resident descriptors."""
     import torch
     import miphy
@@ -146,16 +333,20 @@ def test_large_uniform_batch_device_descs(ctx):
         msgs.append(msg)
     idx = rng.integers(0, n_unique, n)
     batch = llrs[idx]
-    descs = make_dec_descs(n, bg, Z, N, miphy.CRC24B, 6, nf)
+    in_len = (E + Z - 1) // Z * Z  # 24 nodes of input: the four layers of the headline codeblock
+    descs = make_dec_descs(n, bg, Z, in_len, miphy.CRC24B, 6, nf, llr_stride=N)
     d_descs = torch.from_numpy(descs.view(np.uint8)).cuda()
     llr_d = torch.from_numpy(batch.reshape(-1)).cuda()
     out_d = torch.zeros(n * K // 8, dtype=torch.uint8, device="cuda")
     it_d = torch.zeros(n, dtype=torch.int32, device="cuda")
-    ctx.ldpc_decode_batch(d_descs, llr_d, out_d, it_d)
+    kernels_used()
+    ctx.ldpc_decode_batch(d_descs, llr_d, out_d, it_d, limits=(Z, in_len))
     torch.cuda.synchronize()
+    used = kernels_used()
+    assert (used == SCALAR) if ldpc_kernel == "scalar" else (used & PACKED and not used & (SCALAR | WAVE)), used
     out = out_d.cpu().numpy().reshape(n, K // 8)
     its = it_d.cpu().numpy()
-    exp = [o_ldpc_decode(bg, Z, llrs[u], nf, CRC24B, 6) for u in range(n_unique)]
+    exp = [o_ldpc_decode(bg, Z, llrs[u][:in_len], nf, CRC24B, 6) for u in range(n_unique)]
     for i in range(n):
         assert its[i] == exp[idx[i]][0]
         assert np.array_equal(out[i], exp[idx[i]][1])

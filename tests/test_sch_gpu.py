@@ -66,8 +66,9 @@ def test_pusch_decode_batch_with_harq(ctx, early_stop, max_iter):
             tb = rng.integers(0, 256, tbs_bits // 8, dtype=np.uint8)
             seg = o_segmentation(tbs_bits, bg, mod, nl, nsym)
             llrs = [noisy(o_pdsch_encode(bg, rv, mod, 0, nl, nsym, tb), sigma, rng) for rv in rvs]
-            tbs.append(dict(bg=bg, mod=mod, nl=nl, nsym=nsym, tb=tb, llrs=llrs, slot=slot, ncb=seg.nof_cbs,
-                            od=OraclePuschDecoder(bg, mod, 0, nl, nsym, tbs_bits // 8)))
+            od = OraclePuschDecoder(bg, mod, 0, nl, nsym, tbs_bits // 8)
+            od.softbuf[:] = 33  # the same stale garbage as the device buffers
+            tbs.append(dict(bg=bg, mod=mod, nl=nl, nsym=nsym, tb=tb, llrs=llrs, slot=slot, ncb=seg.nof_cbs, od=od))
             slot += seg.nof_cbs
     n = len(tbs)
     soft_d = torch.full((slot * miphy.HARQ_CB_STRIDE,), 33, dtype=torch.int8, device="cuda")  # stale garbage, new_data must cope
@@ -87,6 +88,7 @@ def test_pusch_decode_batch_with_harq(ctx, early_stop, max_iter):
         torch.cuda.synchronize()
         res = res_d.cpu().numpy().view(miphy.PuschResult)
         tb_out = tb_d.cpu().numpy()
+        soft = soft_d.cpu().numpy().reshape(slot, miphy.HARQ_CB_STRIDE)
         for i, x in enumerate(tbs):
             ok, tbo, mm = x["od"].decode(x["llrs"][t], rv, t == 0, max_iter, bool(early_stop))
             r = res[i]
@@ -100,6 +102,12 @@ def test_pusch_decode_batch_with_harq(ctx, early_stop, max_iter):
                 assert np.array_equal(got, tbo) and np.array_equal(got, x["tb"]), key
             elif not np.all(x["od"].cb_crc):
                 assert np.all(got == 0xEE), key  # untouched unless every codeblock passed
+            # the HARQ soft buffers hold what the reference's dematcher leaves there, whichever launch class dematched the codeblock
+            # (inside the packed decoder for first transmissions with Z >= 128, the dematcher kernel for the rest)
+            N = x["od"].softbuf.size // x["ncb"]
+            exp_soft = x["od"].softbuf.reshape(x["ncb"], N)
+            for c in range(x["ncb"]):
+                assert np.array_equal(soft[x["slot"] + c, :N], exp_soft[c]), (key, c)
 
 
 FUSABLE = [  # bg, mod, nof_layers, nprb, tbs bits, sigma: every codeblock Z >= 128 (a multiple of 16), rv 0 fits the circular buffer
@@ -149,8 +157,13 @@ def test_first_transmission_dematched_by_the_decoder(ctx, early_stop):
             tb_off += x["tb"].size
         tb_d = torch.full((tb_off,), 0xEE, dtype=torch.uint8, device="cuda")
         llr_all = np.concatenate([np.zeros(3, np.int8)] + chunks)  # every codeword starts at an odd offset
+        miphy.lib().miphy_debug_ldpc_kernels_used(1)
         ctx.pusch_decode_batch(d, torch.from_numpy(llr_all).cuda(), soft_d, msgs_d, crc_d, tb_d, res_d)
         torch.cuda.synchronize()
+        used = int(miphy.lib().miphy_debug_ldpc_kernels_used(1))
+        # first transmissions: the packed kernel dematches while it loads (FUSED), with the messages in LDS for the high-rate classes
+        # and in global memory (GMSG) for the rate-1/3 one; the retransmission runs the dematcher as a launch of its own
+        assert used == ((2 | 4 | 8) if t == 0 else (2 | 8)), used
         res = res_d.cpu().numpy().view(miphy.PuschResult)
         tb_out = tb_d.cpu().numpy()
         soft = soft_d.cpu().numpy().reshape(slot, miphy.HARQ_CB_STRIDE)
