@@ -99,6 +99,14 @@ int miphy_ldpc_decode_batch(miphy_ctx*                 ctx,
                             int32_t*                   iters,    /* device, n entries */
                             const miphy_ldpc_dec_limits* limits, /* may be NULL */
                             void*                      stream);
+/* Prepared form of miphy_ldpc_decode_batch for batches whose geometry repeats (same descriptors slot after slot): the descriptors
+ * are validated, sorted into launch classes and uploaded once; a run only launches (no host synchronisation, no staging). */
+typedef struct miphy_ldpc_decode_plan miphy_ldpc_decode_plan;
+int      miphy_ldpc_decode_plan_create(miphy_ctx* ctx, const miphy_ldpc_dec_desc* descs /* host */, uint32_t n, miphy_ldpc_decode_plan** out);
+int      miphy_ldpc_decode_plan_run(miphy_ldpc_decode_plan* plan, const int8_t* llr, uint8_t* out_bits, int32_t* iters, void* stream);
+uint32_t miphy_ldpc_decode_plan_nof_launches(const miphy_ldpc_decode_plan* plan); /* kernel launches per run = launch classes */
+void     miphy_ldpc_decode_plan_destroy(miphy_ldpc_decode_plan* plan);
+
 /* Test / A-B knob: 0 = automatic choice (host descriptors: sorted into launch classes by lifting size and code rate, one launch per
  * class; device descriptors: one launch), 1 = one-row-per-lane kernel, 2 = packed two-rows-per-lane kernel as one launch,
  * 3 = class-sorted launches. All kernels produce identical results. */

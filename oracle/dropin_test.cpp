@@ -1125,6 +1125,30 @@ static void test_downlink_processor(std::shared_ptr<miphy::context> c)
   dl.finish_processing_pdus();
   CHECK(gw.count == 2, "downlink_processor: sent without a grid");
   printf("downlink_processor (slot batch) done, failures so far %d\n", failures);
+  // Back-to-back reuse: the pool hands the processor out again the moment is_reserved() reads false. A slot that is configured and
+  // finished right then must not lose its grid to the completion thread still tidying up the previous one (the reservation is
+  // released last, under the lock): every slot's grid is sent exactly once and the processor never stays reserved.
+  {
+    const unsigned base = gw.count, slots = 300;
+    auto           g    = create_resource_grid(nof_ports, 14, nsc);
+    unsigned       stuck = 0;
+    for (unsigned k = 0; k != slots && !stuck; ++k) {
+      resource_grid_context ctx;
+      ctx.slot = slot_point(1, k % 20), ctx.sector = 3;
+      dl.configure_resource_grid(ctx, *g);
+      dl.finish_processing_pdus(); // no PDU: the completion thread only sends the grid
+      unsigned spin = 0;
+      while (dl.is_reserved() && spin != 2000000) {
+        ++spin; // busy wait: reconfigure in the very instant the flag flips
+      }
+      stuck += dl.is_reserved();
+    }
+    CHECK(stuck == 0, "downlink_processor: processor stayed reserved in back-to-back reuse");
+    for (unsigned spin = 0; gw.count != base + slots && spin != 2000; ++spin) {
+      std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    CHECK(gw.count == base + slots, "downlink_processor: %u of %u back-to-back slots reached the gateway", gw.count - base, slots);
+  }
 }
 
 // Block error behaviour at moderate SNR: many random slots through the all-software processor and through the fused HIP processor,

@@ -71,11 +71,14 @@ inline void require(bool condition, const char* fmtstr, Args&&... args)
 class context
 {
 public:
-  explicit context(int device = 0)
+  explicit context(int device_ = 0) : device(device_)
   {
-    check(miphy_create(device, &ctx), "miphy_create");
+    check(miphy_create(device, &ctx), "miphy_create"); // makes `device` the calling thread's current device
     hip(hipStreamCreate(&stream), "hipStreamCreate");
   }
+  /// Makes the context's device the current one of the calling thread. A new thread starts on device 0: every thread that
+  /// drives this context (allocations in buf(), the library's workspaces, launches) has to call this first.
+  void bind_thread() const { hip(hipSetDevice(device), "hipSetDevice"); }
   ~context()
   {
     for (auto& b : bufs) {
@@ -119,6 +122,7 @@ public:
 
   miphy_ctx*  ctx    = nullptr;
   hipStream_t stream = nullptr;
+  const int   device;
 
 private:
   struct dbuf {
@@ -1239,7 +1243,8 @@ public:
     linger(std::chrono::microseconds(linger_us))
   {
     if (linger_us != 0) {
-      wc     = std::make_shared<context>(device_of(*this->c)); // the delivery thread drives the device through its own context
+      wc     = std::make_shared<context>(this->c->device); // the delivery thread drives the caller's device through its own context
+      this->c->bind_thread();                              // (creating it left wc's device current, which is the same one)
       worker = std::thread([this]() { deliver_loop(); });
     }
   }
@@ -1349,12 +1354,6 @@ public:
 private:
   struct entry;
   struct batch;
-  static int device_of(const context&)
-  {
-    int d = 0;
-    (void)hipGetDevice(&d);
-    return d;
-  }
   // Moves the open batch to the ready list (asynchronous mode) or runs it in place (synchronous mode). Called with the lock held.
   void close_open_batch(std::unique_lock<std::mutex>& lk)
   {
@@ -1370,6 +1369,7 @@ private:
   }
   void deliver_loop()
   {
+    wc->bind_thread(); // a new thread starts on device 0
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
       if (ready.empty() && !open.entries.empty()) {
@@ -2027,9 +2027,7 @@ public:
                          unsigned                                      grid_nof_prb) :
     c(std::move(c)), gateway(gateway), pdcch(std::move(pdcch)), ssb(std::move(ssb)), csi_rs(std::move(csi_rs)), nports(grid_nof_ports), nprb(grid_nof_prb)
   {
-    int dev = 0;
-    (void)hipGetDevice(&dev); // the device the caller's context was created on is the current one
-    wc     = std::make_shared<context>(dev); // the completion thread drives the device through its own context and stream
+    wc     = std::make_shared<context>(this->c->device); // the completion thread drives the caller's device through its own context and stream
     worker = std::thread([this] { completion_loop(); });
   }
 
@@ -2114,6 +2112,7 @@ public:
 private:
   void completion_loop()
   {
+    wc->bind_thread(); // a new thread starts on device 0
     std::unique_lock<std::mutex> lk(mtx);
     for (;;) {
       cv.wait(lk, [this] { return pending || stop; });
@@ -2121,10 +2120,13 @@ private:
         lk.unlock();
         run_pdsch_batch();
         gateway.send(rg_context, *grid);
-        grid = nullptr;
-        reserved.store(false, std::memory_order_release);
         lk.lock();
+        // Everything of this slot is cleared BEFORE the reservation is released: once is_reserved() reads false the pool may hand the
+        // processor out again, and the next slot's configure_resource_grid() / finish_processing_pdus() set `grid` and `pending` anew --
+        // nothing written here may come after that.
+        grid    = nullptr;
         pending = false;
+        reserved.store(false, std::memory_order_release);
         cv.notify_all();
         continue;
       }

@@ -17,6 +17,7 @@
 #include "miphy_internal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -714,4 +715,77 @@ extern "C" int miphy_ldpc_decode_batch(miphy_ctx*                   ctx,
                                        void*                        stream)
 {
   return miphy_ldpc_decode_launch(ctx, descs, descs_on_device, n, llr, out_bits, iters, limits, nullptr, nullptr, stream);
+}
+
+// ---- prepared form: descriptors validated, sorted into launch classes and uploaded once; every run is launches only -------------------
+struct miphy_ldpc_decode_plan {
+  miphy_ctx*         ctx;
+  uint32_t           n;
+  miphy_ldpc_classes cls; // classes only (order / bundles live in d_buf)
+  void*              d_buf;
+  const miphy_ldpc_dec_desc* d_descs;
+  const uint32_t*    d_order;
+  const uint32_t*    d_bundles;
+};
+
+extern "C" int miphy_ldpc_decode_plan_create(miphy_ctx* ctx, const miphy_ldpc_dec_desc* descs, uint32_t n, miphy_ldpc_decode_plan** out)
+{
+  MIPHY_REQUIRE(ctx && descs && out && n > 0, "miphy_ldpc_decode_plan_create: null argument or empty batch");
+  for (uint32_t i = 0; i < n; ++i) {
+    const miphy_ldpc_dec_desc& d = descs[i];
+    MIPHY_REQUIRE(d.bg == 1 || d.bg == 2, "ldpc_decode: desc %u: invalid base graph %u", i, d.bg);
+    MIPHY_REQUIRE(d.Z <= MIPHY_MAX_Z && ctx->h_tables->z_pos[d.Z] != 0xffff, "ldpc_decode: desc %u: invalid lifting size %u", i, d.Z);
+    const unsigned bgK = (d.bg == 1) ? 22 : 10, nshort = (d.bg == 1) ? 66 : 50;
+    MIPHY_REQUIRE(d.in_len >= (bgK + 2) * d.Z && d.in_len <= nshort * d.Z, "ldpc_decode: desc %u: input length %u out of range", i, d.in_len);
+    MIPHY_REQUIRE(d.max_iter > 0, "ldpc_decode: desc %u: max_iter must be > 0", i);
+    MIPHY_REQUIRE(d.crc_poly == MIPHY_CRC_NONE || d.crc_poly <= MIPHY_CRC11, "ldpc_decode: desc %u: invalid CRC", i);
+    MIPHY_REQUIRE(d.nof_filler_bits < bgK * d.Z, "ldpc_decode: desc %u: invalid number of filler bits", i);
+  }
+  auto* p = new miphy_ldpc_decode_plan();
+  p->ctx = ctx, p->n = n, p->d_buf = nullptr;
+  miphy_ldpc_build_classes(descs, n, nullptr, p->cls);
+  const size_t b0 = sizeof(miphy_ldpc_dec_desc) * (size_t)n, b1 = 4 * (size_t)n, b2 = 4 * p->cls.bundles.size();
+  std::vector<uint8_t> host(b0 + b1 + b2);
+  memcpy(host.data(), descs, b0);
+  memcpy(host.data() + b0, p->cls.order.data(), b1);
+  if (b2)
+    memcpy(host.data() + b0 + b1, p->cls.bundles.data(), b2);
+  hipError_t e = hipMalloc(&p->d_buf, host.size());
+  if (e == hipSuccess)
+    e = hipMemcpy(p->d_buf, host.data(), host.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    miphy_set_error("miphy_ldpc_decode_plan_create: %s", hipGetErrorString(e));
+    if (p->d_buf)
+      (void)hipFree(p->d_buf);
+    delete p;
+    return MIPHY_EHIP;
+  }
+  p->d_descs   = reinterpret_cast<const miphy_ldpc_dec_desc*>(p->d_buf);
+  p->d_order   = reinterpret_cast<const uint32_t*>((uint8_t*)p->d_buf + b0);
+  p->d_bundles = reinterpret_cast<const uint32_t*>((uint8_t*)p->d_buf + b0 + b1);
+  std::vector<uint32_t>().swap(p->cls.order);
+  std::vector<uint32_t>().swap(p->cls.bundles);
+  *out = p;
+  return MIPHY_OK;
+}
+
+extern "C" int miphy_ldpc_decode_plan_run(miphy_ldpc_decode_plan* p, const int8_t* llr, uint8_t* out_bits, int32_t* iters, void* stream)
+{
+  MIPHY_REQUIRE(p && llr && out_bits && iters, "miphy_ldpc_decode_plan_run: null argument");
+  return miphy_ldpc_decode_classes_launch(p->ctx, p->d_descs, p->cls, p->d_order, p->d_bundles, llr, out_bits, iters, nullptr, nullptr, (hipStream_t)stream,
+                                          nullptr, nullptr, false);
+}
+
+extern "C" uint32_t miphy_ldpc_decode_plan_nof_launches(const miphy_ldpc_decode_plan* p)
+{
+  return p ? (uint32_t)p->cls.classes.size() : 0u;
+}
+
+extern "C" void miphy_ldpc_decode_plan_destroy(miphy_ldpc_decode_plan* p)
+{
+  if (!p)
+    return;
+  if (p->d_buf)
+    (void)hipFree(p->d_buf);
+  delete p;
 }

@@ -199,14 +199,36 @@ int miphy_next_queue_counter(miphy_ctx* ctx, uint32_t** out)
 }
 
 // Front-to-back allocation in the staging ring. Regions handed out since the last wrap are never overwritten; on a wrap every
-// consumer of the old regions must be done, whatever stream it ran on, hence the device-wide synchronisation (once per
-// desc_staging_bytes of descriptors, not once per call).
-static int staging_take(miphy_ctx* ctx, size_t bytes, size_t* off)
+// consumer of the old regions must be done. The consumers run on the streams the regions were staged for, so the wrap waits for
+// THOSE streams (up to four are remembered between wraps; more than that falls back to the device-wide wait) -- not for the other
+// contexts and cells that share the device -- once per desc_staging_bytes of descriptors, not once per call. A stream that is being
+// captured cannot be waited for: the wrap then fails with MIPHY_EUNSUPP (capture with device-resident descriptors or a prepared plan).
+static int staging_take(miphy_ctx* ctx, size_t bytes, hipStream_t s, size_t* off)
 {
   const size_t need = (bytes + 255) & ~(size_t)255;
   if (ctx->staging_head + need > ctx->desc_staging_bytes) {
-    MIPHY_HIP_CHECK(hipDeviceSynchronize());
-    ctx->staging_head = 0;
+    if (ctx->nof_ring_streams > 4) {
+      MIPHY_HIP_CHECK(hipDeviceSynchronize());
+    } else {
+      for (int i = 0; i < ctx->nof_ring_streams; ++i) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (ctx->ring_streams[i] && hipStreamIsCapturing((hipStream_t)ctx->ring_streams[i], &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+          miphy_set_error("descriptor staging ring wrapped while a stream that consumes it is being captured");
+          return MIPHY_EUNSUPP;
+        }
+        MIPHY_HIP_CHECK(hipStreamSynchronize((hipStream_t)ctx->ring_streams[i]));
+      }
+    }
+    ctx->staging_head     = 0;
+    ctx->nof_ring_streams = 0;
+  }
+  int k = 0;
+  while (k < ctx->nof_ring_streams && k < 4 && ctx->ring_streams[k] != (void*)s)
+    ++k;
+  if (k == ctx->nof_ring_streams || k == 4) {
+    if (k < 4)
+      ctx->ring_streams[k] = (void*)s;
+    ctx->nof_ring_streams = k < 4 ? k + 1 : 5;
   }
   *off = ctx->staging_head;
   ctx->staging_head += need;
@@ -221,7 +243,7 @@ int miphy_stage_descs(miphy_ctx* ctx, const void* descs, int on_device, size_t b
   }
   MIPHY_REQUIRE(bytes <= ctx->desc_staging_bytes, "descriptor batch too large (%zu bytes > %zu)", bytes, ctx->desc_staging_bytes);
   size_t off = 0;
-  int    rc  = staging_take(ctx, bytes, &off);
+  int    rc  = staging_take(ctx, bytes, s, &off);
   if (rc)
     return rc;
   uint8_t* h = static_cast<uint8_t*>(ctx->h_desc_staging) + off;
@@ -242,7 +264,7 @@ int miphy_upload(miphy_ctx* ctx, void* dst, const void* src, size_t bytes, hipSt
     return MIPHY_OK;
   }
   size_t off = 0;
-  int    rc  = staging_take(ctx, bytes, &off);
+  int    rc  = staging_take(ctx, bytes, s, &off);
   if (rc)
     return rc;
   uint8_t* h = static_cast<uint8_t*>(ctx->h_desc_staging) + off;

@@ -56,6 +56,8 @@ struct miphy_ctx {
   size_t               desc_staging_bytes; // handed out front to back (miphy_stage_descs, miphy_upload); the device is synchronised only when
   void*                h_desc_staging; // pinned    // the ring wraps, so a call with host descriptors never waits for the stream
   size_t               staging_head;
+  void*                ring_streams[4]; // streams that regions of the ring were staged for since its last wrap (the wrap waits for them)
+  int                  nof_ring_streams; // 5 = more than four
   void*                d_work[5];      // scratch workspaces, grown on demand: [0] the transport-block level entry points, DFT, polar;
   size_t               work_bytes[5];  // [1] intermediate buffers of miphy_pusch_process_batch, [2] codewords of miphy_pdsch_process_batch,
                                        // [3] check-to-variable messages of the LDPC decoder when they do not stay in LDS,

@@ -122,7 +122,10 @@ extern "C" int miphy_pusch_process_batch_ex(miphy_ctx* ctx, const miphy_pusch_pd
       sch_llr_offset = sch_bytes; // relative to the SCH region, rebased below
       sch_bytes += (nof_sch_llr + 15u) & ~15u;
     }
-    if (!u || u->has_codeword || !has_uci) {
+    // include/miphy.h: has_codeword = 0 means the PDU carries no transport block -- whatever its UCI fields say. A PDU with neither is
+    // not a PUSCH transmission.
+    MIPHY_REQUIRE(!u || u->has_codeword || has_uci, "pusch_process: PDU %u: neither a codeword nor UCI", i);
+    if (!u || u->has_codeword) {
       miphy_pusch_tb_desc t = {};
       t.bg = p.bg, t.rv = p.rv, t.mod = p.mod, t.nof_layers = 1, t.new_data = p.new_data, t.use_early_stop = p.use_early_stop;
       t.nof_ldpc_iterations = p.nof_ldpc_iterations, t.Nref = p.Nref, t.nof_ch_symbols = nof_sch_llr / p.mod, t.tb_bytes = p.tb_bytes;

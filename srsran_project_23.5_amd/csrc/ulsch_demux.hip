@@ -83,6 +83,11 @@ int ulsch_plan_symbols(const miphy_ulsch_demux_job& j, ulsch_plan& out)
       }
     }
     m_rvd += rvd_n * bpr, m_ack += ack_n * bpr, m_c1 += c1_n * bpr, m_c2 += c2_n * bpr;
+    // the symbol plan stores strides and counts in 16 bits: a stride beyond that (a field of fewer bits than one element holds, on a
+    // wide allocation) must be refused, not truncated
+    MIPHY_REQUIRE(M <= 0xffffu && rvd_d <= 0xffffu && ack_d <= 0xffffu && c1_d <= 0xffffu && c2_d <= 0xffffu,
+                  "ulsch_demultiplex: symbol %u: stride out of range (%u reserved, %u HARQ-ACK, %u CSI-1, %u CSI-2, %u elements): field lengths must be multiples of the bits per element",
+                  l, rvd_d, ack_d, c1_d, c2_d, M);
     p.nof_re = (uint16_t)M;
     p.rvd_d = (uint16_t)rvd_d, p.rvd_cnt = (uint16_t)rvd_n, p.ack_d = (uint16_t)ack_d, p.ack_cnt = (uint16_t)ack_n;
     p.csi1_d = (uint16_t)c1_d, p.csi1_cnt = (uint16_t)c1_n, p.csi2_d = (uint16_t)c2_d, p.csi2_cnt = (uint16_t)c2_n;

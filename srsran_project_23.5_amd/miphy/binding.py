@@ -60,6 +60,14 @@ def lib():
         l.miphy_pusch_decode_plan_read_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_pusch_decode_plan_info.argtypes = [C.c_void_p, C.c_void_p]
         l.miphy_sch_segmentation_info.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+        l.miphy_ldpc_decode_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        l.miphy_ldpc_decode_plan_run.argtypes = [C.c_void_p] * 5
+        l.miphy_ldpc_decode_plan_nof_launches.argtypes = [C.c_void_p]
+        l.miphy_ldpc_decode_plan_nof_launches.restype = C.c_uint32
+        l.miphy_ldpc_decode_plan_destroy.argtypes = [C.c_void_p]
+        l.miphy_ldpc_decode_plan_destroy.restype = None
+        l.miphy_debug_ldpc_kernels_used.argtypes = [C.c_int]
+        l.miphy_debug_ldpc_kernels_used.restype = C.c_uint32
         l.miphy_polar_decode_list_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_pbch_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -588,6 +596,35 @@ class Context:
         check(lib().miphy_polar_decode_list_batch(self.h, C.byref(code), list_size, crc_mode, n, _dptr(llr),
                                                   _dptr(rnti) if rnti is not None else None, _dptr(msg_out), _dptr(crc_ok_out),
                                                   _dptr(metric_out) if metric_out is not None else None, _stream_ptr(stream)))
+
+
+class LdpcDecodePlan:
+    """miphy_ldpc_decode_plan_*: codeblock descriptors validated, sorted into launch classes and uploaded once; run() is launches only."""
+
+    def __init__(self, ctx, descs):
+        assert isinstance(descs, np.ndarray) and descs.dtype == LdpcDecDesc
+        descs = np.ascontiguousarray(descs)
+        self.ctx, self.n = ctx, descs.size
+        h = C.c_void_p()
+        check(lib().miphy_ldpc_decode_plan_create(ctx.h, C.c_void_p(descs.ctypes.data), descs.size, C.byref(h)))
+        self.h = h
+
+    def run(self, llr, out_bits, iters, stream=None):
+        check(lib().miphy_ldpc_decode_plan_run(self.h, _dptr(llr), _dptr(out_bits), _dptr(iters), _stream_ptr(stream)))
+
+    def nof_launches(self):
+        return int(lib().miphy_ldpc_decode_plan_nof_launches(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().miphy_ldpc_decode_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PuschDecodePlan:

@@ -423,3 +423,44 @@ def test_many_launches_queued_back_to_back(ctx, ldpc_kernel):
             assert its[base + i] == it, (l, i)
             assert np.array_equal(out[base + i], packed[:nb]), (l, i)
         base += int(sizes[l])
+
+
+def test_prepared_plan_matches_the_batch_call(ctx, ldpc_kernel):
+    """miphy_ldpc_decode_plan_*: the class-sorted launches of a heterogeneous batch prepared once and run twice (the second time on
+    other inputs) give the oracle's results; the plan reports one launch per class."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(29)
+    cases = graph_cases(rng, (2, 7, 15, 16, 36, 64, 72, 128, 144, 256, 352, 384))
+    rng.shuffle(cases)
+    n = len(cases)
+    descs = np.zeros(n, dtype=miphy.LdpcDecDesc)
+    llr_off, out_off = 0, 0
+    for i, c in enumerate(cases):
+        descs[i] = (c["bg"], c["crc"] if c["crc"] >= 0 else miphy.CRC_NONE, c["Z"], c["max_iter"], c["nf"], c["llr"].size, c.get("flags", 0), llr_off, out_off)
+        llr_off += c["llr"].size
+        out_off += (BG_K[c["bg"]] * c["Z"] + 7) // 8
+    plan = miphy.LdpcDecodePlan(ctx, descs)
+    assert 2 <= plan.nof_launches() <= 60
+    for rep in range(2):
+        if rep == 1:  # same geometry, other soft bits: sign flips keep the zero / infinity structure of every case
+            for c in cases:
+                flip = rng.random(c["llr"].size) < 0.03
+                c["llr"] = np.where(flip, -c["llr"], c["llr"]).astype(np.int8)
+        llr_d = torch.from_numpy(np.concatenate([c["llr"] for c in cases])).cuda()
+        out_d = torch.full((out_off,), 0x5A, dtype=torch.uint8, device="cuda")
+        it_d = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        kernels_used()
+        plan.run(llr_d, out_d, it_d)
+        torch.cuda.synchronize()
+        used = kernels_used()
+        assert (used == SCALAR) if ldpc_kernel == "scalar" else (used & PACKED and used & WAVE and not used & SCALAR), used
+        out, its = out_d.cpu().numpy(), it_d.cpu().numpy()
+        for i, c in enumerate(cases):
+            if c.get("flags", 0) & 1:
+                continue  # covered by run_batch
+            nb = (BG_K[c["bg"]] * c["Z"] + 7) // 8
+            ito, oo = o_ldpc_decode(c["bg"], c["Z"], c["llr"], c["nf"], c["crc"], c["max_iter"], out_init=np.full(nb, 0x5A, np.uint8))
+            o0 = int(descs[i]["out_offset"])
+            assert ito == its[i] and np.array_equal(oo, out[o0:o0 + nb]), (rep, i, c["bg"], c["Z"], ito, int(its[i]))
+    plan.close()
