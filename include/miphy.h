@@ -598,6 +598,9 @@ int  miphy_pusch_decode_plan_read_timing(miphy_pusch_decode_plan* plan, float ms
  * kernel reads the rate-matched LLRs and writes the soft-buffer image; the "rate dematch" time of _read_timing is then only the HARQ
  * flag reset), 0 when the dematcher runs as its own launch, info[2] = largest number of variable nodes a codeblock can reach. */
 int  miphy_pusch_decode_plan_info(const miphy_pusch_decode_plan* plan, uint32_t info[3]);
+/* LDPC decoder launches per run: the codeblocks of the batch are sorted into launch classes (lifting size, base graph, reachable
+ * layers, dematch-in-decoder or not), one launch each. A batch of identical allocations has one. */
+uint32_t miphy_pusch_decode_plan_nof_launches(const miphy_pusch_decode_plan* plan);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * PUSCH processor  --  replaces srsran::pusch_processor::process for PDUs without UCI

@@ -28,6 +28,9 @@
 #include "srsran/phy/upper/sequence_generators/sequence_generator_factories.h"
 #include "srsran/phy/upper/signal_processors/signal_processor_factories.h"
 #include "lib/phy/generic_functions/dft_processor_generic_impl.h"
+#include "lib/scheduler/support/tbs_calculator.h"
+#include "srsran/ran/sch_mcs.h"
+#include "srsran/ran/ldpc_base_graph.h"
 #include <atomic>
 #include <chrono>
 #include <pthread.h>
@@ -1543,6 +1546,352 @@ double ref_pusch_decoder_bench(unsigned      nthreads,
         ++k;
       }
       ref_pusch_decoder_destroy(h);
+    });
+  }
+  while (ready.load() != (int)nthreads) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  const double t0 = now_s();
+  go.store(true);
+  std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+  stop.store(true);
+  for (auto& w : workers) {
+    w.join();
+  }
+  return now_s() - t0;
+}
+
+// ---------------------------------------------------------------- TBS / base graph of an allocation (the reference's own calculators)
+// tbs_calculator_calculate (lib/scheduler/support/tbs_calculator.cpp, TS 38.214 5.1.3.2) and get_ldpc_base_graph (sch_mcs / ldpc helpers).
+unsigned ref_tbs_calculate(unsigned nof_symb_sh, unsigned nof_dmrs_prb, unsigned nof_oh_prb, int mod_bits, float rate_x1024, unsigned nof_layers, unsigned n_prb)
+{
+  tbs_calculator_configuration c;
+  c.nof_symb_sh = nof_symb_sh, c.nof_dmrs_prb = nof_dmrs_prb, c.nof_oh_prb = nof_oh_prb;
+  c.mcs_descr.modulation = mod_from_bits(mod_bits), c.mcs_descr.target_code_rate = rate_x1024;
+  c.nof_layers = nof_layers, c.tb_scaling_field = 0, c.n_prb = n_prb;
+  return tbs_calculator_calculate(c);
+}
+
+int ref_ldpc_base_graph(float rate_x1024, unsigned tbs_bits)
+{
+  return get_ldpc_base_graph(rate_x1024 / 1024.0F, units::bits(tbs_bits)) == ldpc_base_graph_type::BG1 ? 1 : 2;
+}
+
+// ---------------------------------------------------------------- receive chain of a slot that carries SEVERAL PUSCH PDUs
+// ofdm_slot_demodulator once per slot, then pusch_processor::process per PDU (what upper_phy_rx_symbol_handler_impl does with the
+// PDUs of a slot), one processor instance per pinned thread like pusch_processor_benchmark. pdus: npdus records of 8 unsigned
+// {rb_start, nof_prb, mod bits, TBS bits, base graph, rnti, n_id, target code rate x1024}. isa: 1 = avx2, 2 = avx512 decoder / dematcher.
+double ref_pusch_chain_bench_multi(unsigned        nthreads,
+                                   const int*      cpus,
+                                   double          seconds,
+                                   int             with_ofdm,
+                                   const float*    samples,
+                                   unsigned        nslots,
+                                   unsigned        slot_samples,
+                                   unsigned        grid_prb,
+                                   unsigned        npdus,
+                                   const unsigned* pdus,
+                                   unsigned        dmrs_scrambling_id,
+                                   unsigned        dft_size,
+                                   unsigned        window_offset,
+                                   float           ofdm_scale,
+                                   double          center_freq_hz,
+                                   unsigned        max_iter,
+                                   int             early_stop,
+                                   int             isa,
+                                   uint64_t*       slots_done,
+                                   uint64_t*       tb_ok)
+{
+  const unsigned           nsc = grid_prb * 12;
+  std::atomic<int>         ready{0};
+  std::atomic<bool>        go{false}, stop{false};
+  std::vector<std::thread> workers;
+  for (unsigned t = 0; t != nthreads; ++t) {
+    slots_done[t] = 0, tb_ok[t] = 0;
+    workers.emplace_back([&, t]() {
+      if (cpus != nullptr && cpus[t] >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(cpus[t], &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+      }
+      auto                               prg = create_pseudo_random_generator_sw_factory();
+      ofdm_factory_generic_configuration fc;
+      fc.dft_factory = std::make_shared<generic_dft_factory>();
+      ofdm_demodulator_configuration oc;
+      oc.numerology = 1, oc.bw_rb = grid_prb, oc.dft_size = dft_size, oc.cp = cyclic_prefix::NORMAL;
+      oc.nof_samples_window_offset = window_offset, oc.scale = ofdm_scale, oc.center_freq_hz = center_freq_hz;
+      auto ofdm = create_ofdm_demodulator_factory_generic(fc)->create_ofdm_slot_demodulator(oc);
+      pusch_decoder_factory_sw_configuration dc;
+      dc.crc_factory       = create_crc_calculator_factory_sw("auto");
+      dc.decoder_factory   = create_ldpc_decoder_factory_sw(impl_name(isa));
+      dc.dematcher_factory = create_ldpc_rate_dematcher_factory_sw(impl_name(isa));
+      dc.segmenter_factory = create_ldpc_segmenter_rx_factory_sw();
+      uci_decoder_factory_sw_configuration uc;
+      uc.decoder_factory = create_short_block_detector_factory_sw();
+      pusch_processor_factory_sw_configuration pc;
+      pc.estimator_factory =
+          create_dmrs_pusch_estimator_factory_sw(prg, create_port_channel_estimator_factory_sw(std::make_shared<generic_dft_factory>()));
+      pc.demodulator_factory = create_pusch_demodulator_factory_sw(create_channel_equalizer_factory_zf(), create_channel_modulation_sw_factory(), prg);
+      pc.demux_factory       = create_ulsch_demultiplex_factory_sw();
+      pc.decoder_factory     = create_pusch_decoder_factory_sw(dc);
+      pc.uci_dec_factory     = create_uci_decoder_factory_sw(uc);
+      pc.ch_estimate_dimensions.nof_prb = MAX_RB, pc.ch_estimate_dimensions.nof_symbols = MAX_NSYMB_PER_SLOT;
+      pc.ch_estimate_dimensions.nof_rx_ports = 1, pc.ch_estimate_dimensions.nof_tx_layers = 1;
+      pc.dec_nof_iterations = max_iter, pc.dec_enable_early_stop = early_stop != 0;
+      auto proc = create_pusch_processor_factory_sw(pc)->create();
+      rx_softbuffer_pool_config spc;
+      spc.max_codeblock_size = ldpc::MAX_CODEBLOCK_SIZE, spc.max_softbuffers = 2 * npdus, spc.max_nof_codeblocks = 256, spc.expire_timeout_slots = 100000;
+      auto                 pool = create_rx_softbuffer_pool(spc);
+      std::vector<uint8_t> tb(1277992 / 8);
+      std::vector<std::unique_ptr<resource_grid>> grids;
+      for (unsigned s = 0; s != nslots; ++s) {
+        grids.push_back(create_resource_grid(1, 14, nsc));
+        ofdm->demodulate(*grids[s], span<const cf_t>(reinterpret_cast<const cf_t*>(samples) + size_t(s) * slot_samples, slot_samples), 0, s % 2);
+      }
+      symbol_slot_mask dm(14);
+      dm.set(2);
+      ready.fetch_add(1);
+      while (!go.load()) {
+        std::this_thread::yield();
+      }
+      unsigned k = t;
+      while (!stop.load(std::memory_order_relaxed)) {
+        const unsigned s = k % nslots;
+        if (with_ofdm == 1) {
+          ofdm->demodulate(*grids[s], span<const cf_t>(reinterpret_cast<const cf_t*>(samples) + size_t(s) * slot_samples, slot_samples), 0, s % 2);
+        }
+        for (unsigned u = 0; u != npdus; ++u) {
+          const unsigned*        q = pdus + 8 * u;
+          pusch_processor::pdu_t pdu;
+          pdu.slot = slot_point(1, s), pdu.rnti = q[5], pdu.bwp_size_rb = grid_prb, pdu.bwp_start_rb = 0, pdu.cp = cyclic_prefix::NORMAL;
+          pdu.mcs_descr.modulation = mod_from_bits(q[2]), pdu.mcs_descr.target_code_rate = static_cast<float>(q[7]); // R x 1024 (sch_mcs.h)
+          pdu.codeword.emplace();
+          pdu.codeword.value().rv = 0, pdu.codeword.value().new_data = true;
+          pdu.codeword.value().ldpc_base_graph = q[4] == 1 ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+          pdu.uci = {};
+          pdu.uci.alpha_scaling = 1.0F, pdu.uci.beta_offset_harq_ack = 20.0F, pdu.uci.beta_offset_csi_part1 = 6.25F, pdu.uci.beta_offset_csi_part2 = 6.25F;
+          pdu.n_id = q[6], pdu.nof_tx_layers = 1;
+          pdu.rx_ports.push_back(0);
+          pdu.dmrs_symbol_mask = dm, pdu.dmrs = dmrs_type::TYPE1, pdu.scrambling_id = dmrs_scrambling_id, pdu.n_scid = false;
+          pdu.nof_cdm_groups_without_data = 2;
+          pdu.freq_alloc         = rb_allocation::make_type1(q[0], q[1]);
+          pdu.start_symbol_index = 0, pdu.nof_symbols = 14, pdu.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8;
+          rx_softbuffer_identifier id;
+          id.rnti = static_cast<uint16_t>(q[5]), id.harq_ack_id = 0;
+          const unsigned nof_cbs = ldpc::compute_nof_codeblocks(units::bits(q[3]), pdu.codeword.value().ldpc_base_graph);
+          unique_rx_softbuffer sb = pool->reserve_softbuffer(slot_point(1, s), id, nof_cbs);
+          chain_notifier       n;
+          proc->process(span<uint8_t>(tb.data(), q[3] / 8), sb.get(), n, *grids[s], pdu);
+          sb.release();
+          tb_ok[t] += n.ok ? 1 : 0;
+        }
+        ++slots_done[t];
+        ++k;
+      }
+    });
+  }
+  while (ready.load() != (int)nthreads) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  const double t0 = now_s();
+  go.store(true);
+  std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+  stop.store(true);
+  for (auto& w : workers) {
+    w.join();
+  }
+  return now_s() - t0;
+}
+
+// Decoder-only leg with the instruction set of the decoder / dematcher as a parameter (1 = avx2, 2 = avx512: the reference's
+// "avx512" classes, ldpc_decoder_avx512.cpp), otherwise ref_pusch_decoder_bench.
+double ref_pusch_decoder_bench_isa(unsigned nthreads, const int* cpus, double seconds, const int8_t* llrs, unsigned nslots, unsigned cw_len, int mod,
+                                   unsigned nof_ch_symbols, unsigned tbs_bits, unsigned max_iter, int early_stop, int isa, uint64_t* slots_done,
+                                   uint64_t* tb_ok)
+{
+  std::atomic<int>         ready{0};
+  std::atomic<bool>        go{false}, stop{false};
+  std::atomic<int>         failed{0};
+  std::vector<std::thread> workers;
+  for (unsigned t = 0; t != nthreads; ++t) {
+    slots_done[t] = 0, tb_ok[t] = 0;
+    workers.emplace_back([&, t]() {
+      if (cpus != nullptr && cpus[t] >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(cpus[t], &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+      }
+      void* h = ref_pusch_decoder_create(isa);
+      if (h == nullptr) {
+        failed.fetch_add(1);
+        ready.fetch_add(1);
+        return;
+      }
+      int                  rv0 = 0, ok = 0, mm[2];
+      std::vector<uint8_t> tb(tbs_bits / 8);
+      ready.fetch_add(1);
+      while (!go.load()) {
+        std::this_thread::yield();
+      }
+      unsigned k = t;
+      while (!stop.load(std::memory_order_relaxed)) {
+        ref_pusch_decode(h, 1, mod, 0, 1, nof_ch_symbols, tbs_bits / 8, 1, &rv0, llrs + size_t(k % nslots) * cw_len, cw_len, max_iter, early_stop, tb.data(), &ok, mm);
+        ++slots_done[t];
+        tb_ok[t] += ok;
+        ++k;
+      }
+      ref_pusch_decoder_destroy(h);
+    });
+  }
+  while (ready.load() != (int)nthreads) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  const double t0 = now_s();
+  go.store(true);
+  std::this_thread::sleep_for(std::chrono::duration<double>(failed.load() ? 0.0 : seconds));
+  stop.store(true);
+  for (auto& w : workers) {
+    w.join();
+  }
+  return failed.load() ? -1.0 : now_s() - t0;
+}
+
+// ---------------------------------------------------------------- transmit chain: pdsch_processor + ofdm_slot_modulator
+// pdsch_processor::process of one full-band PDU (pdsch_processor_benchmark.cpp:416-520 style: one processor per pinned thread) followed,
+// with_ofdm = 1, by ofdm_slot_modulator::modulate of the slot's grid. tbs: nslots transport blocks of tbs_bits / 8 bytes.
+double ref_pdsch_chain_bench(unsigned nthreads, const int* cpus, double seconds, int with_ofdm, const uint8_t* tbs, unsigned nslots, unsigned nof_prb, int mod,
+                             unsigned tbs_bits, unsigned rnti, unsigned n_id, unsigned dmrs_scrambling_id, unsigned dft_size, float ofdm_scale,
+                             double center_freq_hz, uint64_t* slots_done, float* checksum)
+{
+  const unsigned           nsc = nof_prb * 12;
+  std::atomic<int>         ready{0};
+  std::atomic<bool>        go{false}, stop{false};
+  std::vector<std::thread> workers;
+  for (unsigned t = 0; t != nthreads; ++t) {
+    slots_done[t] = 0;
+    workers.emplace_back([&, t]() {
+      if (cpus != nullptr && cpus[t] >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(cpus[t], &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+      }
+      auto                                   crcf = create_crc_calculator_factory_sw("auto");
+      auto                                   prg  = create_pseudo_random_generator_sw_factory();
+      pdsch_encoder_factory_sw_configuration ec;
+      ec.encoder_factory      = create_ldpc_encoder_factory_sw("avx2");
+      ec.rate_matcher_factory = create_ldpc_rate_matcher_factory_sw();
+      ec.segmenter_factory    = create_ldpc_segmenter_tx_factory_sw(crcf);
+      auto proc = create_pdsch_processor_factory_sw(create_pdsch_encoder_factory_sw(ec),
+                                                    create_pdsch_modulator_factory_sw(create_channel_modulation_sw_factory(), prg),
+                                                    create_dmrs_pdsch_processor_factory_sw(prg))
+                      ->create();
+      ofdm_factory_generic_configuration fc;
+      fc.dft_factory = std::make_shared<generic_dft_factory>();
+      ofdm_modulator_configuration oc;
+      oc.numerology = 1, oc.bw_rb = nof_prb, oc.dft_size = dft_size, oc.cp = cyclic_prefix::NORMAL, oc.scale = ofdm_scale, oc.center_freq_hz = center_freq_hz;
+      auto              ofdm = create_ofdm_modulator_factory_generic(fc)->create_ofdm_slot_modulator(oc);
+      auto              grid = create_resource_grid(1, 14, nsc);
+      std::vector<cf_t> out(ofdm->get_slot_size(0));
+      symbol_slot_mask  dm(14);
+      dm.set(2);
+      ready.fetch_add(1);
+      while (!go.load()) {
+        std::this_thread::yield();
+      }
+      unsigned k = t;
+      while (!stop.load(std::memory_order_relaxed)) {
+        const unsigned         s = k % nslots;
+        pdsch_processor::pdu_t pdu;
+        pdu.slot = slot_point(1, s % 20), pdu.rnti = rnti, pdu.bwp_size_rb = nof_prb, pdu.bwp_start_rb = 0, pdu.cp = cyclic_prefix::NORMAL;
+        pdu.codewords.push_back(pdsch_processor::codeword_description{mod_from_bits(mod), 0});
+        pdu.n_id = n_id;
+        pdu.ports.push_back(0);
+        pdu.ref_point = pdsch_processor::pdu_t::CRB0, pdu.dmrs_symbol_mask = dm, pdu.dmrs = dmrs_type::TYPE1, pdu.scrambling_id = dmrs_scrambling_id, pdu.n_scid = false;
+        pdu.nof_cdm_groups_without_data = 2, pdu.freq_alloc = rb_allocation::make_type1(0, nof_prb), pdu.start_symbol_index = 0, pdu.nof_symbols = 14;
+        pdu.ldpc_base_graph = ldpc_base_graph_type::BG1, pdu.tbs_lbrm_bytes = ldpc::MAX_CODEBLOCK_SIZE / 8;
+        pdu.ratio_pdsch_dmrs_to_sss_dB = -3.0F, pdu.ratio_pdsch_data_to_sss_dB = 0.0F;
+        static_vector<span<const uint8_t>, pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS> data;
+        data.emplace_back(span<const uint8_t>(tbs + size_t(s) * (tbs_bits / 8), tbs_bits / 8));
+        proc->process(*grid, data, pdu);
+        if (with_ofdm == 1) {
+          ofdm->modulate(out, *grid, 0, s % 2);
+        }
+        ++slots_done[t];
+        ++k;
+      }
+      if (t == 0 && checksum != nullptr) {
+        float a = 0.0F;
+        for (const cf_t& v : out) {
+          a += std::abs(v);
+        }
+        *checksum = a;
+      }
+    });
+  }
+  while (ready.load() != (int)nthreads) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  const double t0 = now_s();
+  go.store(true);
+  std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+  stop.store(true);
+  for (auto& w : workers) {
+    w.join();
+  }
+  return now_s() - t0;
+}
+
+// ---------------------------------------------------------------- polar: PDCCH encode and SSC decode chain (polar_chain_test.cpp:156-210)
+// Per codeword: pdcch_encoder::encode (CRC24C + RNTI mask, interleaver, polar encoder, rate matcher) when stage = 0; rate dematcher +
+// SSC decoder + deallocator on the given LLRs when stage = 1. payloads: ncw x A bits, llrs: ncw x E. Objects created once per thread.
+double ref_polar_chain_bench(unsigned nthreads, const int* cpus, double seconds, int stage, unsigned A, unsigned E, const uint8_t* payloads, const int8_t* llrs,
+                             unsigned ncw, uint64_t* done)
+{
+  std::atomic<int>         ready{0};
+  std::atomic<bool>        go{false}, stop{false};
+  std::vector<std::thread> workers;
+  const unsigned           K = A + 24;
+  for (unsigned t = 0; t != nthreads; ++t) {
+    done[t] = 0;
+    workers.emplace_back([&, t]() {
+      if (cpus != nullptr && cpus[t] >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(cpus[t], &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+      }
+      auto enc  = create_pdcch_encoder_factory_sw(create_crc_calculator_factory_sw("auto"), create_polar_factory_sw())->create();
+      auto f    = create_polar_factory_sw();
+      auto code = f->create_code();
+      code->set(K, E, 9, polar_code_ibil::not_present);
+      const unsigned                    N   = code->get_N();
+      auto                              rdm = f->create_rate_dematcher();
+      auto                              dec = f->create_decoder(9);
+      auto                              dea = f->create_deallocator();
+      std::vector<log_likelihood_ratio> dem(N);
+      std::vector<uint8_t>              u(N), msg(K), out(E);
+      ready.fetch_add(1);
+      while (!go.load()) {
+        std::this_thread::yield();
+      }
+      unsigned k = t;
+      while (!stop.load(std::memory_order_relaxed)) {
+        const unsigned c = k % ncw;
+        if (stage == 0) {
+          pdcch_encoder::config_t cfg;
+          cfg.E = E, cfg.rnti = 0x1234 + c;
+          enc->encode(out, span<const uint8_t>(payloads + size_t(c) * A, A), cfg);
+        } else {
+          rdm->rate_dematch(dem, span<const log_likelihood_ratio>(reinterpret_cast<const log_likelihood_ratio*>(llrs) + size_t(c) * E, E), *code);
+          dec->decode(u, dem, *code);
+          dea->deallocate(msg, u, *code);
+        }
+        ++done[t];
+        ++k;
+      }
     });
   }
   while (ready.load() != (int)nthreads) {

@@ -576,7 +576,7 @@ pusch_decode_dev layout_pusch_decode(const pusch_decode_build& b, uint8_t* h, ui
 // Launches of at most 65535 codeblocks each; transport blocks are never split across launches.
 int launch_pusch_decode(miphy_ctx* ctx, const pusch_decode_build& b, const pusch_decode_dev& v, uint32_t n, const int8_t* llrs, int8_t* harq_softbits,
                         uint8_t* harq_msgs, uint8_t* harq_crc_ok, uint8_t* tb_out, miphy_pusch_result* results, hipStream_t s,
-                        hipEvent_t* ev = nullptr /* optional: 4 events around dematch / decode / assembly (single-launch batches) */)
+                        hipEvent_t* ev = nullptr /* optional: 4 events around the dematch launches / the decoder launches / the assembly */)
 {
   int rc;
   miphy_ldpc_rdm_limits rlim = {b.max_E};
@@ -724,10 +724,6 @@ extern "C" int miphy_pusch_decode_plan_run(miphy_pusch_decode_plan* p,
 extern "C" int miphy_pusch_decode_plan_enable_timing(miphy_pusch_decode_plan* p, uint32_t max_runs)
 {
   MIPHY_REQUIRE(p && max_runs > 0 && max_runs <= 4096, "miphy_pusch_decode_plan_enable_timing: invalid argument");
-  if (p->ncb > 65535) {
-    miphy_set_error("miphy_pusch_decode_plan_enable_timing: %u codeblocks need several launches per kernel; per-kernel timing is only kept for single-launch batches", p->ncb);
-    return MIPHY_EUNSUPP;
-  }
   for (hipEvent_t e : p->events)
     (void)hipEventDestroy(e);
   p->events.assign((size_t)max_runs * 4, nullptr);
@@ -766,6 +762,15 @@ extern "C" int miphy_pusch_decode_plan_info(const miphy_pusch_decode_plan* p, ui
   info[1] = p->b.all_fused ? 1u : 0u;
   info[2] = p->b.max_nodes;
   return MIPHY_OK;
+}
+
+extern "C" uint32_t miphy_pusch_decode_plan_nof_launches(const miphy_pusch_decode_plan* p)
+{
+  uint32_t n = 0;
+  if (p)
+    for (const auto& ch : p->b.chunks)
+      n += (uint32_t)ch.cls.classes.size();
+  return n;
 }
 
 extern "C" void miphy_pusch_decode_plan_destroy(miphy_pusch_decode_plan* p)

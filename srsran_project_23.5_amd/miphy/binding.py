@@ -59,6 +59,8 @@ def lib():
         l.miphy_pusch_decode_plan_enable_timing.argtypes = [C.c_void_p, C.c_uint32]
         l.miphy_pusch_decode_plan_read_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         l.miphy_pusch_decode_plan_info.argtypes = [C.c_void_p, C.c_void_p]
+        l.miphy_pusch_decode_plan_nof_launches.argtypes = [C.c_void_p]
+        l.miphy_pusch_decode_plan_nof_launches.restype = C.c_uint32
         l.miphy_sch_segmentation_info.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         l.miphy_ldpc_decode_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
         l.miphy_ldpc_decode_plan_run.argtypes = [C.c_void_p] * 5
@@ -647,6 +649,10 @@ class PuschDecodePlan:
         a = (C.c_uint32 * 3)()
         check(lib().miphy_pusch_decode_plan_info(self.h, a))
         return int(a[0]), bool(a[1]), int(a[2])
+
+    def nof_launches(self):
+        """LDPC decoder launches per run (= launch classes of the batch)."""
+        return int(lib().miphy_pusch_decode_plan_nof_launches(self.h))
 
     def enable_timing(self, max_runs=64):
         check(lib().miphy_pusch_decode_plan_enable_timing(self.h, max_runs))

@@ -413,6 +413,80 @@ def r_pusch_decoder_bench(nthreads, cpus, seconds, llrs, mod, nof_ch_symbols, tb
     return float(dt), int(sum(done)), int(sum(ok))
 
 
+def r_tbs_calculate(nof_symb_sh, nof_dmrs_prb, mod_bits, rate_x1024, nof_layers, n_prb, nof_oh_prb=0):
+    """The reference's tbs_calculator_calculate (TS 38.214 5.1.3.2)."""
+    f = ref().ref_tbs_calculate
+    f.restype = C.c_uint
+    return int(f(C.c_uint(nof_symb_sh), C.c_uint(nof_dmrs_prb), C.c_uint(nof_oh_prb), int(mod_bits), C.c_float(rate_x1024), C.c_uint(nof_layers), C.c_uint(n_prb)))
+
+
+def r_ldpc_base_graph(rate_x1024, tbs_bits):
+    return int(ref().ref_ldpc_base_graph(C.c_float(rate_x1024), C.c_uint(tbs_bits)))
+
+
+def r_pusch_chain_bench_multi(nthreads, cpus, seconds, stage, samples, grid_prb, pdus, dmrs_scr_id, dft_size, window_offset, scale, center_freq_hz, max_iter,
+                              early_stop, isa=1):
+    """Reference receive chain of slots that carry several PUSCH PDUs (ref_capi.cpp::ref_pusch_chain_bench_multi): OFDM demodulation once per
+    slot, pusch_processor per PDU. pdus: rows of (rb_start, nof_prb, mod bits, TBS bits, base graph, rnti, n_id, R x 1024).
+    Returns (elapsed_s, slots_done, transport blocks CRC-ok)."""
+    samples = np.ascontiguousarray(samples, dtype=np.complex64)
+    nslots, slot_samples = samples.shape
+    pd = np.ascontiguousarray(np.asarray(pdus, dtype=np.uint32).reshape(-1, 8))
+    cp = (C.c_int * nthreads)(*[int(cpus[t % len(cpus)]) if cpus else -1 for t in range(nthreads)])
+    done = (C.c_uint64 * nthreads)()
+    ok = (C.c_uint64 * nthreads)()
+    f = ref().ref_pusch_chain_bench_multi
+    f.restype = C.c_double
+    dt = f(C.c_uint(nthreads), cp, C.c_double(seconds), int(stage), _p(samples), C.c_uint(nslots), C.c_uint(slot_samples), C.c_uint(grid_prb),
+           C.c_uint(pd.shape[0]), _p(pd), C.c_uint(dmrs_scr_id), C.c_uint(dft_size), C.c_uint(window_offset), C.c_float(scale), C.c_double(center_freq_hz),
+           C.c_uint(max_iter), int(early_stop), int(isa), done, ok)
+    return float(dt), int(sum(done)), int(sum(ok))
+
+
+def r_pusch_decoder_bench_isa(nthreads, cpus, seconds, llrs, mod, nof_ch_symbols, tbs_bits, max_iter, early_stop, isa):
+    """ref_pusch_decoder_bench with the reference's decoder / dematcher classes of one instruction set: isa 1 = avx2, 2 = avx512.
+    Returns None when the host (or the build) lacks it."""
+    llrs = np.ascontiguousarray(llrs, dtype=np.int8)
+    nslots, cw_len = llrs.shape
+    cp = (C.c_int * nthreads)(*[int(cpus[t % len(cpus)]) if cpus else -1 for t in range(nthreads)])
+    done = (C.c_uint64 * nthreads)()
+    ok = (C.c_uint64 * nthreads)()
+    f = ref().ref_pusch_decoder_bench_isa
+    f.restype = C.c_double
+    dt = f(C.c_uint(nthreads), cp, C.c_double(seconds), _p(llrs), C.c_uint(nslots), C.c_uint(cw_len), int(mod), C.c_uint(nof_ch_symbols), C.c_uint(tbs_bits),
+           C.c_uint(max_iter), int(early_stop), int(isa), done, ok)
+    return None if dt < 0 else (float(dt), int(sum(done)), int(sum(ok)))
+
+
+def r_pdsch_chain_bench(nthreads, cpus, seconds, with_ofdm, tbs, nof_prb, mod, tbs_bits, rnti, n_id, dmrs_scr_id, dft_size, scale, center_freq_hz):
+    """Reference transmit chain (ref_capi.cpp::ref_pdsch_chain_bench): pdsch_processor::process of one full-band PDU per slot and, with_ofdm,
+    ofdm_slot_modulator::modulate of its grid. tbs: [nslots][tbs_bits / 8] uint8. Returns (elapsed_s, slots_done)."""
+    tbs = np.ascontiguousarray(tbs, dtype=np.uint8)
+    nslots = tbs.shape[0]
+    cp = (C.c_int * nthreads)(*[int(cpus[t % len(cpus)]) if cpus else -1 for t in range(nthreads)])
+    done = (C.c_uint64 * nthreads)()
+    chk = C.c_float()
+    f = ref().ref_pdsch_chain_bench
+    f.restype = C.c_double
+    dt = f(C.c_uint(nthreads), cp, C.c_double(seconds), int(with_ofdm), _p(tbs), C.c_uint(nslots), C.c_uint(nof_prb), int(mod), C.c_uint(tbs_bits), C.c_uint(rnti),
+           C.c_uint(n_id), C.c_uint(dmrs_scr_id), C.c_uint(dft_size), C.c_float(scale), C.c_double(center_freq_hz), done, C.byref(chk))
+    return float(dt), int(sum(done))
+
+
+def r_polar_chain_bench(nthreads, cpus, seconds, stage, A, E, payloads, llrs):
+    """Reference PDCCH polar chains (ref_capi.cpp::ref_polar_chain_bench): stage 0 = pdcch_encoder::encode, stage 1 = rate dematcher + SSC
+    decoder + deallocator. payloads [ncw][A] bits, llrs [ncw][E] int8. Returns (elapsed_s, codewords done)."""
+    payloads = np.ascontiguousarray(payloads, dtype=np.uint8)
+    llrs = np.ascontiguousarray(llrs, dtype=np.int8)
+    ncw = payloads.shape[0]
+    cp = (C.c_int * nthreads)(*[int(cpus[t % len(cpus)]) if cpus else -1 for t in range(nthreads)])
+    done = (C.c_uint64 * nthreads)()
+    f = ref().ref_polar_chain_bench
+    f.restype = C.c_double
+    dt = f(C.c_uint(nthreads), cp, C.c_double(seconds), int(stage), C.c_uint(A), C.c_uint(E), _p(payloads), _p(llrs), C.c_uint(ncw), done)
+    return float(dt), int(sum(done))
+
+
 def r_dft(x, inverse=False):
     x = np.ascontiguousarray(x, dtype=np.complex64)
     out = np.zeros_like(x)

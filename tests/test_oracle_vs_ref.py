@@ -380,3 +380,18 @@ def test_nzp_csi_rs_generator():
         out = np.zeros_like(g)
         assert O.o_csi_rs_map(slot, scr, amp, start_rb, nof_rb, bes, row, cdm, dens, list(range(nports)), rm, sm, 80, out) == 0
         assert np.array_equal(out.view(np.uint32), g.view(np.uint32)), (row, dens, start_rb, nof_rb)
+
+
+def test_mixed_slot_table_is_the_reference_calculators():
+    """bench_legs.MIXED_PDUS (the mixed-slot leg of bench.py): TBS and base graph of every PDU are what the reference's
+    tbs_calculator_calculate (lib/scheduler/support/tbs_calculator.cpp) and get_ldpc_base_graph (ldpc_base_graph.h:38) return for its
+    PRBs, modulation and code rate; the PDUs tile the 273-PRB grid. The headline allocation gives BASELINE's 319 784 bits."""
+    import bench_legs as BL
+    nxt = 0
+    for rb0, nprb, mod, tbs, bg, R in BL.MIXED_PDUS:
+        assert rb0 == nxt
+        nxt += nprb
+        assert O.r_tbs_calculate(14, 12, mod, R, 1, nprb) == tbs
+        assert O.r_ldpc_base_graph(R, tbs) == bg
+    assert nxt == 273
+    assert O.r_tbs_calculate(14, 12, 8, 948, 1, 273) == 319784
