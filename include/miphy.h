@@ -109,7 +109,7 @@ void     miphy_ldpc_decode_plan_destroy(miphy_ldpc_decode_plan* plan);
 
 /* Test / A-B knob: 0 = automatic choice (host descriptors: sorted into launch classes by lifting size and code rate, one launch per
  * class; device descriptors: one launch), 1 = one-row-per-lane kernel, 2 = packed two-rows-per-lane kernel as one launch,
- * 3 = class-sorted launches. All kernels produce identical results. */
+ * 3 = class-sorted launches, 4 = class-sorted launches without the latency form of the packed kernel. All kernels produce identical results. */
 void miphy_debug_force_ldpc_kernel(int mode);
 /* Which decoder kernels have been launched since the last reset (tests assert that a forced choice really ran): */
 #define MIPHY_LDPC_KERNEL_SCALAR 1u /* one check row per lane */
@@ -117,6 +117,7 @@ void miphy_debug_force_ldpc_kernel(int mode);
 #define MIPHY_LDPC_KERNEL_FUSED  4u /* ... that rate-dematches while it loads */
 #define MIPHY_LDPC_KERNEL_GMSG   8u /* ... with the check-to-variable messages in global memory */
 #define MIPHY_LDPC_KERNEL_WAVE  16u /* several small codeblocks per wavefront (Z <= 64) */
+#define MIPHY_LDPC_KERNEL_SPLIT 32u /* packed kernel in its latency form: twice the wavefronts per codeblock (launches of at most one codeblock per CU) */
 unsigned miphy_debug_ldpc_kernels_used(int reset);
 
 /* ------------------------------------------------------------------------------------------------------------------

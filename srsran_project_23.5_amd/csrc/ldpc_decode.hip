@@ -502,14 +502,93 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
                                      const uint32_t* d_bundles, const int8_t* llr, uint8_t* out_bits, int32_t* iters, const uint32_t* harq_slot,
                                      uint8_t* harq_crc_ok, hipStream_t s, const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in, bool allow_fuse)
 {
-  for (const miphy_ldpc_class& c : C.classes) {
-    int rc;
+  const size_t nc = C.classes.size();
+  if (nc == 0)
+    return MIPHY_OK;
+  // Geometry of every class first: the launches of one call run side by side, so each needs message scratch of its own.
+  struct geom {
+    bool   fuse, gm, split;
+    int    threads, pairs;
+    size_t lds, gmsg_bytes, gmsg_off;
+    double cost;
+    int    stream; // 0 = the caller's, 1 .. = side streams
+  };
+  std::vector<geom> g(nc);
+  size_t            gmsg_total = 0;
+  for (size_t i = 0; i < nc; ++i) {
+    const miphy_ldpc_class& c = C.classes[i];
+    geom&                   q = g[i];
+    q = geom{};
+    const int bgK = c.bgi ? 10 : 22;
+    q.cost        = (double)c.count * (bgK + c.lay) * c.max_Z;
+    if (g_force_kernel == 1)
+      continue;
+    if (c.kind == 0) {
+      q.gmsg_bytes = miphy_ldpc_pkw_gmsg_bytes(ctx, c.bundle_count, c.bgi, c.lay, c.soft_total);
+    } else {
+      q.threads = 64 * c.kind;
+      q.pairs   = ctx->h_tables->pair_start[c.bgi][c.lay];
+      q.fuse    = c.fused && allow_fuse && d_rdm;
+      const size_t lds_l = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, q.pairs), lds_g = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, 0);
+      // messages in LDS while that keeps as many codeblocks resident per CU as the registers allow; otherwise in global memory
+      auto per_cu = [&](size_t lds) { return std::max(1, std::min((int)((size_t)160 * 1024 / lds), miphy_ldpc_pk_waves_per_cu(q.fuse) / (int)c.kind)); };
+      q.gm         = per_cu(lds_g) > per_cu(lds_l);
+      q.lds        = q.gm ? lds_g : lds_l;
+      // Latency form where the class cannot fill the chip anyway (at most one codeblock per CU): twice the wavefronts per codeblock,
+      // messages in LDS (residency is no concern then).
+      const size_t lds_s = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, q.pairs, true);
+      q.split            = g_force_kernel != 4 && c.count <= (uint32_t)ctx->num_cus && lds_s <= (size_t)160 * 1024;
+      if (q.split)
+        q.gm = false, q.lds = lds_s;
+      q.gmsg_bytes = miphy_ldpc_pk_gmsg_bytes(ctx, c.count, q.threads, q.lds, q.fuse, q.gm ? q.pairs : 0);
+    }
+    q.gmsg_off = gmsg_total;
+    gmsg_total += (q.gmsg_bytes + 255) & ~(size_t)255;
+  }
+  uint8_t* gmsg_base = nullptr;
+  int      rc;
+  if (gmsg_total) {
+    void* w = nullptr;
+    if ((rc = miphy_get_workspace(ctx, gmsg_total, s, &w, 3)))
+      return rc;
+    gmsg_base = (uint8_t*)w;
+  }
+  // Classes to streams: the most expensive class stays on the caller's stream, the others go to the least loaded of all streams (the
+  // small classes are latency chains of a few hundred wavefronts: next to a large class they cost nothing, one after another they
+  // each cost their full latency with the chip idle). One class: no fork.
+  int nstreams = 1;
+  if (nc > 1) {
+    if ((rc = miphy_side_streams(ctx)))
+      return rc;
+    nstreams = 1 + MIPHY_NOF_SIDE_STREAMS;
+    std::vector<size_t> by_cost(nc);
+    for (size_t i = 0; i < nc; ++i)
+      by_cost[i] = i;
+    std::sort(by_cost.begin(), by_cost.end(), [&](size_t a, size_t b) { return g[a].cost > g[b].cost; });
+    double load[1 + MIPHY_NOF_SIDE_STREAMS] = {};
+    for (size_t i : by_cost) {
+      int best = 0;
+      for (int k = 1; k < nstreams; ++k)
+        if (load[k] < load[best])
+          best = k;
+      g[i].stream = best;
+      load[best] += g[i].cost;
+    }
+    MIPHY_HIP_CHECK(hipEventRecord((hipEvent_t)ctx->ev_fork, s));
+    for (int k = 0; k < MIPHY_NOF_SIDE_STREAMS; ++k)
+      MIPHY_HIP_CHECK(hipStreamWaitEvent((hipStream_t)ctx->side_stream[k], (hipEvent_t)ctx->ev_fork, 0));
+  }
+  for (size_t i = 0; i < nc; ++i) {
+    const miphy_ldpc_class& c  = C.classes[i];
+    const geom&             q  = g[i];
+    hipStream_t             st = q.stream == 0 ? s : (hipStream_t)ctx->side_stream[q.stream - 1];
+    void*                   gb = q.gmsg_bytes ? gmsg_base + q.gmsg_off : nullptr;
     if (g_force_kernel == 1) { // A-B knob: the one-row-per-lane kernel on every class (the caller has dematched: allow_fuse is false then)
       const int    bgK = c.bgi ? 10 : 22, threads = ((c.max_Z + 63) / 64) * 64;
       const size_t lds = ((((size_t)bgK + c.lay) * threads + 15) & ~(size_t)15) + (size_t)(c.lay + 4) * threads * 4 + 64;
       if (lds > 48 * 1024)
         MIPHY_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(ldpc_decode_kernel, dim3(c.count), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, bgK + c.lay, harq_slot,
+      hipLaunchKernelGGL(ldpc_decode_kernel, dim3(c.count), dim3(threads), lds, st, d_descs, ctx->d_tables, llr, out_bits, iters, bgK + c.lay, harq_slot,
                          harq_crc_ok, d_order + c.first);
       MIPHY_HIP_CHECK(hipGetLastError());
       g_kernels_used |= MIPHY_LDPC_KERNEL_SCALAR;
@@ -518,23 +597,24 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
     if (c.kind == 0) {
       int gm = 0;
       if ((rc = miphy_ldpc_pkw_launch(ctx, d_descs, d_order, d_bundles + 2 * (size_t)c.bundle_first, c.bundle_count, c.bgi, c.lay, c.soft_total, llr, out_bits,
-                                      iters, harq_slot, harq_crc_ok, s, &gm)))
+                                      iters, harq_slot, harq_crc_ok, st, &gm, gb)))
         return rc;
       g_kernels_used |= MIPHY_LDPC_KERNEL_WAVE | (gm ? MIPHY_LDPC_KERNEL_GMSG : 0u);
       continue;
     }
-    const int    bgK = c.bgi ? 10 : 22, threads = 64 * c.kind, waves = c.kind;
-    const int    pairs = ctx->h_tables->pair_start[c.bgi][c.lay];
-    const bool   fuse  = c.fused && allow_fuse && d_rdm;
-    const size_t lds_l = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, pairs), lds_g = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, 0);
-    // messages in LDS while that keeps as many codeblocks resident per CU as the registers allow; otherwise in global memory
-    auto       per_cu = [&](size_t lds) { return std::max(1, std::min((int)((size_t)160 * 1024 / lds), miphy_ldpc_pk_waves_per_cu(fuse) / waves)); };
-    const bool gm     = per_cu(lds_g) > per_cu(lds_l);
-    if ((rc = miphy_ldpc_pk_launch(ctx, d_descs, c.count, threads, gm ? lds_g : lds_l, llr, out_bits, iters, bgK + c.lay, harq_slot, harq_crc_ok, s,
-                                   fuse ? d_rdm : nullptr, fuse ? rm_in : nullptr, gm ? pairs : 0,
-                                   (C.identity && C.classes.size() == 1) ? nullptr : d_order + c.first)))
+    const int bgK = c.bgi ? 10 : 22;
+    if ((rc = miphy_ldpc_pk_launch(ctx, d_descs, c.count, q.threads, q.lds, llr, out_bits, iters, bgK + c.lay, harq_slot, harq_crc_ok, st,
+                                   q.fuse ? d_rdm : nullptr, q.fuse ? rm_in : nullptr, q.gm ? q.pairs : 0,
+                                   (C.identity && nc == 1) ? nullptr : d_order + c.first, gb, q.split)))
       return rc;
-    g_kernels_used |= MIPHY_LDPC_KERNEL_PACKED | (fuse ? MIPHY_LDPC_KERNEL_FUSED : 0u) | (gm ? MIPHY_LDPC_KERNEL_GMSG : 0u);
+    g_kernels_used |= MIPHY_LDPC_KERNEL_PACKED | (q.fuse ? MIPHY_LDPC_KERNEL_FUSED : 0u) | (q.gm ? MIPHY_LDPC_KERNEL_GMSG : 0u) |
+                      (q.split ? MIPHY_LDPC_KERNEL_SPLIT : 0u);
+  }
+  if (nc > 1) {
+    for (int k = 0; k < MIPHY_NOF_SIDE_STREAMS; ++k) {
+      MIPHY_HIP_CHECK(hipEventRecord((hipEvent_t)ctx->ev_join[k], (hipStream_t)ctx->side_stream[k]));
+      MIPHY_HIP_CHECK(hipStreamWaitEvent(s, (hipEvent_t)ctx->ev_join[k], 0));
+    }
   }
   return MIPHY_OK;
 }
@@ -586,7 +666,7 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
       MIPHY_REQUIRE(d.nof_filler_bits < bgK * d.Z, "ldpc_decode: desc %u: invalid number of filler bits", i);
       account(d.bg, d.Z, d.in_len);
     }
-    if (g_force_kernel == 0 || g_force_kernel == 3) {
+    if (g_force_kernel == 0 || g_force_kernel >= 3) {
       // host descriptors: sorted into launch classes (nothing is dematched by the decoder on this path: fuse_rdm comes with device
       // descriptors only)
       miphy_ldpc_classes C;
@@ -677,7 +757,7 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   bool use_pk = pk_ok && 1.6 * rows_in_flight(pk_lds, pk_threads, 4, 2) >= 1.0 * rows_in_flight(max_lds, max_threads, 8, 1);
   if (g_force_kernel == 1)
     use_pk = false;
-  if (g_force_kernel == 2 || g_force_kernel == 3)
+  if (g_force_kernel >= 2)
     use_pk = pk_ok;
   // The fused form needs 16-byte aligned soft buffers (its write-back is vectorised) and lifting sizes that are multiples of 16 (the
   // caller vouches for that when it passes fuse_rdm); otherwise the dematcher runs on its own.

@@ -252,8 +252,11 @@ __device__ __forceinline__ int pk_fused_image_out(const int8_t* __restrict__ sof
   return last;
 }
 
-template <bool FUSED, bool GMSG>
-__global__ void __launch_bounds__(192, FUSED ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN)
+// SPLIT = the latency form for launches that leave most of the chip idle (a single slot is 38 codeblocks on 256 CUs): twice the
+// wavefronts per codeblock, the two halves of the workgroup share the edges of every layer (update_rows_pk, SPLIT) -- about half the
+// instructions per wavefront and layer for one more barrier, same results, same LDS image (messages always in LDS).
+template <bool FUSED, bool GMSG, bool SPLIT = false>
+__global__ void __launch_bounds__(SPLIT ? 384 : 192, FUSED ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN)
 ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                       const miphy_graph_tables* __restrict__ tab,
                       const int8_t* __restrict__ llr_base,
@@ -273,6 +276,10 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int nt  = blockDim.x;
+  static_assert(!(SPLIT && GMSG), "the latency form keeps its messages in LDS");
+  const int nth  = SPLIT ? (nt >> 1) : nt;       // threads that own rows: the whole workgroup, or each half of it
+  const int half = SPLIT ? (tid >= nth ? 1 : 0) : 0;
+  const int lr   = tid - half * nth;             // row pair (lr, lr + H) of this lane
   raw_in16  pre[PK_PRE];
   if (FUSED) {
     if (blockIdx.x < n) {
@@ -315,8 +322,11 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   const int soft_bytes = ((bgK + lay_alloc) * Z + 15) & ~15;
   const int pairs_all  = tab->pair_start[bgi][lay_alloc];
   uint32_t* c2v_lane   = GMSG ? gmsg + ((size_t)blockIdx.x * (nt >> 6) + (tid >> 6)) * ((size_t)gmsg_pairs * 64) + (tid & 63)
-                              : reinterpret_cast<uint32_t*>(smem + soft_bytes) + (tid >> 6) * (pairs_all * 64) + (tid & 63);
-  uint32_t* red        = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (GMSG ? 0 : (nt >> 6) * (pairs_all * 64));
+                              : reinterpret_cast<uint32_t*>(smem + soft_bytes) + (lr >> 6) * (pairs_all * 64) + (lr & 63);
+  uint32_t* red        = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (GMSG ? 0 : (nth >> 6) * (pairs_all * 64));
+  // latency form: exchange slots behind the reduction words, [half][3][nth] dwords
+  uint32_t*       xw = red + 16 + half * 3 * nth + lr;
+  const uint32_t* xr = red + 16 + (1 - half) * 3 * nth + lr;
 
   // Next codeblock of this workgroup (taken now so that the queue round trip is off the critical path).
   __syncthreads(); // the previous codeblock's readers of red[] / soft[] are done
@@ -458,7 +468,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   // Odd lifting size: the last lane would own rows H - 1 and Z (= row 0 again, a lane's second row is l + H). Its distance to the
   // second row is set to zero instead: both halves of its packed registers then carry row H - 1, read the same soft bits, compute
   // the same values and store them to the same addresses -- no row is visited twice and no instruction is added.
-  int Zv = Z, Hv = (tid + H < Z) ? H : 0;
+  int Zv = Z, Hv = (lr + H < Z) ? H : 0;
 #ifndef LDPC_PK_SCALAR_WRAP
   asm volatile("" : "+v"(Zv), "+v"(Hv));
 #endif
@@ -469,7 +479,13 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       const int       d     = (int)((li >> 10) & 0x3fu);
       const uint32_t* edges = edges_g + 2 * e0;
       PROF_T(p_l0);
-      if (tid < H) {
+      if (SPLIT) { // every thread: the function holds the barrier of the exchange
+        uint32_t* cl = c2v_lane + 64 * (li >> 16);
+        if (it == 0)
+          update_rows_pk_split<true>(d, half, soft, cl, edges, lr, Hv, Zv, lr < H, xw, xr, nth);
+        else
+          update_rows_pk_split<false>(d, half, soft, cl, edges, lr, Hv, Zv, lr < H, xw, xr, nth);
+      } else if (tid < H) {
         uint32_t* cl = c2v_lane + 64 * (li >> 16);
         if (it == 0)
           update_rows_pk_any<true>(d, soft, cl, edges, tid, Hv, Zv);
@@ -558,41 +574,60 @@ int miphy_ldpc_pk_waves_per_cu(bool fused)
   return 4 * (fused ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN); // what __launch_bounds__ of the kernel guarantees per CU
 }
 
-size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all)
+size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all, bool split)
 {
   const size_t waves = ((Zt + 1) / 2 + 63) / 64;
-  return ((((size_t)bgK + lay) * Zt + 15) & ~(size_t)15) + waves * (size_t)pairs_all * 256 + 64;
+  return ((((size_t)bgK + lay) * Zt + 15) & ~(size_t)15) + waves * (size_t)pairs_all * 256 + 64 + (split ? 6 * 64 * waves * 4 : 0);
+}
+
+uint32_t miphy_ldpc_pk_grid(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused)
+{
+  // (threads = those of the launch: the latency form passes twice the row-owning threads)
+  // Resident workgroups per CU: LDS, the wavefronts per CU the register budget of the kernel allows (__launch_bounds__), 32 slots.
+  const int waves  = threads / 64;
+  int       per_cu = (int)((size_t)160 * 1024 / lds);
+  per_cu           = std::min(per_cu, miphy_ldpc_pk_waves_per_cu(fused) / waves);
+  per_cu           = std::max(per_cu, 1);
+  return std::min<uint32_t>(n, (uint32_t)(ctx->num_cus * per_cu));
+}
+
+size_t miphy_ldpc_pk_gmsg_bytes(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused, int gmsg_pairs)
+{
+  return gmsg_pairs > 0 ? (size_t)miphy_ldpc_pk_grid(ctx, n, threads, lds, fused) * (threads / 64) * (size_t)gmsg_pairs * 256 : 0;
 }
 
 int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                          uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
-                         const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in, int gmsg_pairs, const uint32_t* d_order)
+                         const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in, int gmsg_pairs, const uint32_t* d_order, void* gmsg_buf, bool split)
 {
-  const bool  fused = d_rdm != nullptr, gm = gmsg_pairs > 0;
-  const void* kern  = fused ? (gm ? (const void*)ldpc_decode_pk_kernel<true, true> : (const void*)ldpc_decode_pk_kernel<true, false>)
-                            : (gm ? (const void*)ldpc_decode_pk_kernel<false, true> : (const void*)ldpc_decode_pk_kernel<false, false>);
+  const bool fused = d_rdm != nullptr, gm = gmsg_pairs > 0;
+  MIPHY_REQUIRE(!(split && gm), "ldpc_decode: the latency form keeps its messages in LDS");
+  if (split)
+    threads *= 2; // `threads` = the row-owning threads of a codeblock; `lds` already holds the exchange slots
+  const void* kern = split ? (fused ? (const void*)ldpc_decode_pk_kernel<true, false, true> : (const void*)ldpc_decode_pk_kernel<false, false, true>)
+                           : fused ? (gm ? (const void*)ldpc_decode_pk_kernel<true, true> : (const void*)ldpc_decode_pk_kernel<true, false>)
+                                   : (gm ? (const void*)ldpc_decode_pk_kernel<false, true> : (const void*)ldpc_decode_pk_kernel<false, false>);
   // Above the default 64 KB of dynamic LDS the limit has to be raised; it is a per-device attribute of the kernel, so it is set on
   // every such launch (a cache per thread would be wrong for a thread that drives several devices).
   if (lds > 48 * 1024) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  // Resident workgroups per CU: LDS, the 12 wavefronts per CU the register budget of the kernel allows (__launch_bounds__), 32 slots.
-  const int waves = threads / 64;
-  int       per_cu = (int)((size_t)160 * 1024 / lds);
-  per_cu           = std::min(per_cu, miphy_ldpc_pk_waves_per_cu(fused) / waves);
-  per_cu           = std::max(per_cu, 1);
-  const uint32_t grid = std::min<uint32_t>(n, (uint32_t)(ctx->num_cus * per_cu));
+  const uint32_t grid  = miphy_ldpc_pk_grid(ctx, n, threads, lds, fused);
   uint32_t*      queue = nullptr;
   int            rc    = miphy_next_queue_counter(ctx, &queue);
   if (rc)
     return rc;
-  void* gmsg = nullptr;
-  if (gm && (rc = miphy_get_workspace(ctx, (size_t)grid * waves * (size_t)gmsg_pairs * 256, s, &gmsg, 3)))
+  void* gmsg = gmsg_buf;
+  if (gm && !gmsg && (rc = miphy_get_workspace(ctx, miphy_ldpc_pk_gmsg_bytes(ctx, n, threads, lds, fused, gmsg_pairs), s, &gmsg, 3)))
     return rc;
-#define PK_LAUNCH(F, G)                                                                                                                              \
-  hipLaunchKernelGGL((ldpc_decode_pk_kernel<F, G>), dim3(grid), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, harq_slot, \
-                     harq_crc_ok, n, queue, d_rdm, rm_in, (uint32_t*)gmsg, gmsg_pairs, d_order)
-  if (fused && gm)
+#define PK_LAUNCH(F, G, ...)                                                                                                                         \
+  hipLaunchKernelGGL((ldpc_decode_pk_kernel<F, G, ##__VA_ARGS__>), dim3(grid), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, \
+                     harq_slot, harq_crc_ok, n, queue, d_rdm, rm_in, (uint32_t*)gmsg, gmsg_pairs, d_order)
+  if (split && fused)
+    PK_LAUNCH(true, false, true);
+  else if (split)
+    PK_LAUNCH(false, false, true);
+  else if (fused && gm)
     PK_LAUNCH(true, true);
   else if (fused)
     PK_LAUNCH(true, false);

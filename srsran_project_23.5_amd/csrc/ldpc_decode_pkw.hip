@@ -318,38 +318,61 @@ size_t miphy_ldpc_pkw_lds_bytes(size_t soft_total, int pairs_all)
   return soft_total + (size_t)pairs_all * 256 + 512;
 }
 
-int miphy_ldpc_pkw_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, const uint32_t* d_order, const uint32_t* d_bundles, uint32_t nof_bundles,
-                          int bgi, int lay, size_t soft_total, const int8_t* llr, uint8_t* out_bits, int32_t* iters, const uint32_t* harq_slot,
-                          uint8_t* harq_crc_ok, hipStream_t s, int* used_gmsg)
+namespace {
+struct pkw_geometry {
+  bool     gm;
+  size_t   lds;
+  uint32_t grid;
+  int      pairs;
+};
+pkw_geometry pkw_geom(const miphy_ctx* ctx, uint32_t nof_bundles, int bgi, int lay, size_t soft_total)
 {
-  if (nof_bundles == 0)
-    return MIPHY_OK;
-  const int    pairs = ctx->h_tables->pair_start[bgi][lay];
-  const size_t lds_l = miphy_ldpc_pkw_lds_bytes(soft_total, pairs), lds_g = miphy_ldpc_pkw_lds_bytes(soft_total, 0);
+  pkw_geometry g;
+  g.pairs            = ctx->h_tables->pair_start[bgi][lay];
+  const size_t lds_l = miphy_ldpc_pkw_lds_bytes(soft_total, g.pairs), lds_g = miphy_ldpc_pkw_lds_bytes(soft_total, 0);
   // Wavefronts per CU: LDS and the 16 the register budget of the kernel allows. The messages move to global memory (one coalesced
   // dword per lane, edge pair and layer visit, re-read out of L2 an iteration later) where LDS would leave fewer than two wavefronts
   // per SIMD and the move buys residency.
   auto per_cu = [](size_t lds) { return std::max(1, std::min((int)((size_t)160 * 1024 / lds), 16)); };
-  const bool   gm  = per_cu(lds_l) < 8 && per_cu(lds_g) > per_cu(lds_l);
-  const size_t lds = gm ? lds_g : lds_l;
+  g.gm        = per_cu(lds_l) < 8 && per_cu(lds_g) > per_cu(lds_l);
+  g.lds       = g.gm ? lds_g : lds_l;
+  g.grid      = std::min<uint32_t>(nof_bundles, (uint32_t)(ctx->num_cus * per_cu(g.lds)));
+  return g;
+}
+} // namespace
+
+size_t miphy_ldpc_pkw_gmsg_bytes(const miphy_ctx* ctx, uint32_t nof_bundles, int bgi, int lay, size_t soft_total)
+{
+  if (nof_bundles == 0)
+    return 0;
+  const pkw_geometry g = pkw_geom(ctx, nof_bundles, bgi, lay, soft_total);
+  return g.gm ? (size_t)g.grid * (size_t)g.pairs * 256 : 0;
+}
+
+int miphy_ldpc_pkw_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, const uint32_t* d_order, const uint32_t* d_bundles, uint32_t nof_bundles,
+                          int bgi, int lay, size_t soft_total, const int8_t* llr, uint8_t* out_bits, int32_t* iters, const uint32_t* harq_slot,
+                          uint8_t* harq_crc_ok, hipStream_t s, int* used_gmsg, void* gmsg_buf)
+{
+  if (nof_bundles == 0)
+    return MIPHY_OK;
+  const pkw_geometry g = pkw_geom(ctx, nof_bundles, bgi, lay, soft_total);
   if (used_gmsg)
-    *used_gmsg = gm ? 1 : 0;
-  const void* kern = gm ? (const void*)ldpc_decode_pkw_kernel<true> : (const void*)ldpc_decode_pkw_kernel<false>;
-  if (lds > 48 * 1024)
-    MIPHY_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const uint32_t grid  = std::min<uint32_t>(nof_bundles, (uint32_t)(ctx->num_cus * per_cu(lds)));
-  uint32_t*      queue = nullptr;
-  int            rc    = miphy_next_queue_counter(ctx, &queue);
+    *used_gmsg = g.gm ? 1 : 0;
+  const void* kern = g.gm ? (const void*)ldpc_decode_pkw_kernel<true> : (const void*)ldpc_decode_pkw_kernel<false>;
+  if (g.lds > 48 * 1024)
+    MIPHY_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+  uint32_t* queue = nullptr;
+  int       rc    = miphy_next_queue_counter(ctx, &queue);
   if (rc)
     return rc;
-  void* gmsg = nullptr;
-  if (gm && (rc = miphy_get_workspace(ctx, (size_t)grid * (size_t)pairs * 256, s, &gmsg, 3)))
+  void* gmsg = gmsg_buf;
+  if (g.gm && !gmsg && (rc = miphy_get_workspace(ctx, (size_t)g.grid * (size_t)g.pairs * 256, s, &gmsg, 3)))
     return rc;
-  if (gm)
-    hipLaunchKernelGGL((ldpc_decode_pkw_kernel<true>), dim3(grid), dim3(64), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, lay, (int)soft_total,
-                       harq_slot, harq_crc_ok, d_order, d_bundles, nof_bundles, queue, (uint32_t*)gmsg, pairs);
+  if (g.gm)
+    hipLaunchKernelGGL((ldpc_decode_pkw_kernel<true>), dim3(g.grid), dim3(64), g.lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, lay, (int)soft_total,
+                       harq_slot, harq_crc_ok, d_order, d_bundles, nof_bundles, queue, (uint32_t*)gmsg, g.pairs);
   else
-    hipLaunchKernelGGL((ldpc_decode_pkw_kernel<false>), dim3(grid), dim3(64), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, lay, (int)soft_total,
+    hipLaunchKernelGGL((ldpc_decode_pkw_kernel<false>), dim3(g.grid), dim3(64), g.lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, lay, (int)soft_total,
                        harq_slot, harq_crc_ok, d_order, d_bundles, nof_bundles, queue, (uint32_t*)nullptr, 0);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;

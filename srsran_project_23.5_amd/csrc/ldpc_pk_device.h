@@ -54,34 +54,29 @@ __device__ __forceinline__ uint32_t c2v_pack(s16x2 c0, s16x2 c1)
   return __builtin_amdgcn_perm(as_u(c0), as_u(c1), 0x06020400u);
 }
 
-// p mod Z for p < 2 Z: min(p, p - Z) on the LOW HALVES. The 16-bit VOP2 minimum issues at the fast rate (1.93 cycles at three waves
-// per SIMD, where v_min_u32 takes 2.88: tools/valu_probe) and clears the upper half of its destination (tools/min16_probe), so the
-// result is the address term itself. Positions are below 2 * 384.
-__device__ __forceinline__ uint32_t wrap_z(uint32_t p, uint32_t Z)
-{
-#ifdef LDPC_PK_MIN32
-  return min(p, p - Z);
-#else
-  const uint32_t t = p - Z;
-  uint32_t       r;
-  asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(p), "v"(t));
-  return r;
-#endif
-}
-
 constexpr int LLR_MAX = 120;
 constexpr int LLR_INF = 127;
 constexpr int INF_MUL = 255; // an infinite soft bit (|s| > 120) becomes a message of magnitude >= 255 + 24
 
 // `base` = LDS byte offset of the codeblock's soft bits (0 where a workgroup holds one codeblock: the term then folds away).
-template <int D, bool FIRST>
+// SPLIT (latency form of the packed kernel: twice the wavefronts per codeblock, each half of the workgroup owns HALF of the edges of a
+// layer): D is the number of edges of THIS half; between the two phases the halves exchange their partial {min1, min2, sign parity}
+// through LDS (`xw` = this lane's slot, `xr` = the slot of the lane that owns the same rows in the other half, three dwords `xs` apart)
+// and merge them -- the two smallest magnitudes of the union are min(a1, b1) and min(max(a1, b1), min(a2, b2)). The function then
+// contains a workgroup barrier: EVERY thread calls it, `active` = the lane owns rows (an idle lane computes on soft bits it may read
+// but stores nothing).
+template <int D, bool FIRST, bool SPLIT = false>
 __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
                                                uint32_t* __restrict__ c2v, // this lane's message dword of edges 0,1 of the layer
                                                const uint32_t* __restrict__ edges, // {shift, column*Z} per edge
                                                int l,
                                                int H,
                                                int Z,
-                                               uint32_t base = 0)
+                                               uint32_t base = 0,
+                                               bool active = true,
+                                               uint32_t* xw = nullptr,
+                                               const uint32_t* xr = nullptr,
+                                               int xs = 0)
 {
   s16x2    v2c[D], mabs[D];
   uint32_t adrA[D], adrB[D];
@@ -89,12 +84,21 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
   uint32_t cw[(D + 1) / 2];
   // Stage A: every address of the layer, then every LDS read of the layer in one go (2 soft bits per edge + the old
   // messages): the latency of the LDS pipe is paid once per layer instead of once per group of edges.
+  // Both rows' addresses with packed 16-bit arithmetic: {l, l + H} + shift, wrap at Z by the unsigned minimum of p and p - Z, + column
+  // offset -- four packed instructions for the two rows, then one mask and one shift to split the pair (LDS addresses stay below 2^16).
+  {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 X  = {(unsigned short)l, (unsigned short)(l + H)};
+    const u16x2 Zs = {(unsigned short)Z, (unsigned short)Z};
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const uint32_t pA = wrap_z((uint32_t)l + edges[2 * j], (uint32_t)Z);
-    const uint32_t pB = wrap_z(pA + (uint32_t)H, (uint32_t)Z);
-    adrA[j]     = edges[2 * j + 1] + pA + base;
-    adrB[j]     = edges[2 * j + 1] + pB + base;
+    for (int j = 0; j < D; ++j) {
+      const unsigned short sh = (unsigned short)edges[2 * j], co = (unsigned short)edges[2 * j + 1];
+      const u16x2 T = X + u16x2{sh, sh};
+      const u16x2 R = __builtin_elementwise_min(T, (u16x2)(T - Zs));
+      const uint32_t P = __builtin_bit_cast(uint32_t, (u16x2)(R + u16x2{co, co}));
+      adrA[j] = (P & 0xffffu) + base;
+      adrB[j] = (P >> 16) + base;
+    }
   }
 #pragma unroll
   for (int j = 0; j < D; ++j) {
@@ -130,6 +134,14 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
     mag1             = pk_min(mag1, av);
     mag2             = pk_min(mag2, help);
   }
+  if (SPLIT) {
+    xw[0] = as_u(mag1), xw[xs] = as_u(mag2), xw[2 * xs] = spx;
+    __syncthreads();
+    const s16x2 o1 = as_s2(xr[0]), o2 = as_s2(xr[xs]);
+    spx ^= xr[2 * xs];
+    mag2 = pk_min(pk_max(mag1, o1), pk_min(mag2, o2));
+    mag1 = pk_min(mag1, o1);
+  }
   // Scaling by 0.8 = floor(x * 52428 / 65536), per row (avx2_support.h:65-106).
   const uint32_t s1A = ((uint32_t)(uint16_t)mag1.x * 52428u) >> 16, s1B = ((uint32_t)(uint16_t)mag1.y * 52428u) >> 16;
   const uint32_t s2A = ((uint32_t)(uint16_t)mag2.x * 52428u) >> 16, s2B = ((uint32_t)(uint16_t)mag2.y * 52428u) >> 16;
@@ -148,14 +160,46 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
     const s16x2 mag = x * dsp + s2p;
     const s16x2 m   = pk_ashr15(v); // -1 where this edge's own message is negative
     const s16x2 c   = as_s2(as_u(mag) ^ as_u(m)) - m;
-    if (j & 1)
-      c2v[64 * (j >> 1)] = c2v_pack(cprev, c);
-    else if (j == D - 1)
-      c2v[64 * (j >> 1)] = c2v_pack(c, c);
-    cprev = c;
     const uint32_t r = as_u(pk_min(pk_max(c + v, splat(-LLR_INF)), splat(LLR_INF)));
-    soft[adrA[j]]    = (int8_t)r;
-    soft[adrB[j]]    = (int8_t)(r >> 16);
+    if (!SPLIT || active) {
+      if (j & 1)
+        c2v[64 * (j >> 1)] = c2v_pack(cprev, c);
+      else if (j == D - 1)
+        c2v[64 * (j >> 1)] = c2v_pack(c, c);
+      soft[adrA[j]] = (int8_t)r;
+      soft[adrB[j]] = (int8_t)(r >> 16);
+    }
+    cprev = c;
+  }
+}
+
+// The latency form: this half's edges of a layer of degree d. The first half takes D0 = 2 * ((d + 2) / 4) edges (an even number, so
+// the split falls on a message pair: the message layout is that of the throughput form), the second the rest.
+template <bool FIRST>
+__device__ __forceinline__ void update_rows_pk_split(int d, int half, int8_t* soft, uint32_t* c2v, const uint32_t* edges, int l, int H, int Z, bool active,
+                                                     uint32_t* xw, const uint32_t* xr, int xs)
+{
+  const int d0 = 2 * ((d + 2) >> 2);
+  const int da = half ? d - d0 : d0;
+  if (half) {
+    edges += 2 * d0;
+    c2v += 64 * (d0 >> 1);
+  }
+  switch (da) {
+#define PK_SPLIT_CASE(N)                                                                        \
+  case N:                                                                                       \
+    update_rows_pk<N, FIRST, true>(soft, c2v, edges, l, H, Z, 0, active, xw, xr, xs);           \
+    break;
+    PK_SPLIT_CASE(10)
+    PK_SPLIT_CASE(9)
+    PK_SPLIT_CASE(6)
+    PK_SPLIT_CASE(5)
+    PK_SPLIT_CASE(4)
+    PK_SPLIT_CASE(3)
+    PK_SPLIT_CASE(2)
+    default:
+      PK_SPLIT_CASE(1)
+#undef PK_SPLIT_CASE
   }
 }
 

@@ -181,6 +181,14 @@ extern "C" void miphy_destroy(miphy_ctx* c)
   for (void* p : c->ext->to_free)
     (void)hipFree(p);
   delete c->ext;
+  for (int k = 0; k < MIPHY_NOF_SIDE_STREAMS; ++k) {
+    if (c->side_stream[k])
+      (void)hipStreamDestroy((hipStream_t)c->side_stream[k]);
+    if (c->ev_join[k])
+      (void)hipEventDestroy((hipEvent_t)c->ev_join[k]);
+  }
+  if (c->ev_fork)
+    (void)hipEventDestroy((hipEvent_t)c->ev_fork);
   (void)hipFree(c->d_desc_staging);
   (void)hipFree(c->d_queue);
   for (void* w : c->d_work)
@@ -188,6 +196,23 @@ extern "C" void miphy_destroy(miphy_ctx* c)
   (void)hipHostFree(c->h_desc_staging);
   free(c->h_tables);
   delete c;
+}
+
+int miphy_side_streams(miphy_ctx* ctx)
+{
+  if (ctx->ev_fork)
+    return MIPHY_OK;
+  for (int k = 0; k < MIPHY_NOF_SIDE_STREAMS; ++k) {
+    hipStream_t st = nullptr;
+    hipEvent_t  e  = nullptr;
+    MIPHY_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    MIPHY_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->side_stream[k] = st, ctx->ev_join[k] = e;
+  }
+  hipEvent_t f = nullptr;
+  MIPHY_HIP_CHECK(hipEventCreateWithFlags(&f, hipEventDisableTiming));
+  ctx->ev_fork = f;
+  return MIPHY_OK;
 }
 
 int miphy_next_queue_counter(miphy_ctx* ctx, uint32_t** out)

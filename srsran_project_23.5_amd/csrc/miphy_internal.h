@@ -11,6 +11,7 @@
 #define MIPHY_BG2_EDGES 197
 #define MIPHY_MAX_EDGES 316
 #define MIPHY_CRC_ZMASK_WORDS 264 // 8448 bits: the largest codeblock
+#define MIPHY_NOF_SIDE_STREAMS 3
 
 // Per-(base graph, lifting size) edge table entry: low 16 bits = column*Z (LDS byte offset of the variable node),
 // high 16 bits = cyclic shift (already reduced modulo Z).
@@ -65,6 +66,12 @@ struct miphy_ctx {
   int                  num_cus; // compute units of the device (persistent-kernel grid sizing)
   uint32_t*            d_queue; // work-queue counters of the persistent kernels: a ring of MIPHY_NOF_QUEUE_COUNTERS words, one per launch
   uint32_t             queue_next;
+  // Side streams of the class-sorted LDPC decoder launches (created on first use): the launch classes of one call are independent, and the
+  // small ones are latency-bound chains that leave the chip idle -- they run next to the large ones, forked from / joined to the caller's
+  // stream with events (a pattern a HIP graph capture records as is).
+  void*                side_stream[MIPHY_NOF_SIDE_STREAMS];
+  void*                ev_fork;
+  void*                ev_join[MIPHY_NOF_SIDE_STREAMS];
 };
 #define MIPHY_NOF_QUEUE_COUNTERS 256
 
@@ -161,18 +168,26 @@ int miphy_ldpc_flags_reset(const uint32_t* d_slots, uint32_t n, uint8_t* harq_cr
 // Wave kernel (ldpc_decode_pkw.hip).
 int miphy_ldpc_pkw_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, const uint32_t* d_order, const uint32_t* d_bundles, uint32_t nof_bundles,
                           int bgi, int lay, size_t soft_total, const int8_t* llr, uint8_t* out_bits, int32_t* iters, const uint32_t* harq_slot,
-                          uint8_t* harq_crc_ok, hipStream_t s, int* used_gmsg);
+                          uint8_t* harq_crc_ok, hipStream_t s, int* used_gmsg, void* gmsg_buf = nullptr);
+size_t miphy_ldpc_pkw_gmsg_bytes(const miphy_ctx* ctx, uint32_t nof_bundles, int bgi, int lay, size_t soft_total);
 #endif
 
 // Returns a device scratch buffer of at least `bytes` (reallocated, after a stream sync, when it has to grow).
 int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out, int which = 0);
 
 // Packed (two rows per lane) LDPC decoder kernel, ldpc_decode_pk.hip.
-size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all); // pairs_all = 0: messages in global memory
+size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all, bool split = false); // pairs_all = 0: messages in global memory; split: + exchange slots of the latency form
 int    miphy_ldpc_pk_waves_per_cu(bool fused);
 int    miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                             uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
                             const miphy_ldpc_rdm_desc* d_rdm = nullptr, const int8_t* rm_in = nullptr, int gmsg_pairs = 0,
-                            const uint32_t* d_order = nullptr /* the launch decodes codeblocks d_order[0 .. n) of the arrays */);
+                            const uint32_t* d_order = nullptr /* the launch decodes codeblocks d_order[0 .. n) of the arrays */,
+                            void* gmsg_buf = nullptr /* message scratch of miphy_ldpc_pk_gmsg_bytes() bytes; null: the context's workspace */,
+                            bool split = false /* latency form: twice the wavefronts per codeblock (lds from miphy_ldpc_pk_lds_bytes(..., true)) */);
+// Resident workgroups of such a launch and the bytes of global message scratch it needs (0 with the messages in LDS).
+uint32_t miphy_ldpc_pk_grid(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused);
+size_t   miphy_ldpc_pk_gmsg_bytes(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused, int gmsg_pairs);
+// The context's side streams and fork / join events, created on first use.
+int miphy_side_streams(miphy_ctx* ctx);
 // The next work-queue counter of the context (zero: every launch leaves its counter cleared).
 int miphy_next_queue_counter(miphy_ctx* ctx, uint32_t** out);

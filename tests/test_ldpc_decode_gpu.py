@@ -7,16 +7,18 @@ from oracle_lib import (ALL_Z, BG_K, BG_NS, CRC16, CRC24A, CRC24B, o_crc_bits, o
 pytestmark = pytest.mark.gpu
 
 
-SCALAR, PACKED, FUSED, GMSG, WAVE = 1, 2, 4, 8, 16  # MIPHY_LDPC_KERNEL_* (include/miphy.h)
+SCALAR, PACKED, FUSED, GMSG, WAVE, SPLIT = 1, 2, 4, 8, 16, 32  # MIPHY_LDPC_KERNEL_* (include/miphy.h)
 
 
-@pytest.fixture(params=["auto", "scalar", "packed"], autouse=True)
+@pytest.fixture(params=["auto", "scalar", "packed", "throughput"], autouse=True)
 def ldpc_kernel(request):
     """Every test of this file runs with the automatic choice (host descriptors: class-sorted launches -- the wave kernel for Z <= 64,
-    the packed kernel above; device descriptors: one launch), with the one-row-per-lane kernel forced and with the packed kernel
-    forced as ONE launch for the whole batch. `kernels_used()` tells which kernels really ran; the tests assert it."""
+    the packed kernel above, in its latency form because these batches hold fewer codeblocks than the chip has CUs; device descriptors:
+    one launch), with the one-row-per-lane kernel forced, with the packed kernel forced as ONE launch for the whole batch, and with the
+    class-sorted launches in their throughput form (what a batch that fills the chip gets). `kernels_used()` tells which kernels really
+    ran; the tests assert it."""
     import miphy
-    miphy.lib().miphy_debug_force_ldpc_kernel({"auto": 0, "scalar": 1, "packed": 2}[request.param])
+    miphy.lib().miphy_debug_force_ldpc_kernel({"auto": 0, "scalar": 1, "packed": 2, "throughput": 4}[request.param])
     miphy.lib().miphy_debug_ldpc_kernels_used(1)
     yield request.param
     miphy.lib().miphy_debug_force_ldpc_kernel(0)
@@ -33,9 +35,13 @@ def check_kernels(mode, used, cases):
     if mode == "scalar":
         assert used == SCALAR, used
     elif mode == "packed":
-        assert used & PACKED and not used & (SCALAR | WAVE), used
+        assert used & PACKED and not used & (SCALAR | WAVE | SPLIT), used
     else:
         assert not used & SCALAR, used
+        if mode == "throughput":
+            assert not used & SPLIT, used
+        elif any(c["Z"] > 64 and c["llr"].size // c["Z"] < 40 for c in cases):
+            assert used & SPLIT, used  # small batches: the latency form wherever its LDS image fits a CU
         assert bool(used & WAVE) == any(c["Z"] <= 64 for c in cases), used
         assert bool(used & PACKED) == any(c["Z"] > 64 for c in cases), used
 
@@ -154,8 +160,8 @@ def test_all_graphs_noisy(ctx, ldpc_kernel):
 def test_message_placement_of_the_packed_kernel(ctx, ldpc_kernel):
     """The packed kernel keeps its check-to-variable messages in LDS at high code rates and in global memory (GMSG instance) where that
     keeps more codeblocks per CU: both instances must be reached and agree with the oracle."""
-    if ldpc_kernel == "scalar":
-        return  # nothing to place: the one-row-per-lane kernel keeps compressed check-node state
+    if ldpc_kernel in ("scalar", "auto"):
+        return  # nothing to place: the one-row-per-lane kernel keeps compressed check-node state, the latency form always uses LDS
     rng = np.random.default_rng(17)
     seen = set()
     for bg, Z, nodes in ((2, 384, 12), (1, 384, 24), (1, 384, 66), (2, 384, 50), (1, 256, 66), (2, 128, 50), (1, 128, 24), (1, 72, 66)):
@@ -455,6 +461,7 @@ def test_prepared_plan_matches_the_batch_call(ctx, ldpc_kernel):
         torch.cuda.synchronize()
         used = kernels_used()
         assert (used == SCALAR) if ldpc_kernel == "scalar" else (used & PACKED and used & WAVE and not used & SCALAR), used
+        assert bool(used & SPLIT) == (ldpc_kernel == "auto")
         out, its = out_d.cpu().numpy(), it_d.cpu().numpy()
         for i, c in enumerate(cases):
             if c.get("flags", 0) & 1:
