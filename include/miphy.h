@@ -109,7 +109,8 @@ void     miphy_ldpc_decode_plan_destroy(miphy_ldpc_decode_plan* plan);
 
 /* Test / A-B knob: 0 = automatic choice (host descriptors: sorted into launch classes by lifting size and code rate, one launch per
  * class; device descriptors: one launch), 1 = one-row-per-lane kernel, 2 = packed two-rows-per-lane kernel as one launch,
- * 3 = class-sorted launches, 4 = class-sorted launches without the latency form of the packed kernel. All kernels produce identical results. */
+ * 3 = class-sorted launches, 4 = class-sorted launches with the geometry of a batch that fills the chip whatever its size (no latency form, messages in global
+ * memory wherever that buys residency). All kernels produce identical results. */
 void miphy_debug_force_ldpc_kernel(int mode);
 /* Which decoder kernels have been launched since the last reset (tests assert that a forced choice really ran): */
 #define MIPHY_LDPC_KERNEL_SCALAR 1u /* one check row per lane */
@@ -119,6 +120,8 @@ void miphy_debug_force_ldpc_kernel(int mode);
 #define MIPHY_LDPC_KERNEL_WAVE  16u /* several small codeblocks per wavefront (Z <= 64) */
 #define MIPHY_LDPC_KERNEL_SPLIT 32u /* packed kernel in its latency form: twice the wavefronts per codeblock (launches of at most one codeblock per CU) */
 unsigned miphy_debug_ldpc_kernels_used(int reset);
+/* A-B knob: streams the launch classes of one call are spread over (1 = one after another on the caller's stream). */
+void miphy_debug_set_ldpc_class_streams(int n);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * LDPC rate dematcher  --  replaces srsran::ldpc_rate_dematcher::rate_dematch

@@ -387,6 +387,13 @@ bool miphy_ldpc_scalar_forced()
   return g_force_kernel == 1;
 }
 
+static int g_class_streams = 1 + MIPHY_NOF_SIDE_STREAMS; // streams the launch classes of a call are spread over (miphy_debug_set_ldpc_class_streams)
+
+extern "C" void miphy_debug_set_ldpc_class_streams(int n)
+{
+  g_class_streams = n < 1 ? 1 : (n > 1 + MIPHY_NOF_SIDE_STREAMS ? 1 + MIPHY_NOF_SIDE_STREAMS : n);
+}
+
 extern "C" unsigned miphy_debug_ldpc_kernels_used(int reset)
 {
   const unsigned m = g_kernels_used;
@@ -510,7 +517,6 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
     bool   fuse, gm, split;
     int    threads, pairs;
     size_t lds, gmsg_bytes, gmsg_off;
-    double cost;
     int    stream; // 0 = the caller's, 1 .. = side streams
   };
   std::vector<geom> g(nc);
@@ -520,11 +526,10 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
     geom&                   q = g[i];
     q = geom{};
     const int bgK = c.bgi ? 10 : 22;
-    q.cost        = (double)c.count * (bgK + c.lay) * c.max_Z;
     if (g_force_kernel == 1)
       continue;
     if (c.kind == 0) {
-      q.gmsg_bytes = miphy_ldpc_pkw_gmsg_bytes(ctx, c.bundle_count, c.bgi, c.lay, c.soft_total);
+      q.gmsg_bytes = miphy_ldpc_pkw_gmsg_bytes(ctx, c.bundle_count, c.bgi, c.lay, c.soft_total, g_force_kernel == 4);
     } else {
       q.threads = 64 * c.kind;
       q.pairs   = ctx->h_tables->pair_start[c.bgi][c.lay];
@@ -532,7 +537,9 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
       const size_t lds_l = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, q.pairs), lds_g = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, 0);
       // messages in LDS while that keeps as many codeblocks resident per CU as the registers allow; otherwise in global memory
       auto per_cu = [&](size_t lds) { return std::max(1, std::min((int)((size_t)160 * 1024 / lds), miphy_ldpc_pk_waves_per_cu(q.fuse) / (int)c.kind)); };
-      q.gm         = per_cu(lds_g) > per_cu(lds_l);
+      // (and only where the class has more codeblocks than stay resident with the messages in LDS: otherwise the global round trip per
+      // layer visit buys nothing)
+      q.gm         = per_cu(lds_g) > per_cu(lds_l) && (g_force_kernel == 4 || c.count > (uint32_t)(ctx->num_cus * per_cu(lds_l)));
       q.lds        = q.gm ? lds_g : lds_l;
       // Latency form where the class cannot fill the chip anyway (at most one codeblock per CU): twice the wavefronts per codeblock,
       // messages in LDS (residency is no concern then).
@@ -553,32 +560,36 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
       return rc;
     gmsg_base = (uint8_t*)w;
   }
-  // Classes to streams: the most expensive class stays on the caller's stream, the others go to the least loaded of all streams (the
-  // small classes are latency chains of a few hundred wavefronts: next to a large class they cost nothing, one after another they
-  // each cost their full latency with the chip idle). One class: no fork.
+  // Classes to streams. A class whose whole grid is a fraction of the chip (at most four wavefronts per CU: a few hundred small
+  // codeblocks) is a latency chain -- one after another such classes each cost their full latency with the chip idle, next to a
+  // large class they cost nothing: they go to the side streams, round robin. The large classes stay on the caller's stream one
+  // after another: two chip-filling persistent grids side by side was measured slower and erratic (4.6 ms in sequence, 4.1 to 6.7
+  // side by side on the mixed slot of bench.py), each holds the registers and LDS the other was tuned to have.
   int nstreams = 1;
-  if (nc > 1) {
+  if (nc > 1 && g_class_streams > 1) {
+    int small = 0;
+    for (size_t i = 0; i < nc; ++i) {
+      const miphy_ldpc_class& c = C.classes[i];
+      const uint64_t waves = c.kind == 0 ? c.bundle_count : (uint64_t)c.count * c.kind * (g[i].split ? 2 : 1);
+      if (waves <= (uint64_t)ctx->num_cus * 4)
+        g[i].stream = 1 + (small++ % (g_class_streams - 1));
+    }
+    if (small == (int)nc) // nothing large: the first small class takes the caller's stream
+      g[0].stream = 0;
+    if (small > 0)
+      nstreams = g_class_streams;
+  }
+  if (nstreams > 1) {
     if ((rc = miphy_side_streams(ctx)))
       return rc;
-    nstreams = 1 + MIPHY_NOF_SIDE_STREAMS;
-    std::vector<size_t> by_cost(nc);
-    for (size_t i = 0; i < nc; ++i)
-      by_cost[i] = i;
-    std::sort(by_cost.begin(), by_cost.end(), [&](size_t a, size_t b) { return g[a].cost > g[b].cost; });
-    double load[1 + MIPHY_NOF_SIDE_STREAMS] = {};
-    for (size_t i : by_cost) {
-      int best = 0;
-      for (int k = 1; k < nstreams; ++k)
-        if (load[k] < load[best])
-          best = k;
-      g[i].stream = best;
-      load[best] += g[i].cost;
-    }
     MIPHY_HIP_CHECK(hipEventRecord((hipEvent_t)ctx->ev_fork, s));
     for (int k = 0; k < MIPHY_NOF_SIDE_STREAMS; ++k)
       MIPHY_HIP_CHECK(hipStreamWaitEvent((hipStream_t)ctx->side_stream[k], (hipEvent_t)ctx->ev_fork, 0));
   }
-  for (size_t i = 0; i < nc; ++i) {
+  for (size_t k2 = 0; k2 < 2 * nc; ++k2) { // the side-stream classes first: they start while the large ones are being enqueued
+    const size_t i = k2 % nc;
+    if ((g[i].stream != 0) != (k2 < nc))
+      continue;
     const miphy_ldpc_class& c  = C.classes[i];
     const geom&             q  = g[i];
     hipStream_t             st = q.stream == 0 ? s : (hipStream_t)ctx->side_stream[q.stream - 1];
@@ -597,7 +608,7 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
     if (c.kind == 0) {
       int gm = 0;
       if ((rc = miphy_ldpc_pkw_launch(ctx, d_descs, d_order, d_bundles + 2 * (size_t)c.bundle_first, c.bundle_count, c.bgi, c.lay, c.soft_total, llr, out_bits,
-                                      iters, harq_slot, harq_crc_ok, st, &gm, gb)))
+                                      iters, harq_slot, harq_crc_ok, st, &gm, gb, g_force_kernel == 4)))
         return rc;
       g_kernels_used |= MIPHY_LDPC_KERNEL_WAVE | (gm ? MIPHY_LDPC_KERNEL_GMSG : 0u);
       continue;
@@ -610,7 +621,7 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
     g_kernels_used |= MIPHY_LDPC_KERNEL_PACKED | (q.fuse ? MIPHY_LDPC_KERNEL_FUSED : 0u) | (q.gm ? MIPHY_LDPC_KERNEL_GMSG : 0u) |
                       (q.split ? MIPHY_LDPC_KERNEL_SPLIT : 0u);
   }
-  if (nc > 1) {
+  if (nstreams > 1) {
     for (int k = 0; k < MIPHY_NOF_SIDE_STREAMS; ++k) {
       MIPHY_HIP_CHECK(hipEventRecord((hipEvent_t)ctx->ev_join[k], (hipStream_t)ctx->side_stream[k]));
       MIPHY_HIP_CHECK(hipStreamWaitEvent(s, (hipEvent_t)ctx->ev_join[k], 0));
@@ -743,7 +754,7 @@ int miphy_ldpc_decode_launch(miphy_ctx*                   ctx,
   const int  pk_waves   = pk_threads / 64;
   const bool will_fuse  = fuse_rdm && ((uintptr_t)llr & 15) == 0;
   auto       pk_per_cu  = [&](size_t lds) { return std::max(1, std::min((int)((size_t)160 * 1024 / (lds ? lds : 1)), miphy_ldpc_pk_waves_per_cu(will_fuse) / pk_waves)); };
-  const bool pk_gmsg    = pk_ok && pk_per_cu(pk_lds_g) > pk_per_cu(pk_lds);
+  const bool pk_gmsg    = pk_ok && pk_per_cu(pk_lds_g) > pk_per_cu(pk_lds) && (g_force_kernel >= 2 || n > (uint32_t)(ctx->num_cus * pk_per_cu(pk_lds)));
   if (pk_gmsg)
     pk_lds = pk_lds_g;
   auto rows_in_flight = [](size_t lds, int threads, int waves_per_simd_by_regs, int rows_per_lane) {

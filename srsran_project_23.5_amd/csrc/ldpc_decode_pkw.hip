@@ -325,7 +325,7 @@ struct pkw_geometry {
   uint32_t grid;
   int      pairs;
 };
-pkw_geometry pkw_geom(const miphy_ctx* ctx, uint32_t nof_bundles, int bgi, int lay, size_t soft_total)
+pkw_geometry pkw_geom(const miphy_ctx* ctx, uint32_t nof_bundles, int bgi, int lay, size_t soft_total, bool throughput_form)
 {
   pkw_geometry g;
   g.pairs            = ctx->h_tables->pair_start[bgi][lay];
@@ -334,28 +334,30 @@ pkw_geometry pkw_geom(const miphy_ctx* ctx, uint32_t nof_bundles, int bgi, int l
   // dword per lane, edge pair and layer visit, re-read out of L2 an iteration later) where LDS would leave fewer than two wavefronts
   // per SIMD and the move buys residency.
   auto per_cu = [](size_t lds) { return std::max(1, std::min((int)((size_t)160 * 1024 / lds), 16)); };
-  g.gm        = per_cu(lds_l) < 8 && per_cu(lds_g) > per_cu(lds_l);
+  // ... and only where the launch has more bundles than stay resident with the messages in LDS: a launch that fits the chip anyway is a
+  // latency chain, and a global round trip per layer visit would sit on it.
+  g.gm        = per_cu(lds_l) < 8 && per_cu(lds_g) > per_cu(lds_l) && (throughput_form || nof_bundles > (uint32_t)(ctx->num_cus * per_cu(lds_l)));
   g.lds       = g.gm ? lds_g : lds_l;
   g.grid      = std::min<uint32_t>(nof_bundles, (uint32_t)(ctx->num_cus * per_cu(g.lds)));
   return g;
 }
 } // namespace
 
-size_t miphy_ldpc_pkw_gmsg_bytes(const miphy_ctx* ctx, uint32_t nof_bundles, int bgi, int lay, size_t soft_total)
+size_t miphy_ldpc_pkw_gmsg_bytes(const miphy_ctx* ctx, uint32_t nof_bundles, int bgi, int lay, size_t soft_total, bool throughput_form)
 {
   if (nof_bundles == 0)
     return 0;
-  const pkw_geometry g = pkw_geom(ctx, nof_bundles, bgi, lay, soft_total);
+  const pkw_geometry g = pkw_geom(ctx, nof_bundles, bgi, lay, soft_total, throughput_form);
   return g.gm ? (size_t)g.grid * (size_t)g.pairs * 256 : 0;
 }
 
 int miphy_ldpc_pkw_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, const uint32_t* d_order, const uint32_t* d_bundles, uint32_t nof_bundles,
                           int bgi, int lay, size_t soft_total, const int8_t* llr, uint8_t* out_bits, int32_t* iters, const uint32_t* harq_slot,
-                          uint8_t* harq_crc_ok, hipStream_t s, int* used_gmsg, void* gmsg_buf)
+                          uint8_t* harq_crc_ok, hipStream_t s, int* used_gmsg, void* gmsg_buf, bool throughput_form)
 {
   if (nof_bundles == 0)
     return MIPHY_OK;
-  const pkw_geometry g = pkw_geom(ctx, nof_bundles, bgi, lay, soft_total);
+  const pkw_geometry g = pkw_geom(ctx, nof_bundles, bgi, lay, soft_total, throughput_form);
   if (used_gmsg)
     *used_gmsg = g.gm ? 1 : 0;
   const void* kern = g.gm ? (const void*)ldpc_decode_pkw_kernel<true> : (const void*)ldpc_decode_pkw_kernel<false>;

@@ -168,8 +168,9 @@ int miphy_ldpc_flags_reset(const uint32_t* d_slots, uint32_t n, uint8_t* harq_cr
 // Wave kernel (ldpc_decode_pkw.hip).
 int miphy_ldpc_pkw_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, const uint32_t* d_order, const uint32_t* d_bundles, uint32_t nof_bundles,
                           int bgi, int lay, size_t soft_total, const int8_t* llr, uint8_t* out_bits, int32_t* iters, const uint32_t* harq_slot,
-                          uint8_t* harq_crc_ok, hipStream_t s, int* used_gmsg, void* gmsg_buf = nullptr);
-size_t miphy_ldpc_pkw_gmsg_bytes(const miphy_ctx* ctx, uint32_t nof_bundles, int bgi, int lay, size_t soft_total);
+                          uint8_t* harq_crc_ok, hipStream_t s, int* used_gmsg, void* gmsg_buf = nullptr,
+                          bool throughput_form = false /* A-B knob: geometry of a launch that fills the chip, whatever its size */);
+size_t miphy_ldpc_pkw_gmsg_bytes(const miphy_ctx* ctx, uint32_t nof_bundles, int bgi, int lay, size_t soft_total, bool throughput_form = false);
 #endif
 
 // Returns a device scratch buffer of at least `bytes` (reallocated, after a stream sync, when it has to grow).

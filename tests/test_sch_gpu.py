@@ -122,14 +122,18 @@ FUSABLE = [  # bg, mod, nof_layers, nprb, tbs bits, sigma: every codeblock Z >= 
 ]
 
 
+@pytest.mark.parametrize("form", ["auto", "throughput"])
 @pytest.mark.parametrize("early_stop", [0, 1])
-def test_first_transmission_dematched_by_the_decoder(ctx, early_stop):
+def test_first_transmission_dematched_by_the_decoder(ctx, early_stop, form):
     """A batch of first transmissions (rv 0, new data) takes the path where the LDPC decoder rate-dematches while it loads its
     codeblock: the HARQ soft buffers must hold exactly what the reference's dematcher leaves there (oracle, pinned against the
     reference), results and transport blocks as the oracle; a retransmission (separate dematcher launch, combining into those
     buffers) then also matches."""
     import torch
     import miphy
+    # "throughput": the launch geometry of a batch that fills the chip (these few transport blocks would otherwise all take the latency
+    # form of the packed kernel with its messages in LDS)
+    miphy.lib().miphy_debug_force_ldpc_kernel(4 if form == "throughput" else 0)
     rng = np.random.default_rng(77 + early_stop)
     tbs, slot = [], 0
     for bg, mod, nl, nprb, tbs_bits, sigma in FUSABLE:
@@ -161,11 +165,14 @@ def test_first_transmission_dematched_by_the_decoder(ctx, early_stop):
         ctx.pusch_decode_batch(d, torch.from_numpy(llr_all).cuda(), soft_d, msgs_d, crc_d, tb_d, res_d)
         torch.cuda.synchronize()
         used = int(miphy.lib().miphy_debug_ldpc_kernels_used(1))
-        # first transmissions: the packed kernel dematches while it loads (FUSED), with the messages in LDS for the high-rate classes
-        # and in global memory (GMSG) for the rate-1/3 one; the retransmission runs the dematcher as a launch of its own
-        # (these batches hold fewer codeblocks than the chip has CUs: the packed kernel runs in its latency form, bit 32, except for the
-        # rate-1/3 class, whose LDS image with the messages would not fit a CU)
-        assert used == ((2 | 4 | 8 | 32) if t == 0 else (2 | 8 | 32)), used
+        # first transmissions: the packed kernel (2) dematches while it loads (FUSED, 4); the retransmission runs the dematcher as a launch of
+        # its own. Throughput form: messages in LDS for the high-rate classes, in global memory (GMSG, 8) for the others. Automatic
+        # choice: these few codeblocks take the latency form (32) with the messages in LDS -- except the rate-1/3 codeblock, whose LDS
+        # image with messages and exchange slots exceeds a CU.
+        if form == "throughput":
+            assert used == ((2 | 4 | 8) if t == 0 else (2 | 8)), used
+        else:
+            assert used == ((2 | 4 | 32) if t == 0 else (2 | 32)), used
         res = res_d.cpu().numpy().view(miphy.PuschResult)
         tb_out = tb_d.cpu().numpy()
         soft = soft_d.cpu().numpy().reshape(slot, miphy.HARQ_CB_STRIDE)
@@ -181,4 +188,5 @@ def test_first_transmission_dematched_by_the_decoder(ctx, early_stop):
             if ok:
                 o0 = int(d[i]["tb_offset"])
                 assert np.array_equal(tb_out[o0:o0 + x["tb"].size], x["tb"]), key
+    miphy.lib().miphy_debug_force_ldpc_kernel(0)
     assert any(bool(r["tb_crc_ok"]) for r in res)

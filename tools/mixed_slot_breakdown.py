@@ -31,4 +31,6 @@ def run(pdus, label):
 for p in BL.MIXED_PDUS:
     tot += run([p], "PRB %3d Qm %d R %4d TBS %6d" % (p[1], p[2], p[5], p[3]))
 print("sum of the separate types: %.3f ms" % tot)
-run(BL.MIXED_PDUS, "all eight per slot")
+for ns in (1, 2, 4, 1, 4):
+    miphy.lib().miphy_debug_set_ldpc_class_streams(ns)
+    run(BL.MIXED_PDUS, "all eight per slot, %d streams" % ns)
