@@ -64,6 +64,7 @@ def parse_args():
                     help="scatter: add the separately timed single-ingest leg (rank 0 scatters the LLR slabs over RCCL, results all-gathered); "
                          "local (default): every rank owns its slots, no collective in the data path")
     ap.add_argument("--ingest-slots", type=int, default=128, help="slots per rank in the scatter leg")
+    ap.add_argument("--ldpc-force", type=int, default=0, help="A-B knob of tools/ab_bench.py: miphy_debug_force_ldpc_kernel mode (0 = automatic)")
     ap.add_argument("--extra-multi", action="store_true", help="run the extra GPU legs on rank 0 of a multi-GPU job as well (default: single GPU only)")
     return ap.parse_args()
 
@@ -443,6 +444,8 @@ def main():
     import oracle_lib as O
     from miphy import shard
     ctx = miphy.Context(local_rank)
+    if args.ldpc_force:
+        miphy.lib().miphy_debug_force_ldpc_kernel(args.ldpc_force)
     w = pusch_workload()
     S = args.slots
     # Segmentation of the transport block through the library's own host logic (ldpc.h:128-207 restated in csrc/sch.hip).

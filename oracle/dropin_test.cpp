@@ -1552,6 +1552,60 @@ static void test_softbuffer_pool(std::shared_ptr<miphy::context> c)
 // The flow of polar_chain_test.cpp:156-210 run block by block on the HIP objects of polar_factory_hip next to the reference's
 // software objects: every intermediate must be identical (noisy LLRs, so that the decoder really works), and the pdcch_encoder
 // the reference builds from a polar_factory works unchanged on the HIP factory.
+// Placement policy of a multi-GPU node: cells pinned to devices round robin, one HARQ pool per device, contexts bound to their device.
+// (One GPU here: every cell lands on device 0 -- the mapping, the lazily created pool and a decode through the placed context are checked;
+// with two visible devices cells 0 and 1 get different contexts and pools.)
+static void test_device_placement()
+{
+  rx_softbuffer_pool_config pc;
+  pc.max_codeblock_size = ldpc::MAX_CODEBLOCK_SIZE, pc.max_softbuffers = 4, pc.max_nof_codeblocks = 64, pc.expire_timeout_slots = 10;
+  miphy::device_placement place(pc);
+  const unsigned          nd = place.nof_devices();
+  CHECK(nd >= 1, "device_placement: no device");
+  for (unsigned cell = 0; cell != 8; ++cell) {
+    CHECK(place.device_of_cell(cell) == cell % nd, "device_placement: cell %u on device %u", cell, place.device_of_cell(cell));
+    CHECK(place.context_of_cell(cell)->device == static_cast<int>(cell % nd), "device_placement: context of cell %u is on device %d", cell,
+          place.context_of_cell(cell)->device);
+    CHECK(&place.softbuffer_pool_of_cell(cell) == &place.softbuffer_pool_of_cell(cell % nd), "device_placement: cells of one device must share its pool");
+  }
+  if (nd > 1) {
+    CHECK(&place.softbuffer_pool_of_cell(0) != &place.softbuffer_pool_of_cell(1), "device_placement: one pool per device");
+  }
+  // a block created with the placed context decodes on that device (a thread bound by the policy)
+  std::thread th([&]() {
+    const unsigned cell = nd - 1;
+    place.bind_thread(cell);
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    CHECK(dev == static_cast<int>(place.device_of_cell(cell)), "device_placement: bind_thread left device %d current", dev);
+    auto dec = miphy::create_ldpc_decoder_factory_hip(place.context_of_cell(cell))->create();
+    auto enc = create_ldpc_encoder_factory_sw("avx2")->create();
+    const unsigned Z = 96, K = 22 * Z, N = 66 * Z;
+    std::vector<uint8_t> msg(K), cw(N);
+    for (auto& b : msg) {
+      b = rgen() & 1;
+    }
+    codeblock_metadata m = {};
+    m.tb_common.base_graph = ldpc_base_graph_type::BG1, m.tb_common.lifting_size = static_cast<ldpc::lifting_size_t>(Z);
+    enc->encode(cw, msg, m.tb_common);
+    std::vector<log_likelihood_ratio> llr(N);
+    for (unsigned i = 0; i != N; ++i) {
+      llr[i] = cw[i] ? -20 : 20;
+    }
+    dynamic_bit_buffer          out(K);
+    ldpc_decoder::configuration cfg;
+    cfg.block_conf = m, cfg.algorithm_conf.max_iterations = 4;
+    dec->decode(out, llr, nullptr, cfg);
+    unsigned bad = 0;
+    for (unsigned i = 0; i != K; ++i) {
+      bad += out.extract(i, 1) != msg[i];
+    }
+    CHECK(bad == 0, "device_placement: decode through the placed context: %u bit errors", bad);
+  });
+  th.join();
+  printf("device_placement done (%u device(s)), failures so far %d\n", nd, failures);
+}
+
 static void test_polar_blocks(std::shared_ptr<miphy::context> c)
 {
   auto fs = create_polar_factory_sw();
@@ -2099,6 +2153,7 @@ int main()
   test_rate_matching(c);
   test_sch(c);
   test_softbuffer_pool(c);
+  test_device_placement();
   test_ofdm_and_estimator(c);
   test_dft(c);
   test_pdcch(c);

@@ -2925,4 +2925,54 @@ inline std::unique_ptr<srsran::nzp_csi_rs_configuration_validator> nzp_csi_rs_ge
   return srsran::create_nzp_csi_rs_generator_factory_sw(srsran::create_pseudo_random_generator_sw_factory())->create_validator();
 }
 
+// --------------------------------------------------------------------------------------------------- multi-GPU placement
+/// Device placement of a node with several GPUs: the path shards by cell / transport block with no cross-unit
+/// dependency, exactly like the reference runs one processor instance per worker (lib/phy/upper/uplink_processor_concurrent.h:41-54).
+/// One context per device; a CELL is pinned to one device -- `cell % devices` -- so that everything stateful of its UEs (the HARQ
+/// soft buffers of rx_softbuffer_pool_hip, which a retransmission must find where the first transmission left them) lives on
+/// that device and no PHY data ever crosses xGMI. One HARQ pool per device, created on first use with the configuration given here.
+/// A thread that drives a cell calls bind_thread(cell) once (a new thread starts on device 0).
+class device_placement
+{
+public:
+  /// \param nof_devices Devices to use, -1 = all visible ones.
+  explicit device_placement(const srsran::rx_softbuffer_pool_config& pool_config_, int nof_devices = -1) : pool_config(pool_config_)
+  {
+    int n = 0;
+    context::hip(hipGetDeviceCount(&n), "hipGetDeviceCount");
+    if (nof_devices > 0 && nof_devices < n) {
+      n = nof_devices;
+    }
+    require(n > 0, "No GPU visible.");
+    for (int d = 0; d != n; ++d) {
+      contexts.emplace_back(std::make_shared<context>(d));
+    }
+    pools.resize(contexts.size());
+  }
+  unsigned nof_devices() const { return contexts.size(); }
+  /// Device index a cell is pinned to.
+  unsigned device_of_cell(unsigned cell_index) const { return cell_index % contexts.size(); }
+  /// The context every block of that cell is created with (create_*_factory_hip(placement.context_of_cell(cell))).
+  std::shared_ptr<context> context_of_cell(unsigned cell_index) const { return contexts[device_of_cell(cell_index)]; }
+  /// The HARQ pool of the cell's device (shared by the cells pinned to it).
+  srsran::rx_softbuffer_pool& softbuffer_pool_of_cell(unsigned cell_index)
+  {
+    const unsigned              d = device_of_cell(cell_index);
+    std::lock_guard<std::mutex> lk(mutex);
+    if (!pools[d]) {
+      contexts[d]->bind_thread();
+      pools[d] = create_rx_softbuffer_pool_hip(contexts[d], pool_config);
+    }
+    return *pools[d];
+  }
+  /// Makes the cell's device the current one of the calling thread.
+  void bind_thread(unsigned cell_index) const { contexts[device_of_cell(cell_index)]->bind_thread(); }
+
+private:
+  srsran::rx_softbuffer_pool_config                         pool_config;
+  std::vector<std::shared_ptr<context>>                     contexts;
+  std::vector<std::unique_ptr<srsran::rx_softbuffer_pool>>  pools;
+  std::mutex                                                mutex;
+};
+
 } // namespace miphy

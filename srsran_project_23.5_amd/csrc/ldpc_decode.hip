@@ -544,7 +544,7 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
       // Latency form where the class cannot fill the chip anyway (at most one codeblock per CU): twice the wavefronts per codeblock,
       // messages in LDS (residency is no concern then).
       const size_t lds_s = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, q.pairs, true);
-      q.split            = g_force_kernel != 4 && c.count <= (uint32_t)ctx->num_cus && lds_s <= (size_t)160 * 1024;
+      q.split            = g_force_kernel != 4 && (c.count <= (uint32_t)ctx->num_cus || g_force_kernel == 5) && lds_s <= (size_t)160 * 1024;
       if (q.split)
         q.gm = false, q.lds = lds_s;
       q.gmsg_bytes = miphy_ldpc_pk_gmsg_bytes(ctx, c.count, q.threads, q.lds, q.fuse, q.gm ? q.pairs : 0);

@@ -133,6 +133,9 @@ __device__ unsigned long long g_ldpc_prof[2048 * 8]; // per workgroup: 7 phase s
 // launcher moves the messages to global memory for a fifth codeblock per CU, and that traffic next to the soft-buffer image stream
 // costs more than the occupancy gives (4.63 ms).
 #define LDPC_PK_MIN_WAVES_PLAIN 4
+#ifndef LDPC_PK_MIN_WAVES_SPLIT
+#define LDPC_PK_MIN_WAVES_SPLIT 3 // the latency form: its launches never fill a CU, the register budget is free
+#endif
 #ifndef LDPC_PK_MIN_WAVES_FUSED
 #define LDPC_PK_MIN_WAVES_FUSED 3
 #endif
@@ -256,7 +259,7 @@ __device__ __forceinline__ int pk_fused_image_out(const int8_t* __restrict__ sof
 // wavefronts per codeblock, the two halves of the workgroup share the edges of every layer (update_rows_pk, SPLIT) -- about half the
 // instructions per wavefront and layer for one more barrier, same results, same LDS image (messages always in LDS).
 template <bool FUSED, bool GMSG, bool SPLIT = false>
-__global__ void __launch_bounds__(SPLIT ? 384 : 192, FUSED ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN)
+__global__ void __launch_bounds__(SPLIT ? 384 : 192, SPLIT ? LDPC_PK_MIN_WAVES_SPLIT : (FUSED ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN))
 ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                       const miphy_graph_tables* __restrict__ tab,
                       const int8_t* __restrict__ llr_base,
@@ -569,9 +572,9 @@ extern "C" int miphy_debug_ldpc_profile(unsigned long long out[8], int reset)
 
 // LDS bytes the packed kernel needs for a given geometry (Zt >= Z of every codeblock, lay = layer bound, pairs_all = message
 // dwords per lane of those layers).
-int miphy_ldpc_pk_waves_per_cu(bool fused)
+int miphy_ldpc_pk_waves_per_cu(bool fused, bool split)
 {
-  return 4 * (fused ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN); // what __launch_bounds__ of the kernel guarantees per CU
+  return 4 * (split ? LDPC_PK_MIN_WAVES_SPLIT : (fused ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN)); // what __launch_bounds__ of the kernel guarantees per CU
 }
 
 size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all, bool split)
@@ -580,13 +583,13 @@ size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all, bool 
   return ((((size_t)bgK + lay) * Zt + 15) & ~(size_t)15) + waves * (size_t)pairs_all * 256 + 64 + (split ? 6 * 64 * waves * 4 : 0);
 }
 
-uint32_t miphy_ldpc_pk_grid(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused)
+uint32_t miphy_ldpc_pk_grid(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused, bool split)
 {
   // (threads = those of the launch: the latency form passes twice the row-owning threads)
   // Resident workgroups per CU: LDS, the wavefronts per CU the register budget of the kernel allows (__launch_bounds__), 32 slots.
   const int waves  = threads / 64;
   int       per_cu = (int)((size_t)160 * 1024 / lds);
-  per_cu           = std::min(per_cu, miphy_ldpc_pk_waves_per_cu(fused) / waves);
+  per_cu           = std::min(per_cu, miphy_ldpc_pk_waves_per_cu(fused, split) / waves);
   per_cu           = std::max(per_cu, 1);
   return std::min<uint32_t>(n, (uint32_t)(ctx->num_cus * per_cu));
 }
@@ -612,7 +615,7 @@ int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uin
   if (lds > 48 * 1024) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  const uint32_t grid  = miphy_ldpc_pk_grid(ctx, n, threads, lds, fused);
+  const uint32_t grid  = miphy_ldpc_pk_grid(ctx, n, threads, lds, fused, split);
   uint32_t*      queue = nullptr;
   int            rc    = miphy_next_queue_counter(ctx, &queue);
   if (rc)

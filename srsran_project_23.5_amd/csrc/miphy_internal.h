@@ -178,7 +178,7 @@ int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out,
 
 // Packed (two rows per lane) LDPC decoder kernel, ldpc_decode_pk.hip.
 size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all, bool split = false); // pairs_all = 0: messages in global memory; split: + exchange slots of the latency form
-int    miphy_ldpc_pk_waves_per_cu(bool fused);
+int    miphy_ldpc_pk_waves_per_cu(bool fused, bool split = false);
 int    miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                             uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
                             const miphy_ldpc_rdm_desc* d_rdm = nullptr, const int8_t* rm_in = nullptr, int gmsg_pairs = 0,
@@ -186,7 +186,7 @@ int    miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, 
                             void* gmsg_buf = nullptr /* message scratch of miphy_ldpc_pk_gmsg_bytes() bytes; null: the context's workspace */,
                             bool split = false /* latency form: twice the wavefronts per codeblock (lds from miphy_ldpc_pk_lds_bytes(..., true)) */);
 // Resident workgroups of such a launch and the bytes of global message scratch it needs (0 with the messages in LDS).
-uint32_t miphy_ldpc_pk_grid(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused);
+uint32_t miphy_ldpc_pk_grid(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused, bool split = false);
 size_t   miphy_ldpc_pk_gmsg_bytes(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused, int gmsg_pairs);
 // The context's side streams and fork / join events, created on first use.
 int miphy_side_streams(miphy_ctx* ctx);
