@@ -7,9 +7,9 @@ import numpy as np
 
 RNTI0, N_ID0, DMRS_SCR_ID = 0x4601, 935, 1
 DMRS_SCALING = 1.4125375  # DM-RS boosted by 3 dB with two CDM groups without data (sch_dmrs_power.h)
-# The 23.5 pdsch_processor takes the limited-buffer size from the PDU (encoder Nref = tbs_lbrm_bytes * 8, pdsch_processor_impl.cpp:192,238) and
-# asserts tbs_lbrm_bytes <= MAX_CODEBLOCK_SIZE / 8; its benchmark uses exactly that value.
-LBRM_BYTES = 8448 // 8
+# The 23.5 pdsch_processor takes the rate-matching buffer size from the PDU (encoder Nref = tbs_lbrm_bytes * 8, pdsch_processor_impl.cpp:192,238,
+# at most ldpc::MAX_CODEBLOCK_SIZE / 8 = 66 * 384 / 8 bytes); its benchmark passes exactly that maximum: the full circular buffer.
+LBRM_BYTES = 66 * 384 // 8
 
 # One 273-PRB slot shared by eight UEs: (first PRB, PRBs, bits per symbol, TBS bits, base graph, R x 1024). 14 symbols, DM-RS in symbol 2
 # (12 RE per PRB with two CDM groups without data), one layer. TBS and base graph are what the reference's tbs_calculator_calculate /
@@ -273,19 +273,32 @@ def pdsch_tx_leg(ctx, miphy, torch, dev, w, S, max_iter, cpu_seconds, with_cpu, 
            "dmrs_pdsch": ev_ms(torch, lambda: ctx.dmrs_pdsch_map_batch(dj_d, grid, st), 5),
            "ofdm_mod": ev_ms(torch, lambda: ctx.ofdm_modulate_slots(mcfg, oj_d, grid, samples, st), 5)}
 
+    plan = miphy.PdschProcessPlan(ctx, pdus)
+
     def chain():
+        plan.run(tb_d, grid, st)
+        ctx.ofdm_modulate_slots(mcfg, oj_d, grid, samples, st)
+
+    def chain_per_call():  # host descriptors every call: validation, segmentation and MBs of descriptors through the staging ring per call
         ctx.pdsch_process_batch(pdus, tb_d, grid, st)
         ctx.ofdm_modulate_slots(mcfg, oj_d, grid, samples, st)
 
+    t0 = time.perf_counter()
+    for _ in range(3):
+        chain_per_call()
+    torch.cuda.synchronize()
+    ms_per_call = (time.perf_counter() - t0) / 3 * 1e3
+    grid_pc = grid.clone()
+    grid.zero_()
     ms_chain = ev_ms(torch, chain, 5)
+    plan_equals_per_call = bool(torch.equal(torch.view_as_real(grid), torch.view_as_real(grid_pc)))
     # algorithmic bytes: TB in + rate-matched codeword out (one byte per bit) | codeword in + data REs out | DM-RS REs out | grid in + samples out
     alg = {"pdsch_encode": S * (tb_bytes + G), "pdsch_modulate": S * (G + w["nsym"] * 8), "dmrs_pdsch": S * (nsc // 2) * 8, "ofdm_mod": S * (14 * nsc * 8 + ss * 8)}
     gbs = {k: alg[k] / (kms[k] * 1e-3) / 1e9 for k in kms}
-    # ---- verification (not timed). The 23.5 pdsch_processor only knows limited buffers of at most one codeblock's K bits (LBRM_BYTES above), which at
-    # this code rate transmits no parity at all -- its output cannot be decoded by anyone, the reference's own benchmark only times it. So instead of a
-    # decode: (1) the composed call's grid equals the grid of the separate entry points bit for bit; (2) the codeword of slot 0 equals the oracle's
-    # (pinned against the reference encoder); (3) the samples demodulate back to the grid; (4) the receive front end of this library (estimator +
-    # demodulator) returns LLRs whose hard decisions are the codeword bits of 8 slots.
+    # ---- verification (not timed): (1) the plan's grid equals the per-call grid and the grid of the separate entry points; (2) the codeword of slot 0
+    # equals the oracle's (pinned against the reference encoder); (3) the samples demodulate back to the grid; (4) the receive chain of this library
+    # (OFDM demodulator, estimator, demodulator, decoder) recovers the transport blocks of 8 slots from the samples, and the hard decisions of its
+    # LLRs are the codeword bits.
     grid_c = grid.clone()
     grid.zero_()
     ctx.pdsch_encode_batch(td, tb_d, cw, st)
@@ -314,25 +327,37 @@ def pdsch_tx_leg(ctx, miphy, torch, dev, w, S, max_iter, cpu_seconds, with_cpu, 
     ce = torch.zeros(nchk * nsc, dtype=torch.complex64, device=dev)
     sc = torch.zeros(nchk * 5, dtype=torch.float32, device=dev)
     llr = torch.zeros(nchk * G, dtype=torch.int8, device=dev)
+    tdr = np.zeros(nchk, dtype=miphy.PuschTbDesc)
+    for s in range(nchk):
+        tdr[s] = (w["bg"], 0, mod, 1, 1, 0, max_iter, 8 * LBRM_BYTES, w["nsym"], tb_bytes, s * C, s * G, s * tb_bytes)
+    soft = torch.zeros(nchk * C * miphy.HARQ_CB_STRIDE, dtype=torch.int8, device=dev)
+    msgs = torch.zeros(nchk * C * miphy.HARQ_MSG_STRIDE, dtype=torch.uint8, device=dev)
+    crc = torch.zeros(nchk * C, dtype=torch.uint8, device=dev)
+    tbo = torch.zeros(nchk * tb_bytes, dtype=torch.uint8, device=dev)
+    res = torch.zeros(nchk * miphy.PuschResult.itemsize, dtype=torch.uint8, device=dev)
     ctx.ofdm_demodulate_slots(ocfg, oj[:nchk], samples, grid_rx, st)
     ctx.dmrs_pusch_estimate_batch(cj, grid_rx, ce, sc, st)
     ctx.pusch_demodulate_batch(qj, grid_rx, ce, sc, llr, st)
+    ctx.pusch_decode_batch(tdr, llr, soft, msgs, crc, tbo, res, st)
     torch.cuda.synchronize()
+    rr = res.cpu().numpy().view(miphy.PuschResult)
+    tb_back = int(sum(int(rr[s]["tb_crc_ok"] != 0 and np.array_equal(tbo[s * tb_bytes:(s + 1) * tb_bytes].cpu().numpy(), tb_u[s % n_u])) for s in range(nchk)))
     ref_g = grid[:nchk * 14 * nsc]
     ofdm_err = float((grid_rx - ref_g).abs().max() / ref_g.abs().pow(2).mean().sqrt())
     bit_errors = int(((llr < 0).to(torch.uint8) != cw[:nchk * G]).sum().item())
-    verified = same_grid and cw_oracle and ofdm_err < 2e-4 and bit_errors == 0
+    verified = same_grid and cw_oracle and ofdm_err < 2e-4 and bit_errors == 0 and plan_equals_per_call and tb_back == nchk
+    plan.close()
     out = {"config": "%d transport blocks of the headline allocation (273 PRB, 256QAM R=948/1024, TBS %d, %d codeblocks BG1 Z=%d) -> pdsch_processor (CRC, segmentation, LDPC "
                      "encode, rate match, scrambling, modulation, RE mapping, DM-RS) -> ofdm_slot_modulator (4096-point)" % (S, w["tbs"], C, sg.Z),
-           "slots": S, "ms_per_step": ms_chain, "kernel_ms": kms, "kernel_algorithmic_GBps": gbs,
+           "slots": S, "ms_per_step": ms_chain, "entry_points": "miphy_pdsch_process_plan_run (descriptors prepared once) + miphy_ofdm_modulate_slots",
+           "ms_per_step_host_descriptors_every_call": ms_per_call, "info_bits_per_s_host_descriptors_every_call": S * w["tbs"] / (ms_per_call * 1e-3),
+           "kernel_ms": kms, "kernel_algorithmic_GBps": gbs,
            "kernel_hbm_frac": {k: gbs[k] / hbm_peak for k in gbs},
            "info_bits_per_s": S * w["tbs"] / (ms_chain * 1e-3), "slots_per_s": S / (ms_chain * 1e-3), "ofdm_mod_slots_per_s": S / (kms["ofdm_mod"] * 1e-3),
            "ldpc_encode_info_bits_per_s": S * w["tbs"] / (kms["pdsch_encode"] * 1e-3),
-           "verification": {"composed_grid_vs_separate_entry_points_max_abs_diff": grid_diff, "codeword_equals_oracle": cw_oracle,
+           "verification": {"plan_grid_equals_per_call_grid": plan_equals_per_call, "composed_grid_vs_separate_entry_points_max_abs_diff": grid_diff, "codeword_equals_oracle": cw_oracle,
                             "ofdm_demod_of_the_samples_vs_grid_rel_err": ofdm_err, "hard_decisions_of_received_llrs_vs_codeword_bit_errors": bit_errors,
-                            "slots_received_again": nchk,
-                            "note": "no decode: the 23.5 pdsch_processor's limited buffer (Nref = 8448 = K, pdsch_processor_impl.cpp:192,238) transmits no parity "
-                                    "at this code rate"}}
+                            "slots_received_again": nchk, "transport_blocks_recovered_by_the_receive_chain": "%d/%d" % (tb_back, nchk)}}
     if with_cpu and O.ref_available():
         cpus, t_all = host_threads(O)
         for key, T in (("cpu_reference_all_cores", t_all), ("cpu_reference_t1", 1)):

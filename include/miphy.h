@@ -766,6 +766,12 @@ typedef struct {
 uint32_t miphy_pdsch_pdu_nof_re(const miphy_pdsch_pdu* pdu);
 int miphy_pdsch_process_batch(miphy_ctx* ctx, const miphy_pdsch_pdu* pdus /* host */, uint32_t n, const uint8_t* tb_in /* device */,
                               float* grid /* device cf_t; only the mapped REs are written */, void* stream);
+/* Prepared form for allocations that repeat slot after slot: PDU validation, segmentation and descriptor uploads once, a run only
+ * launches (TB CRC, codeblock preparation, LDPC encoder, rate matcher, modulator, DM-RS), no staging, no host synchronisation. */
+typedef struct miphy_pdsch_process_plan miphy_pdsch_process_plan;
+int  miphy_pdsch_process_plan_create(miphy_ctx* ctx, const miphy_pdsch_pdu* pdus /* host */, uint32_t n, miphy_pdsch_process_plan** out);
+int  miphy_pdsch_process_plan_run(miphy_pdsch_process_plan* plan, const uint8_t* tb_in /* device */, float* grid /* device cf_t */, void* stream);
+void miphy_pdsch_process_plan_destroy(miphy_pdsch_process_plan* plan);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * PDCCH processor (whole PDUs)  --  replaces srsran::pdcch_processor::process after the CCE-to-PRB mapping

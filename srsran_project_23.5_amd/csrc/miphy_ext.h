@@ -40,3 +40,27 @@ struct miphy_ctx_ext {
 
 // Returns the device twiddle table for size N (creates and caches it).
 int miphy_get_twiddles(miphy_ctx* ctx, uint32_t N, const float** out);
+
+// Prepared PDSCH encode (sch.hip): segmentation and descriptor upload once; used by the PDSCH processor plan (pdsch_proc.hip).
+struct miphy_pdsch_encode_prepared;
+int  miphy_pdsch_encode_prepare(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs, uint32_t n, miphy_pdsch_encode_prepared** out);
+int  miphy_pdsch_encode_prepared_run(miphy_pdsch_encode_prepared* p, const uint8_t* tb_in, uint8_t* codeword_out, hipStream_t s);
+void miphy_pdsch_encode_prepared_destroy(miphy_pdsch_encode_prepared* p);
+
+// One codeblock of the transport-block level PDSCH encoder (pdsch_cb_encode.hip): assembly from the transport block, LDPC encoding and rate
+// matching in one kernel.
+struct miphy_pdsch_cb_desc {
+  uint64_t tb_offset;       // packed transport-block bytes
+  uint64_t cw_offset;       // byte offset of this codeblock's E rate-matched bits (one per byte) in the codeword array
+  uint32_t tb_bit_offset;   // first transport-block bit of the codeblock
+  uint32_t take_bits;       // transport-block bits copied
+  uint32_t tb_index;        // index into the TB CRC array
+  uint32_t E, Nref, out_len; // rate-matched length, limited buffer (0 = none), part of the circular buffer the rate matcher reads
+  uint16_t nof_tb_crc_bits, zero_pad; // > 0 on the last codeblock: append the TB CRC and the zero padding
+  uint16_t Z, nof_filler_bits;
+  uint8_t  nof_cb_crc_bits, bg, rv, mod;
+  uint32_t K;
+};
+size_t miphy_pdsch_cb_encode_lds(uint32_t K, uint32_t Z, uint32_t out_len);
+int    miphy_pdsch_cb_encode_launch(miphy_ctx* ctx, const miphy_pdsch_cb_desc* d_descs, uint32_t ncb, size_t max_lds, const uint8_t* tb_in, const uint32_t* tb_crc,
+                                    uint8_t* cw_out, hipStream_t s);

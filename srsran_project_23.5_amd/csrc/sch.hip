@@ -261,81 +261,6 @@ __global__ void __launch_bounds__(1024) pusch_tb_assemble_kernel(const tb_asm_de
       harq_crc_ok[d.harq_cb_index + c] = 0;
 }
 
-struct cb_prep_desc { // per codeblock, consumed by pdsch_cb_prepare_kernel
-  uint64_t tb_offset;     // packed TB bytes
-  uint32_t tb_bit_offset; // first TB bit of this codeblock
-  uint32_t take_bits;     // TB bits copied
-  uint32_t tb_index;      // index into the TB CRC array
-  uint32_t nof_tb_crc_bits; // > 0 on the last codeblock: append the TB CRC ...
-  uint32_t zero_pad;        // ... and the zero padding
-  uint32_t nof_cb_crc_bits;
-  uint32_t K;
-  uint32_t pad;
-  uint64_t msg_offset;    // output: K bytes in the message workspace
-};
-
-// One workgroup per codeblock (ldpc_segmenter_impl.cpp:150-220, pdsch_encoder_impl.cpp:46-50): unpack the TB bits, append the
-// TB CRC and zero padding on the last codeblock, append CRC24B, mark the fillers.
-__global__ void __launch_bounds__(256) pdsch_cb_prepare_kernel(const cb_prep_desc* __restrict__ descs,
-                                                               const miphy_graph_tables* __restrict__ tab,
-                                                               const uint8_t* __restrict__ tb_in,
-                                                               const uint32_t* __restrict__ tb_crc,
-                                                               uint8_t* __restrict__ msg_ws)
-{
-  __shared__ uint32_t red[4];
-  const cb_prep_desc  d   = descs[blockIdx.x];
-  const int           tid = threadIdx.x;
-  uint8_t*            msg = msg_ws + d.msg_offset;
-  const uint8_t*      tb  = tb_in + d.tb_offset;
-  uint32_t            used = d.take_bits;
-  for (uint32_t i = tid; i < d.take_bits; i += blockDim.x) {
-    const uint32_t bit = d.tb_bit_offset + i;
-    msg[i]             = (tb[bit >> 3] >> (7 - (bit & 7))) & 1u;
-  }
-  if (d.nof_tb_crc_bits) {
-    const uint32_t crc = tb_crc[d.tb_index];
-    for (uint32_t i = tid; i < d.nof_tb_crc_bits + d.zero_pad; i += blockDim.x)
-      msg[used + i] = (i < d.nof_tb_crc_bits) ? (uint8_t)((crc >> (d.nof_tb_crc_bits - 1 - i)) & 1u) : 0;
-    used += d.nof_tb_crc_bits + d.zero_pad;
-  }
-  __syncthreads();
-  if (d.nof_cb_crc_bits) {
-    // CRC24B over the `used` unpacked bits: lane t reduces its run of bits, weights with x^(remaining).
-    const uint32_t poly = tab->crc_poly[MIPHY_CRC24B], order = 24, top = 1u << 24;
-    const uint32_t per  = (used + blockDim.x - 1) / blockDim.x;
-    const uint32_t b0   = tid * per;
-    uint32_t       reg  = 0;
-    if (b0 < used) {
-      const uint32_t b1 = min(b0 + per, used);
-      for (uint32_t i = b0; i < b1; ++i) {
-        reg = (reg << 1) ^ ((uint32_t)msg[i] << order);
-        reg ^= (reg & top) ? poly : 0u;
-      }
-      reg &= top - 1u;
-      const uint32_t after = used - b1;
-      if (after) {
-        reg = crc_gf2_mulmod(reg, crc_pow32(tab, MIPHY_CRC24B, after >> 5, poly, order), poly, order);
-        for (uint32_t b = 0; b < (after & 31u); ++b) {
-          reg <<= 1;
-          reg ^= (reg & top) ? poly : 0u;
-        }
-      }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-      reg ^= __shfl_xor(reg, off);
-    if ((tid & 63) == 0)
-      red[tid >> 6] = reg;
-    __syncthreads();
-    const uint32_t crc = red[0] ^ red[1] ^ red[2] ^ red[3];
-    if (tid < 24)
-      msg[used + tid] = (uint8_t)((crc >> (23 - tid)) & 1u);
-    used += 24;
-  }
-  for (uint32_t i = used + tid; i < d.K; i += blockDim.x)
-    msg[i] = 254; // ldpc::FILLER_BIT
-}
-
 template <typename T>
 T* stage_vec(uint8_t*& h, uint8_t*& d, const std::vector<T>& v, size_t& off)
 {
@@ -784,17 +709,25 @@ extern "C" void miphy_pusch_decode_plan_destroy(miphy_pusch_decode_plan* p)
   delete p;
 }
 
-extern "C" int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs, uint32_t n, const uint8_t* tb_in, uint8_t* codeword_out, void* stream)
+namespace {
+// Host-side product of the segmentation of a batch of downlink transport blocks: what the four launches of a PDSCH encode need.
+struct pdsch_encode_build {
+  std::vector<miphy_crc_desc>      crcd;
+  std::vector<miphy_pdsch_cb_desc> cbs; // one record per codeblock for the fused kernel (pdsch_cb_encode.hip)
+  size_t                           max_lds = 0;
+  uint32_t                         n = 0, ncb = 0;
+};
+struct pdsch_encode_dev {
+  const miphy_crc_desc*      crcd;
+  const miphy_pdsch_cb_desc* cbs;
+  uint32_t*                  tbcrc;
+  size_t                     staged, total;
+};
+
+int build_pdsch_encode(const miphy_pdsch_tb_desc* tbs, uint32_t n, pdsch_encode_build& b)
 {
-  MIPHY_REQUIRE(ctx && tbs && tb_in && codeword_out, "miphy_pdsch_encode_batch: null argument");
-  if (n == 0)
-    return MIPHY_OK;
-  hipStream_t                      s = (hipStream_t)stream;
-  std::vector<miphy_crc_desc>      crcd(n);
-  std::vector<cb_prep_desc>        prep;
-  std::vector<miphy_ldpc_enc_desc> enc;
-  std::vector<miphy_ldpc_rdm_desc> rm;
-  uint64_t                         msg_bytes = 0, cb_bytes = 0;
+  b.n = n;
+  b.crcd.resize(n);
   for (uint32_t t = 0; t < n; ++t) {
     const miphy_pdsch_tb_desc& d = tbs[t];
     seg_t                      sg;
@@ -805,25 +738,24 @@ extern "C" int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_des
     MIPHY_REQUIRE(d.nof_layers >= 1 && d.nof_layers <= 4, "pdsch_encode: TB %u: invalid number of layers", t);
     MIPHY_REQUIRE(d.mod == 1 || d.mod == 2 || d.mod == 4 || d.mod == 6 || d.mod == 8, "pdsch_encode: TB %u: invalid modulation", t);
     MIPHY_REQUIRE(d.nof_ch_symbols % d.nof_layers == 0, "pdsch_encode: TB %u: channel symbols not a multiple of the layers", t);
-    crcd[t].bit_offset = d.tb_offset * 8;
-    crcd[t].nbits      = sg.tbs;
-    crcd[t].poly       = (sg.nof_tb_crc_bits == 16) ? MIPHY_CRC16 : MIPHY_CRC24A;
+    b.crcd[t].bit_offset = d.tb_offset * 8;
+    b.crcd[t].nbits      = sg.tbs;
+    b.crcd[t].poly       = (sg.nof_tb_crc_bits == 16) ? MIPHY_CRC16 : MIPHY_CRC24A;
     uint32_t tb_bit = 0, cw_off = 0;
     for (uint32_t c = 0; c < sg.nof_cbs; ++c) {
-      const bool   last = (c == sg.nof_cbs - 1);
-      cb_prep_desc p    = {};
+      const bool          last = (c == sg.nof_cbs - 1);
+      miphy_pdsch_cb_desc p    = {};
       p.tb_offset = d.tb_offset, p.tb_bit_offset = tb_bit, p.tb_index = t;
       p.take_bits       = sg.cb_info_bits - (last ? sg.nof_tb_crc_bits + sg.zero_pad : 0);
-      p.nof_tb_crc_bits = last ? sg.nof_tb_crc_bits : 0;
-      p.zero_pad        = last ? sg.zero_pad : 0;
-      p.nof_cb_crc_bits = sg.nof_cb_crc_bits;
+      p.nof_tb_crc_bits = (uint16_t)(last ? sg.nof_tb_crc_bits : 0);
+      p.zero_pad        = (uint16_t)(last ? sg.zero_pad : 0);
+      p.nof_cb_crc_bits = (uint8_t)sg.nof_cb_crc_bits;
       p.K               = sg.K;
-      p.msg_offset      = msg_bytes;
-      prep.push_back(p);
       tb_bit += p.take_bits;
-      const uint32_t      E = rm_length(sg, c, d.mod, d.nof_layers, d.nof_ch_symbols);
-      miphy_ldpc_enc_desc e = {};
-      e.bg = d.bg, e.Z = (uint16_t)sg.Z, e.in_offset = msg_bytes, e.out_offset = cb_bytes;
+      const uint32_t E = rm_length(sg, c, d.mod, d.nof_layers, d.nof_ch_symbols);
+      MIPHY_REQUIRE(E > 0, "pdsch_encode: TB %u: empty codeblock", t);
+      p.bg = d.bg, p.rv = d.rv, p.mod = d.mod, p.Z = (uint16_t)sg.Z, p.nof_filler_bits = (uint16_t)sg.nof_filler_bits, p.Nref = d.Nref, p.E = E;
+      p.cw_offset = d.codeword_offset + cw_off;
       {
         // Only the part of the circular buffer the rate matcher will read is encoded: from k0 (TS 38.212 Table 5.4.2.1-2) over E
         // bits plus the fillers it may skip, or the whole buffer when that wraps. A high-rate codeblock needs 2 of the 42 extension
@@ -833,53 +765,119 @@ extern "C" int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_des
                                          : ((d.rv == 0) ? 0u : (d.rv == 1) ? 13u : (d.rv == 2) ? 25u : 43u);
         const uint32_t k0  = (uint32_t)(((uint64_t)num * Ncb) / sg.N) * sg.Z;
         const uint64_t end = (uint64_t)k0 + E + sg.nof_filler_bits;
-        e.out_len          = (end >= Ncb) ? Ncb : (uint32_t)end;
+        p.out_len          = (end >= Ncb) ? Ncb : (uint32_t)end;
       }
-      enc.push_back(e);
-      miphy_ldpc_rdm_desc r = {};
-      r.bg = d.bg, r.rv = d.rv, r.mod = d.mod, r.new_data = 1, r.Z = (uint16_t)sg.Z, r.nof_filler_bits = (uint16_t)sg.nof_filler_bits;
-      r.Nref = d.Nref, r.E = E, r.in_offset = cb_bytes, r.out_offset = d.codeword_offset + cw_off;
-      MIPHY_REQUIRE(E > 0, "pdsch_encode: TB %u: empty codeblock", t);
-      rm.push_back(r);
+      b.max_lds = std::max(b.max_lds, miphy_pdsch_cb_encode_lds(sg.K, sg.Z, p.out_len));
+      b.cbs.push_back(p);
       cw_off += E;
-      msg_bytes += (sg.K + 15) & ~15u;
-      cb_bytes += (sg.N + 15) & ~15u;
     }
     MIPHY_REQUIRE(cw_off == d.nof_ch_symbols * d.mod, "pdsch_encode: TB %u: codeblock lengths (%u) do not add up to the codeword (%u)", t, cw_off,
                   d.nof_ch_symbols * d.mod);
   }
-  const uint32_t ncb = (uint32_t)enc.size();
-  MIPHY_REQUIRE(ncb <= 65535, "pdsch_encode: %u codeblocks in one call (max 65535)", ncb);
-  size_t bytes = 128 + crcd.size() * sizeof(crcd[0]) + prep.size() * sizeof(prep[0]) + enc.size() * sizeof(enc[0]) + rm.size() * sizeof(rm[0]) + n * 4 +
-                 msg_bytes + cb_bytes + 16 * 8;
-  void* wsv = nullptr;
-  int   rc  = miphy_get_workspace(ctx, bytes, s, &wsv);
+  b.ncb = (uint32_t)b.cbs.size();
+  MIPHY_REQUIRE(b.ncb <= 65535, "pdsch_encode: %u codeblocks in one call (max 65535)", b.ncb);
+  return MIPHY_OK;
+}
+
+size_t pdsch_encode_bytes(const pdsch_encode_build& b)
+{
+  return 128 + b.crcd.size() * sizeof(b.crcd[0]) + b.cbs.size() * sizeof(b.cbs[0]) + (size_t)b.n * 4 + 16 * 8;
+}
+
+// Lays the descriptors out in a host image `h` of the device buffer `dv` (same offsets); the TB checksums follow the staged part.
+pdsch_encode_dev layout_pdsch_encode(const pdsch_encode_build& b, uint8_t* h, uint8_t* dv)
+{
+  pdsch_encode_dev v;
+  size_t           off = 0;
+  v.crcd   = stage_vec(h, dv, b.crcd, off);
+  v.cbs    = stage_vec(h, dv, b.cbs, off);
+  v.staged = off;
+  off      = (off + 15) & ~(size_t)15;
+  v.tbcrc  = reinterpret_cast<uint32_t*>(dv + off);
+  v.total  = off + (size_t)b.n * 4;
+  return v;
+}
+
+// TB CRC of every transport block, then ONE kernel per codeblock: assembly (TB bits, TB CRC, padding, CRC24B, fillers), LDPC encoder and
+// rate matcher with the codeblock in LDS (pdsch_cb_encode.hip).
+int launch_pdsch_encode(miphy_ctx* ctx, uint32_t n, uint32_t ncb, size_t max_lds, const pdsch_encode_dev& v, const uint8_t* tb_in, uint8_t* codeword_out,
+                        hipStream_t s)
+{
+  int rc;
+  if ((rc = miphy_crc_batch(ctx, v.crcd, 1, n, tb_in, v.tbcrc, s)))
+    return rc;
+  return miphy_pdsch_cb_encode_launch(ctx, v.cbs, ncb, max_lds, tb_in, v.tbcrc, codeword_out, s);
+}
+} // namespace
+
+extern "C" int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs, uint32_t n, const uint8_t* tb_in, uint8_t* codeword_out, void* stream)
+{
+  MIPHY_REQUIRE(ctx && tbs && tb_in && codeword_out, "miphy_pdsch_encode_batch: null argument");
+  if (n == 0)
+    return MIPHY_OK;
+  hipStream_t        s = (hipStream_t)stream;
+  pdsch_encode_build b;
+  int                rc = build_pdsch_encode(tbs, n, b);
   if (rc)
     return rc;
-  std::vector<uint8_t> host(bytes - msg_bytes - cb_bytes);
-  uint8_t *            h = host.data(), *dv = (uint8_t*)wsv;
-  size_t               off = 0;
-  auto*                d_crcd = stage_vec(h, dv, crcd, off);
-  auto*                d_prep = stage_vec(h, dv, prep, off);
-  auto*                d_enc  = stage_vec(h, dv, enc, off);
-  auto*                d_rm   = stage_vec(h, dv, rm, off);
-  const size_t         staged = off;
-  off                         = (off + 15) & ~(size_t)15;
-  uint32_t* d_tbcrc           = reinterpret_cast<uint32_t*>(dv + off);
-  off += (size_t)n * 4;
-  off            = (off + 15) & ~(size_t)15;
-  uint8_t* d_msg = dv + off;
-  off += msg_bytes;
-  uint8_t* d_cb = dv + off;
-  if ((rc = miphy_upload(ctx, dv, h, staged, s)))
+  const size_t bytes = pdsch_encode_bytes(b);
+  void*        wsv   = nullptr;
+  if ((rc = miphy_get_workspace(ctx, bytes, s, &wsv)))
     return rc;
-  if ((rc = miphy_crc_batch(ctx, d_crcd, 1, n, tb_in, d_tbcrc, s)))
+  std::vector<uint8_t>   host(bytes);
+  const pdsch_encode_dev v = layout_pdsch_encode(b, host.data(), (uint8_t*)wsv);
+  if ((rc = miphy_upload(ctx, wsv, host.data(), v.staged, s)))
     return rc;
-  hipLaunchKernelGGL(pdsch_cb_prepare_kernel, dim3(ncb), dim3(256), 0, s, d_prep, ctx->d_tables, tb_in, d_tbcrc, d_msg);
-  MIPHY_HIP_CHECK(hipGetLastError());
-  if ((rc = miphy_ldpc_encode_batch(ctx, d_enc, 1, ncb, d_msg, d_cb, s)))
+  return launch_pdsch_encode(ctx, n, b.ncb, b.max_lds, v, tb_in, codeword_out, s);
+}
+
+// ---- prepared form (internal: the PDSCH processor plan of pdsch_proc.hip builds on it): segmentation and descriptor upload once, a run
+// is launches only.
+struct miphy_pdsch_encode_prepared {
+  miphy_ctx*       ctx;
+  uint32_t         n, ncb;
+  size_t           max_lds;
+  pdsch_encode_dev v;
+  void*            d_buf;
+};
+
+int miphy_pdsch_encode_prepare(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs, uint32_t n, miphy_pdsch_encode_prepared** out)
+{
+  MIPHY_REQUIRE(ctx && tbs && out && n > 0, "miphy_pdsch_encode_prepare: null argument or empty batch");
+  pdsch_encode_build b;
+  int                rc = build_pdsch_encode(tbs, n, b);
+  if (rc)
     return rc;
-  if ((rc = miphy_ldpc_rate_match_batch(ctx, d_rm, 1, ncb, d_cb, codeword_out, s)))
-    return rc;
+  const size_t bytes = pdsch_encode_bytes(b);
+  auto*        p     = new miphy_pdsch_encode_prepared();
+  p->ctx = ctx, p->n = n, p->ncb = b.ncb, p->max_lds = b.max_lds, p->d_buf = nullptr;
+  std::vector<uint8_t> host(bytes);
+  hipError_t           e = hipMalloc(&p->d_buf, bytes);
+  if (e == hipSuccess) {
+    p->v = layout_pdsch_encode(b, host.data(), (uint8_t*)p->d_buf);
+    e    = hipMemcpy(p->d_buf, host.data(), p->v.staged, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    miphy_set_error("miphy_pdsch_encode_prepare: %s", hipGetErrorString(e));
+    if (p->d_buf)
+      (void)hipFree(p->d_buf);
+    delete p;
+    return MIPHY_EHIP;
+  }
+  *out = p;
   return MIPHY_OK;
+}
+
+int miphy_pdsch_encode_prepared_run(miphy_pdsch_encode_prepared* p, const uint8_t* tb_in, uint8_t* codeword_out, hipStream_t s)
+{
+  return launch_pdsch_encode(p->ctx, p->n, p->ncb, p->max_lds, p->v, tb_in, codeword_out, s);
+}
+
+void miphy_pdsch_encode_prepared_destroy(miphy_pdsch_encode_prepared* p)
+{
+  if (!p)
+    return;
+  if (p->d_buf)
+    (void)hipFree(p->d_buf);
+  delete p;
 }

@@ -62,6 +62,10 @@ def lib():
         l.miphy_pusch_decode_plan_nof_launches.argtypes = [C.c_void_p]
         l.miphy_pusch_decode_plan_nof_launches.restype = C.c_uint32
         l.miphy_sch_segmentation_info.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+        l.miphy_pdsch_process_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        l.miphy_pdsch_process_plan_run.argtypes = [C.c_void_p] * 4
+        l.miphy_pdsch_process_plan_destroy.argtypes = [C.c_void_p]
+        l.miphy_pdsch_process_plan_destroy.restype = None
         l.miphy_ldpc_decode_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
         l.miphy_ldpc_decode_plan_run.argtypes = [C.c_void_p] * 5
         l.miphy_ldpc_decode_plan_nof_launches.argtypes = [C.c_void_p]
@@ -598,6 +602,32 @@ class Context:
         check(lib().miphy_polar_decode_list_batch(self.h, C.byref(code), list_size, crc_mode, n, _dptr(llr),
                                                   _dptr(rnti) if rnti is not None else None, _dptr(msg_out), _dptr(crc_ok_out),
                                                   _dptr(metric_out) if metric_out is not None else None, _stream_ptr(stream)))
+
+
+class PdschProcessPlan:
+    """miphy_pdsch_process_plan_*: PDU validation, segmentation and descriptor uploads once; run() is the launches of the transmit chain only."""
+
+    def __init__(self, ctx, pdus):
+        assert isinstance(pdus, np.ndarray) and pdus.dtype == PdschPdu
+        pdus = np.ascontiguousarray(pdus)
+        self.ctx, self.n = ctx, pdus.size
+        h = C.c_void_p()
+        check(lib().miphy_pdsch_process_plan_create(ctx.h, C.c_void_p(pdus.ctypes.data), pdus.size, C.byref(h)))
+        self.h = h
+
+    def run(self, tb_in, grid, stream=None):
+        check(lib().miphy_pdsch_process_plan_run(self.h, _dptr(tb_in), _dptr(grid), _stream_ptr(stream)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().miphy_pdsch_process_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class LdpcDecodePlan:

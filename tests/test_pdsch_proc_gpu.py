@@ -76,6 +76,14 @@ def test_batch_matches_oracle_chain(ctx):
     for i, (p, g) in enumerate(zip(pdus, want)):
         o = int(p["grid_offset"])
         assert np.array_equal(got[o:o + g.size].view(np.uint32), g.reshape(-1).view(np.uint32)), i
+    # the prepared plan (descriptors uploaded once) gives the same grid, run after run
+    plan = miphy.PdschProcessPlan(ctx, pdus)
+    for _ in range(2):
+        gp = torch.zeros(grid_off, dtype=torch.complex64, device="cuda")
+        plan.run(torch.from_numpy(tb_all).cuda(), gp)
+        torch.cuda.synchronize()
+        assert np.array_equal(gp.cpu().numpy().view(np.uint32), got.view(np.uint32))
+    plan.close()
     # a second call reuses the work buffer; one PDU alone gives the same REs
     gd2 = torch.zeros(want[2].size, dtype=torch.complex64, device="cuda")
     one = pdus[2:3].copy()
@@ -106,3 +114,10 @@ def test_rejects_what_the_reference_asserts(ctx):
     q["rb_mask"][0][0] = 0
     with pytest.raises(RuntimeError, match="empty allocation"):
         ctx.pdsch_process_batch(q, tb, g)
+    # the plan refuses the same PDUs when it is created
+    with pytest.raises(RuntimeError, match="empty allocation"):
+        miphy.PdschProcessPlan(ctx, q)
+    q = p.copy()
+    q["mod"] = 3
+    with pytest.raises(RuntimeError, match="modulation"):
+        miphy.PdschProcessPlan(ctx, q)
