@@ -110,7 +110,7 @@ void     miphy_ldpc_decode_plan_destroy(miphy_ldpc_decode_plan* plan);
 /* Test / A-B knob: 0 = automatic choice (host descriptors: sorted into launch classes by lifting size and code rate, one launch per
  * class; device descriptors: one launch), 1 = one-row-per-lane kernel, 2 = packed two-rows-per-lane kernel as one launch,
  * 3 = class-sorted launches, 4 = class-sorted launches with the geometry of a batch that fills the chip whatever its size (no latency form, messages in global
- * memory wherever that buys residency). All kernels produce identical results. */
+ * memory wherever that buys residency), 5 = class-sorted launches with the latency form of the packed kernel on every class (A-B measurement only). All kernels produce identical results. */
 void miphy_debug_force_ldpc_kernel(int mode);
 /* Which decoder kernels have been launched since the last reset (tests assert that a forced choice really ran): */
 #define MIPHY_LDPC_KERNEL_SCALAR 1u /* one check row per lane */
