@@ -317,6 +317,9 @@ __global__ void __launch_bounds__(64) pdcch_encode_kernel(polar_plan p, uint32_t
 }
 
 // LLR algebra of log_likelihood_ratio.cpp:38-85 / .h:208-216.
+#ifndef POLAR_SSC_CW
+#define POLAR_SSC_CW 4
+#endif
 __device__ __forceinline__ int llr_add(int a, int b)
 { // a + b (special cases inspect the right operand first, like `rhs += *this`)
   if (b == -a)
@@ -344,18 +347,28 @@ __device__ __forceinline__ int llr_soft_xor(int x, int y)
   return (x * y < 0) ? -m : m;
 }
 
-__global__ void __launch_bounds__(64) polar_decode_kernel(polar_plan p, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ msg_out,
+// C codewords per wavefront, W = 64 / C lanes each. Every codeword of a batch has the same code, hence the same pruned schedule: the codewords of a
+// wavefront run it in lockstep, each on its own LDS slice. One codeword per wavefront kept 23 % of the lanes busy (SQ_THREAD_CYCLES_VALU, profiles/r03):
+// below stage 6 an operation is narrower than the wavefront, and the pruned schedule spends most of its operations there; with C codewords the narrow
+// operations fill C times the lanes and every operation's fixed cost (schedule word, barrier) is shared by C codewords.
+template <int C>
+__global__ void __launch_bounds__(64) polar_decode_kernel(polar_plan p, uint32_t ncw, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ msg_out,
                                                           int8_t* __restrict__ dem_tap, uint8_t* __restrict__ u_tap)
 {
-  __shared__ int8_t  L[2048]; // stage s buffer at offset 2^s (size 2^s)
-  __shared__ uint8_t est[1024];
-  __shared__ uint8_t u[1024];
-  const int          lane = threadIdx.x;
-  const size_t       cw   = blockIdx.x;
+  constexpr int W = 64 / C;
+  __shared__ int8_t  L_all[C][2048]; // stage s buffer at offset 2^s (size 2^s)
+  __shared__ uint8_t est_all[C][1024];
+  __shared__ uint8_t u_all[C][1024];
+  const int          c = threadIdx.x / W, lane = threadIdx.x % W;
+  const size_t       cw = (size_t)blockIdx.x * C + c;
+  const bool         live = cw < ncw;
+  int8_t*            L    = L_all[c];
+  uint8_t*           est  = est_all[c];
+  uint8_t*           u    = u_all[c];
   const int          N = (int)p.N, n = (int)p.n, E = (int)p.E;
-  const int8_t*      f = llr_in + cw * p.E;
+  const int8_t*      f = llr_in + (live ? cw : 0) * p.E;
   // Rate dematching (polar_rate_dematcher_impl.cpp:29-118) as a gather: repetitions are accumulated in order.
-  for (int q = lane; q < N; q += 64) {
+  for (int q = lane; q < N; q += W) {
     const int first = p.d_rx_first[q];
     int       v;
     if (first == -1) {
@@ -370,7 +383,7 @@ __global__ void __launch_bounds__(64) polar_decode_kernel(polar_plan p, const in
     L[N + q] = (int8_t)v;
     est[q]   = 0;
     u[q]     = 0;
-    if (dem_tap)
+    if (dem_tap && live)
       dem_tap[cw * N + q] = (int8_t)v;
   }
   __syncthreads();
@@ -381,39 +394,41 @@ __global__ void __launch_bounds__(64) polar_decode_kernel(polar_plan p, const in
     int8_t*        ls    = L + size;
     int8_t*        lc    = L + half;
     if (type == OP_F) {
-      for (int i = lane; i < half; i += 64)
+      for (int i = lane; i < half; i += W)
         lc[i] = (int8_t)llr_soft_xor(ls[i], ls[i + half]);
     } else if (type == OP_G) {
-      for (int i = lane; i < half; i += 64) {
+      for (int i = lane; i < half; i += W) {
         const int x = ls[i], y = ls[i + half];
         lc[i]       = (int8_t)(est[pos + i] ? llr_add(y, -x) : llr_add(y, x));
       }
     } else if (type == OP_R1) {
-      for (int i = lane; i < size; i += 64) {
+      for (int i = lane; i < size; i += W) {
         const uint8_t b = ls[i] <= 0;
         est[pos + i]    = b;
         u[pos + i]      = b;
       }
       __syncthreads();
       for (int h = 1; h < size; h <<= 1) { // re-encode the subtree (polar_decoder_impl.cpp:243-248)
-        for (int t = lane; t < half; t += 64) {
+        for (int t = lane; t < half; t += W) {
           const int b = ((t / h) * 2 * h) + (t % h);
           u[pos + b] ^= u[pos + b + h];
         }
         __syncthreads();
       }
     } else { // OP_COMB
-      for (int i = lane; i < half; i += 64)
+      for (int i = lane; i < half; i += W)
         est[pos + i] ^= est[pos + half + i];
     }
     __syncthreads();
   }
+  if (!live)
+    return;
   if (u_tap)
-    for (int i = lane; i < N; i += 64)
+    for (int i = lane; i < N; i += W)
       u_tap[cw * N + i] = u[i];
   // Deallocation (polar_deallocator_impl.cpp:27-42): K-set positions that are not parity checks, ascending.
   if (p.nPC == 0) {
-    for (int i = lane; i < (int)p.K; i += 64)
+    for (int i = lane; i < (int)p.K; i += W)
       msg_out[cw * p.K + i] = u[p.d_info_pos[i]];
   } else if (lane == 0) {
     int iK = 0;
@@ -632,7 +647,15 @@ extern "C" int miphy_polar_decode_batch(miphy_ctx*              ctx,
   int               rc = get_plan(ctx, code, &p);
   if (rc || n == 0)
     return rc;
-  hipLaunchKernelGGL(polar_decode_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, *p, llr, msg_out, dematched_tap, decoded_u_tap);
+  // Codewords per wavefront: four (16 lanes each) once the batch fills the chip several times over, fewer for small batches (a lone codeword
+  // keeps the whole wavefront: its wide stages finish in fewer steps).
+  const uint32_t per_chip = (uint32_t)ctx->num_cus * 8u;
+  if (n >= 4u * per_chip)
+    hipLaunchKernelGGL((polar_decode_kernel<POLAR_SSC_CW>), dim3((n + POLAR_SSC_CW - 1) / POLAR_SSC_CW), dim3(64), 0, (hipStream_t)stream, *p, n, llr, msg_out, dematched_tap, decoded_u_tap);
+  else if (n >= 2u * per_chip)
+    hipLaunchKernelGGL((polar_decode_kernel<2>), dim3((n + 1) / 2), dim3(64), 0, (hipStream_t)stream, *p, n, llr, msg_out, dematched_tap, decoded_u_tap);
+  else
+    hipLaunchKernelGGL((polar_decode_kernel<1>), dim3(n), dim3(64), 0, (hipStream_t)stream, *p, n, llr, msg_out, dematched_tap, decoded_u_tap);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

@@ -73,6 +73,48 @@ def test_polar_chains(ctx, K, E, nMax, ibil):
             assert np.array_equal(got_m[i], msgs[i])
 
 
+@pytest.mark.parametrize("K,E,nMax,ibil", [(64, 108, 9, 0), (64, 432, 9, 0), (164, 1728, 9, 0), (56, 864, 9, 0), (25, 300, 10, 1), (1023, 2000, 10, 0)])
+@pytest.mark.parametrize("n", [4099, 8195])
+def test_polar_decode_large_batches_share_wavefronts(ctx, K, E, nMax, ibil, n):
+    """Batches that fill the chip decode two (n >= 4096) or four (n >= 8192) codewords per wavefront in lockstep on the shared schedule
+    (polar_decode_kernel<2>, <4>); ragged last wavefronts. Every codeword -- message, dematcher tap, decoder tap -- must equal the oracle's
+    (the reference's SSC decoder), whatever its neighbours in the wavefront are: noiseless, AWGN and arbitrary LLRs with infinities side by side."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(K * 11 + E + n)
+    code = miphy.PolarCode(K, E, nMax, ibil)
+    _, N, _ = code.info()
+    pool = 23
+    msgs = rng.integers(0, 2, (pool, K), dtype=np.uint8)
+    llrs = np.zeros((pool, E), dtype=np.int8)
+    for i in range(pool):
+        cwd = o_polar_encode_chain(K, E, nMax, ibil, msgs[i])[0]
+        if i % 3 == 0:
+            llrs[i] = 1 - 2 * cwd.astype(np.int16)
+        elif i % 3 == 1:
+            y = (1.0 - 2.0 * cwd) + [0.6, 0.9, 1.3][i % 9 // 3] * rng.standard_normal(E)
+            llrs[i] = np.round(np.clip(4 * y, -20, 20) / 20 * 120)
+        else:
+            v = rng.integers(-120, 121, E)
+            v[rng.random(E) < 0.1] = 0
+            v[rng.random(E) < 0.05] = 127
+            v[rng.random(E) < 0.05] = -127
+            llrs[i] = v
+    exp = [o_polar_decode_chain(K, E, nMax, ibil, llrs[i]) for i in range(pool)]
+    idx = rng.integers(0, pool, n)
+    l_d = torch.from_numpy(llrs[idx].reshape(-1)).cuda()
+    msg_d = torch.zeros(n * K, dtype=torch.uint8, device="cuda")
+    dem_d = torch.zeros(n * N, dtype=torch.int8, device="cuda")
+    u_d = torch.zeros(n * N, dtype=torch.uint8, device="cuda")
+    ctx.polar_decode_batch(code, n, l_d, msg_d, dem_d, u_d)
+    torch.cuda.synchronize()
+    got_m, got_d, got_u = msg_d.cpu().numpy().reshape(n, K), dem_d.cpu().numpy().reshape(n, N), u_d.cpu().numpy().reshape(n, N)
+    em, ed, eu = (np.stack([e[j] for e in exp]) for j in range(3))
+    assert np.array_equal(got_d, ed[idx]), "dematch"
+    assert np.array_equal(got_u, eu[idx]), "decode"
+    assert np.array_equal(got_m, em[idx]), "deallocate"
+
+
 def test_pdcch_encoder_batch(ctx):
     import torch
     rng = np.random.default_rng(41)
