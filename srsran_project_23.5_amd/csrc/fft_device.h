@@ -211,8 +211,11 @@ __device__ __forceinline__ void fft_lds(cplx* x, int N, const cplx* __restrict__
 // N = 4096 = 8^4 on 512 threads (the 100 MHz / 30 kHz symbol): one radix-8 butterfly per thread and pass with every stride a
 // compile-time constant, so that the padded LDS addresses of a pass are one base plus immediates (reads: fpad(t) + 576 k; writes:
 // 9 t + k, then fpad(q) + 9 S p + (9 S / 8) k). Same butterflies, twiddles and order of operations as fft_lds: identical results.
-template <bool INV, int S, bool SKEW>
-__device__ __forceinline__ void fft4096_pass(cplx* x, const cplx* __restrict__ tw, int t)
+// IN_REGS: the butterfly's inputs x[t + 512 k] are already in a[] (the first pass of a transform whose input the caller loads from
+// global memory in exactly that pattern -- consecutive lanes, consecutive elements); OUT_REGS: the outputs stay in a[] (the last pass
+// writes natural order X[t + 512 k], which the caller stores to global memory). Either way the LDS sweep and its barrier are skipped.
+template <bool INV, int S, bool SKEW, bool IN_REGS = false, bool OUT_REGS = false>
+__device__ __forceinline__ void fft4096_pass(cplx* x, const cplx* __restrict__ tw, int t, cplx* a)
 {
   constexpr int M  = 512 / S;            // sub-transform length / 8
   constexpr int RS = SKEW ? 577 : 576;   // read stride: fpad(_skew)(t + 512 k) = fpad(t) + RS k
@@ -220,12 +223,14 @@ __device__ __forceinline__ void fft4096_pass(cplx* x, const cplx* __restrict__ t
   cplx          w1 = {1.f, 0.f};
   if (M > 1)
     w1 = tw[p * S];
-  const cplx* xr = x + fpad(t);
-  cplx        a[8];
+  if (!IN_REGS) {
+    const cplx* xr = x + fpad(t);
 #pragma unroll
-  for (int k = 0; k < 8; ++k)
-    a[k] = xr[RS * k];
-  __syncthreads();
+    for (int k = 0; k < 8; ++k)
+      a[k] = xr[RS * k];
+    if (!OUT_REGS)
+      __syncthreads(); // every lane has read before any lane overwrites
+  }
   dft8<INV>(a);
   if (M > 1) {
     w1     = cconj_if<INV>(w1);
@@ -237,6 +242,8 @@ __device__ __forceinline__ void fft4096_pass(cplx* x, const cplx* __restrict__ t
         w = cmul(w, w1);
     }
   }
+  if (OUT_REGS)
+    return;
   // write index q + S (8 p + k), padded: S = 1: 9 t + k [+ t / 64]; S = 8: q + 72 p + 9 k [+ p / 8]; S = 64: fpad(q) + 576 p + 72 k
   // [+ p]; S = 512: fpad(q) + 576 k [+ k]
   constexpr int WS = (S == 1) ? 1 : (S == 512 ? RS : 9 * S / 8);
@@ -253,8 +260,21 @@ __device__ __forceinline__ void fft4096_pass(cplx* x, const cplx* __restrict__ t
 template <bool INV, bool SKEW = false>
 __device__ __forceinline__ void fft4096_lds(cplx* x, const cplx* __restrict__ tw, int t)
 {
-  fft4096_pass<INV, 1, SKEW>(x, tw, t);
-  fft4096_pass<INV, 8, SKEW>(x, tw, t);
-  fft4096_pass<INV, 64, SKEW>(x, tw, t);
-  fft4096_pass<INV, 512, SKEW>(x, tw, t);
+  cplx a[8];
+  fft4096_pass<INV, 1, SKEW>(x, tw, t, a);
+  fft4096_pass<INV, 8, SKEW>(x, tw, t, a);
+  fft4096_pass<INV, 64, SKEW>(x, tw, t, a);
+  fft4096_pass<INV, 512, SKEW>(x, tw, t, a);
+}
+
+// The same transform from registers to registers: lane t brings x[t + 512 k] in a[k] and takes X[t + 512 k] away in a[k]. Six LDS sweeps
+// and five barriers instead of ten and ten (the LDS buffer must not be in use by the workgroup when it is called). Same butterflies,
+// twiddles and order of operations: identical results.
+template <bool INV, bool SKEW = false>
+__device__ __forceinline__ void fft4096_regs(cplx* x, const cplx* __restrict__ tw, int t, cplx* a)
+{
+  fft4096_pass<INV, 1, SKEW, true, false>(x, tw, t, a);
+  fft4096_pass<INV, 8, SKEW>(x, tw, t, a);
+  fft4096_pass<INV, 64, SKEW>(x, tw, t, a);
+  fft4096_pass<INV, 512, SKEW, false, true>(x, tw, t, a);
 }

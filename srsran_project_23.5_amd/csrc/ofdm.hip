@@ -10,6 +10,9 @@
 #include <cmath>
 #include <complex>
 
+#ifndef OFDM_MOD_WAVES
+#define OFDM_MOD_WAVES 8
+#endif
 namespace {
 
 template <bool INV>
@@ -151,6 +154,33 @@ __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict
     const int             sym = (per == 1) ? (int)job.slot_index : (int)job.slot_index * 14 + l;
     // FFT window: starts `window_offset` samples before the end of the cyclic prefix (demodulator_impl.cpp:115).
     const float2* src = samples + job.samples_offset + ((per == 1) ? 0 : plan->sym_off[sym]) + plan->cp_len[sym] - plan->window_offset;
+    if (NCT == 4096) {
+      // Register to register: lane t loads samples t + 512 k (consecutive lanes, consecutive samples) straight into its first
+      // butterfly and stores bins t + 512 k straight from its last one -- the staging sweeps of the LDS buffer before the first and
+      // after the last pass, and their barriers, are gone (ten LDS sweeps and ten barriers per symbol before, six and five now).
+      const int t = threadIdx.x;
+      cplx      a[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float2 v = src[t + 512 * k];
+        a[k]           = {v.x, v.y};
+      }
+      fft4096_regs<false, true>(x, tw, t, a);
+      const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
+      float2*    dst  = grid + job.grid_offset + (size_t)l * rg;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int bin = t + 512 * k;
+        const int sc  = (bin < half) ? bin + half : bin - (4096 - half); // demodulator_impl.cpp:131-137, inverted
+        if (bin < half || bin >= 4096 - half) {
+          cplx v = cmul(a[k], coef); // sc_prod(dft_output, phase * scale)
+          if (ramp)
+            v = cmul(v, ramp[bin]);  // window-offset phase ramp (:60-76,127-129)
+          dst[sc] = make_float2(v.x, v.y);
+        }
+      }
+      return;
+    }
     if ((((uintptr_t)src) & 15) == 0) { // 16-byte loads: two samples per lane
       const float4* src4 = reinterpret_cast<const float4*>(src);
       for (int i = threadIdx.x; i < N / 2; i += nt) {
@@ -235,6 +265,33 @@ __device__ __forceinline__ void ofdm_mod_body(const miphy_ofdm_job* __restrict__
   }
   const float2* src  = grid + job.grid_offset + (size_t)l * rg;
   const int     half = rg / 2;
+  if (NCT == 4096) {
+    // Register to register (see the demodulator): lane t gathers bins t + 512 k from the grid row, transforms, and stores samples
+    // t + 512 k (and their copies in the cyclic prefix) straight from its last butterfly.
+    const int t = threadIdx.x;
+    cplx      a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      // bins [0, rg/2) <- upper half of the grid row, bins [N - rg/2, N) <- lower half, the rest zero (:82-86); branch-free: an
+      // unused bin loads element 0 and discards it (per-element branches made the compiler carry copies of a[] through scratch)
+      const int    i  = t + 512 * k;
+      const bool   lo = i < half, hi = i >= 4096 - half;
+      const float2 g  = src[lo ? half + i : (hi ? i - (4096 - half) : 0)];
+      a[k]            = (lo || hi) ? cplx{g.x, g.y} : cplx{0.f, 0.f};
+    }
+    fft4096_regs<true, true>(x, tw, t, a);
+    const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int    j = t + 512 * k;
+      const cplx   v = cmul(a[k], coef);
+      const float2 o = make_float2(v.x, v.y);
+      dst[cp + j]    = o;
+      if (k == 7 && j >= 4096 - cp) // cyclic prefix = copy of the tail (:98); shorter than 512 samples: only the last octet reaches it
+        dst[j - (4096 - cp)] = o;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     // bins [0, rg/2) <- upper half of the grid, bins [N - rg/2, N) <- lower half, the rest stays zero (:82-86)
     cplx v = {0.f, 0.f};
@@ -266,7 +323,7 @@ ofdm_mod_wide_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_de
 {
   ofdm_mod_body<true, 0>(jobs, plan, tw, grid, samples, per);
 }
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OFDM_MOD_WAVES, 8)))
 ofdm_mod_4096_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const float2* __restrict__ grid,
                      float2* __restrict__ samples, int per)
 {
