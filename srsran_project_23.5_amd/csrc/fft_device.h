@@ -278,113 +278,3 @@ __device__ __forceinline__ void fft4096_regs(cplx* x, const cplx* __restrict__ t
   fft4096_pass<INV, 64, SKEW>(x, tw, t, a);
   fft4096_pass<INV, 512, SKEW, false, true>(x, tw, t, a);
 }
-
-// ---- N = 4096 = 16^3 on 256 threads, register to register: lane t brings x[t + 256 k] in a[k] (k = 0 .. 15) and takes X[t + 256 k] away.
-// Three radix-16 passes instead of four radix-8 ones: FOUR sweeps of the LDS buffer (write, read, write, read) and three barriers per
-// transform, against six and five for fft4096_regs -- the OFDM kernels are HBM-bound with the LDS pipe as the second resource.
-// A radix-16 butterfly is two layers of radix-4 with the W16 twiddles between them; its outputs come out digit-reversed (position
-// 4 k1 + k2 holds X[k1 + 4 k2]), which the stores undo with compile-time indices. Pass twiddles w^k, k = 1 .. 15, from four table
-// entries (w, w^2, w^4, w^8) and eleven products, each at most three exactly rounded factors deep.
-// LDS padding: one element after every 16 and one after every 256 (pad16): the butterfly outputs of a lane are 16 consecutive elements
-// (lane stride 17 elements = 34 dwords: 16 lanes cover the 32 banks with their 64-bit accesses), the reads are consecutive.
-__device__ __forceinline__ int pad16(int i)
-{
-  return i + (i >> 4) + (i >> 8);
-}
-template <bool INV>
-__device__ __forceinline__ void dft16(cplx* a)
-{
-  const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, r = 0.70710678118654752440f;
-#pragma unroll
-  for (int n2 = 0; n2 < 4; ++n2)
-    dft4<INV>(a[n2], a[n2 + 4], a[n2 + 8], a[n2 + 12]); // a[n2 + 4 k1] = sum over n1 of x[4 n1 + n2] W4^(n1 k1)
-  // W16^(n2 k1), conjugated for the inverse transform
-  auto tw16 = [&](cplx v, float re, float im) { // v * (re - i im) forward, v * (re + i im) inverse
-    const float si = INV ? im : -im;
-    return cplx{v.x * re - v.y * si, v.x * si + v.y * re};
-  };
-  a[5]  = tw16(a[5], c1, s1);   // n2 = 1, k1 = 1: W16^1
-  a[9]  = tw16(a[9], r, r);     // n2 = 1, k1 = 2: W16^2
-  a[13] = tw16(a[13], s1, c1);  // n2 = 1, k1 = 3: W16^3
-  a[6]  = tw16(a[6], r, r);     // n2 = 2, k1 = 1: W16^2
-  a[10] = cmul_mi<INV>(a[10]);  // n2 = 2, k1 = 2: W16^4 = -+ i
-  a[14] = tw16(a[14], -r, r);   // n2 = 2, k1 = 3: W16^6
-  a[7]  = tw16(a[7], s1, c1);   // n2 = 3, k1 = 1: W16^3
-  a[11] = tw16(a[11], -r, r);   // n2 = 3, k1 = 2: W16^6
-  a[15] = tw16(a[15], -c1, -s1); // n2 = 3, k1 = 3: W16^9
-#pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1)
-    dft4<INV>(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]); // a[4 k1 + k2] = X[k1 + 4 k2]
-}
-// index in a[] (after dft16) of output k
-__device__ __forceinline__ constexpr int r16_out(int k)
-{
-  return 4 * (k & 3) + (k >> 2);
-}
-// a[r16_out(k)] *= w^k for k = 1 .. 15, w = tw[j] (conjugated for the inverse), from tw[j], tw[2 j], tw[4 j], tw[8 j]
-template <bool INV>
-__device__ __forceinline__ void r16_twiddle(cplx* a, const cplx* __restrict__ tw, int j)
-{
-  cplx w[16];
-  w[1] = cconj_if<INV>(tw[j]), w[2] = cconj_if<INV>(tw[2 * j]), w[4] = cconj_if<INV>(tw[4 * j]), w[8] = cconj_if<INV>(tw[8 * j]);
-  w[3]  = cmul(w[1], w[2]);
-  w[5]  = cmul(w[4], w[1]);
-  w[6]  = cmul(w[4], w[2]);
-  w[7]  = cmul(w[4], w[3]);
-  w[9]  = cmul(w[8], w[1]);
-  w[10] = cmul(w[8], w[2]);
-  w[11] = cmul(w[8], w[3]);
-  w[12] = cmul(w[8], w[4]);
-  w[13] = cmul(w[8], w[5]);
-  w[14] = cmul(w[8], w[6]);
-  w[15] = cmul(w[8], w[7]);
-#pragma unroll
-  for (int k = 1; k < 16; ++k)
-    a[r16_out(k)] = cmul(a[r16_out(k)], w[k]);
-}
-template <bool INV>
-__device__ __forceinline__ void fft4096_r16(cplx* x, const cplx* __restrict__ tw, int t, cplx* a)
-{
-  // pass A: sub-transform length 4096, stride 1: butterfly t on x[t + 256 k] (in a[]), twiddle W_4096^(t k), outputs to x[16 t + k]
-  dft16<INV>(a);
-  r16_twiddle<INV>(a, tw, t);
-  {
-    cplx* xw = x + 17 * t + (t >> 4); // pad16(16 t + k) = 17 t + (t >> 4) + k
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      xw[k] = a[r16_out(k)];
-  }
-  __syncthreads();
-  // pass B: length 256, stride 16: t = 16 p + q reads x[q + 16 (p + 16 k)] = x[t + 256 k], twiddle W_256^(p k) = W_4096^(16 p k),
-  // writes x[q + 16 (16 p + k)]
-  const int p = t >> 4, q = t & 15;
-  {
-    const cplx* xr = x + t + (t >> 4); // pad16(t + 256 k) = t + (t >> 4) + 273 k
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      a[k] = xr[273 * k];
-  }
-  __syncthreads();
-  dft16<INV>(a);
-  r16_twiddle<INV>(a, tw, 16 * p);
-  {
-    cplx* xw = x + q + 273 * p; // pad16(q + 256 p + 16 k) = q + 273 p + 17 k
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      xw[17 * k] = a[r16_out(k)];
-  }
-  __syncthreads();
-  // pass C: length 16, stride 256: reads x[t + 256 k], no twiddles, natural order out
-  {
-    const cplx* xr = x + t + (t >> 4);
-    cplx        b[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      b[k] = xr[273 * k];
-    dft16<INV>(b);
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      a[k] = b[r16_out(k)];
-  }
-}
-

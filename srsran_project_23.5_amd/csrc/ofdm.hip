@@ -13,9 +13,6 @@
 #ifndef OFDM_MOD_WAVES
 #define OFDM_MOD_WAVES 8
 #endif
-#ifndef OFDM_R16
-#define OFDM_R16 1 // the 4096-point symbol with three radix-16 passes on 256 threads (0: four radix-8 passes on 512)
-#endif
 namespace {
 
 template <bool INV>
@@ -136,7 +133,7 @@ bool four_step_factors(uint32_t N, uint32_t& N1, uint32_t& N2)
 // Each workgroup loops over (slot, symbol) pairs with stride gridDim.x; the launcher starts as many workgroups as the chip
 // holds at once. (Keeping the next symbol's samples in flight in registers while transforming the current one was measured:
 // the 16 extra registers cost a resident workgroup per CU and the time stayed the same, so the loads are plain.)
-template <bool WIDE, int NCT, bool R16 = false>
+template <bool WIDE, int NCT>
 __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict__ jobs,
                                                 const ofdm_plan_dev* __restrict__ plan,
                                                 const cplx* __restrict__ tw,
@@ -149,7 +146,7 @@ __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cplx*     x  = reinterpret_cast<cplx*>(smem);
   const int N  = NCT != 0 ? NCT : plan->N, rg = plan->rg, half = rg / 2;
-  const int nt = NCT != 0 ? NCT / (R16 ? 16 : 8) : (int)blockDim.x;
+  const int nt = NCT != 0 ? NCT / 8 : (int)blockDim.x;
   auto pad = [](int i) { return NCT == 4096 ? fpad_skew(i) : fpad(i); };
   auto symbol = [&](int idx) {
     const miphy_ofdm_job& job = jobs[idx / per];
@@ -161,24 +158,19 @@ __device__ __forceinline__ void ofdm_demod_body(const miphy_ofdm_job* __restrict
       // Register to register: lane t loads samples t + 512 k (consecutive lanes, consecutive samples) straight into its first
       // butterfly and stores bins t + 512 k straight from its last one -- the staging sweeps of the LDS buffer before the first and
       // after the last pass, and their barriers, are gone (ten LDS sweeps and ten barriers per symbol before, six and five now).
-      // (R16: 256 lanes with 16 points each and three radix-16 passes -- four LDS sweeps and three barriers, fft4096_r16)
-      constexpr int PTS = R16 ? 16 : 8, STR = 4096 / PTS;
-      const int     t   = threadIdx.x;
-      cplx          a[PTS];
+      const int t = threadIdx.x;
+      cplx      a[8];
 #pragma unroll
-      for (int k = 0; k < PTS; ++k) {
-        const float2 v = src[t + STR * k];
+      for (int k = 0; k < 8; ++k) {
+        const float2 v = src[t + 512 * k];
         a[k]           = {v.x, v.y};
       }
-      if (R16)
-        fft4096_r16<false>(x, tw, t, a);
-      else
-        fft4096_regs<false, true>(x, tw, t, a);
+      fft4096_regs<false, true>(x, tw, t, a);
       const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
       float2*    dst  = grid + job.grid_offset + (size_t)l * rg;
 #pragma unroll
-      for (int k = 0; k < PTS; ++k) {
-        const int bin = t + STR * k;
+      for (int k = 0; k < 8; ++k) {
+        const int bin = t + 512 * k;
         const int sc  = (bin < half) ? bin + half : bin - (4096 - half); // demodulator_impl.cpp:131-137, inverted
         if (bin < half || bin >= 4096 - half) {
           cplx v = cmul(a[k], coef); // sc_prod(dft_output, phase * scale)
@@ -243,13 +235,6 @@ ofdm_demod_4096_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_
 {
   ofdm_demod_body<true, 4096>(jobs, plan, tw, ramp, samples, grid, total, per);
 }
-// The same symbol on 256 threads with three radix-16 passes (fft4096_r16): the default for the 4096-point symbol.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
-ofdm_demod_4096r_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const cplx* __restrict__ ramp,
-                        const float2* __restrict__ samples, float2* __restrict__ grid, int total, int per)
-{
-  ofdm_demod_body<true, 4096, true>(jobs, plan, tw, ramp, samples, grid, total, per);
-}
 __global__ void __launch_bounds__(512)
 ofdm_demod_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const cplx* __restrict__ ramp,
                   const float2* __restrict__ samples, float2* __restrict__ grid, int total, int per)
@@ -257,7 +242,7 @@ ofdm_demod_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* 
   ofdm_demod_body<false, 0>(jobs, plan, tw, ramp, samples, grid, total, per);
 }
 
-template <bool WIDE, int NCT, bool R16 = false>
+template <bool WIDE, int NCT>
 __device__ __forceinline__ void ofdm_mod_body(const miphy_ofdm_job* __restrict__ jobs,
                                               const ofdm_plan_dev* __restrict__ plan,
                                               const cplx* __restrict__ tw,
@@ -283,30 +268,26 @@ __device__ __forceinline__ void ofdm_mod_body(const miphy_ofdm_job* __restrict__
   if (NCT == 4096) {
     // Register to register (see the demodulator): lane t gathers bins t + 512 k from the grid row, transforms, and stores samples
     // t + 512 k (and their copies in the cyclic prefix) straight from its last butterfly.
-    constexpr int PTS = R16 ? 16 : 8, STR = 4096 / PTS;
-    const int     t   = threadIdx.x;
-    cplx          a[PTS];
+    const int t = threadIdx.x;
+    cplx      a[8];
 #pragma unroll
-    for (int k = 0; k < PTS; ++k) {
+    for (int k = 0; k < 8; ++k) {
       // bins [0, rg/2) <- upper half of the grid row, bins [N - rg/2, N) <- lower half, the rest zero (:82-86); branch-free: an
       // unused bin loads element 0 and discards it (per-element branches made the compiler carry copies of a[] through scratch)
-      const int    i  = t + STR * k;
+      const int    i  = t + 512 * k;
       const bool   lo = i < half, hi = i >= 4096 - half;
       const float2 g  = src[lo ? half + i : (hi ? i - (4096 - half) : 0)];
       a[k]            = (lo || hi) ? cplx{g.x, g.y} : cplx{0.f, 0.f};
     }
-    if (R16)
-      fft4096_r16<true>(x, tw, t, a);
-    else
-      fft4096_regs<true, true>(x, tw, t, a);
+    fft4096_regs<true, true>(x, tw, t, a);
     const cplx coef = {plan->coef_re[sym], plan->coef_im[sym]};
 #pragma unroll
-    for (int k = 0; k < PTS; ++k) {
-      const int    j = t + STR * k;
+    for (int k = 0; k < 8; ++k) {
+      const int    j = t + 512 * k;
       const cplx   v = cmul(a[k], coef);
       const float2 o = make_float2(v.x, v.y);
       dst[cp + j]    = o;
-      if (STR * (k + 1) > 4096 - 512 && j >= 4096 - cp) // cyclic prefix = copy of the tail (:98); it is shorter than 512 samples
+      if (k == 7 && j >= 4096 - cp) // cyclic prefix = copy of the tail (:98); shorter than 512 samples: only the last octet reaches it
         dst[j - (4096 - cp)] = o;
     }
     return;
@@ -347,12 +328,6 @@ ofdm_mod_4096_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_de
                      float2* __restrict__ samples, int per)
 {
   ofdm_mod_body<true, 4096>(jobs, plan, tw, grid, samples, per);
-}
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
-ofdm_mod_4096r_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const float2* __restrict__ grid,
-                      float2* __restrict__ samples, int per)
-{
-  ofdm_mod_body<true, 4096, true>(jobs, plan, tw, grid, samples, per);
 }
 __global__ void __launch_bounds__(512)
 ofdm_mod_kernel(const miphy_ofdm_job* __restrict__ jobs, const ofdm_plan_dev* __restrict__ plan, const cplx* __restrict__ tw, const float2* __restrict__ grid,
@@ -591,10 +566,7 @@ int ofdm_demodulate(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_of
   // As many workgroups as the chip holds at once (LDS-bound), each looping over its share of the symbols.
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / (lds + 512)));
   const int nwg    = std::min(total, ctx->num_cus * per_cu);
-  if (wide && cfg->dft_size == 4096 && nt == 512 && OFDM_R16)
-    hipLaunchKernelGGL(ofdm_demod_4096r_kernel, dim3(total), dim3(256), lds, s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw, (const cplx*)ramp,
-                       (const float2*)samples, (float2*)grid, total, per);
-  else if (wide && cfg->dft_size == 4096 && nt == 512)
+  if (wide && cfg->dft_size == 4096 && nt == 512)
     hipLaunchKernelGGL(ofdm_demod_4096_kernel, dim3(total), dim3(nt), lds, s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw, (const cplx*)ramp,
                        (const float2*)samples, (float2*)grid, total, per);
   else if (wide)
@@ -631,10 +603,7 @@ int ofdm_modulate(miphy_ctx* ctx, const miphy_ofdm_config* cfg, const miphy_ofdm
     return rc;
   const int  nt = threads_for(cfg->dft_size);
   const dim3 g(per, n);
-  if (cfg->dft_size == 4096 && nt == 512 && OFDM_R16)
-    hipLaunchKernelGGL(ofdm_mod_4096r_kernel, g, dim3(256), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
-                       (const float2*)grid, (float2*)samples, per);
-  else if (cfg->dft_size == 4096 && nt == 512)
+  if (cfg->dft_size == 4096 && nt == 512)
     hipLaunchKernelGGL(ofdm_mod_4096_kernel, g, dim3(nt), fft_lds_bytes(cfg->dft_size), s, (const miphy_ofdm_job*)d_jobs, plan, (const cplx*)tw,
                        (const float2*)grid, (float2*)samples, per);
   else if (cfg->dft_size <= 8u * (uint32_t)nt)
