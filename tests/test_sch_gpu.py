@@ -190,3 +190,73 @@ def test_first_transmission_dematched_by_the_decoder(ctx, early_stop, form):
                 assert np.array_equal(tb_out[o0:o0 + x["tb"].size], x["tb"]), key
     miphy.lib().miphy_debug_force_ldpc_kernel(0)
     assert any(bool(r["tb_crc_ok"]) for r in res)
+
+
+def test_mixed_class_plan_replays_as_a_hip_graph(ctx):
+    """A prepared PUSCH decode plan whose codeblocks fall into several launch classes (wave kernel, packed kernel with one and three wavefronts,
+    small classes forked to side streams and joined with events) is captured once in a HIP graph and replayed on new LLRs: the results equal the
+    plain runs' and the oracle's verdicts."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(91)
+    cases = [(2, 2, 1, 4, 144), (2, 2, 1, 8, 768), (1, 6, 1, 40, 31752), (1, 8, 1, 90, 104496), (2, 4, 1, 16, 3752)]
+    tbs, slot = [], 0
+    for rep in range(3):
+        for bg, mod, nl, nprb, tbs_bits in cases:
+            nsym = nprb * 156 * nl
+            tb = rng.integers(0, 256, tbs_bits // 8, dtype=np.uint8)
+            seg = o_segmentation(tbs_bits, bg, mod, nl, nsym)
+            cw = o_pdsch_encode(bg, 0, mod, 0, nl, nsym, tb)
+            tbs.append(dict(bg=bg, mod=mod, nl=nl, nsym=nsym, tb=tb, cw=cw, slot=slot, ncb=seg.nof_cbs))
+            slot += seg.nof_cbs
+    n = len(tbs)
+    d = np.zeros(n, dtype=miphy.PuschTbDesc)
+    llr_off, tb_off = 0, 0
+    for i, x in enumerate(tbs):
+        d[i] = (x["bg"], 0, x["mod"], x["nl"], 1, 1, 6, 0, x["nsym"], x["tb"].size, x["slot"], llr_off, tb_off)
+        x["llr_off"], x["tb_off"] = llr_off, tb_off
+        llr_off += (x["cw"].size + 15) // 16 * 16
+        tb_off += (x["tb"].size + 15) // 16 * 16
+    plan = ctx.pusch_decode_plan(d)
+    assert plan.nof_launches() >= 4
+    soft_d = torch.zeros(slot * miphy.HARQ_CB_STRIDE, dtype=torch.int8, device="cuda")
+    msgs_d = torch.zeros(slot * miphy.HARQ_MSG_STRIDE, dtype=torch.uint8, device="cuda")
+    crc_d = torch.zeros(slot, dtype=torch.uint8, device="cuda")
+    res_d = torch.zeros(n * miphy.PuschResult.itemsize, dtype=torch.uint8, device="cuda")
+    tb_d = torch.zeros(tb_off, dtype=torch.uint8, device="cuda")
+    llr_d = torch.zeros(llr_off, dtype=torch.int8, device="cuda")
+
+    def fill(sigma):
+        h = np.zeros(llr_off, np.int8)
+        for x in tbs:
+            h[x["llr_off"]:x["llr_off"] + x["cw"].size] = noisy(x["cw"], sigma, rng)
+        llr_d.copy_(torch.from_numpy(h))
+        return h
+
+    fill(0.3)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        plan.run(llr_d, soft_d, msgs_d, crc_d, tb_d, res_d, st)  # warm-up outside the capture: workspaces and side streams exist afterwards
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.run(llr_d, soft_d, msgs_d, crc_d, tb_d, res_d, torch.cuda.current_stream())
+    for sigma in (0.25, 0.5):
+        h = fill(sigma)
+        tb_d.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        res = res_d.cpu().numpy().view(miphy.PuschResult).copy()
+        got = tb_d.cpu().numpy().copy()
+        tb_d.zero_()
+        plan.run(llr_d, soft_d, msgs_d, crc_d, tb_d, res_d)
+        torch.cuda.synchronize()
+        assert np.array_equal(res_d.cpu().numpy().view(miphy.PuschResult), res)
+        assert np.array_equal(tb_d.cpu().numpy(), got)
+        for i, x in enumerate(tbs):
+            od = OraclePuschDecoder(x["bg"], x["mod"], 0, x["nl"], x["nsym"], x["tb"].size)
+            ok, tbo, mm = od.decode(h[x["llr_off"]:x["llr_off"] + x["cw"].size], 0, True, 6, True)
+            assert bool(res[i]["tb_crc_ok"]) == ok and (int(res[i]["iters_min"]), int(res[i]["iters_max"])) == mm, (i, sigma)
+            if ok:
+                assert np.array_equal(got[x["tb_off"]:x["tb_off"] + x["tb"].size], x["tb"]), (i, sigma)
+    plan.close()
