@@ -374,12 +374,14 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 } // namespace
 
 
+static bool     g_hybrid_msgs  = true; // A-B: miphy_debug_force_ldpc_kernel(mode | 0x100) = all messages of a GMSG launch in global memory
 static int      g_force_kernel = 0; // 0 auto, 1 one-row-per-lane kernel, 2 packed kernel as ONE launch, 3 class-sorted launches (miphy_debug_force_ldpc_kernel)
 static unsigned g_kernels_used = 0; // MIPHY_LDPC_KERNEL_* of every decoder launch since the last reset (miphy_debug_ldpc_kernels_used)
 
 extern "C" void miphy_debug_force_ldpc_kernel(int mode)
 {
-  g_force_kernel = mode;
+  g_force_kernel = mode & 0xff;
+  g_hybrid_msgs  = !(mode & 0x100);
 }
 
 bool miphy_ldpc_scalar_forced()
@@ -514,8 +516,9 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
     return MIPHY_OK;
   // Geometry of every class first: the launches of one call run side by side, so each needs message scratch of its own.
   struct geom {
-    bool   fuse, gm, split;
-    int    threads, pairs;
+    bool   fuse, gm;
+    int    split; // parts of the latency form (0: throughput form)
+    int    threads, pairs, lds_pairs;
     size_t lds, gmsg_bytes, gmsg_off;
     int    stream; // 0 = the caller's, 1 .. = side streams
   };
@@ -541,13 +544,27 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
       // layer visit buys nothing)
       q.gm         = per_cu(lds_g) > per_cu(lds_l) && (g_force_kernel == 4 || c.count > (uint32_t)(ctx->num_cus * per_cu(lds_l)));
       q.lds        = q.gm ? lds_g : lds_l;
+      // Only as many layers' messages leave LDS as that residency needs: the first layers keep theirs (a lane's messages are private to it,
+      // so the split is free), the global round trip and its L2 traffic are paid for the rest.
+      if (q.gm && g_force_kernel != 4 && g_hybrid_msgs) {
+        for (int k = c.lay - 1; k > 0; --k) {
+          const int    pk_ = ctx->h_tables->pair_start[c.bgi][k];
+          const size_t l_  = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, pk_);
+          if (per_cu(l_) == per_cu(lds_g)) {
+            q.lds_pairs = pk_, q.lds = l_;
+            break;
+          }
+        }
+      }
       // Latency form where the class cannot fill the chip anyway (at most one codeblock per CU): twice the wavefronts per codeblock,
       // messages in LDS (residency is no concern then).
-      const size_t lds_s = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, q.pairs, true);
-      q.split            = g_force_kernel != 4 && (c.count <= (uint32_t)ctx->num_cus || g_force_kernel == 5) && lds_s <= (size_t)160 * 1024;
+      // (four parts while the codeblocks of the class still find a CU each and the workgroup stays within 1024 threads; forced mode 6: two)
+      const int    parts = (g_force_kernel == 5 || g_force_kernel == 6) ? 2 : 4;
+      const size_t lds_s = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, q.pairs, parts);
+      q.split            = (g_force_kernel != 4 && (c.count <= (uint32_t)ctx->num_cus || g_force_kernel == 5) && lds_s <= (size_t)160 * 1024) ? parts : 0;
       if (q.split)
         q.gm = false, q.lds = lds_s;
-      q.gmsg_bytes = miphy_ldpc_pk_gmsg_bytes(ctx, c.count, q.threads, q.lds, q.fuse, q.gm ? q.pairs : 0);
+      q.gmsg_bytes = miphy_ldpc_pk_gmsg_bytes(ctx, c.count, q.threads, q.lds, q.fuse, q.gm ? q.pairs - q.lds_pairs : 0);
     }
     q.gmsg_off = gmsg_total;
     gmsg_total += (q.gmsg_bytes + 255) & ~(size_t)255;
@@ -570,7 +587,7 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
     int small = 0;
     for (size_t i = 0; i < nc; ++i) {
       const miphy_ldpc_class& c = C.classes[i];
-      const uint64_t waves = c.kind == 0 ? c.bundle_count : (uint64_t)c.count * c.kind * (g[i].split ? 2 : 1);
+      const uint64_t waves = c.kind == 0 ? c.bundle_count : (uint64_t)c.count * c.kind * (g[i].split ? g[i].split : 1);
       if (waves <= (uint64_t)ctx->num_cus * 4)
         g[i].stream = 1 + (small++ % (g_class_streams - 1));
     }
@@ -615,8 +632,8 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
     }
     const int bgK = c.bgi ? 10 : 22;
     if ((rc = miphy_ldpc_pk_launch(ctx, d_descs, c.count, q.threads, q.lds, llr, out_bits, iters, bgK + c.lay, harq_slot, harq_crc_ok, st,
-                                   q.fuse ? d_rdm : nullptr, q.fuse ? rm_in : nullptr, q.gm ? q.pairs : 0,
-                                   (C.identity && nc == 1) ? nullptr : d_order + c.first, gb, q.split)))
+                                   q.fuse ? d_rdm : nullptr, q.fuse ? rm_in : nullptr, q.gm ? q.pairs - q.lds_pairs : 0,
+                                   (C.identity && nc == 1) ? nullptr : d_order + c.first, gb, q.split, q.gm ? q.lds_pairs : 0)))
       return rc;
     g_kernels_used |= MIPHY_LDPC_KERNEL_PACKED | (q.fuse ? MIPHY_LDPC_KERNEL_FUSED : 0u) | (q.gm ? MIPHY_LDPC_KERNEL_GMSG : 0u) |
                       (q.split ? MIPHY_LDPC_KERNEL_SPLIT : 0u);

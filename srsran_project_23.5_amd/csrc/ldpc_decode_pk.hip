@@ -255,11 +255,11 @@ __device__ __forceinline__ int pk_fused_image_out(const int8_t* __restrict__ sof
   return last;
 }
 
-// SPLIT = the latency form for launches that leave most of the chip idle (a single slot is 38 codeblocks on 256 CUs): twice the
-// wavefronts per codeblock, the two halves of the workgroup share the edges of every layer (update_rows_pk, SPLIT) -- about half the
+// PARTS > 1 = the latency form for launches that leave most of the chip idle (a single slot is 38 codeblocks on 256 CUs): PARTS times the
+// wavefronts per codeblock, the PARTS parts of the workgroup share the edges of every layer (update_rows_pk, PARTS) -- about 1 / PARTS of the
 // instructions per wavefront and layer for one more barrier, same results, same LDS image (messages always in LDS).
-template <bool FUSED, bool GMSG, bool SPLIT = false>
-__global__ void __launch_bounds__(SPLIT ? 384 : 192, SPLIT ? LDPC_PK_MIN_WAVES_SPLIT : (FUSED ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN))
+template <bool FUSED, bool GMSG, int PARTS = 1>
+__global__ void __launch_bounds__(192 * PARTS, PARTS > 1 ? LDPC_PK_MIN_WAVES_SPLIT : (FUSED ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN))
 ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                       const miphy_graph_tables* __restrict__ tab,
                       const int8_t* __restrict__ llr_base,
@@ -274,15 +274,19 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
                       const int8_t* __restrict__ rm_in_base,
                       uint32_t* __restrict__ gmsg,
                       int gmsg_pairs,
+                      int lds_pairs, // GMSG: the first lds_pairs message dwords of a lane stay in LDS (a layer boundary), the other gmsg_pairs are global
                       const uint32_t* __restrict__ cb_order) // optional: the launch decodes codeblocks order[0 .. n) of the arrays (one class of a sorted batch)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int nt  = blockDim.x;
+  constexpr bool SPLIT = PARTS > 1;
+  static_assert(PARTS == 1 || PARTS == 2 || PARTS == 4, "parts of the latency form");
   static_assert(!(SPLIT && GMSG), "the latency form keeps its messages in LDS");
-  const int nth  = SPLIT ? (nt >> 1) : nt;       // threads that own rows: the whole workgroup, or each half of it
-  const int half = SPLIT ? (tid >= nth ? 1 : 0) : 0;
-  const int lr   = tid - half * nth;             // row pair (lr, lr + H) of this lane
+  const int nth  = nt / PARTS;                   // threads that own rows: the whole workgroup, or each part of it
+  // (wave-uniform by construction -- nth is a multiple of 64 --, and said so: the part selects the edges of a layer, which must stay scalar loads)
+  const int part = SPLIT ? __builtin_amdgcn_readfirstlane((tid >= nth) + (PARTS > 2 ? (tid >= 2 * nth) + (tid >= 3 * nth) : 0)) : 0;
+  const int lr   = tid - part * nth;             // row pair (lr, lr + H) of this lane
   raw_in16  pre[PK_PRE];
   if (FUSED) {
     if (blockIdx.x < n) {
@@ -324,12 +328,12 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   const int lay_alloc  = min(bgM, max(4, max_nodes - bgK));
   const int soft_bytes = ((bgK + lay_alloc) * Z + 15) & ~15;
   const int pairs_all  = tab->pair_start[bgi][lay_alloc];
-  uint32_t* c2v_lane   = GMSG ? gmsg + ((size_t)blockIdx.x * (nt >> 6) + (tid >> 6)) * ((size_t)gmsg_pairs * 64) + (tid & 63)
-                              : reinterpret_cast<uint32_t*>(smem + soft_bytes) + (lr >> 6) * (pairs_all * 64) + (lr & 63);
-  uint32_t* red        = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (GMSG ? 0 : (nth >> 6) * (pairs_all * 64));
-  // latency form: exchange slots behind the reduction words, [half][3][nth] dwords
-  uint32_t*       xw = red + 16 + half * 3 * nth + lr;
-  const uint32_t* xr = red + 16 + (1 - half) * 3 * nth + lr;
+  const int pairs_lds  = GMSG ? lds_pairs : pairs_all;
+  uint32_t* c2v_lane   = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (lr >> 6) * (pairs_lds * 64) + (lr & 63);
+  uint32_t* c2v_glob   = GMSG ? gmsg + ((size_t)blockIdx.x * (nt >> 6) + (tid >> 6)) * ((size_t)gmsg_pairs * 64) + (tid & 63) - 64 * (size_t)pairs_lds : nullptr;
+  uint32_t* red        = reinterpret_cast<uint32_t*>(smem + soft_bytes) + (nth >> 6) * (pairs_lds * 64);
+  // latency form: exchange slots behind the reduction words, [part][3][nth] dwords
+  uint32_t* xch = red + 16 + lr;
 
   // Next codeblock of this workgroup (taken now so that the queue round trip is off the critical path).
   __syncthreads(); // the previous codeblock's readers of red[] / soft[] are done
@@ -475,6 +479,9 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 #ifndef LDPC_PK_SCALAR_WRAP
   asm volatile("" : "+v"(Zv), "+v"(Hv));
 #endif
+  part_edges<PARTS> pe; // latency form: this part's edges of the layer about to run, fetched while the layer before it runs
+  if (SPLIT)
+    load_part_edges<PARTS>(pe, edges_g, (uint32_t)__builtin_amdgcn_readlane((int)lay_info, 0), part);
   for (int it = 0; it < max_iter; ++it) {
     for (int m = 0; m < nof_layers; ++m) {
       const uint32_t  li    = (uint32_t)__builtin_amdgcn_readlane((int)lay_info, m);
@@ -483,17 +490,29 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
       const uint32_t* edges = edges_g + 2 * e0;
       PROF_T(p_l0);
       if (SPLIT) { // every thread: the function holds the barrier of the exchange
+        part_edges<PARTS> pn;
+        const uint32_t    lin  = (uint32_t)__builtin_amdgcn_readlane((int)lay_info, (m + 1 < nof_layers) ? m + 1 : 0);
+        auto              next = [&]() { load_part_edges<PARTS>(pn, edges_g, lin, part); };
         uint32_t* cl = c2v_lane + 64 * (li >> 16);
         if (it == 0)
-          update_rows_pk_split<true>(d, half, soft, cl, edges, lr, Hv, Zv, lr < H, xw, xr, nth);
+          update_rows_pk_split<true, PARTS>(pe, part, soft, cl, lr, Hv, Zv, lr < H, xch, nth, next);
         else
-          update_rows_pk_split<false>(d, half, soft, cl, edges, lr, Hv, Zv, lr < H, xw, xr, nth);
+          update_rows_pk_split<false, PARTS>(pe, part, soft, cl, lr, Hv, Zv, lr < H, xch, nth, next);
+        pe = pn;
       } else if (tid < H) {
-        uint32_t* cl = c2v_lane + 64 * (li >> 16);
-        if (it == 0)
-          update_rows_pk_any<true>(d, soft, cl, edges, tid, Hv, Zv);
-        else
-          update_rows_pk_any<false>(d, soft, cl, edges, tid, Hv, Zv);
+        if (GMSG && (int)(li >> 16) >= pairs_lds) { // this layer's messages live in global memory (separate code: the address space is part of the instruction)
+          uint32_t* cl = c2v_glob + 64 * (li >> 16);
+          if (it == 0)
+            update_rows_pk_any<true>(d, soft, cl, edges, tid, Hv, Zv);
+          else
+            update_rows_pk_any<false>(d, soft, cl, edges, tid, Hv, Zv);
+        } else {
+          uint32_t* cl = c2v_lane + 64 * (li >> 16);
+          if (it == 0)
+            update_rows_pk_any<true>(d, soft, cl, edges, tid, Hv, Zv);
+          else
+            update_rows_pk_any<false>(d, soft, cl, edges, tid, Hv, Zv);
+        }
       }
       PROF_T(p_l1);
       __syncthreads();
@@ -570,26 +589,44 @@ extern "C" int miphy_debug_ldpc_profile(unsigned long long out[8], int reset)
 }
 #endif
 
+#ifdef LDPC_PK_PROFILE2
+extern "C" int miphy_debug_ldpc_profile2(unsigned long long out[8], int reset)
+{
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ldpc_prof2), 8 * sizeof(unsigned long long)) != hipSuccess)
+    return -1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ldpc_prof2), z, sizeof(z)) != hipSuccess)
+      return -1;
+  }
+  return 0;
+}
+#endif
+
 // LDS bytes the packed kernel needs for a given geometry (Zt >= Z of every codeblock, lay = layer bound, pairs_all = message
 // dwords per lane of those layers).
-int miphy_ldpc_pk_waves_per_cu(bool fused, bool split)
+int miphy_ldpc_pk_waves_per_cu(bool fused, int parts)
 {
-  return 4 * (split ? LDPC_PK_MIN_WAVES_SPLIT : (fused ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN)); // what __launch_bounds__ of the kernel guarantees per CU
+#ifdef LDPC_PK_REPORT_WAVES_FUSED // A-B: the register allocation of one occupancy run at another
+  if (fused && parts <= 1)
+    return 4 * LDPC_PK_REPORT_WAVES_FUSED;
+#endif
+  return 4 * (parts > 1 ? LDPC_PK_MIN_WAVES_SPLIT : (fused ? LDPC_PK_MIN_WAVES_FUSED : LDPC_PK_MIN_WAVES_PLAIN)); // what __launch_bounds__ of the kernel guarantees per CU
 }
 
-size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all, bool split)
+size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all, int parts)
 {
   const size_t waves = ((Zt + 1) / 2 + 63) / 64;
-  return ((((size_t)bgK + lay) * Zt + 15) & ~(size_t)15) + waves * (size_t)pairs_all * 256 + 64 + (split ? 6 * 64 * waves * 4 : 0);
+  return ((((size_t)bgK + lay) * Zt + 15) & ~(size_t)15) + waves * (size_t)pairs_all * 256 + 64 + (parts > 1 ? (size_t)parts * 3 * 64 * waves * 4 : 0);
 }
 
-uint32_t miphy_ldpc_pk_grid(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused, bool split)
+uint32_t miphy_ldpc_pk_grid(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused, int parts)
 {
   // (threads = those of the launch: the latency form passes twice the row-owning threads)
   // Resident workgroups per CU: LDS, the wavefronts per CU the register budget of the kernel allows (__launch_bounds__), 32 slots.
   const int waves  = threads / 64;
   int       per_cu = (int)((size_t)160 * 1024 / lds);
-  per_cu           = std::min(per_cu, miphy_ldpc_pk_waves_per_cu(fused, split) / waves);
+  per_cu           = std::min(per_cu, miphy_ldpc_pk_waves_per_cu(fused, parts) / waves);
   per_cu           = std::max(per_cu, 1);
   return std::min<uint32_t>(n, (uint32_t)(ctx->num_cus * per_cu));
 }
@@ -601,13 +638,17 @@ size_t miphy_ldpc_pk_gmsg_bytes(const miphy_ctx* ctx, uint32_t n, int threads, s
 
 int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                          uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
-                         const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in, int gmsg_pairs, const uint32_t* d_order, void* gmsg_buf, bool split)
+                         const miphy_ldpc_rdm_desc* d_rdm, const int8_t* rm_in, int gmsg_pairs, const uint32_t* d_order, void* gmsg_buf, int parts, int lds_pairs)
 {
   const bool fused = d_rdm != nullptr, gm = gmsg_pairs > 0;
+  const bool split = parts > 1;
+  MIPHY_REQUIRE(parts <= 1 || parts == 2 || parts == 4, "ldpc_decode: the latency form has two or four parts");
   MIPHY_REQUIRE(!(split && gm), "ldpc_decode: the latency form keeps its messages in LDS");
   if (split)
-    threads *= 2; // `threads` = the row-owning threads of a codeblock; `lds` already holds the exchange slots
-  const void* kern = split ? (fused ? (const void*)ldpc_decode_pk_kernel<true, false, true> : (const void*)ldpc_decode_pk_kernel<false, false, true>)
+    threads *= parts; // `threads` = the row-owning threads of a codeblock; `lds` already holds the exchange slots
+  MIPHY_REQUIRE(threads <= 1024, "ldpc_decode: workgroup of %d threads", threads);
+  const void* kern = parts == 4 ? (fused ? (const void*)ldpc_decode_pk_kernel<true, false, 4> : (const void*)ldpc_decode_pk_kernel<false, false, 4>)
+                     : split    ? (fused ? (const void*)ldpc_decode_pk_kernel<true, false, 2> : (const void*)ldpc_decode_pk_kernel<false, false, 2>)
                            : fused ? (gm ? (const void*)ldpc_decode_pk_kernel<true, true> : (const void*)ldpc_decode_pk_kernel<true, false>)
                                    : (gm ? (const void*)ldpc_decode_pk_kernel<false, true> : (const void*)ldpc_decode_pk_kernel<false, false>);
   // Above the default 64 KB of dynamic LDS the limit has to be raised; it is a per-device attribute of the kernel, so it is set on
@@ -615,7 +656,7 @@ int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uin
   if (lds > 48 * 1024) {
     MIPHY_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  const uint32_t grid  = miphy_ldpc_pk_grid(ctx, n, threads, lds, fused, split);
+  const uint32_t grid  = miphy_ldpc_pk_grid(ctx, n, threads, lds, fused, parts);
   uint32_t*      queue = nullptr;
   int            rc    = miphy_next_queue_counter(ctx, &queue);
   if (rc)
@@ -625,11 +666,15 @@ int miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uin
     return rc;
 #define PK_LAUNCH(F, G, ...)                                                                                                                         \
   hipLaunchKernelGGL((ldpc_decode_pk_kernel<F, G, ##__VA_ARGS__>), dim3(grid), dim3(threads), lds, s, d_descs, ctx->d_tables, llr, out_bits, iters, nodes_all, \
-                     harq_slot, harq_crc_ok, n, queue, d_rdm, rm_in, (uint32_t*)gmsg, gmsg_pairs, d_order)
-  if (split && fused)
-    PK_LAUNCH(true, false, true);
+                     harq_slot, harq_crc_ok, n, queue, d_rdm, rm_in, (uint32_t*)gmsg, gmsg_pairs, lds_pairs, d_order)
+  if (parts == 4 && fused)
+    PK_LAUNCH(true, false, 4);
+  else if (parts == 4)
+    PK_LAUNCH(false, false, 4);
+  else if (split && fused)
+    PK_LAUNCH(true, false, 2);
   else if (split)
-    PK_LAUNCH(false, false, true);
+    PK_LAUNCH(false, false, 2);
   else if (fused && gm)
     PK_LAUNCH(true, true);
   else if (fused)

@@ -54,18 +54,37 @@ __device__ __forceinline__ uint32_t c2v_pack(s16x2 c0, s16x2 c1)
   return __builtin_amdgcn_perm(as_u(c0), as_u(c1), 0x06020400u);
 }
 
+// Finer stamps inside a layer of the latency form (tools/ldpc_phase_probe.py --inner; debug build with -DLDPC_PK_PROFILE2 only).
+#ifdef LDPC_PK_PROFILE2
+__device__ unsigned long long g_ldpc_prof2[8];
+#define P2_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define P2_ADD(slot, a, b)                                                 \
+  do {                                                                     \
+    if (threadIdx.x == 0)                                                  \
+      atomicAdd(&g_ldpc_prof2[slot], (unsigned long long)((b) - (a)));     \
+  } while (0)
+#else
+#define P2_T(var)
+#define P2_ADD(slot, a, b)
+#endif
+
 constexpr int LLR_MAX = 120;
 constexpr int LLR_INF = 127;
 constexpr int INF_MUL = 255; // an infinite soft bit (|s| > 120) becomes a message of magnitude >= 255 + 24
 
 // `base` = LDS byte offset of the codeblock's soft bits (0 where a workgroup holds one codeblock: the term then folds away).
-// SPLIT (latency form of the packed kernel: twice the wavefronts per codeblock, each half of the workgroup owns HALF of the edges of a
-// layer): D is the number of edges of THIS half; between the two phases the halves exchange their partial {min1, min2, sign parity}
-// through LDS (`xw` = this lane's slot, `xr` = the slot of the lane that owns the same rows in the other half, three dwords `xs` apart)
-// and merge them -- the two smallest magnitudes of the union are min(a1, b1) and min(max(a1, b1), min(a2, b2)). The function then
+// PARTS > 1 (latency form of the packed kernel: PARTS times the wavefronts per codeblock, each part of the workgroup owns a share of
+// the edges of a layer): D is the number of edges of THIS part; between the two phases the parts exchange their partial {min1, min2,
+// sign parity} through LDS (`xch` = this lane's column of the exchange area [part][3][xs], `part` = this part) and merge them -- the
+// two smallest magnitudes of a union are min(a1, b1) and min(max(a1, b1), min(a2, b2)), an associative rule. The function then
 // contains a workgroup barrier: EVERY thread calls it, `active` = the lane owns rows (an idle lane computes on soft bits it may read
 // but stores nothing).
-template <int D, bool FIRST, bool SPLIT = false>
+struct pk_no_hook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `mid` is called once between the two phases (the latency form issues the scalar loads of the next layer's edges there: behind the last LDS
+// read of the layer, so that they do not turn the partial lgkmcnt waits on the in-order LDS returns into waits for everything).
+template <int D, bool FIRST, int PARTS = 1, typename MID = pk_no_hook>
 __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
                                                uint32_t* __restrict__ c2v, // this lane's message dword of edges 0,1 of the layer
                                                const uint32_t* __restrict__ edges, // {shift, column*Z} per edge
@@ -74,14 +93,17 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
                                                int Z,
                                                uint32_t base = 0,
                                                bool active = true,
-                                               uint32_t* xw = nullptr,
-                                               const uint32_t* xr = nullptr,
-                                               int xs = 0)
+                                               uint32_t* xch = nullptr,
+                                               int part = 0,
+                                               int xs = 0,
+                                               MID mid = MID())
 {
+  constexpr bool SPLIT = PARTS > 1;
   s16x2    v2c[D], mabs[D];
   uint32_t adrA[D], adrB[D];
   int      rawA[D], rawB[D];
   uint32_t cw[(D + 1) / 2];
+  P2_T(q0);
   // Stage A: every address of the layer, then every LDS read of the layer in one go (2 soft bits per edge + the old
   // messages): the latency of the LDS pipe is paid once per layer instead of once per group of edges.
   // Both rows' addresses with packed 16-bit arithmetic: {l, l + H} + shift, wrap at Z by the unsigned minimum of p and p - Z, + column
@@ -92,7 +114,11 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
     const u16x2 Zs = {(unsigned short)Z, (unsigned short)Z};
 #pragma unroll
     for (int j = 0; j < D; ++j) {
+#ifdef LDPC_PK_EMU_NOSLOAD // timing-only (WRONG results): no scalar loads of the edge table
+      const unsigned short sh = (unsigned short)(7 * j + (l & 1)), co = (unsigned short)(j * Z);
+#else
       const unsigned short sh = (unsigned short)edges[2 * j], co = (unsigned short)edges[2 * j + 1];
+#endif
       const u16x2 T = X + u16x2{sh, sh};
       const u16x2 R = __builtin_elementwise_min(T, (u16x2)(T - Zs));
       const uint32_t P = __builtin_bit_cast(uint32_t, (u16x2)(R + u16x2{co, co}));
@@ -100,6 +126,7 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
       adrB[j] = (P >> 16) + base;
     }
   }
+  P2_T(q1);
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     rawA[j] = soft[adrA[j]];
@@ -111,6 +138,7 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
       cw[jj] = c2v[64 * jj];
   }
   __builtin_amdgcn_sched_barrier(0);
+  P2_T(q2);
   s16x2    mag1 = splat(LLR_MAX), mag2 = splat(LLR_MAX);
   uint32_t spx  = 0;
 #pragma unroll
@@ -134,14 +162,31 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
     mag1             = pk_min(mag1, av);
     mag2             = pk_min(mag2, help);
   }
+  P2_T(q3);
+#ifdef LDPC_PK_PROFILE2
+  unsigned long long q4 = q3;
+#endif
   if (SPLIT) {
+    uint32_t* xw = xch + 3 * part * xs;
     xw[0] = as_u(mag1), xw[xs] = as_u(mag2), xw[2 * xs] = spx;
+#ifndef LDPC_PK_EMU_NOXBAR // timing-only (WRONG results): no barrier in the exchange
     __syncthreads();
-    const s16x2 o1 = as_s2(xr[0]), o2 = as_s2(xr[xs]);
-    spx ^= xr[2 * xs];
-    mag2 = pk_min(pk_max(mag1, o1), pk_min(mag2, o2));
-    mag1 = pk_min(mag1, o1);
+#endif
+#ifdef LDPC_PK_PROFILE2
+    q4 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+    for (int o = 1; o < PARTS; ++o) {
+      const int       other = (part + o) & (PARTS - 1); // the merge is commutative: any order gives the same two minima
+      const uint32_t* xr    = xch + 3 * other * xs;
+      const s16x2     o1 = as_s2(xr[0]), o2 = as_s2(xr[xs]);
+      spx ^= xr[2 * xs];
+      mag2 = pk_min(pk_max(mag1, o1), pk_min(mag2, o2));
+      mag1 = pk_min(mag1, o1);
+    }
   }
+  P2_T(q5);
+  mid();
   // Scaling by 0.8 = floor(x * 52428 / 65536), per row (avx2_support.h:65-106).
   const uint32_t s1A = ((uint32_t)(uint16_t)mag1.x * 52428u) >> 16, s1B = ((uint32_t)(uint16_t)mag1.y * 52428u) >> 16;
   const uint32_t s2A = ((uint32_t)(uint16_t)mag2.x * 52428u) >> 16, s2B = ((uint32_t)(uint16_t)mag2.y * 52428u) >> 16;
@@ -171,24 +216,62 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
     }
     cprev = c;
   }
+  P2_T(q6);
+  P2_ADD(0, q0, q1); // scalar edge loads + address arithmetic
+  P2_ADD(1, q1, q2); // LDS reads issued and returned
+  P2_ADD(2, q2, q3); // phase 1
+  P2_ADD(3, q3, q4); // exchange: stores + barrier
+  P2_ADD(4, q4, q5); // exchange: loads + merge
+  P2_ADD(5, q5, q6); // scaling + phase 2 + stores
+  P2_ADD(6, q0, q6);
 }
 
-// The latency form: this half's edges of a layer of degree d. The first half takes D0 = 2 * ((d + 2) / 4) edges (an even number, so
-// the split falls on a message pair: the message layout is that of the throughput form), the second the rest.
-template <bool FIRST>
-__device__ __forceinline__ void update_rows_pk_split(int d, int half, int8_t* soft, uint32_t* c2v, const uint32_t* edges, int l, int H, int Z, bool active,
-                                                     uint32_t* xw, const uint32_t* xr, int xs)
+// A part without edges in this layer (a low-degree layer split four ways): it contributes the neutral partial result and takes part in
+// the exchange barrier.
+template <int PARTS, typename MID>
+__device__ __forceinline__ void update_rows_pk_none(uint32_t* xch, int part, int xs, MID mid)
 {
-  const int d0 = 2 * ((d + 2) >> 2);
-  const int da = half ? d - d0 : d0;
-  if (half) {
-    edges += 2 * d0;
-    c2v += 64 * (d0 >> 1);
-  }
-  switch (da) {
-#define PK_SPLIT_CASE(N)                                                                        \
-  case N:                                                                                       \
-    update_rows_pk<N, FIRST, true>(soft, c2v, edges, l, H, Z, 0, active, xw, xr, xs);           \
+  uint32_t* xw = xch + 3 * part * xs;
+  xw[0] = as_u(splat(LLR_MAX)), xw[xs] = as_u(splat(LLR_MAX)), xw[2 * xs] = 0u;
+  __syncthreads();
+  mid();
+}
+
+// The latency form: this part's edges of a layer of degree d. The ceil(d / 2) message pairs of the layer are dealt to the parts in
+// contiguous runs (part i takes pairs [P i / PARTS, P (i + 1) / PARTS)), so every split falls on a message pair and the message layout
+// is that of the throughput form. A part's share is at most PK_PART_EDGES edges (degree <= 19: 10 of two parts, 6 of four).
+// Its {shift, column} words are fetched ONE LAYER AHEAD as scalar values (load_part_edges): with one codeblock per CU nothing hides the
+// scalar-load round trip at the head of a layer (0.14 us per layer visit, measured by replacing the table with constants).
+template <int PARTS>
+struct part_edges {
+  static constexpr int EMAX = PARTS == 4 ? 6 : 10;
+  uint32_t             w[2 * EMAX]; // {shift, column * Z} of this part's edges (words behind its share belong to the next edges: unused)
+  int                  da;          // edges of this part in the layer
+  int                  p0;          // first message pair of this part in the layer
+};
+
+template <int PARTS>
+__device__ __forceinline__ void load_part_edges(part_edges<PARTS>& pe, const uint32_t* __restrict__ edges_g, uint32_t li, int part)
+{
+  const int d = (int)((li >> 10) & 0x3fu), P = (d + 1) >> 1;
+  const int p0 = (P * part) / PARTS, p1 = (P * (part + 1)) / PARTS;
+  pe.p0 = p0, pe.da = min(2 * p1, d) - 2 * p0;
+  const uint32_t* e = edges_g + 2 * ((int)(li & 0x3ffu) + 2 * p0); // (reads past a layer's or the table's last edge stay inside miphy_graph_tables)
+#pragma unroll
+  for (int k = 0; k < 2 * part_edges<PARTS>::EMAX; ++k)
+    pe.w[k] = e[k];
+}
+
+template <bool FIRST, int PARTS, typename MID>
+__device__ __forceinline__ void update_rows_pk_split(const part_edges<PARTS>& pe, int part, int8_t* soft, uint32_t* c2v, int l, int H, int Z, bool active,
+                                                     uint32_t* xch, int xs, MID mid)
+{
+  c2v += 64 * pe.p0;
+  switch (pe.da) {
+#define PK_SPLIT_CASE(N)                                                                            \
+  case N:                                                                                           \
+    if (N <= part_edges<PARTS>::EMAX)                                                               \
+      update_rows_pk<(N <= part_edges<PARTS>::EMAX ? N : 1), FIRST, PARTS, MID>(soft, c2v, pe.w, l, H, Z, 0, active, xch, part, xs, mid); \
     break;
     PK_SPLIT_CASE(10)
     PK_SPLIT_CASE(9)
@@ -197,8 +280,10 @@ __device__ __forceinline__ void update_rows_pk_split(int d, int half, int8_t* so
     PK_SPLIT_CASE(4)
     PK_SPLIT_CASE(3)
     PK_SPLIT_CASE(2)
+    PK_SPLIT_CASE(1)
     default:
-      PK_SPLIT_CASE(1)
+      update_rows_pk_none<PARTS, MID>(xch, part, xs, mid);
+      break;
 #undef PK_SPLIT_CASE
   }
 }

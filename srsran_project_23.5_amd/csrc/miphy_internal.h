@@ -177,16 +177,17 @@ size_t miphy_ldpc_pkw_gmsg_bytes(const miphy_ctx* ctx, uint32_t nof_bundles, int
 int miphy_get_workspace(miphy_ctx* ctx, size_t bytes, hipStream_t s, void** out, int which = 0);
 
 // Packed (two rows per lane) LDPC decoder kernel, ldpc_decode_pk.hip.
-size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all, bool split = false); // pairs_all = 0: messages in global memory; split: + exchange slots of the latency form
-int    miphy_ldpc_pk_waves_per_cu(bool fused, bool split = false);
+size_t miphy_ldpc_pk_lds_bytes(int bgK, int lay, size_t Zt, int pairs_all, int parts = 1); // pairs_all = 0: messages in global memory; parts = 2 / 4: + exchange slots of the latency form
+int    miphy_ldpc_pk_waves_per_cu(bool fused, int parts = 1);
 int    miphy_ldpc_pk_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* d_descs, uint32_t n, int threads, size_t lds, const int8_t* llr,
                             uint8_t* out_bits, int32_t* iters, int nodes_all, const uint32_t* harq_slot, uint8_t* harq_crc_ok, hipStream_t s,
                             const miphy_ldpc_rdm_desc* d_rdm = nullptr, const int8_t* rm_in = nullptr, int gmsg_pairs = 0,
                             const uint32_t* d_order = nullptr /* the launch decodes codeblocks d_order[0 .. n) of the arrays */,
                             void* gmsg_buf = nullptr /* message scratch of miphy_ldpc_pk_gmsg_bytes() bytes; null: the context's workspace */,
-                            bool split = false /* latency form: twice the wavefronts per codeblock (lds from miphy_ldpc_pk_lds_bytes(..., true)) */);
+                            int parts = 1 /* latency form: 2 or 4 times the wavefronts per codeblock (lds from miphy_ldpc_pk_lds_bytes(..., parts)) */,
+                            int lds_pairs = 0 /* with gmsg_pairs > 0: message dwords per lane that stay in LDS in front of the global ones (a layer boundary of the base graph) */);
 // Resident workgroups of such a launch and the bytes of global message scratch it needs (0 with the messages in LDS).
-uint32_t miphy_ldpc_pk_grid(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused, bool split = false);
+uint32_t miphy_ldpc_pk_grid(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused, int parts = 1);
 size_t   miphy_ldpc_pk_gmsg_bytes(const miphy_ctx* ctx, uint32_t n, int threads, size_t lds, bool fused, int gmsg_pairs);
 // The context's side streams and fork / join events, created on first use.
 int miphy_side_streams(miphy_ctx* ctx);

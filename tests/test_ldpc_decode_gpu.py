@@ -10,15 +10,15 @@ pytestmark = pytest.mark.gpu
 SCALAR, PACKED, FUSED, GMSG, WAVE, SPLIT = 1, 2, 4, 8, 16, 32  # MIPHY_LDPC_KERNEL_* (include/miphy.h)
 
 
-@pytest.fixture(params=["auto", "scalar", "packed", "throughput"], autouse=True)
+@pytest.fixture(params=["auto", "scalar", "packed", "throughput", "latency2"], autouse=True)
 def ldpc_kernel(request):
     """Every test of this file runs with the automatic choice (host descriptors: class-sorted launches -- the wave kernel for Z <= 64,
     the packed kernel above, in its latency form because these batches hold fewer codeblocks than the chip has CUs; device descriptors:
     one launch), with the one-row-per-lane kernel forced, with the packed kernel forced as ONE launch for the whole batch, and with the
-    class-sorted launches in their throughput form (what a batch that fills the chip gets). `kernels_used()` tells which kernels really
-    ran; the tests assert it."""
+    class-sorted launches in their throughput form (what a batch that fills the chip gets), and with the latency form cut in two parts
+    instead of four. `kernels_used()` tells which kernels really ran; the tests assert it."""
     import miphy
-    miphy.lib().miphy_debug_force_ldpc_kernel({"auto": 0, "scalar": 1, "packed": 2, "throughput": 4}[request.param])
+    miphy.lib().miphy_debug_force_ldpc_kernel({"auto": 0, "scalar": 1, "packed": 2, "throughput": 4, "latency2": 6}[request.param])
     miphy.lib().miphy_debug_ldpc_kernels_used(1)
     yield request.param
     miphy.lib().miphy_debug_force_ldpc_kernel(0)
@@ -160,7 +160,7 @@ def test_all_graphs_noisy(ctx, ldpc_kernel):
 def test_message_placement_of_the_packed_kernel(ctx, ldpc_kernel):
     """The packed kernel keeps its check-to-variable messages in LDS at high code rates and in global memory (GMSG instance) where that
     keeps more codeblocks per CU: both instances must be reached and agree with the oracle."""
-    if ldpc_kernel in ("scalar", "auto"):
+    if ldpc_kernel in ("scalar", "auto", "latency2"):
         return  # nothing to place: the one-row-per-lane kernel keeps compressed check-node state, the latency form always uses LDS
     rng = np.random.default_rng(17)
     seen = set()
@@ -461,7 +461,7 @@ def test_prepared_plan_matches_the_batch_call(ctx, ldpc_kernel):
         torch.cuda.synchronize()
         used = kernels_used()
         assert (used == SCALAR) if ldpc_kernel == "scalar" else (used & PACKED and used & WAVE and not used & SCALAR), used
-        assert bool(used & SPLIT) == (ldpc_kernel in ("auto", "packed"))  # (the plan is class-sorted whatever single-launch kernel is forced)
+        assert bool(used & SPLIT) == (ldpc_kernel in ("auto", "packed", "latency2"))  # (the plan is class-sorted whatever single-launch kernel is forced)
         out, its = out_d.cpu().numpy(), it_d.cpu().numpy()
         for i, c in enumerate(cases):
             if c.get("flags", 0) & 1:

@@ -23,7 +23,7 @@ lib = miphy.lib()
 n = 38912
 names = ["prologue (descriptor, zero fill, LLR load)", "layer work (wave 0)", "barrier wait after a layer (wave 0)", "final CRC", "hard decision + output",
          "whole codeblock"]
-for lay in [int(a) for a in sys.argv[1:] if a.isdigit()] or [4, 15, 46]:
+for lay in ([] if "--fused-only" in sys.argv else ([int(a) for a in sys.argv[1:] if a.isdigit() and sys.argv[sys.argv.index(a) - 1] != "--slots"] or [4, 15, 46])):
     bg, Z = 1, 384
     N, K = 66 * Z, 22 * Z
     in_len = min(N, (22 + lay - 2) * Z)
@@ -51,7 +51,8 @@ for lay in [int(a) for a in sys.argv[1:] if a.isdigit()] or [4, 15, 46]:
 
 # ---- the headline plan (dematch inside the decoder): 1024 transport blocks of 273 PRB / 256QAM / 38 codeblocks, random LLRs
 if "--fused" in sys.argv:
-    S, NCB, G, tb_bytes = 1024, 38, 273 * 156 * 8, 319784 // 8
+    S = int(sys.argv[sys.argv.index("--slots") + 1]) if "--slots" in sys.argv else 1024  # --slots 1: the single slot, latency form of the decoder
+    NCB, G, tb_bytes = 38, 273 * 156 * 8, 319784 // 8
     td = np.zeros(S, dtype=miphy.PuschTbDesc)
     for s_ in range(S):
         td[s_] = (1, 0, 8, 1, 1, 0, 6, 0, 273 * 156, tb_bytes, s_ * NCB, s_ * G, s_ * tb_bytes)
@@ -74,5 +75,11 @@ if "--fused" in sys.argv:
         lib.miphy_debug_ldpc_profile(buf, 0)
     cnt = max(1, buf[7])
     print("FUSED plan: %d codeblocks, %.3f ms whole plan; %d codeblocks stamped" % (S * NCB, a.elapsed_time(b), cnt))
+    if "--inner" in sys.argv:  # build with -DLDPC_PK_PROFILE2: stamps inside the layer function (thread 0 of every workgroup, the whole run incl. the warm-up pass)
+        b2 = (C.c_ulonglong * 8)()
+        lib.miphy_debug_ldpc_profile2(b2, 1)
+        nm2 = ["scalar edge loads + addresses", "LDS reads issued and returned", "phase 1", "exchange: stores + barrier", "exchange: loads + merge", "scaling + phase 2 + stores", "whole layer function"]
+        for k in range(7):
+            print("   inner: %-40s %9.0f cycles per codeblock and pass (%5.1f %%)" % (nm2[k], b2[k] / (2.0 * S * NCB), 100.0 * b2[k] / max(1, b2[6])))
     for k, nm in enumerate(names):
         print("   %-46s %9.0f cycles per codeblock  (%5.1f %%)" % (nm, buf[k] / cnt, 100.0 * buf[k] / max(1, buf[5])))
