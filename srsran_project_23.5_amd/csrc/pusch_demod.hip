@@ -37,27 +37,41 @@ __device__ __forceinline__ int demod_quantize_fast(float v, float scale)
   return (int)rintf(__builtin_amdgcn_fmed3f(v * scale, -120.0f, 120.0f));
 }
 
-// LDS copy of the interval tables of one modulation: level k (bits 2k, 2k+1) at tab[16 k ...], {slope, intercept} pairs.
-template <int MOD>
-__device__ __forceinline__ void demod_tables_to_lds(float2* tab, int tid)
+// LDS copy of the interval tables of one modulation: level k (bits 2k, 2k+1) at tab[16 k ...], {slope, intercept} pairs. In two steps:
+// the lanes request their table entry from memory (demod_table_entry) as soon as the modulation is known, and put it into LDS
+// (demod_table_store) after the work that does not need it -- the request is one of the dependent memory round trips at the head of every
+// workgroup (arguments -> descriptor -> tables -> samples), this takes it off the chain.
+struct demod_tab_entry {
+  int    idx; // position in tab[], -1: this lane holds none
+  float2 v;
+};
+__device__ __forceinline__ demod_tab_entry demod_table_entry(int mod, int tid)
 {
-  if (MOD == 6) {
+  demod_tab_entry e;
+  e.idx = -1, e.v = make_float2(0.f, 0.f);
+  if (mod == 6) {
     if (tid < 8)
-      tab[tid] = make_float2(NR_DEMOD_QAM64_B0_SLOPE[tid], NR_DEMOD_QAM64_B0_INTERCEPT[tid]);
+      e.idx = tid, e.v = make_float2(NR_DEMOD_QAM64_B0_SLOPE[tid], NR_DEMOD_QAM64_B0_INTERCEPT[tid]);
     else if (tid < 16)
-      tab[16 + tid - 8] = make_float2(NR_DEMOD_QAM64_B1_SLOPE[tid - 8], NR_DEMOD_QAM64_B1_INTERCEPT[tid - 8]);
+      e.idx = 16 + tid - 8, e.v = make_float2(NR_DEMOD_QAM64_B1_SLOPE[tid - 8], NR_DEMOD_QAM64_B1_INTERCEPT[tid - 8]);
     else if (tid < 20)
-      tab[32 + tid - 16] = make_float2(NR_DEMOD_QAM64_B2_SLOPE[tid - 16], NR_DEMOD_QAM64_B2_INTERCEPT[tid - 16]);
-  } else if (MOD == 8) {
+      e.idx = 32 + tid - 16, e.v = make_float2(NR_DEMOD_QAM64_B2_SLOPE[tid - 16], NR_DEMOD_QAM64_B2_INTERCEPT[tid - 16]);
+  } else if (mod == 8) {
     if (tid < 16)
-      tab[tid] = make_float2(NR_DEMOD_QAM256_B0_SLOPE[tid], NR_DEMOD_QAM256_B0_INTERCEPT[tid]);
+      e.idx = tid, e.v = make_float2(NR_DEMOD_QAM256_B0_SLOPE[tid], NR_DEMOD_QAM256_B0_INTERCEPT[tid]);
     else if (tid < 32)
-      tab[tid] = make_float2(NR_DEMOD_QAM256_B1_SLOPE[tid - 16], NR_DEMOD_QAM256_B1_INTERCEPT[tid - 16]);
+      e.idx = tid, e.v = make_float2(NR_DEMOD_QAM256_B1_SLOPE[tid - 16], NR_DEMOD_QAM256_B1_INTERCEPT[tid - 16]);
     else if (tid < 48)
-      tab[tid] = make_float2(NR_DEMOD_QAM256_B2_SLOPE[tid - 32], NR_DEMOD_QAM256_B2_INTERCEPT[tid - 32]);
+      e.idx = tid, e.v = make_float2(NR_DEMOD_QAM256_B2_SLOPE[tid - 32], NR_DEMOD_QAM256_B2_INTERCEPT[tid - 32]);
     else if (tid < 56)
-      tab[tid] = make_float2(NR_DEMOD_QAM256_B3_SLOPE[tid - 48], NR_DEMOD_QAM256_B3_INTERCEPT[tid - 48]);
+      e.idx = tid, e.v = make_float2(NR_DEMOD_QAM256_B3_SLOPE[tid - 48], NR_DEMOD_QAM256_B3_INTERCEPT[tid - 48]);
   }
+  return e;
+}
+__device__ __forceinline__ void demod_table_store(float2* tab, const demod_tab_entry& e)
+{
+  if (e.idx >= 0)
+    tab[e.idx] = e.v;
 }
 
 __device__ __forceinline__ int demod_interval_idx(float x, float rcp_width, int count)
@@ -212,10 +226,125 @@ constexpr int DEMOD_MAX_CHUNKS = (275 * 12 + DEMOD_THREADS - 1) / DEMOD_THREADS;
 // before the current one is worked on). The values are those of the per-element computation (same operations, same order).
 // active: the thread owns a subcarrier; a_idx: its index among the allocated subcarriers (= its rank among the data elements of a
 // symbol without DM-RS); r_dm: its rank among the data elements of a DM-RS symbol, -1 when it carries DM-RS there.
+// The common case of demod_columns (below) with every memory request of the thread in flight at once: compact estimate, NP receive
+// ports known at compile time, no EVM, no placeholders, MOD >= 2. The walk over the OFDM symbols is unrolled; the received samples of
+// ALL symbols and their descrambling words are requested before the first one is worked on (one memory latency per thread instead of
+// one per symbol: with a lookahead of one symbol the wavefronts of a CU spent 54 % of their cycles waiting), and are consumed in
+// request order (the counter waits of the in-order returns fall out of the unrolled code). Same operations in the same order as the
+// general walk, so the LLRs are identical. A descrambling window of MOD bits never straddles a word unless MOD == 6: one word then.
+template <int MOD, int NP>
+__device__ __forceinline__ void demod_columns_deep(const demod_args& a, bool active, int sc, int a_idx, int r_dm, const float2* tab)
+{
+#pragma clang fp contract(off)
+  constexpr int NS  = 14;
+  const int     nsc = a.nsc;
+  const float2* gp[NP];
+  float2        h[NP];
+  // Every request is unconditional (a branch around a load makes the compiler wait for ALL outstanding loads where the paths join):
+  // symbols behind the allocation repeat its last one, a lane without a subcarrier uses subcarrier sc = 0 and element 0, a DM-RS element
+  // reads the word of element 0 of its symbol; what they compute is never stored.
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    gp[p] = a.grid + (size_t)((a.rxp >> (8 * p)) & 0xffu) * 14 * nsc + sc;
+    h[p]  = a.ce[(size_t)p * nsc + sc];
+  }
+  const int a_ld = active ? a_idx : 0, r_ld = (active && r_dm >= 0) ? r_dm : 0;
+  float2    y[NS][NP];
+  uint32_t  w0[NS], w1[NS];
+  {
+    int prefix = a.prefix0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int  sy  = min(a.start_symbol + k, a.end_symbol - 1);
+      const bool dm  = (a.dmrs_syms >> sy) & 1;
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        y[k][p] = gp[p][(size_t)sy * nsc];
+      const uint32_t bo = (uint32_t)(prefix + (dm ? r_ld : a_ld)) * (uint32_t)MOD;
+      w0[k]             = a.seq[bo >> 5];
+      w1[k]             = (MOD == 6) ? a.seq[(bo >> 5) + 1] : 0u;
+      if (a.start_symbol + k < a.end_symbol - 1) // uniform (scalar arithmetic)
+        prefix += a.nprb * (dm ? a.per_dm : 12);
+    }
+  }
+  // equalize_zf_1xn.h:120-158, the part that only depends on the estimate (as in demod_columns)
+  float ch_mod_sq = 0.f;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const float t = h[p].x * h[p].x, u = h[p].y * h[p].y;
+    ch_mod_sq     = ch_mod_sq + (t + u);
+  }
+  const float d_pinv  = 1.0f * ch_mod_sq;
+  const float rcpd    = 1.0f / d_pinv;
+  const float vv      = rcpd * (a.noise_var / 1.0f);
+  const float nv      = (d_pinv > 0.f && d_pinv < INFINITY && vv > 0.f && vv < INFINITY) ? vv : INFINITY;
+  const float rcp_chk = (nv > 0.f) ? 1.0f / nv : 0.0f;
+  int         prefix  = a.prefix0;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int  sy = a.start_symbol + k;
+    const bool dm = (a.dmrs_syms >> min(sy, 13)) & 1;
+    const int  r  = dm ? (a.per_dm ? r_dm : -1) : a_idx;
+    float acc_re = 0.f, acc_im = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const float2 c  = h[p];
+      const float  aa = y[k][p].x * c.x, b = y[k][p].y * c.y, cc = y[k][p].y * c.x, d = y[k][p].x * c.y;
+      acc_re          = acc_re + (aa + b);
+      acc_im          = acc_im + (cc - d);
+    }
+    float z_re = 0.f, z_im = 0.f;
+    if (nv < INFINITY) {
+      z_re = acc_re * rcpd;
+      z_im = acc_im * rcpd;
+    }
+    const bool     fast    = fabsf(z_re) < INFINITY && fabsf(z_im) < INFINITY && rcp_chk < INFINITY;
+    const unsigned re      = (unsigned)(prefix + max(r, 0));
+    int8_t*        q       = a.llr + (size_t)re * MOD;
+    const bool     aligned = ((uintptr_t)(a.llr + (size_t)prefix * MOD) % (MOD == 8 ? 8 : MOD == 4 ? 4 : 2)) == 0;
+    const uint32_t sh      = (re * (uint32_t)MOD) & 31u;
+    const uint32_t bits    = (MOD == 6) ? (uint32_t)((((uint64_t)w1[k] << 32) | w0[k]) >> sh) : (w0[k] >> sh);
+    const uint64_t w       = demod_symbol_packed<MOD>(z_re, z_im, nv, tab, bits); // (garbage where !fast: replaced below)
+    const bool     has     = active && r >= 0 && sy < a.end_symbol;
+    if (has) {
+      if (fast && aligned) {
+        if (MOD == 8)
+          *reinterpret_cast<uint2*>(q) = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+        else if (MOD == 6) {
+          uint16_t* q2 = reinterpret_cast<uint16_t*>(q);
+          q2[0] = (uint16_t)w, q2[1] = (uint16_t)(w >> 16), q2[2] = (uint16_t)(w >> 32);
+        } else if (MOD == 4)
+          *reinterpret_cast<uint32_t*>(q) = (uint32_t)w;
+        else
+          *reinterpret_cast<uint16_t*>(q) = (uint16_t)w;
+      } else {
+        int l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (fast)
+          demod_symbol<MOD, true>(z_re, z_im, nv, re, tab, l);
+        else
+          demod_symbol<MOD, false>(z_re, z_im, nv, re, tab, l);
+#pragma unroll
+        for (int b = 0; b < MOD; ++b) {
+          const int m = -(int)((bits >> b) & 1u);
+          q[b]        = (int8_t)((l[b] ^ m) - m);
+        }
+      }
+    }
+    if (sy < a.end_symbol)
+      prefix += a.nprb * (dm ? a.per_dm : 12);
+  }
+}
+
 template <int MOD>
 __device__ __forceinline__ void demod_columns(const demod_args& a, bool active, int sc, int a_idx, int r_dm, const float2* tab, float* evm_red, int tid)
 {
 #pragma clang fp contract(off)
+#ifndef DEMOD_NO_DEEP
+  if (MOD >= 2 && a.ce_nof_symbols == 1 && !a.evm_part && !a.nph && a.nports == 1) { // uniform
+    demod_columns_deep<(MOD >= 2 ? MOD : 2), 1>(a, active, sc, a_idx, r_dm, tab);
+    return;
+  }
+#endif
   const int   nsc = a.nsc, nports = a.nports;
   const float noise_var = a.noise_var;
   const bool  compact   = a.ce_nof_symbols == 1;
@@ -497,7 +626,10 @@ __device__ __forceinline__ int demod_prb_list(const demod_job_words& j, uint64_t
 // grid (transmissions, chunks of 256 allocated subcarriers, parts of the OFDM symbols): a batch that fills the chip walks all symbols of a
 // chunk in one workgroup (the channel row is set up once); a small one (a single slot: 13 chunks) is cut along the symbols as well, which
 // shortens the dependent walk of every thread.
-__global__ void __launch_bounds__(DEMOD_THREADS) pusch_demod_kernel(const miphy_pusch_demod_job* __restrict__ jobs, const float2* __restrict__ grid,
+#ifndef DEMOD_MIN_WAVES
+#define DEMOD_MIN_WAVES 6 // 80 registers (four of them spilled outside the walk): 0.207 against 0.214 ms per 1024 slots at five
+#endif
+__global__ void __launch_bounds__(DEMOD_THREADS, DEMOD_MIN_WAVES) pusch_demod_kernel(const miphy_pusch_demod_job* __restrict__ jobs, const float2* __restrict__ grid,
                                                                     const float2* __restrict__ ce, const float* __restrict__ scalars,
                                                                     int8_t* __restrict__ llr, const uint16_t* __restrict__ placeholders,
                                                                     float* __restrict__ evm_part, const uint32_t* __restrict__ seq)
@@ -509,7 +641,10 @@ __global__ void __launch_bounds__(DEMOD_THREADS) pusch_demod_kernel(const miphy_
   __shared__ float    evm_red[4];
   const demod_job_words j    = demod_load_job(jobs + blockIdx.x);
   const int             tid  = threadIdx.x;
+  const demod_tab_entry te   = demod_table_entry(j.mod(), tid);            // requested now, stored behind the PRB list
+  const float           noise_var_early = scalars[j.scalars_offset() + 2]; // likewise
   const int             nprb = demod_prb_list(j, rbm, prb_of, &nprb_s, tid, DEMOD_THREADS);
+  demod_table_store(tab, te); // (made visible by the barrier in front of the walk; a workgroup that leaves below needs no table)
   if ((int)blockIdx.y * DEMOD_THREADS >= nprb * 12)
     return; // uniform
   const unsigned dmask = dmrs_prb_mask(j.dmrs_type(), j.cdm_groups());
@@ -537,7 +672,7 @@ __global__ void __launch_bounds__(DEMOD_THREADS) pusch_demod_kernel(const miphy_
   a.grid           = grid + j.grid_offset();
   a.ce             = ce + j.ce_offset();
   a.llr            = llr + j.llr_offset();
-  a.noise_var      = scalars[j.scalars_offset() + 2];
+  a.noise_var      = noise_var_early;
   a.nph            = placeholders ? (int)j.nof_placeholders() : 0;
   a.ph             = placeholders ? placeholders + j.placeholders_offset() : nullptr;
   a.evm_part       = evm_part ? evm_part + (size_t)blockIdx.x * 14 * DEMOD_MAX_CHUNKS : nullptr;
@@ -549,15 +684,12 @@ __global__ void __launch_bounds__(DEMOD_THREADS) pusch_demod_kernel(const miphy_
   const int  sc     = active ? (int)prb_of[pr] * 12 + k : 0;
   const int  r_dm   = ((dmask >> k) & 1u) ? -1 : pr * a.per_dm + __popc(~dmask & ((1u << k) - 1u));
   const int  mod    = j.mod();
+  __syncthreads(); // interval tables in LDS
   switch (mod) {
     case 8:
-      demod_tables_to_lds<8>(tab, tid);
-      __syncthreads();
       demod_columns<8>(a, active, sc, a_idx, r_dm, tab, evm_red, tid);
       break;
     case 6:
-      demod_tables_to_lds<6>(tab, tid);
-      __syncthreads();
       demod_columns<6>(a, active, sc, a_idx, r_dm, tab, evm_red, tid);
       break;
     case 4:
