@@ -17,40 +17,17 @@ constexpr int CE_DFT = 4096;                       // port_channel_estimator_ave
 constexpr int HALF_CP = ((144 / 2) * CE_DFT) / 2048; // 144
 constexpr int MAX_PILOTS = 275 * 6;
 
-// Gold sequences c(0..nbits-1) of `nseq` initial values (one per DM-RS symbol), bit-packed LSB-first, 104 words apart in
-// `out`. Cooperative over the workgroup: 2*nseq lanes produce the 31-word heads of x1/x2; the Frobenius identity
-// p(D)^32 = p(D^32) then turns the bit recurrences into WORD recurrences that reach 28 words back,
-//   W1[i] = W1[i-28] ^ W1[i-31],   W2[i] = W2[i-28] ^ W2[i-29] ^ W2[i-30] ^ W2[i-31],
-// so 28 new words per sequence are produced per step by 28 lanes. tmp: nseq x 2 x 104 words of LDS scratch.
-__device__ __forceinline__ void gold_bits_block(const gold_jump& gj, const uint32_t* c_init, int nseq, int nbits, uint32_t* out, uint32_t* tmp,
+// Gold sequences c(0..nbits-1) of `nseq` <= 4 initial values (one per DM-RS symbol), bit-packed LSB-first, 104 words apart in `out`:
+// every word on a lane of its own from the tables (x1 is a constant sequence, x2 is linear in c_init: gold_device.h) -- 31 independent
+// loads per lane instead of the serial 31-word LFSR head and three recurrence steps.
+__device__ __forceinline__ void gold_bits_block(const gold_tables& gt, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int nseq, int nbits, uint32_t* out,
                                                 int tid, int nt)
 {
-  const int nwords = (nbits + 31) >> 5;
-  const int head   = nwords < 31 ? nwords : 31;
-  if (tid < 2 * nseq) {
-    const int  q = tid >> 1;
-    const bool is_x2 = tid & 1;
-    uint32_t   st = gj.x1_1600;
-    if (is_x2) {
-      st = 0;
-      for (int k = 0; k < 31; ++k)
-        st ^= ((c_init[q] >> k) & 1u) ? gj.x2_col[k] : 0u;
-    }
-    lfsr_head(st, is_x2, head, tmp + (2 * q + (is_x2 ? 1 : 0)) * 104);
-  }
-  __syncthreads();
-  for (int i0 = 31; i0 < nwords; i0 += 28) {
-    if (tid < 2 * nseq * 28) {
-      const int qs = tid / 28, j = tid - qs * 28, i = i0 + j;
-      uint32_t* w  = tmp + qs * 104;
-      if (i < nwords)
-        w[i] = (qs & 1) ? (w[i - 28] ^ w[i - 29] ^ w[i - 30] ^ w[i - 31]) : (w[i - 28] ^ w[i - 31]);
-    }
-    __syncthreads();
-  }
+  const int nwords = (nbits + 31) >> 5; // <= GOLD_BASIS_WORDS (3 300 bits)
   for (int k = tid; k < nseq * nwords; k += nt) {
-    const int q = k / nwords, i = k - q * nwords;
-    out[q * 104 + i] = tmp[(2 * q) * 104 + i] ^ tmp[(2 * q + 1) * 104 + i];
+    const int      q  = k / nwords, i = k - q * nwords;
+    const uint32_t ci = q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
+    out[q * 104 + i]  = gt.x1_seq[i] ^ gold_x2_word(gt, ci, i);
   }
   __syncthreads();
 }
@@ -74,7 +51,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid)
 // GENERAL = false: the PUSCH DM-RS estimator proper (pilots generated from the job, one hop: dmrs_pusch_estimator_impl.cpp never
 // configures hopping); true: pilots from the caller and intra-slot frequency hopping (the port estimator on its own).
 template <bool GENERAL>
-__global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job* __restrict__ jobs,
+__global__ void __launch_bounds__(512, GENERAL ? 2 : 4) chest_kernel(const miphy_pusch_chest_job* __restrict__ jobs,
                                                     const gold_jump* __restrict__ gj,
                                                     const cplx* __restrict__ tw,
                                                     const float2* __restrict__ grid,
@@ -91,7 +68,6 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
   uint32_t* gtmp   = cbits + 4 * 104;                                 // Gold scratch: 4 symbols x 2 x 104 words
   uint16_t* prb_of = reinterpret_cast<uint16_t*>(gtmp + 4 * 208);     // allocated PRB list (<= 275)
   float*    red    = reinterpret_cast<float*>(prb_of + 276);          // reductions
-  int*      ired   = reinterpret_cast<int*>(red + 8);
 
   // Read field by field (uniform loads); the arrays go through LDS / a packed word: a private copy of the descriptor indexed at
   // run time would live in scratch memory.
@@ -147,11 +123,31 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
       prb_of[idx] = (uint16_t)r;
     }
   }
-  if (tid == 0) {
-    int c = 0;
-    for (int w = 0; w < 5; ++w)
-      c += __popcll(w * 64 < nprb_grid ? (rbm[w] & ((nprb_grid - w * 64 >= 64) ? ~0ull : ((1ull << (nprb_grid - w * 64)) - 1ull))) : 0ull);
-    ired[0] = c;
+  int nprb = 0; // every thread: the same popcounts
+  for (int w = 0; w < 5; ++w)
+    nprb += __popcll(w * 64 < nprb_grid ? (rbm[w] & ((nprb_grid - w * 64 >= 64) ? ~0ull : ((1ull << (nprb_grid - w * 64)) - 1ull))) : 0ull);
+  const int np = nprb * 6;
+  np_sym       = np;
+  __syncthreads(); // prb_of[]
+  if (sgrp == 0) // the IDFT buffer of the time-alignment step, cleared here: nothing waits for it
+    for (int i = tid; i < (int)(fft_lds_bytes(CE_DFT) / 8); i += nt)
+      fbuf[i] = {0.f, 0.f};
+  // The received DM-RS elements of this thread's pilots (at most four per thread and DM-RS symbol: 1 650 pilots on 512 threads) are
+  // requested NOW, before the pilot sequences are put together: the two memory round trips overlap, and both the LS phase and the noise
+  // phase then work from registers (they used to fetch the same elements one after the other).
+  constexpr int XK = 4;
+  float2        xq[XK][4];
+#pragma unroll
+  for (int kk = 0; kk < XK; ++kk) {
+    const int i = tid + kk * nt;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      xq[kk][d] = make_float2(0.f, 0.f);
+      if (i < np && d < nds) {
+        const int r = prb_of[i / 6], q = i % 6;
+        xq[kk][d]   = g[(size_t)dsym[d] * nsc + r * 12 + 2 * q + delta];
+      }
+    }
   }
   if (!ext_pilots) {
     // Gold sequences of the DM-RS symbols (dmrs_pusch_estimator_impl.cpp:158-162).
@@ -160,13 +156,10 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
       const uint64_t t = ((uint64_t)(14u * job.slot_in_frame + (uint32_t)dsym[q] + 1u) * (2ull * job.scrambling_id + 1ull)) % (1ull << 31);
       c_init[q]        = (uint32_t)((t * (1ull << 17) + (2ull * job.scrambling_id + (job.n_scid ? 1u : 0u))) % (1ull << 31));
     }
-    gold_bits_block(*gj, c_init, min(nds, 4), 12 * nprb_grid, cbits, gtmp, tid, nt);
+    gold_bits_block(*reinterpret_cast<const gold_tables*>(gj), c_init[0], c_init[1], c_init[2], c_init[3], min(nds, 4), 12 * nprb_grid, cbits, tid, nt);
   } else {
     __syncthreads();
   }
-  const int nprb = ired[0];
-  const int np   = nprb * 6;
-  np_sym         = np;
   // pilot of DM-RS symbol d (of this hop), pilot i of the allocation: generated from the Gold sequence counted from PRB 0
   // (dmrs_helper.h:45-96) with the layer's frequency weight, or read from the caller's list
   const float2* xp = ext_pilots ? ext_pilots + job.pilots_offset + ((size_t)layer * nds_all + hop_offset) * np : nullptr;
@@ -185,13 +178,20 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
 
   // ---- LS estimate, EPRE (port_channel_estimator_average_impl.cpp:180-201)
   float epre_acc = 0.f, rsrp_acc = 0.f;
-  for (int i = tid; i < np; i += nt) {
+#pragma unroll
+  for (int kk = 0; kk < XK; ++kk) {
+    const int i = tid + kk * nt;
+    if (i >= np)
+      continue;
     const int r = prb_of[i / 6], q = i % 6;
     const int gp = r * 6 + q;                      // pilot index counted from PRB 0
     cplx      acc = {0.f, 0.f};
-    for (int d = 0; d < nds && d < 4; ++d) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (d >= nds)
+        continue;
       const cplx   p = pilot(d, i, gp);
-      const float2 x = g[(size_t)dsym[d] * nsc + r * 12 + 2 * q + delta];
+      const float2 x = xq[kk][d];
       acc.x += x.x * p.x + x.y * p.y; // rx * conj(pilot)
       acc.y += x.y * p.x - x.x * p.y;
       epre_acc += x.x * x.x + x.y * x.y;
@@ -206,7 +206,11 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
 
   // ---- noise (:271-310): per-PRB mean of the estimates, predicted observation, residual power (symbol group 0 only)
   float noise_acc = 0.f;
-  for (int i = tid; i < ((sgrp == 0) ? np : 0); i += nt) {
+#pragma unroll
+  for (int kk = 0; kk < XK; ++kk) {
+    const int i = tid + kk * nt;
+    if (i >= ((sgrp == 0) ? np : 0))
+      continue;
     const int b = (i / 6) * 6;
     cplx      avg = {0.f, 0.f};
 #pragma unroll
@@ -214,9 +218,12 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
       avg = cadd(avg, lse[b + k]);
     avg = {avg.x / 6.f * -beta, avg.y / 6.f * -beta};
     const int r = prb_of[i / 6], q = i % 6, gp = r * 6 + q;
-    for (int d = 0; d < nds && d < 4; ++d) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (d >= nds)
+        continue;
       const cplx   pred = cmul(avg, pilot(d, i, gp));
-      const float2 x    = g[(size_t)dsym[d] * nsc + r * 12 + 2 * q + delta];
+      const float2 x    = xq[kk][d];
       const float  er = pred.x + x.x, ei = pred.y + x.y;
       noise_acc += er * er + ei * ei;
     }
@@ -225,9 +232,7 @@ __global__ void __launch_bounds__(512) chest_kernel(const miphy_pusch_chest_job*
 
   // ---- time alignment (:312-347): zero-padded IDFT of the LS estimates at their RE positions
   if (sgrp == 0) {
-  for (int i = tid; i < (int)(fft_lds_bytes(CE_DFT) / 8); i += nt)
-    fbuf[i] = {0.f, 0.f};
-  __syncthreads();
+  // (fbuf was cleared at the head of the hop, under the memory requests; the barriers of the reductions above order it)
   for (int i = tid; i < np; i += nt)
     fbuf[fpad(prb_of[i / 6] * 12 + 2 * (i % 6) + delta)] = lse[i];
   __syncthreads();

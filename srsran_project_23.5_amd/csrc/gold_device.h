@@ -56,12 +56,18 @@ __device__ __forceinline__ void lfsr_head(uint32_t s, bool is_x2, int head, uint
 // Jump-ahead: the 31-bit window s (bit i = x(n+i)) advances by one position through a linear map M; pow[k] holds the columns
 // of M^(2^k), so any offset costs one matrix-vector product (31 conditional XORs) per set bit of the offset.
 constexpr int GOLD_POW = 26; // offsets below 2^26
+constexpr int GOLD_BASIS_WORDS = 104;
 constexpr int GOLD_X1_WORDS = 11584; // x1 of c(0 .. 370687): the longest PUSCH codeword (275 PRB x 12 x 14 symbols x 8 bits) and a window word
 struct gold_tables {
   gold_jump j; // state after the Nc = 1600 warm-up (first member: the estimator only needs this part)
   uint32_t  x1_pow[GOLD_POW][31];
   uint32_t  x2_pow[GOLD_POW][31];
   uint32_t  x1_seq[GOLD_X1_WORDS]; // x1 does not depend on c_init: its contribution to c(n), bit-packed LSB first from n = 0
+  // x2 is LINEAR in c_init: word k of its contribution to c(n) is the XOR, over the set bits b of c_init, of x2_basis[b][k] (the sequence
+  // of c_init = 2^b). The first GOLD_BASIS_WORDS words of any sequence therefore cost 31 independent loads and XORs per word, all words
+  // side by side -- no serial LFSR walk (the 31-word head by one lane was the longest single step of the DM-RS estimator and of the
+  // scrambling-sequence kernel). 104 words = 3 328 bits: a whole DM-RS symbol of 275 PRBs.
+  uint32_t  x2_basis[31][GOLD_BASIS_WORDS];
 };
 
 __host__ __device__ inline uint32_t gold_mat_apply(const uint32_t* cols, uint32_t v)
@@ -94,32 +100,52 @@ inline void gold_tables_init(gold_tables& t)
     }
     t.x1_seq[wd] = v;
   }
+  for (int bit = 0; bit < 31; ++bit) {
+    uint32_t s2 = t.j.x2_col[bit]; // window of x2 at position 1600 for c_init = 2^bit
+    for (int wd = 0; wd < GOLD_BASIS_WORDS; ++wd) {
+      uint32_t v = 0;
+      for (int b = 0; b < 32; ++b) {
+        v |= (s2 & 1u) << b;
+        s2 = (s2 >> 1) | ((((s2 >> 3) ^ (s2 >> 2) ^ (s2 >> 1) ^ s2) & 1u) << 30);
+      }
+      t.x2_basis[bit][wd] = v;
+    }
+  }
 }
 
-// The x2 half of c(0 .. 32 nwords - 1) in LDS, by a whole workgroup (nt >= 64 threads, a multiple of 64): thread 0 produces the 31-word
-// head 28 bits per step; then the word recurrence w[i] = w[i-28] ^ w[i-29] ^ w[i-30] ^ w[i-31] (the bit recurrence raised to the 32nd
-// power) and its further squares w[i] = w[i-28d] ^ w[i-29d] ^ w[i-30d] ^ w[i-31d], d = 2^k, which need 31 d words of history and
-// yield 28 d independent words per step -- the history doubles with every step (a step larger than the workgroup is a short loop), so
-// a sequence of n words takes about log2(n / 31) + 4 barriers.
-__device__ __forceinline__ void gold_x2_sequence(const gold_jump& j, uint32_t c_init, int nwords, uint32_t* w, int tid, int nt)
+// Word k (< GOLD_BASIS_WORDS) of the x2 half of c(n) for c_init: 31 independent loads (consecutive lanes, consecutive words).
+__device__ __forceinline__ uint32_t gold_x2_word(const gold_tables& t, uint32_t c_init, int k)
 {
-  if (tid < 64) { // state after the warm-up: lane k contributes column k (one parallel load), XOR-reduced over the wavefront
-    uint32_t st = (tid < 31 && ((c_init >> tid) & 1u)) ? j.x2_col[tid] : 0u;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1)
-      st ^= __shfl_xor(st, o);
-    if (tid == 0)
-      lfsr_head(st, true, 31, w);
+  uint32_t v = 0;
+#pragma unroll 8
+  for (int b = 0; b < 31; ++b) {
+    const uint32_t col = t.x2_basis[b][k];
+    v ^= ((c_init >> b) & 1u) ? col : 0u;
   }
+  return v;
+}
+
+// The x2 half of c(0 .. 32 nwords - 1) in LDS, by a whole workgroup (nt >= 128 threads): the first GOLD_BASIS_WORDS words from the basis
+// (gold_x2_word); then the word recurrence w[i] = w[i-28] ^ w[i-29] ^ w[i-30] ^ w[i-31] (the bit recurrence raised to the 32nd power) in
+// its squares w[i] = w[i-28d] ^ w[i-29d] ^ w[i-30d] ^ w[i-31d], d = 2^k, which need 31 d words of history and yield 28 d independent
+// words per step -- the history doubles with every step (a step larger than the workgroup is a short loop), so a sequence of n words
+// takes about log2(n / 104) + 3 barriers.
+__device__ __forceinline__ void gold_x2_sequence(const gold_tables& t, uint32_t c_init, int nwords, uint32_t* w, int tid, int nt)
+{
+  const int head = min(nwords, GOLD_BASIS_WORDS);
+  for (int i = tid; i < head; i += nt)
+    w[i] = gold_x2_word(t, c_init, i);
   __syncthreads();
-  int have = 31, k = 0;
+  int have = head, k = 0;
+  while ((62 << k) <= have) // 31 * 2d words of history allow the square d -> 2d
+    ++k;
   while (have < nwords) {
     const int d = 1 << k, step = 28 * d, end = min(have + step, nwords);
     for (int i = have + tid; i < end; i += nt)
       w[i] = w[i - 28 * d] ^ w[i - 29 * d] ^ w[i - 30 * d] ^ w[i - 31 * d];
     __syncthreads();
     have += step;
-    while ((62 << k) <= have) // 31 * 2d words of history allow the next square
+    while ((62 << k) <= have)
       ++k;
   }
 }

@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(SCR_THREADS) pusch_scrambling_kernel(const mip
   const int tid = threadIdx.x, nt = blockDim.x;
   int       nwords = (int)((jp->nof_llr + 31u) >> 5) + 2; // + the 64-bit window of the last resource element
   nwords           = nwords > SEQ_STRIDE ? SEQ_STRIDE : nwords;
-  gold_x2_sequence(gt->j, (jp->rnti << 15) + jp->n_id, nwords, w, tid, nt);
+  gold_x2_sequence(*gt, (jp->rnti << 15) + jp->n_id, nwords, w, tid, nt);
   uint32_t* o = seq + (size_t)blockIdx.x * SEQ_STRIDE;
   for (int i = tid; i < nwords; i += nt)
     o[i] = w[i] ^ gt->x1_seq[i];
