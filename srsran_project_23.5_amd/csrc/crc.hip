@@ -6,8 +6,15 @@ __global__ void __launch_bounds__(1024)
 crc_kernel(const miphy_crc_desc* __restrict__ descs, const miphy_graph_tables* __restrict__ tab, const uint8_t* __restrict__ data, uint32_t* __restrict__ out)
 {
   __shared__ uint32_t red[16];
-  const miphy_crc_desc d    = descs[blockIdx.x];
-  uint32_t             part = crc_partial(tab, (int)d.poly, data, d.bit_offset, d.nbits, threadIdx.x, blockDim.x);
+  __shared__ uint32_t tab8[256];
+  const miphy_crc_desc d     = descs[blockIdx.x];
+  const uint32_t       order = tab->crc_order[d.poly];
+  const bool           byte_table = order >= 8 && d.nbits >= 64u * blockDim.x; // long messages: the table pays for its 256 x 8 steps
+  if (byte_table) {
+    crc_build_table8(tab8, tab->crc_poly[d.poly], order, threadIdx.x, blockDim.x);
+    __syncthreads();
+  }
+  uint32_t part = crc_partial(tab, (int)d.poly, data, d.bit_offset, d.nbits, threadIdx.x, blockDim.x, byte_table ? tab8 : nullptr);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1)
     part ^= __shfl_xor(part, off);

@@ -61,6 +61,13 @@ struct miphy_pdsch_cb_desc {
   uint8_t  nof_cb_crc_bits, bg, rv, mod;
   uint32_t K;
 };
+// A codeblock the bit-packed kernel takes (pdsch_cb_encode.hip): lifting size a multiple of 32, byte-aligned pieces, selected bits within its LDS buffer.
+__host__ __device__ inline bool miphy_pdsch_cb_packed_ok(const miphy_pdsch_cb_desc& d)
+{
+  return d.Z % 32 == 0 && d.tb_bit_offset % 8 == 0 && d.take_bits % 8 == 0 && d.zero_pad % 8 == 0 && d.nof_tb_crc_bits % 8 == 0 &&
+         (d.nof_cb_crc_bits == 0 || d.nof_cb_crc_bits == 24) && d.E <= (1u << 16);
+}
 size_t miphy_pdsch_cb_encode_lds(uint32_t K, uint32_t Z, uint32_t out_len);
+size_t miphy_pdsch_cb_encode_pk_lds(const miphy_pdsch_cb_desc& d);
 int    miphy_pdsch_cb_encode_launch(miphy_ctx* ctx, const miphy_pdsch_cb_desc* d_descs, uint32_t ncb, size_t max_lds, const uint8_t* tb_in, const uint32_t* tb_crc,
-                                    uint8_t* cw_out, hipStream_t s);
+                                    uint8_t* cw_out, hipStream_t s, uint32_t npacked = 0, size_t max_lds_pk = 0);

@@ -714,7 +714,8 @@ namespace {
 struct pdsch_encode_build {
   std::vector<miphy_crc_desc>      crcd;
   std::vector<miphy_pdsch_cb_desc> cbs; // one record per codeblock for the fused kernel (pdsch_cb_encode.hip)
-  size_t                           max_lds = 0;
+  size_t                           max_lds = 0, max_lds_pk = 0; // of the one-lane-per-bit kernel's codeblocks / of the packed kernel's
+  uint32_t                         npacked = 0;
   uint32_t                         n = 0, ncb = 0;
 };
 struct pdsch_encode_dev {
@@ -767,7 +768,10 @@ int build_pdsch_encode(const miphy_pdsch_tb_desc* tbs, uint32_t n, pdsch_encode_
         const uint64_t end = (uint64_t)k0 + E + sg.nof_filler_bits;
         p.out_len          = (end >= Ncb) ? Ncb : (uint32_t)end;
       }
-      b.max_lds = std::max(b.max_lds, miphy_pdsch_cb_encode_lds(sg.K, sg.Z, p.out_len));
+      if (const size_t lp = miphy_pdsch_cb_encode_pk_lds(p)) // the bit-packed kernel takes it
+        b.max_lds_pk = std::max(b.max_lds_pk, lp), ++b.npacked;
+      else
+        b.max_lds = std::max(b.max_lds, miphy_pdsch_cb_encode_lds(sg.K, sg.Z, p.out_len));
       b.cbs.push_back(p);
       cw_off += E;
     }
@@ -800,15 +804,26 @@ pdsch_encode_dev layout_pdsch_encode(const pdsch_encode_build& b, uint8_t* h, ui
 
 // TB CRC of every transport block, then ONE kernel per codeblock: assembly (TB bits, TB CRC, padding, CRC24B, fillers), LDPC encoder and
 // rate matcher with the codeblock in LDS (pdsch_cb_encode.hip).
+unsigned g_pdsch_cb_counts[2] = {0, 0}; // codeblocks encoded by the bit-packed kernel / in total (miphy_debug_pdsch_cb_counts)
+
 int launch_pdsch_encode(miphy_ctx* ctx, uint32_t n, uint32_t ncb, size_t max_lds, const pdsch_encode_dev& v, const uint8_t* tb_in, uint8_t* codeword_out,
-                        hipStream_t s)
+                        hipStream_t s, uint32_t npacked, size_t max_lds_pk)
 {
   int rc;
+  g_pdsch_cb_counts[0] += npacked, g_pdsch_cb_counts[1] += ncb;
   if ((rc = miphy_crc_batch(ctx, v.crcd, 1, n, tb_in, v.tbcrc, s)))
     return rc;
-  return miphy_pdsch_cb_encode_launch(ctx, v.cbs, ncb, max_lds, tb_in, v.tbcrc, codeword_out, s);
+  return miphy_pdsch_cb_encode_launch(ctx, v.cbs, ncb, max_lds, tb_in, v.tbcrc, codeword_out, s, npacked, max_lds_pk);
 }
 } // namespace
+
+// Test hook: how many codeblocks of the PDSCH encoder launches since the last reset went to the bit-packed kernel, and how many in total.
+extern "C" void miphy_debug_pdsch_cb_counts(unsigned out[2], int reset)
+{
+  out[0] = g_pdsch_cb_counts[0], out[1] = g_pdsch_cb_counts[1];
+  if (reset)
+    g_pdsch_cb_counts[0] = g_pdsch_cb_counts[1] = 0;
+}
 
 extern "C" int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs, uint32_t n, const uint8_t* tb_in, uint8_t* codeword_out, void* stream)
 {
@@ -828,7 +843,7 @@ extern "C" int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_des
   const pdsch_encode_dev v = layout_pdsch_encode(b, host.data(), (uint8_t*)wsv);
   if ((rc = miphy_upload(ctx, wsv, host.data(), v.staged, s)))
     return rc;
-  return launch_pdsch_encode(ctx, n, b.ncb, b.max_lds, v, tb_in, codeword_out, s);
+  return launch_pdsch_encode(ctx, n, b.ncb, b.max_lds, v, tb_in, codeword_out, s, b.npacked, b.max_lds_pk);
 }
 
 // ---- prepared form (internal: the PDSCH processor plan of pdsch_proc.hip builds on it): segmentation and descriptor upload once, a run
@@ -836,7 +851,8 @@ extern "C" int miphy_pdsch_encode_batch(miphy_ctx* ctx, const miphy_pdsch_tb_des
 struct miphy_pdsch_encode_prepared {
   miphy_ctx*       ctx;
   uint32_t         n, ncb;
-  size_t           max_lds;
+  size_t           max_lds, max_lds_pk;
+  uint32_t         npacked;
   pdsch_encode_dev v;
   void*            d_buf;
 };
@@ -850,7 +866,7 @@ int miphy_pdsch_encode_prepare(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs, u
     return rc;
   const size_t bytes = pdsch_encode_bytes(b);
   auto*        p     = new miphy_pdsch_encode_prepared();
-  p->ctx = ctx, p->n = n, p->ncb = b.ncb, p->max_lds = b.max_lds, p->d_buf = nullptr;
+  p->ctx = ctx, p->n = n, p->ncb = b.ncb, p->max_lds = b.max_lds, p->max_lds_pk = b.max_lds_pk, p->npacked = b.npacked, p->d_buf = nullptr;
   std::vector<uint8_t> host(bytes);
   hipError_t           e = hipMalloc(&p->d_buf, bytes);
   if (e == hipSuccess) {
@@ -870,7 +886,7 @@ int miphy_pdsch_encode_prepare(miphy_ctx* ctx, const miphy_pdsch_tb_desc* tbs, u
 
 int miphy_pdsch_encode_prepared_run(miphy_pdsch_encode_prepared* p, const uint8_t* tb_in, uint8_t* codeword_out, hipStream_t s)
 {
-  return launch_pdsch_encode(p->ctx, p->n, p->ncb, p->max_lds, p->v, tb_in, codeword_out, s);
+  return launch_pdsch_encode(p->ctx, p->n, p->ncb, p->max_lds, p->v, tb_in, codeword_out, s, p->npacked, p->max_lds_pk);
 }
 
 void miphy_pdsch_encode_prepared_destroy(miphy_pdsch_encode_prepared* p)

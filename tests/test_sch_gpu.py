@@ -52,6 +52,76 @@ def test_pdsch_encode_batch(ctx):
         assert np.array_equal(cw[co:co + nsym * mod], exp), descs[i]
 
 
+def test_pdsch_encode_packed_kernel_lifting_sizes(ctx):
+    """The bit-packed codeblock kernel (one wavefront per codeblock, lifting sizes that are multiples of 32) against the oracle for
+    every such lifting size of both base graphs, every PDSCH modulation, all redundancy versions, limited buffers, repetition
+    (E beyond the circular buffer: the selected bits wrap) and puncturing; a codeword too long for its LDS buffer (E > 65536) must
+    take the one-lane-per-bit kernel, as must every other lifting size. The test asserts which kernel encoded how many codeblocks."""
+    import ctypes as C
+    import torch
+    import miphy
+    rng = np.random.default_rng(77)
+    want = {(bg, Z) for bg in (1, 2) for Z in range(32, 385, 32)}
+    found = {}
+    for bg in (1, 2):  # transport-block sizes (bytes) that segment into each lifting size
+        for nbytes in list(range(8, 1100, 2)) + list(range(1100, 12000, 40)):
+            seg = o_segmentation(nbytes * 8, bg, 2, 1, 10000)
+            key = (bg, seg.Z)
+            if key in want and key not in found:
+                found[key] = nbytes
+    assert set(found) == want, sorted(want - set(found))
+    descs, tb_list, cw_off, tb_off, npk, ncb = [], [], 0, 0, 0, 0
+    sizes = sorted(found.items())
+    # several codeblocks per transport block: TS 38.214 sizes (byte-aligned codeblock payloads: packed kernel) and sizes the standard cannot
+    # produce (payloads that are not whole bytes: those codeblocks must go to the one-lane-per-bit kernel)
+    for bg, nbytes in ((1, 42016 // 8), (1, 83976 // 8), (2, 9984 // 8), (1, 5000), (2, 1500)):
+        seg = o_segmentation(nbytes * 8, bg, 2, 1, 10000)
+        assert seg.nof_cbs > 1 and seg.Z % 32 == 0, (bg, nbytes, seg.nof_cbs, seg.Z)
+        sizes.append(((bg, seg.Z), nbytes))
+
+    def packed(seg, e_bits):  # miphy_pdsch_cb_packed_ok for every codeblock of a transport block
+        last = seg.cb_info_bits - seg.nof_tb_crc_bits - seg.zero_pad
+        return (seg.Z % 32 == 0 and seg.cb_info_bits % 8 == 0 and last % 8 == 0 and seg.zero_pad % 8 == 0 and e_bits <= 65536)
+    for (bg, Z), nbytes in sizes:
+        seg = o_segmentation(nbytes * 8, bg, 2, 1, 10000)
+        N = seg.N * seg.nof_cbs
+        for mod, rv, Nref, ratio in ((2, 0, 0, 0.5), (4, 1, 0, 0.9), (6, 2, 0, 1.7), (8, 3, (seg.N * 2) // 3, 0.4), (8, 0, 0, 2.6), (4, 3, 0, 1.0)):
+            nsym = max(seg.nof_cbs, int(N * ratio / mod)) // seg.nof_cbs * seg.nof_cbs  # every codeblock the same number of symbols
+            tb = rng.integers(0, 256, nbytes, dtype=np.uint8)
+            descs.append((bg, rv, mod, 1, Nref, nsym, tb.size, tb_off, cw_off))
+            tb_list.append(tb)
+            tb_off += (tb.size + 15) // 16 * 16
+            cw_off += nsym * mod
+            ncb += seg.nof_cbs
+            npk += seg.nof_cbs if packed(seg, nsym * mod // seg.nof_cbs) else 0
+    # one codeblock repeated beyond the packed kernel's buffer, and lifting sizes it does not take
+    for bg, nbytes, mod, nsym in ((1, found[(1, 128)], 8, 9000), (2, 40, 2, 300), (1, 100, 4, 400)):
+        seg = o_segmentation(nbytes * 8, bg, mod, 1, nsym)
+        assert seg.Z % 32 != 0 or nsym * mod // seg.nof_cbs > 65536
+        tb = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        descs.append((bg, 0, mod, 1, 0, nsym, tb.size, tb_off, cw_off))
+        tb_list.append(tb)
+        tb_off += (tb.size + 15) // 16 * 16
+        cw_off += nsym * mod
+        ncb += seg.nof_cbs
+    d = np.zeros(len(descs), dtype=miphy.PdschTbDesc)
+    tb_all = np.zeros(tb_off + 16, dtype=np.uint8)
+    for i, x in enumerate(descs):
+        d[i] = x
+        tb_all[x[7]:x[7] + tb_list[i].size] = tb_list[i]
+    cw_d = torch.full((cw_off,), 9, dtype=torch.uint8, device="cuda")
+    cnt = (C.c_uint * 2)()
+    miphy.lib().miphy_debug_pdsch_cb_counts(cnt, 1)
+    ctx.pdsch_encode_batch(d, torch.from_numpy(tb_all).cuda(), cw_d)
+    torch.cuda.synchronize()
+    miphy.lib().miphy_debug_pdsch_cb_counts(cnt, 1)
+    assert (cnt[0], cnt[1]) == (npk, ncb), (cnt[0], cnt[1], npk, ncb)
+    cw = cw_d.cpu().numpy()
+    for i, (bg, rv, mod, nl, Nref, nsym, nb, to, co) in enumerate(descs):
+        exp = o_pdsch_encode(bg, rv, mod, Nref, nl, nsym, tb_list[i])
+        assert np.array_equal(cw[co:co + nsym * mod], exp), descs[i]
+
+
 @pytest.mark.parametrize("early_stop,max_iter", [(1, 6), (0, 2), (1, 2)])
 def test_pusch_decode_batch_with_harq(ctx, early_stop, max_iter):
     import torch
