@@ -16,7 +16,6 @@
 
 namespace {
 
-constexpr int MAX_SYM_WORDS = 832;
 
 __device__ __forceinline__ unsigned dmrs_prb_mask(int type, unsigned cdm)
 {
@@ -47,10 +46,27 @@ __device__ __forceinline__ void build_prb_list(const uint64_t* rbm, int nprb_gri
   }
 }
 
-__global__ void __launch_bounds__(256) pdsch_mod_kernel(const miphy_pdsch_mod_job* __restrict__ jobs, const gold_tables* __restrict__ gt,
-                                                        const uint8_t* __restrict__ cw_base, float2* __restrict__ grid)
+// Scrambling sequence c(0 .. nof_bits - 1) of every transmission, one workgroup each (c_init = rnti * 2^15 + n_id, TS 38.211 7.3.1.1): x1 from
+// the table, x2 from its linear basis and the doubling word recurrence (gold_device.h) -- as the PUSCH demodulator does. The OFDM symbols
+// of a transmission use consecutive pieces of it; before, every (transmission, symbol) workgroup jumped both LFSRs to its first bit and ran
+// the recurrences on one wavefront while three waited (0.40 ms per 1024 slots of 273 PRB: the longest kernel of the transmit chain).
+constexpr int PDSCH_SEQ_STRIDE = GOLD_X1_WORDS;
+__global__ void __launch_bounds__(512) pdsch_seq_kernel(const miphy_pdsch_mod_job* __restrict__ jobs, const gold_tables* __restrict__ gt, uint32_t* __restrict__ seq)
 {
-  __shared__ uint32_t w1[MAX_SYM_WORDS], w2[MAX_SYM_WORDS];
+  __shared__ uint32_t w[PDSCH_SEQ_STRIDE];
+  const miphy_pdsch_mod_job* __restrict__ jp = jobs + blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  int       nwords = (int)((jp->nof_bits + 31u) >> 5) + 2; // + the 64-bit window of the last resource element
+  nwords           = nwords > PDSCH_SEQ_STRIDE ? PDSCH_SEQ_STRIDE : nwords;
+  gold_x2_sequence(*gt, (jp->rnti << 15) + jp->n_id, nwords, w, tid, nt);
+  uint32_t* o = seq + (size_t)blockIdx.x * PDSCH_SEQ_STRIDE;
+  for (int i = tid; i < nwords; i += nt)
+    o[i] = w[i] ^ gt->x1_seq[i];
+}
+
+__global__ void __launch_bounds__(256) pdsch_mod_kernel(const miphy_pdsch_mod_job* __restrict__ jobs, const gold_tables* __restrict__ gt,
+                                                        const uint8_t* __restrict__ cw_base, float2* __restrict__ grid, const uint32_t* __restrict__ seq_base)
+{
   __shared__ uint16_t prb_of[276];
   __shared__ uint16_t keep_of[276];  // per allocated PRB: 12-bit mask of the REs that carry data in this symbol
   __shared__ uint16_t off_of[276];   // per allocated PRB: index of its first data RE within the symbol
@@ -137,9 +153,8 @@ __global__ void __launch_bounds__(256) pdsch_mod_kernel(const miphy_pdsch_mod_jo
   const int n_re = red[4];
   if (n_re == 0)
     return;
-  const int mod    = jp->mod;
-  const int nwords = ((n_re * mod + 31) >> 5) + 1;
-  gold_long_block(*gt, (jp->rnti << 15) + jp->n_id, (uint32_t)prefix * (uint32_t)mod, nwords, w1, w2, w1, tid, nt);
+  const int       mod = jp->mod;
+  const uint32_t* seq = seq_base + (size_t)blockIdx.x * PDSCH_SEQ_STRIDE;
   const float    scaling = jp->scaling;
   const bool     scale   = isnormal(scaling);
   const uint8_t* cw      = cw_base + jp->cw_offset;
@@ -151,12 +166,30 @@ __global__ void __launch_bounds__(256) pdsch_mod_kernel(const miphy_pdsch_mod_jo
       continue;
     const int      j  = off_of[i] + __popc(keep & ((1u << k) - 1u)); // RE index within the symbol
     const size_t   d  = (size_t)prefix + j;                           // symbol index within the codeword
-    const int      bi = j * mod;
-    const uint64_t two = (uint64_t)w1[bi >> 5] | ((uint64_t)w1[(bi >> 5) + 1] << 32);
+    const uint32_t bi = (uint32_t)d * (uint32_t)mod;                  // its first bit: position in the transmission's scrambling sequence
+    const uint64_t two = (uint64_t)seq[bi >> 5] | ((uint64_t)seq[(bi >> 5) + 1] << 32);
     const uint32_t cb  = (uint32_t)(two >> (bi & 31)); // scrambling bits of this RE, bit t = t-th bit
-    uint32_t       nat = 0;                            // scrambled bits, bit t = t-th bit of the symbol (b0 first)
-    for (int t = 0; t < mod; ++t)
-      nat |= ((uint32_t)(cw[d * mod + t] & 1u) ^ ((cb >> t) & 1u)) << t;
+    // the symbol's bits (one per byte), b0 first, gathered into bit t = t-th bit: one wide load where the run of bytes is aligned, then
+    // bit 0 of every byte through a multiplication ((x & 0x01010101) * 0x01020408 puts bytes 0..3 into bits 24..27)
+    const uint8_t* cp  = cw + d * mod;
+    uint32_t       raw = 0;
+    if (mod == 8 && (((uintptr_t)cp) & 7u) == 0) {
+      const uint2 v = *reinterpret_cast<const uint2*>(cp);
+      raw           = (((v.x & 0x01010101u) * 0x01020408u) >> 24) | ((((v.y & 0x01010101u) * 0x01020408u) >> 24) << 4);
+    } else if (mod == 4 && (((uintptr_t)cp) & 3u) == 0) {
+      raw = ((*reinterpret_cast<const uint32_t*>(cp) & 0x01010101u) * 0x01020408u) >> 24;
+    } else if (mod == 2 && (((uintptr_t)cp) & 1u) == 0) {
+      const uint32_t v = *reinterpret_cast<const uint16_t*>(cp);
+      raw              = (v & 1u) | ((v >> 7) & 2u);
+    } else if (mod == 6 && (((uintptr_t)cp) & 1u) == 0) {
+      const uint16_t* c2 = reinterpret_cast<const uint16_t*>(cp);
+      const uint32_t  v0 = c2[0], v1 = c2[1], v2 = c2[2];
+      raw = (v0 & 1u) | ((v0 >> 7) & 2u) | ((v1 & 1u) << 2) | ((v1 >> 5) & 8u) | ((v2 & 1u) << 4) | ((v2 >> 3) & 32u);
+    } else {
+      for (int t = 0; t < mod; ++t)
+        raw |= (uint32_t)(cp[t] & 1u) << t;
+    }
+    const uint32_t nat = (raw ^ cb) & ((1u << mod) - 1u); // scrambled bits, bit t = t-th bit of the symbol (b0 first)
     float2 x = map_symbol(mod, nat, (unsigned)d);
     if (scale) {
       x.x = x.x * scaling;
@@ -490,7 +523,11 @@ extern "C" int miphy_pdsch_modulate_batch(miphy_ctx* ctx, const miphy_pdsch_mod_
   rc                 = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_pdsch_mod_job) * (size_t)n, s, &d_jobs);
   if (rc)
     return rc;
-  hipLaunchKernelGGL(pdsch_mod_kernel, dim3(n, 14), dim3(256), 0, s, (const miphy_pdsch_mod_job*)d_jobs, gt, codewords, (float2*)grid);
+  void* seq = nullptr; // scrambling sequences of the transmissions: the workspace the PUSCH demodulator keeps its sequences in
+  if ((rc = miphy_get_workspace(ctx, (size_t)n * PDSCH_SEQ_STRIDE * sizeof(uint32_t), s, &seq, 4)))
+    return rc;
+  hipLaunchKernelGGL(pdsch_seq_kernel, dim3(n), dim3(512), 0, s, (const miphy_pdsch_mod_job*)d_jobs, gt, (uint32_t*)seq);
+  hipLaunchKernelGGL(pdsch_mod_kernel, dim3(n, 14), dim3(256), 0, s, (const miphy_pdsch_mod_job*)d_jobs, gt, codewords, (float2*)grid, (const uint32_t*)seq);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }
