@@ -309,6 +309,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
   unsigned long long prof_acc[7] = {};
 #endif
   for (uint32_t q = blockIdx.x; q < n;) {
+  __builtin_amdgcn_s_setprio(LDPC_PK_SETPRIO_OUT); // the phases around the layer loop (load / dematch, CRC, output): ldpc_pk_device.h
   PROF_T(p_start);
   const uint32_t cb = cb_order ? cb_order[q] : q;
   const miphy_ldpc_dec_desc dsc = load_words(descs + cb);
@@ -479,6 +480,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 #ifndef LDPC_PK_SCALAR_WRAP
   asm volatile("" : "+v"(Zv), "+v"(Hv));
 #endif
+  __builtin_amdgcn_s_setprio(LDPC_PK_SETPRIO1);
   part_edges<PARTS> pe; // latency form: this part's edges of the layer about to run, fetched while the layer before it runs
   if (SPLIT)
     load_part_edges<PARTS>(pe, edges_g, (uint32_t)__builtin_amdgcn_readlane((int)lay_info, 0), part);
@@ -528,6 +530,7 @@ ldpc_decode_pk_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
     }
   }
   PROF_T(p_dec);
+  __builtin_amdgcn_s_setprio(LDPC_PK_SETPRIO_OUT);
   if (FUSED) {
     // The input of this workgroup's next codeblock is requested now: the loads fly while the CRC and the hard decision run, and
     // the registers that hold them are not live inside the layer loop.

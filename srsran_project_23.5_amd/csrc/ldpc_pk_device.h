@@ -68,6 +68,25 @@ __device__ unsigned long long g_ldpc_prof2[8];
 #define P2_ADD(slot, a, b)
 #endif
 
+// Wavefront priorities of the packed decoders (s_setprio, 0 = lowest). The SIMD's arbiter otherwise favours the oldest ready wavefront; a
+// wavefront that is about to REQUEST the soft bits and messages of a layer should go first (its LDS round trip then runs under the other
+// wavefronts' arithmetic), the long first phase of the row update last, the second phase (stores, then the barrier the codeblock's other
+// wavefronts wait at) and the phases around the layer loop in between. Measured on the headline launch (38 912 codeblocks, same box):
+// no priorities 3.72 ms, request 1 alone 3.64, request 2 + second phase 1 3.46-3.52, request 3 + second phase 2 3.47, the same + outside 2
+// 3.43 (the values below), outside 3 3.45, second phase 3 3.52, first phase 1 3.48. -D overrides keep the A-B of tools/ab_bench.py possible.
+#ifndef LDPC_PK_SETPRIO
+#define LDPC_PK_SETPRIO 3
+#endif
+#ifndef LDPC_PK_SETPRIO1
+#define LDPC_PK_SETPRIO1 0
+#endif
+#ifndef LDPC_PK_SETPRIO2
+#define LDPC_PK_SETPRIO2 2
+#endif
+#ifndef LDPC_PK_SETPRIO_OUT
+#define LDPC_PK_SETPRIO_OUT 2
+#endif
+
 constexpr int LLR_MAX = 120;
 constexpr int LLR_INF = 127;
 constexpr int INF_MUL = 255; // an infinite soft bit (|s| > 120) becomes a message of magnitude >= 255 + 24
@@ -104,6 +123,7 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
   int      rawA[D], rawB[D];
   uint32_t cw[(D + 1) / 2];
   P2_T(q0);
+  __builtin_amdgcn_s_setprio(LDPC_PK_SETPRIO); // the address arithmetic and the LDS requests of a layer
   // Stage A: every address of the layer, then every LDS read of the layer in one go (2 soft bits per edge + the old
   // messages): the latency of the LDS pipe is paid once per layer instead of once per group of edges.
   // Both rows' addresses with packed 16-bit arithmetic: {l, l + H} + shift, wrap at Z by the unsigned minimum of p and p - Z, + column
@@ -137,6 +157,8 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
     for (int jj = 0; jj < (D + 1) / 2; ++jj)
       cw[jj] = c2v[64 * jj];
   }
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(LDPC_PK_SETPRIO1);
   __builtin_amdgcn_sched_barrier(0);
   P2_T(q2);
   s16x2    mag1 = splat(LLR_MAX), mag2 = splat(LLR_MAX);
@@ -187,6 +209,7 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
   }
   P2_T(q5);
   mid();
+  __builtin_amdgcn_s_setprio(LDPC_PK_SETPRIO2); // the second phase: messages, soft-bit stores, then the layer barrier
   // Scaling by 0.8 = floor(x * 52428 / 65536), per row (avx2_support.h:65-106).
   const uint32_t s1A = ((uint32_t)(uint16_t)mag1.x * 52428u) >> 16, s1B = ((uint32_t)(uint16_t)mag1.y * 52428u) >> 16;
   const uint32_t s2A = ((uint32_t)(uint16_t)mag2.x * 52428u) >> 16, s2B = ((uint32_t)(uint16_t)mag2.y * 52428u) >> 16;
@@ -216,6 +239,7 @@ __device__ __forceinline__ void update_rows_pk(int8_t* __restrict__ soft,
     }
     cprev = c;
   }
+  __builtin_amdgcn_s_setprio(LDPC_PK_SETPRIO1);
   P2_T(q6);
   P2_ADD(0, q0, q1); // scalar edge loads + address arithmetic
   P2_ADD(1, q1, q2); // LDS reads issued and returned
