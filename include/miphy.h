@@ -110,18 +110,22 @@ void     miphy_ldpc_decode_plan_destroy(miphy_ldpc_decode_plan* plan);
 /* Test / A-B knob: 0 = automatic choice (host descriptors: sorted into launch classes by lifting size and code rate, one launch per
  * class; device descriptors: one launch), 1 = one-row-per-lane kernel, 2 = packed two-rows-per-lane kernel as one launch,
  * 3 = class-sorted launches, 4 = class-sorted launches with the geometry of a batch that fills the chip whatever its size (no latency form, messages in global
- * memory wherever that buys residency), 5 = class-sorted launches with the latency form of the packed kernel on every class (A-B measurement only). All kernels produce identical results. */
+ * memory wherever that buys residency), 5 = class-sorted launches with the latency form of the packed kernel (two parts) on every class (A-B measurement only),
+ * 6 = automatic choice with the latency form in two parts instead of four. Adding 0x100 keeps ALL messages of a GMSG launch in global memory (A-B of the
+ * split between LDS and global memory). All kernels produce identical results. */
 void miphy_debug_force_ldpc_kernel(int mode);
 /* Which decoder kernels have been launched since the last reset (tests assert that a forced choice really ran): */
 #define MIPHY_LDPC_KERNEL_SCALAR 1u /* one check row per lane */
 #define MIPHY_LDPC_KERNEL_PACKED 2u /* two check rows per lane, one codeblock per workgroup */
 #define MIPHY_LDPC_KERNEL_FUSED  4u /* ... that rate-dematches while it loads */
-#define MIPHY_LDPC_KERNEL_GMSG   8u /* ... with the check-to-variable messages in global memory */
+#define MIPHY_LDPC_KERNEL_GMSG   8u /* ... with check-to-variable messages (all, or the layers behind a boundary) in global memory */
 #define MIPHY_LDPC_KERNEL_WAVE  16u /* several small codeblocks per wavefront (Z <= 64) */
-#define MIPHY_LDPC_KERNEL_SPLIT 32u /* packed kernel in its latency form: twice the wavefronts per codeblock (launches of at most one codeblock per CU) */
+#define MIPHY_LDPC_KERNEL_SPLIT 32u /* packed kernel in its latency form: four (or two) times the wavefronts per codeblock (launches of at most one codeblock per CU) */
 unsigned miphy_debug_ldpc_kernels_used(int reset);
 /* A-B knob: streams the launch classes of one call are spread over (1 = one after another on the caller's stream). */
 void miphy_debug_set_ldpc_class_streams(int n);
+/* Test hook: codeblocks of the PDSCH encoder launches since the last reset that the bit-packed kernel took (out[0]) and in total (out[1]). */
+void miphy_debug_pdsch_cb_counts(unsigned out[2], int reset);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * LDPC rate dematcher  --  replaces srsran::ldpc_rate_dematcher::rate_dematch

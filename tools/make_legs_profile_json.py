@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from bench import kernel_source_sha  # noqa: E402
 
 PEAK = 1024 * 2.4 / 2.0  # G wave-instr/s
-KEEP = ("polar_decode_kernel", "polar_scl_kernel", "pdcch_encode_kernel", "polar_encode_kernel", "pdsch_cb_encode_kernel", "ldpc_encode_kernel", "rate_match_kernel",
+KEEP = ("polar_decode_kernel", "polar_scl_kernel", "pdcch_encode_kernel", "polar_encode_kernel", "pdsch_cb_encode_kernel", "pdsch_cb_encode_pk_kernel", "pdsch_seq_kernel", "ldpc_encode_kernel", "rate_match_kernel",
         "pdsch_mod_kernel", "dmrs_pdsch_kernel", "ofdm_mod_4096_kernel", "ldpc_decode_pkw_kernel", "crc_kernel")
 
 
