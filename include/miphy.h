@@ -121,6 +121,7 @@ void miphy_debug_force_ldpc_kernel(int mode);
 #define MIPHY_LDPC_KERNEL_GMSG   8u /* ... with check-to-variable messages (all, or the layers behind a boundary) in global memory */
 #define MIPHY_LDPC_KERNEL_WAVE  16u /* several small codeblocks per wavefront (Z <= 64) */
 #define MIPHY_LDPC_KERNEL_SPLIT 32u /* packed kernel in its latency form: four (or two) times the wavefronts per codeblock (launches of at most one codeblock per CU) */
+#define MIPHY_LDPC_KERNEL_GMSG_PART 64u /* ... a GMSG launch that kept the first layers' messages in LDS (only the layers behind a boundary in global memory) */
 unsigned miphy_debug_ldpc_kernels_used(int reset);
 /* A-B knob: streams the launch classes of one call are spread over (1 = one after another on the caller's stream). */
 void miphy_debug_set_ldpc_class_streams(int n);

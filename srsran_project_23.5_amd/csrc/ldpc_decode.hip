@@ -374,6 +374,9 @@ ldpc_decode_kernel(const miphy_ldpc_dec_desc* __restrict__ descs,
 } // namespace
 
 
+#ifndef LDPC_HYBRID_LDS_MARGIN
+#define LDPC_HYBRID_LDS_MARGIN 2048
+#endif
 static bool     g_hybrid_msgs  = true; // A-B: miphy_debug_force_ldpc_kernel(mode | 0x100) = all messages of a GMSG launch in global memory
 static int      g_force_kernel = 0; // 0 auto, 1 one-row-per-lane kernel, 2 packed kernel as ONE launch, 3 class-sorted launches (miphy_debug_force_ldpc_kernel)
 static unsigned g_kernels_used = 0; // MIPHY_LDPC_KERNEL_* of every decoder launch since the last reset (miphy_debug_ldpc_kernels_used)
@@ -550,7 +553,7 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
         for (int k = c.lay - 1; k > 0; --k) {
           const int    pk_ = ctx->h_tables->pair_start[c.bgi][k];
           const size_t l_  = miphy_ldpc_pk_lds_bytes(bgK, c.lay, c.max_Z, pk_);
-          if (per_cu(l_) == per_cu(lds_g)) {
+          if (per_cu(l_ + LDPC_HYBRID_LDS_MARGIN) == per_cu(lds_g)) { // (margin: a CU filled to the last byte of the sum held one workgroup fewer -- allocation granularity)
             q.lds_pairs = pk_, q.lds = l_;
             break;
           }
@@ -636,7 +639,7 @@ int miphy_ldpc_decode_classes_launch(miphy_ctx* ctx, const miphy_ldpc_dec_desc* 
                                    (C.identity && nc == 1) ? nullptr : d_order + c.first, gb, q.split, q.gm ? q.lds_pairs : 0)))
       return rc;
     g_kernels_used |= MIPHY_LDPC_KERNEL_PACKED | (q.fuse ? MIPHY_LDPC_KERNEL_FUSED : 0u) | (q.gm ? MIPHY_LDPC_KERNEL_GMSG : 0u) |
-                      (q.split ? MIPHY_LDPC_KERNEL_SPLIT : 0u);
+                      (q.split ? MIPHY_LDPC_KERNEL_SPLIT : 0u) | ((q.gm && q.lds_pairs > 0) ? MIPHY_LDPC_KERNEL_GMSG_PART : 0u);
   }
   if (nstreams > 1) {
     for (int k = 0; k < MIPHY_NOF_SIDE_STREAMS; ++k) {

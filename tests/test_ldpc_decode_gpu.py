@@ -7,7 +7,7 @@ from oracle_lib import (ALL_Z, BG_K, BG_NS, CRC16, CRC24A, CRC24B, o_crc_bits, o
 pytestmark = pytest.mark.gpu
 
 
-SCALAR, PACKED, FUSED, GMSG, WAVE, SPLIT = 1, 2, 4, 8, 16, 32  # MIPHY_LDPC_KERNEL_* (include/miphy.h)
+SCALAR, PACKED, FUSED, GMSG, WAVE, SPLIT, GMSG_PART = 1, 2, 4, 8, 16, 32, 64  # MIPHY_LDPC_KERNEL_* (include/miphy.h)
 
 
 @pytest.fixture(params=["auto", "scalar", "packed", "throughput", "latency2"], autouse=True)
@@ -181,6 +181,45 @@ def test_message_placement_of_the_packed_kernel(ctx, ldpc_kernel):
         if Z == 384 and nodes > 24:
             assert used & GMSG
     assert seen == {0, GMSG}
+
+
+def test_messages_split_between_lds_and_global_memory(ctx, ldpc_kernel):
+    """A launch class with more codeblocks than stay resident with their messages in LDS moves messages to global memory -- only the
+    layers behind a boundary (the first layers keep theirs in LDS). Needs a batch that fills the chip: 640 codeblocks of BG1 / Z = 384
+    at 15 and at 28 layers and of BG2 at 30 layers, eight distinct codewords each (so the oracle decodes eight). The automatic choice
+    (split) and the same with every message in global memory (mode | 0x100) must both take the GMSG instance and agree with the oracle."""
+    if ldpc_kernel != "auto":
+        return
+    import torch
+    import miphy
+    rng = np.random.default_rng(23)
+    for bg, Z, nodes, crc in ((1, 384, 37, CRC24B), (1, 384, 50, -1), (2, 384, 40, CRC24B)):
+        base = []
+        for t in range(8):
+            msg, cw = make_codeword(bg, Z, rng)
+            base.append(noisy_llr(cw[:nodes * Z], 0.62, rng))
+        n, K = 640, BG_K[bg] * Z
+        nb = (K + 7) // 8
+        descs = np.zeros(n, dtype=miphy.LdpcDecDesc)
+        for i in range(n):
+            descs[i] = (bg, crc if crc >= 0 else miphy.CRC_NONE, Z, 5, 0, nodes * Z, 0, i * nodes * Z, i * nb)
+        llr_d = torch.from_numpy(np.concatenate([base[i % 8] for i in range(n)])).cuda()
+        exp = [o_ldpc_decode(bg, Z, base[t], 0, crc, 5, out_init=np.full(nb, 0x5A, dtype=np.uint8)) for t in range(8)]
+        for mode in (0, 0x100):
+            miphy.lib().miphy_debug_force_ldpc_kernel(mode)
+            out_d = torch.full((n * nb,), 0x5A, dtype=torch.uint8, device="cuda")
+            it_d = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+            kernels_used()
+            ctx.ldpc_decode_batch(descs, llr_d, out_d, it_d)
+            torch.cuda.synchronize()
+            used = kernels_used()
+            assert used & PACKED and used & GMSG and not used & (SPLIT | SCALAR | WAVE), (bg, nodes, mode, used)
+            assert bool(used & GMSG_PART) == (mode == 0), (bg, nodes, mode, used)  # the split really happened / was really switched off
+            out, its = out_d.cpu().numpy().reshape(n, nb), it_d.cpu().numpy()
+            for i in range(n):
+                ito, oo = exp[i % 8]
+                assert its[i] == ito and np.array_equal(out[i], oo), (bg, nodes, mode, i, its[i], ito)
+        miphy.lib().miphy_debug_force_ldpc_kernel(0)
 
 
 def corner_cases(rng, sizes):
