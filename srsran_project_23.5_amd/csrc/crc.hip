@@ -1,6 +1,12 @@
 // Batched CRC calculator (srsran::crc_calculator, include/srsran/phy/upper/channel_coding/crc_calculator.h:45-67).
 #include "crc_device.h"
 
+#ifndef CRC_WIDE_BELOW
+#define CRC_WIDE_BELOW 512
+#endif
+#ifndef CRC_NARROW_THREADS
+#define CRC_NARROW_THREADS 512 // 1024 transport blocks of 40 kB: 57.9 us at 256, 49.0 at 512, 60.5 at 1024 threads
+#endif
 namespace {
 __global__ void __launch_bounds__(1024)
 crc_kernel(const miphy_crc_desc* __restrict__ descs, const miphy_graph_tables* __restrict__ tab, const uint8_t* __restrict__ data, uint32_t* __restrict__ out)
@@ -50,7 +56,7 @@ extern "C" int miphy_crc_batch(miphy_ctx*            ctx,
   if (rc)
     return rc;
   // Few, long messages (transport blocks): 1024 threads each; many short ones: 256 are plenty.
-  hipLaunchKernelGGL(crc_kernel, dim3(n), dim3(n <= 512 ? 1024 : 256), 0, s, (const miphy_crc_desc*)d_descs, ctx->d_tables, data, checksums);
+  hipLaunchKernelGGL(crc_kernel, dim3(n), dim3(n <= CRC_WIDE_BELOW ? 1024 : CRC_NARROW_THREADS), 0, s, (const miphy_crc_desc*)d_descs, ctx->d_tables, data, checksums);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }

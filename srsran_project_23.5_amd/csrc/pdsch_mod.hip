@@ -13,6 +13,7 @@
 #include "mod_device.h"
 #include "miphy_ext.h"
 #include <cmath>
+#include <type_traits>
 
 namespace {
 
@@ -51,11 +52,48 @@ __device__ __forceinline__ void build_prb_list(const uint64_t* rbm, int nprb_gri
 // of a transmission use consecutive pieces of it; before, every (transmission, symbol) workgroup jumped both LFSRs to its first bit and ran
 // the recurrences on one wavefront while three waited (0.40 ms per 1024 slots of 273 PRB: the longest kernel of the transmit chain).
 constexpr int PDSCH_SEQ_STRIDE = GOLD_X1_WORDS;
-__global__ void __launch_bounds__(512) pdsch_seq_kernel(const miphy_pdsch_mod_job* __restrict__ jobs, const gold_tables* __restrict__ gt, uint32_t* __restrict__ seq)
+__global__ void __launch_bounds__(512) pdsch_seq_kernel(const miphy_pdsch_mod_job* __restrict__ jobs, const gold_tables* __restrict__ gt, uint32_t* __restrict__ seq,
+                                                        int* __restrict__ prefix_out)
 {
   __shared__ uint32_t w[PDSCH_SEQ_STRIDE];
+  __shared__ uint64_t rbm[5], resm[4][5];
+  __shared__ int      cnt[14];
   const miphy_pdsch_mod_job* __restrict__ jp = jobs + blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
+  // ---- data elements of the transmission before every OFDM symbol (prefix[job][14]): each (transmission, symbol) workgroup of the
+  // modulator used to recount all earlier symbols itself
+  {
+    const unsigned dmask     = dmrs_prb_mask(jp->dmrs_type, jp->nof_cdm_groups_without_data);
+    const unsigned dmrs_syms = jp->dmrs_symbols_mask;
+    const int      nprb_grid = jp->grid_nof_prb, nres = jp->nof_reserved;
+    const int      bwp0 = jp->bwp_start_rb, bwp1 = bwp0 + jp->bwp_size_rb;
+    const int      s0 = jp->start_symbol, s1 = s0 + jp->nof_symbols;
+    if (tid < 5)
+      rbm[tid] = jp->rb_mask[tid];
+    if (tid >= 32 && tid < 32 + 5 * nres)
+      resm[(tid - 32) / 5][(tid - 32) % 5] = jp->reserved[(tid - 32) / 5].prb_mask[(tid - 32) % 5];
+    if (tid >= 64 && tid < 78)
+      cnt[tid - 64] = 0;
+    __syncthreads();
+    for (int q = tid; q < 14 * nprb_grid; q += nt) {
+      const int s = q / nprb_grid, rb = q - s * nprb_grid;
+      if (s < s0 || s >= s1 || !((rbm[rb >> 6] >> (rb & 63)) & 1ull))
+        continue;
+      unsigned ex = (((dmrs_syms >> s) & 1u) && rb >= bwp0 && rb < bwp1) ? dmask : 0u;
+      for (int r = 0; r < nres; ++r)
+        if (((jp->reserved[r].symbols >> s) & 1u) && ((resm[r][rb >> 6] >> (rb & 63)) & 1ull))
+          ex |= jp->reserved[r].re_mask;
+      atomicAdd(&cnt[s], __popc(~ex & 0xfffu));
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int s = 0; s < 14; ++s) {
+        prefix_out[blockIdx.x * 14 + s] = run;
+        run += cnt[s];
+      }
+    }
+  }
   int       nwords = (int)((jp->nof_bits + 31u) >> 5) + 2; // + the 64-bit window of the last resource element
   nwords           = nwords > PDSCH_SEQ_STRIDE ? PDSCH_SEQ_STRIDE : nwords;
   gold_x2_sequence(*gt, (jp->rnti << 15) + jp->n_id, nwords, w, tid, nt);
@@ -65,7 +103,8 @@ __global__ void __launch_bounds__(512) pdsch_seq_kernel(const miphy_pdsch_mod_jo
 }
 
 __global__ void __launch_bounds__(256) pdsch_mod_kernel(const miphy_pdsch_mod_job* __restrict__ jobs, const gold_tables* __restrict__ gt,
-                                                        const uint8_t* __restrict__ cw_base, float2* __restrict__ grid, const uint32_t* __restrict__ seq_base)
+                                                        const uint8_t* __restrict__ cw_base, float2* __restrict__ grid, const uint32_t* __restrict__ seq_base,
+                                                        const int* __restrict__ prefix_base)
 {
   __shared__ uint16_t prb_of[276];
   __shared__ uint16_t keep_of[276];  // per allocated PRB: 12-bit mask of the REs that carry data in this symbol
@@ -98,9 +137,10 @@ __global__ void __launch_bounds__(256) pdsch_mod_kernel(const miphy_pdsch_mod_jo
       res_re[r] = jp->reserved[r].re_mask;
       res_sy[r] = jp->reserved[r].symbols;
     }
-  // data REs per PRB for every symbol up to this one: `before` = REs of the transmission in earlier symbols (this lane's PRBs)
-  int before = 0;
-  for (int s = start_symbol; s <= sy; ++s) {
+  // data REs per PRB of this symbol; the elements of the transmission in earlier symbols were counted by pdsch_seq_kernel
+  const int prefix = prefix_base[blockIdx.x * 14 + sy];
+  {
+    const int s = sy;
     for (int i = tid; i < nprb; i += nt) {
       const int rb = prb_of[i];
       unsigned  ex = (((dmrs_syms >> s) & 1u) && rb >= bwp0 && rb < bwp1) ? dmask : 0u;
@@ -108,21 +148,10 @@ __global__ void __launch_bounds__(256) pdsch_mod_kernel(const miphy_pdsch_mod_jo
       for (int r = 0; r < 4; ++r)
         if (r < nres && ((res_sy[r] >> s) & 1u) && ((resm[r][rb >> 6] >> (rb & 63)) & 1ull))
           ex |= res_re[r];
-      const unsigned keep = ~ex & 0xfffu;
-      if (s < sy)
-        before += __popc(keep);
-      else
-        keep_of[i] = (uint16_t)keep;
+      keep_of[i] = (uint16_t)(~ex & 0xfffu);
     }
   }
-  // block sum of `before`
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1)
-    before += __shfl_xor(before, o);
-  if ((tid & 63) == 0)
-    red[tid >> 6] = before;
   __syncthreads();
-  const int prefix = red[0] + red[1] + red[2] + red[3];
   // exclusive scan of the per-PRB counts of this symbol (<= 275 entries: one wavefront, 5 entries per lane)
   if (tid < 64) {
     int c[5], sum = 0;
@@ -159,6 +188,58 @@ __global__ void __launch_bounds__(256) pdsch_mod_kernel(const miphy_pdsch_mod_jo
   const bool     scale   = isnormal(scaling);
   const uint8_t* cw      = cw_base + jp->cw_offset;
   float2*        g       = grid + jp->grid_offset + ((size_t)jp->port * 14 + sy) * (nprb_grid * 12);
+  // The common shapes (16QAM / 256QAM, codeword aligned to its element size) in two sweeps: every request of the thread's resource elements --
+  // the element's bytes as one wide load and the two words of its scrambling window -- is issued before the first element is mapped, with
+  // unconditional loads (an element that carries no data reads element 0 of the symbol and is not stored). The one-element-at-a-time loop
+  // below paid one memory round trip per element: thirteen per thread on 273 PRBs.
+  auto fast = [&](auto MODC) {
+    constexpr int MOD = decltype(MODC)::value;
+    constexpr int IT = (275 * 12 + 255) / 256;
+    uint32_t      lo[IT], hi[IT], q0[IT], q1[IT];
+    int           dst[IT]; // grid column of the element, -1: none
+    uint32_t      sh[IT], dd[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int      idx  = tid + it * 256;
+      const bool     in   = idx < nprb * 12;
+      const int      i    = in ? idx / 12 : 0, k = in ? idx - i * 12 : 0;
+      const unsigned keep = keep_of[i];
+      const bool     has  = in && ((keep >> k) & 1u);
+      const int      j    = has ? off_of[i] + __popc(keep & ((1u << k) - 1u)) : 0;
+      const uint32_t d    = (uint32_t)prefix + (uint32_t)j;
+      const uint32_t bi   = d * (uint32_t)MOD;
+      q0[it] = seq[bi >> 5], q1[it] = seq[(bi >> 5) + 1];
+      sh[it] = bi & 31u, dd[it] = d;
+      if (MOD == 8) {
+        const uint2 v = *reinterpret_cast<const uint2*>(cw + (size_t)d * 8);
+        lo[it] = v.x, hi[it] = v.y;
+      } else {
+        lo[it] = *reinterpret_cast<const uint32_t*>(cw + (size_t)d * 4), hi[it] = 0;
+      }
+      dst[it] = has ? (int)prb_of[i] * 12 + k : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const uint32_t cb  = (uint32_t)((((uint64_t)q1[it] << 32) | q0[it]) >> sh[it]);
+      const uint32_t raw = (((lo[it] & 0x01010101u) * 0x01020408u) >> 24) | ((((hi[it] & 0x01010101u) * 0x01020408u) >> 24) << 4);
+      const uint32_t nat = (raw ^ cb) & ((1u << MOD) - 1u);
+      float2         x   = map_symbol(MOD, nat, dd[it]);
+      if (scale) {
+        x.x = x.x * scaling;
+        x.y = x.y * scaling;
+      }
+      if (dst[it] >= 0)
+        g[dst[it]] = x;
+    }
+  };
+  if (mod == 8 && (((uintptr_t)(cw + (size_t)prefix * 8)) & 7u) == 0) {
+    fast(std::integral_constant<int, 8>{});
+    return;
+  }
+  if (mod == 4 && (((uintptr_t)(cw + (size_t)prefix * 4)) & 3u) == 0) {
+    fast(std::integral_constant<int, 4>{});
+    return;
+  }
   for (int idx = tid; idx < nprb * 12; idx += nt) {
     const int      i = idx / 12, k = idx - i * 12;
     const unsigned keep = keep_of[i];
@@ -523,11 +604,14 @@ extern "C" int miphy_pdsch_modulate_batch(miphy_ctx* ctx, const miphy_pdsch_mod_
   rc                 = miphy_stage_descs(ctx, jobs, jobs_on_device, sizeof(miphy_pdsch_mod_job) * (size_t)n, s, &d_jobs);
   if (rc)
     return rc;
-  void* seq = nullptr; // scrambling sequences of the transmissions: the workspace the PUSCH demodulator keeps its sequences in
-  if ((rc = miphy_get_workspace(ctx, (size_t)n * PDSCH_SEQ_STRIDE * sizeof(uint32_t), s, &seq, 4)))
+  void* seq = nullptr; // scrambling sequences of the transmissions (the workspace the PUSCH demodulator keeps its sequences in), then their 14 symbol prefixes
+  const size_t seq_bytes = (size_t)n * PDSCH_SEQ_STRIDE * sizeof(uint32_t);
+  if ((rc = miphy_get_workspace(ctx, seq_bytes + (size_t)n * 14 * sizeof(int), s, &seq, 4)))
     return rc;
-  hipLaunchKernelGGL(pdsch_seq_kernel, dim3(n), dim3(512), 0, s, (const miphy_pdsch_mod_job*)d_jobs, gt, (uint32_t*)seq);
-  hipLaunchKernelGGL(pdsch_mod_kernel, dim3(n, 14), dim3(256), 0, s, (const miphy_pdsch_mod_job*)d_jobs, gt, codewords, (float2*)grid, (const uint32_t*)seq);
+  int* prefix = reinterpret_cast<int*>(static_cast<uint8_t*>(seq) + seq_bytes);
+  hipLaunchKernelGGL(pdsch_seq_kernel, dim3(n), dim3(512), 0, s, (const miphy_pdsch_mod_job*)d_jobs, gt, (uint32_t*)seq, prefix);
+  hipLaunchKernelGGL(pdsch_mod_kernel, dim3(n, 14), dim3(256), 0, s, (const miphy_pdsch_mod_job*)d_jobs, gt, codewords, (float2*)grid, (const uint32_t*)seq,
+                     (const int*)prefix);
   MIPHY_HIP_CHECK(hipGetLastError());
   return MIPHY_OK;
 }
