@@ -641,6 +641,18 @@ __global__ void __launch_bounds__(DEMOD_THREADS, DEMOD_MIN_WAVES) pusch_demod_ke
   __shared__ float    evm_red[4];
   const demod_job_words j    = demod_load_job(jobs + blockIdx.x);
   const int             tid  = threadIdx.x;
+  { // A chunk behind the allocation leaves before it has requested or built anything (the grid is sized for the widest allocation of the
+    // batch: in a slot shared by eight UEs most workgroups of the narrow ones are such chunks). Scalar popcounts of the descriptor words.
+    int c = 0;
+#pragma unroll
+    for (int w = 0; w < 5; ++w) {
+      const int left = j.grid_nof_prb() - 64 * w;
+      if (left > 0)
+        c += __popcll(j.rb_mask(w) & (left >= 64 ? ~0ull : ((1ull << left) - 1ull)));
+    }
+    if ((int)blockIdx.y * DEMOD_THREADS >= c * 12)
+      return; // uniform
+  }
   const demod_tab_entry te   = demod_table_entry(j.mod(), tid);            // requested now, stored behind the PRB list
   const float           noise_var_early = scalars[j.scalars_offset() + 2]; // likewise
   const int             nprb = demod_prb_list(j, rbm, prb_of, &nprb_s, tid, DEMOD_THREADS);
