@@ -77,7 +77,10 @@ __global__ void __launch_bounds__(512, GENERAL ? 2 : 4) chest_kernel(const miphy
   __shared__ uint64_t rbm[5];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int port = blockIdx.y % ports_dim, layer = blockIdx.y / ports_dim;
-  const int sgrp = blockIdx.z, ngrp = gridDim.z; // symbol group: stores OFDM symbols l with l % ngrp == sgrp; group 0 owns the scalars
+  // gridDim.z == 2 (launches that leave most of the chip idle -- a single slot): the time-alignment step -- the 4096-point IDFT and its peak
+  // search, which only the side-band scalar sc[4] needs -- runs in a workgroup of its own (z = 1: LS estimates, IDFT, peak) next to the one
+  // that estimates, interpolates and stores (z = 0): the demodulator behind this kernel waits for the shorter of the two chains + sc[2].
+  const bool ta_only = gridDim.z == 2 && blockIdx.z == 1, do_ta = gridDim.z == 1 || ta_only, do_main = !ta_only;
   if (port >= job.nof_rx_ports || layer >= job.nof_tx_layers)
     return;
   const int nprb_grid = job.grid_nof_prb, nsc = nprb_grid * 12;
@@ -129,7 +132,7 @@ __global__ void __launch_bounds__(512, GENERAL ? 2 : 4) chest_kernel(const miphy
   const int np = nprb * 6;
   np_sym       = np;
   __syncthreads(); // prb_of[]
-  if (sgrp == 0) // the IDFT buffer of the time-alignment step, cleared here: nothing waits for it
+  if (do_ta) // the IDFT buffer of the time-alignment step, cleared here: nothing waits for it
     for (int i = tid; i < (int)(fft_lds_bytes(CE_DFT) / 8); i += nt)
       fbuf[i] = {0.f, 0.f};
   // The received DM-RS elements of this thread's pilots (at most four per thread and DM-RS symbol: 1 650 pilots on 512 threads) are
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(512, GENERAL ? 2 : 4) chest_kernel(const miphy
 #pragma unroll
   for (int kk = 0; kk < XK; ++kk) {
     const int i = tid + kk * nt;
-    if (i >= ((sgrp == 0) ? np : 0))
+    if (i >= (do_main ? np : 0))
       continue;
     const int b = (i / 6) * 6;
     cplx      avg = {0.f, 0.f};
@@ -231,7 +234,7 @@ __global__ void __launch_bounds__(512, GENERAL ? 2 : 4) chest_kernel(const miphy
   noise_tot += block_sum(noise_acc, red, tid) / (float)np * 6.f; // = sum over symbols of |residual|^2 / np * window (:300-309)
 
   // ---- time alignment (:312-347): zero-padded IDFT of the LS estimates at their RE positions
-  if (sgrp == 0) {
+  if (do_ta) {
   // (fbuf was cleared at the head of the hop, under the memory requests; the barriers of the reductions above order it)
   for (int i = tid; i < np; i += nt)
     fbuf[fpad(prb_of[i / 6] * 12 + 2 * (i % 6) + delta)] = lse[i];
@@ -279,11 +282,11 @@ __global__ void __launch_bounds__(512, GENERAL ? 2 : 4) chest_kernel(const miphy
   const int   ia = (int)(0xffffffffu - (unsigned)(keys[1] & 0xffffffffu)) - HALF_CP;
   ta_tot += (md >= ma) ? (float)id : -(float)(HALF_CP - ia);
   __syncthreads();
-  } // sgrp == 0
+  } // do_ta
 
   // ---- linear interpolation over the concatenated allocated PRBs (interpolator_linear_impl.cpp:58-78; offset = delta,
   // stride 2, edges held) written straight to every OFDM symbol of the hop (:216-224).
-  const int nout = nprb * 12;
+  const int nout = do_main ? nprb * 12 : 0;
   for (int k = tid; k < nout; k += nt) {
     cplx v;
     const int kk = k - delta;
@@ -302,18 +305,16 @@ __global__ void __launch_bounds__(512, GENERAL ? 2 : 4) chest_kernel(const miphy
     const int    r   = prb_of[k / 12];
     const size_t col = (size_t)r * 12 + (k % 12);
     if (compact) {
-      if (sgrp == 0)
-        dst0[col] = make_float2(v.x, v.y);
+      dst0[col] = make_float2(v.x, v.y);
     } else {
       for (int l = h_first; l < h_last; ++l)
-        if (l % ngrp == sgrp)
-          dst0[(size_t)l * nsc + col] = make_float2(v.x, v.y);
+        dst0[(size_t)l * nsc + col] = make_float2(v.x, v.y);
     }
   }
   } // hops
 
   // ---- side-band scalars (:118-144)
-  if (tid == 0 && sgrp == 0) {
+  if (tid == 0) {
     const float ndp  = (float)(np_sym * nds_all);
     const float rsrp = rsrp_tot / ndp;
     const float epre = epre_tot / ndp;
@@ -325,11 +326,14 @@ __global__ void __launch_bounds__(512, GENERAL ? 2 : 4) chest_kernel(const miphy
     const float snr    = (noise_var != 0.f) ? datarp / noise_var : 1000.f;
     const float scs_khz = 15.f * (float)(1u << job.numerology);
     float*      sc      = scalars + job.scalars_offset + 5 * ((size_t)port * job.nof_tx_layers + layer);
-    sc[0] = rsrp;
-    sc[1] = epre;
-    sc[2] = noise_var;
-    sc[3] = snr;
-    sc[4] = (nhops == 2 ? ta_tot / 2.0f : ta_tot) / ((float)CE_DFT * scs_khz * 1000.0f);
+    if (do_main) {
+      sc[0] = rsrp;
+      sc[1] = epre;
+      sc[2] = noise_var;
+      sc[3] = snr;
+    }
+    if (do_ta)
+      sc[4] = (nhops == 2 ? ta_tot / 2.0f : ta_tot) / ((float)CE_DFT * scs_khz * 1000.0f);
   }
 }
 
@@ -394,9 +398,10 @@ static int chest_launch(miphy_ctx* ctx, const miphy_pusch_chest_job* jobs, int j
     if (rc)
       return rc;
   }
-  // One workgroup of 512 threads per (job, port, layer). (Splitting the broadcast store over symbol groups -- gridDim.z -- was
-  // measured and does not pay once the per-workgroup prologue is parallel; 256 threads are slower for the 4096-point IDFT.)
-  const int ngrp = 1, cthreads = 512;
+  // One workgroup of 512 threads per (job, port, layer); two -- the time-alignment chain on its own -- where the launch leaves most of the
+  // chip idle anyway. (256 threads are slower for the 4096-point IDFT.)
+  const int cthreads = 512;
+  const int ngrp     = ((uint64_t)n * max_ports * max_layers * 2 <= (uint64_t)ctx->num_cus) ? 2 : 1;
   if (pilots)
     hipLaunchKernelGGL(chest_kernel<true>, dim3(n, max_ports * max_layers, ngrp), dim3(cthreads), lds, s, (const miphy_pusch_chest_job*)d_jobs,
                        (const gold_jump*)ctx->ext->d_gold, (const cplx*)tw, (const float2*)grid, (float2*)ce, scalars, (const float2*)pilots, (int)max_ports);
