@@ -432,8 +432,9 @@ pdsch_cb_encode_pk_kernel(const miphy_pdsch_cb_desc* __restrict__ descs, const m
   // ---- core rows (information part), closed-form core parity (ldpc_encoder_generic.cpp:100-223)
   uint32_t* aux = S;          // [4][W]
   uint32_t* s0  = S + 4 * W;  // [W]
+  const uint32_t invW = (65536u + (uint32_t)W - 1u) / (uint32_t)W; // x / W = (x * invW) >> 16 for the x < 600 divided below (exact: W <= 12)
   if (lane < 4 * W) {
-    const int m = lane / W, k = lane - m * W;
+    const int m = (int)(((uint32_t)lane * invW) >> 16), k = lane - m * W;
     uint32_t  acc = 0;
     const int e1  = lstart[m + 1];
 #pragma unroll 4
@@ -478,7 +479,7 @@ pdsch_cb_encode_pk_kernel(const miphy_pdsch_cb_desc* __restrict__ descs, const m
       ++mend;
     const int CW4 = (bgK + 4) * W;
     for (int idx = lane; idx < (mend - 4) * W; idx += CBP_THREADS) {
-      const int m = 4 + idx / W, k = idx - (m - 4) * W;
+      const int m = 4 + (int)(((uint32_t)idx * invW) >> 16), k = idx - (m - 4) * W;
       uint32_t  acc = 0;
       for (int e = lstart[m]; e < lstart[m + 1]; ++e) {
         const uint32_t ed = ledge[e];
@@ -529,12 +530,13 @@ pdsch_cb_encode_pk_kernel(const miphy_pdsch_cb_desc* __restrict__ descs, const m
   if ((((uintptr_t)out) & 3u) == 0) {
     const int nq = E >> 2;
     if (mod == 8 || mod == 4 || mod == 2 || mod == 1) {
-      const int       adv = 8 / mod; // words of S per 64 dwords of output (256 bytes = 256 / mod elements later)
+      const int       lg  = (mod == 8) ? 3 : (mod == 4) ? 2 : (mod == 2) ? 1 : 0; // the orders of this path are powers of two: shifts, not divisions
+      const int       adv = 8 >> lg; // words of S per 64 dwords of output (256 bytes = 256 / mod elements later)
       uint32_t        sb[4];
       const uint32_t* sp[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int      o0 = 4 * lane + b, i0 = o0 / mod, j = o0 - i0 * mod;
+        const int      o0 = 4 * lane + b, i0 = o0 >> lg, j = o0 - (i0 << lg);
         const uint32_t t0 = (uint32_t)(j * Kq + i0);
         sp[b] = S + (t0 >> 5), sb[b] = 31u - (t0 & 31u);
       }

@@ -20,7 +20,7 @@ __device__ __forceinline__ rm_geom make_geom(const miphy_ldpc_rdm_desc& d)
   // TS 38.212 Table 5.4.2.1-2 (rate_matcher_impl.cpp:64-94): k0 = floor(k0num * Ncb / N) * Z.
   const int num = (d.bg == 1) ? ((d.rv == 0) ? 0 : (d.rv == 1) ? 17 : (d.rv == 2) ? 33 : 56)
                               : ((d.rv == 0) ? 0 : (d.rv == 1) ? 13 : (d.rv == 2) ? 25 : 43);
-  g.k0          = (int)(((long long)num * g.Ncb) / g.N) * Z;
+  g.k0          = (g.Ncb == g.N) ? num * Z : (int)(((long long)num * g.Ncb) / g.N) * Z; // (full buffer: no 64-bit division -- a few hundred instructions per lane)
   g.f1          = (bgK - 2) * Z;
   g.F           = d.nof_filler_bits;
   g.f0          = g.f1 - g.F;
