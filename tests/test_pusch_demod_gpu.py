@@ -107,6 +107,53 @@ def test_random_allocations_match_oracle(ctx, mod, ports, cdm, type2, nprb, star
     assert np.array_equal(out[:exp.size], exp)
 
 
+@pytest.mark.parametrize("device_jobs", [False, True])
+@pytest.mark.parametrize("mod,ports,cdm,type2,nprb,start,nof,dsyms,pad", [
+    (8, 1, 2, 0, 273, 0, 14, (2,), 0),      # the benchmark's slot: every request of a thread in flight at once (demod_columns_deep)
+    (6, 1, 2, 0, 106, 0, 14, (2, 7, 11), 0),
+    (4, 1, 1, 0, 52, 2, 12, (3, 10), 0),
+    (2, 1, 1, 1, 25, 1, 9, (4,), 0),         # DM-RS type 2, a partial slot
+    (8, 1, 2, 0, 40, 0, 14, (2,), 3),        # codeword at an odd address: the byte-wise store path of the same walk
+    (4, 1, 3, 1, 20, 0, 14, (2,), 0),        # type 2, all CDM groups: no data on the DM-RS symbol
+    (6, 2, 2, 0, 60, 0, 14, (2, 11), 0),     # two ports with the compact estimate: the general walk
+    (1, 1, 2, 0, 30, 0, 14, (2,), 0),        # pi/2-BPSK: the general walk
+])
+def test_compact_estimate_matches_oracle(ctx, mod, ports, cdm, type2, nprb, start, nof, dsyms, pad, device_jobs):
+    """The estimate as ONE row per port (ce_compact, what the estimator of this library hands over): the demodulator then keeps the channel
+    row in registers, and with one port it requests the samples of all OFDM symbols at once. Same LLRs as the oracle fed with that row
+    on every symbol, including a zero channel coefficient, a NaN sample and partial allocations; descriptors in host and in device memory."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(2000 * mod + nprb + pad)
+    nsc = nprb * 12
+    rb = (rng.uniform(size=nprb) < 0.85).astype(np.uint8)
+    rb[nprb // 2] = 1
+    if nprb == 273:
+        rb[:] = 1
+    dm = np.zeros(14, np.uint8)
+    dm[list(dsyms)] = 1
+    grid = (rng.standard_normal((ports, 14, nsc)) + 1j * rng.standard_normal((ports, 14, nsc))).astype(np.complex64)
+    row = (rng.standard_normal((ports, 1, nsc)) + 1j * rng.standard_normal((ports, 1, nsc))).astype(np.complex64)
+    row[0, 0, 12 * (nprb // 2) + 5] = 0
+    grid[0, start + 1, 12 * (nprb // 2) + 3] = np.nan
+    rnti, n_id, nv = int(rng.integers(1, 65536)), int(rng.integers(0, 1024)), float(rng.uniform(0.01, 0.5))
+    exp, _, _ = O.o_pusch_demodulate(rnti, n_id, mod, start, nof, dm, type2, cdm, rb, grid, np.repeat(row, 14, axis=1), nv)
+    j = _job(miphy, rnti, n_id, mod, start, nof, dm, type2, cdm, rb, ports, 14, llr_off=pad)
+    j["ce_compact"] = 1
+    assert j["nof_llr"] == exp.size
+    g = torch.from_numpy(grid.reshape(-1)).cuda()
+    h = torch.from_numpy(row.reshape(-1)).cuda()
+    sc = np.zeros(5, dtype=np.float32)
+    sc[2] = nv
+    out = torch.full((exp.size + pad + 64,), 99, dtype=torch.int8, device="cuda")
+    jobs = np.array([j], dtype=miphy.PuschDemodJob)
+    ctx.pusch_demodulate_batch(torch.from_numpy(jobs.view(np.uint8)).cuda() if device_jobs else jobs, g, h, torch.from_numpy(sc).cuda(), out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got[pad:pad + exp.size], exp)
+    assert np.all(got[:pad] == 99) and np.all(got[pad + exp.size:] == 99)
+
+
 def test_rejections(ctx):
     """pusch_demodulator_impl.cpp:76-83 asserts the codeword length and the single layer; the C ABI reports MIPHY_EINVAL."""
     import torch
