@@ -42,6 +42,31 @@ struct raw_access { // interleaved input as received: in[p * mod + q] with i = q
     return in[(i - q * Kq) * mod + q];
   }
 };
+struct lin_access { // de-interleaved copy in LDS: rank index i at byte i
+  const int8_t* a;
+  __device__ __forceinline__ int operator()(int i) const { return a[i]; }
+};
+// Sixteen consecutive bytes of an LDS array at ANY byte offset: five aligned dwords, funnel-shifted (the array has four bytes of slack behind it).
+__device__ __forceinline__ void lds_load16_unaligned(const int8_t* a, int i, uint32_t (&w)[4])
+{
+  const uint32_t* p  = reinterpret_cast<const uint32_t*>(a + (i & ~3));
+  const uint32_t  sh = (uint32_t)(i & 3);
+  uint32_t        d[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    d[k] = p[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    w[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+}
+__device__ __forceinline__ uint32_t combine4(uint32_t o, uint32_t x)
+{
+  uint32_t r = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    r |= (uint32_t)(combine((int)(int8_t)(o >> (8 * b)), (int)(int8_t)(x >> (8 * b))) & 0xff) << (8 * b);
+  return r;
+}
 // Value of output position j. Returns false when the reference leaves the position untouched.
 template <typename IN>
 __device__ __forceinline__ bool rdm_value(const rdm_ctx& c, const IN& in, const int8_t* __restrict__ out, int j, int& result)
@@ -184,6 +209,105 @@ rate_dematch_kernel(const miphy_ldpc_rdm_desc* __restrict__ descs, const int8_t*
   B[8] = c.tail_on ? max(B[7], c.tail_start) : g.N;
   B[9] = g.N;
   const bool fast_out = use_img && (((uintptr_t)out) & 15) == 0;
+  // Wrap-around geometry (the E bits run past the end of the circular buffer: retransmissions at redundancy versions 2 and 3, a first
+  // transmission longer than the buffer). The input is de-interleaved into a LINEAR LDS array (rank index i at byte i); the 16 positions
+  // of an output vector that lies inside the buffer, clear of the filler gap, of the wrap point and of the ends of a pass then take 16
+  // consecutive bytes of that array per pass (at a byte offset of any alignment), combined in pass order as the reference's chunks are
+  // (ldpc_rate_dematcher_impl.cpp:125-198); the few other vectors run the byte-wise rule. Before: byte-wise for every position, with a
+  // division per input element (5 x the time of the single-pass geometry).
+  if (!single && g.E + 64 <= lds_bytes) {
+    rm_geom      g2 = g;
+    image_access im2 = img;
+    g2.r0 = 0, g2.f0 = 0x3fffffff, g2.F = 0; // stage_image with these: LDS byte q * Kq + p <- input byte p * mod + q
+    im2.jbase = 0, im2.gapcut = 0;
+    const int mb = (int)(((uintptr_t)in) & 3);
+    const int nq = (mb == 0) ? (g.E >> 4) : ((g.E >= 4) ? ((g.E - 4) >> 4) : 0);
+    uint4     pre[RDM_PRE];
+#pragma unroll
+    for (int k = 0; k < RDM_PRE; ++k)
+      pre[k] = (tid + k * nt < nq) ? load_in16(in, mb, tid + k * nt) : make_uint4(0, 0, 0, 0);
+    switch (g.mod) {
+      case 8:
+        stage_image<8>(im2, in, lds_in, nq, g2, tid, nt, mb, pre);
+        break;
+      case 6:
+        stage_image<6>(im2, in, lds_in, nq, g2, tid, nt, mb, pre);
+        break;
+      case 4:
+        stage_image<4>(im2, in, lds_in, nq, g2, tid, nt, mb, pre);
+        break;
+      case 2:
+        stage_image<2>(im2, in, lds_in, nq, g2, tid, nt, mb, pre);
+        break;
+      default:
+        stage_image<1>(im2, in, lds_in, nq, g2, tid, nt, mb, pre);
+        break;
+    }
+    __syncthreads();
+    lin_access lin;
+    lin.a              = lds_in;
+    const bool vec_out = (((uintptr_t)out) & 15) == 0;
+    const int  nvec    = (g.N + 15) >> 4;
+    for (int v = tid; v < nvec; v += nt) {
+      const int j0 = v << 4, j1 = j0 + 15;
+      if (vec_out && j1 < g.Ncb && (j1 < g.f0 || j0 >= g.f1)) {
+        const int ra = (j0 < g.f0) ? j0 : j0 - g.F;
+        int       i0 = ra - g.r0;
+        const bool before = i0 < 0; // ranks in front of the starting point: no first pass (copy mode then starts from zero or from the old value)
+        i0 += before ? g.L : 0;
+        if (i0 + 15 < g.L && !(c.nd && before)) {
+          if (i0 >= g.E) {
+            if (!c.nd)
+              continue; // no input maps here: untouched
+          } else {
+            bool partial = false;
+            for (int i = i0; i < g.E; i += g.L)
+              partial |= i + 15 >= g.E;
+            if (!partial) {
+              uint32_t acc[4];
+              int      i = i0;
+              if (c.nd) {
+                lds_load16_unaligned(lds_in, i, acc);
+                i += g.L;
+              } else {
+                const uint4 old = *reinterpret_cast<const uint4*>(out + j0);
+                acc[0] = old.x, acc[1] = old.y, acc[2] = old.z, acc[3] = old.w;
+              }
+              for (; i < g.E; i += g.L) {
+                uint32_t x[4];
+                lds_load16_unaligned(lds_in, i, x);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  acc[k] = combine4(acc[k], x[k]);
+              }
+              *reinterpret_cast<uint4*>(out + j0) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+              continue;
+            }
+          }
+        }
+      }
+      uint32_t w[4] = {0, 0, 0, 0};
+      uint32_t keep = 0;
+#pragma unroll 4
+      for (int b = 0; b < 16; ++b) {
+        const int j  = j0 + b;
+        int       r  = 0;
+        bool      wr = false;
+        if (j < g.N)
+          wr = rdm_value(c, lin, out, j, r);
+        keep |= (wr ? 0u : 1u) << b;
+        w[b >> 2] |= (uint32_t)(r & 0xff) << (8 * (b & 3));
+      }
+      if (keep == 0 && vec_out && j0 + 16 <= g.N) {
+        *reinterpret_cast<uint4*>(out + j0) = make_uint4(w[0], w[1], w[2], w[3]);
+      } else {
+        for (int b = 0; b < 16; ++b)
+          if (!((keep >> b) & 1u) && j0 + b < g.N)
+            out[j0 + b] = (int8_t)(w[b >> 2] >> (8 * (b & 3)));
+      }
+    }
+    return;
+  }
   if (use_img) {
     const int mb = (int)(((uintptr_t)in) & 3);
     const int nq = (mb == 0) ? (g.E >> 4) : ((g.E >= 4) ? ((g.E - 4) >> 4) : 0);
