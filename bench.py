@@ -823,6 +823,9 @@ def main():
         # a slot that mixes allocation sizes and MCS, same chain, with the reference's chain on the host beside it
         legs["pusch_mixed_slot"], ok_leg = BL.mixed_slot_leg(ctx, miphy, torch, dev, min(S, 1024), args.max_iter, args.snr_db, 777, args.cpu_seconds, not args.no_cpu)
         legs_ok &= ok_leg
+        # retransmissions: the rate dematcher combining into full-length soft buffers, the decoder over all layers
+        legs["pusch_harq_retransmissions"], ok_leg = BL.harq_retx_leg(ctx, miphy, torch, dev, 1024, args.max_iter)
+        legs_ok &= ok_leg
         # the transmit half of north_star: PDSCH processor + OFDM modulator
         legs["pdsch_tx_chain"], ok_leg = BL.pdsch_tx_leg(ctx, miphy, torch, dev, w, min(S, 1024), args.max_iter, args.cpu_seconds, not args.no_cpu, HBM_PEAK_GBS)
         legs_ok &= ok_leg

@@ -114,6 +114,62 @@ def test_rate_dematcher(ctx, new_data):
         assert np.array_equal(got, exp), (cases[i], np.flatnonzero(got != exp)[:8], got[got != exp][:8], exp[got != exp][:8])
 
 
+@pytest.mark.parametrize("new_data", [1, 0])
+def test_rate_dematcher_wraparound_on_aligned_soft_buffers(ctx, new_data):
+    """The wrap-around geometry on 16-byte aligned soft buffers (the HARQ pool's layout), where the dematcher works on whole output
+    vectors from a de-interleaved LDS copy: retransmissions whose E bits run past the end of the circular buffer (rv 1-3), first
+    transmissions longer than the buffer (up to three passes over it), limited buffers, fillers, every modulation order, input at any
+    byte alignment -- against the oracle (ldpc_rate_dematcher_impl.cpp:43-254, AVX2 combine rule)."""
+    import torch
+    import miphy
+    rng = np.random.default_rng(131 + new_data)
+    cases = []
+    for bg in (1, 2):
+        for Z in (384, 208, 112, 48, 20):
+            N = BG_NS[bg] * Z
+            for rv in range(4):
+                for mod in (1, 2, 4, 6, 8):
+                    for Nref in (0, N - 3 * Z):
+                        nf = int(rng.integers(0, Z)) if rng.integers(0, 4) else 0
+                        Ncb = Nref or N
+                        L = Ncb - nf
+                        for E in (mod * (-(-L // mod) + int(rng.integers(0, 40))), mod * int(rng.integers(L // (2 * mod), (5 * L) // (2 * mod))), mod * (L // mod)):
+                            if 0 < E <= 60000:
+                                cases.append((bg, Z, rv, mod, Nref, nf, E))
+    descs = np.zeros(len(cases), dtype=miphy.LdpcRdmDesc)
+    llrs, sbs, io, oo = [], [], 0, 0
+    pad_in = []
+    for i, (bg, Z, rv, mod, Nref, nf, E) in enumerate(cases):
+        N = BG_NS[bg] * Z
+        Np = (N + 15) // 16 * 16
+        llrs.append(rng.integers(-120, 121, E).astype(np.int8))
+        sb = rng.integers(-120, 121, Np).astype(np.int8)
+        sbs.append(sb)
+        descs[i] = (bg, rv, mod, new_data, Z, nf, Nref, E, io, oo)
+        io += E + int(rng.integers(0, 4))  # any input alignment
+        pad_in.append(io)
+        oo += Np
+    in_h = np.zeros(io + 64, dtype=np.int8)
+    for i, c in enumerate(cases):
+        o = int(descs[i]["in_offset"])
+        in_h[o:o + c[6]] = llrs[i]
+    in_d = torch.from_numpy(in_h).cuda()
+    sb_d = torch.from_numpy(np.concatenate(sbs)).cuda()
+    step = 500
+    for a in range(0, len(cases), step):
+        ctx.ldpc_rate_dematch_batch(descs[a:a + step], in_d, sb_d)
+    torch.cuda.synchronize()
+    out = sb_d.cpu().numpy()
+    for i, (bg, Z, rv, mod, Nref, nf, E) in enumerate(cases):
+        N = BG_NS[bg] * Z
+        Np = (N + 15) // 16 * 16
+        o0 = int(descs[i]["out_offset"])
+        exp = o_rate_dematch(rv, mod, Nref, nf, new_data, llrs[i], sbs[i][:N])
+        got = out[o0:o0 + N]
+        assert np.array_equal(got, exp), (cases[i], np.flatnonzero(got != exp)[:8], got[got != exp][:8], exp[got != exp][:8])
+        assert np.array_equal(out[o0 + N:o0 + Np], sbs[i][N:]), ("padding behind the soft buffer touched", cases[i])
+
+
 def test_crc_batch(ctx):
     import torch
     import miphy
