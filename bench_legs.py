@@ -427,8 +427,9 @@ def harq_retx_leg(ctx, miphy, torch, dev, n_tb, max_iter):
         ok = int((r["tb_crc_ok"] != 0).sum())
         same = bool(torch.equal(out.reshape(n_tb, tb_bytes), torch.from_numpy(tb_u).to(dev)[idx])) if ok == n_tb else False
         ms = float(np.mean(tms))
-        rows.append({"transmission": k, "rv": rv, "tb_crc_ok": ok, "transport_blocks_recovered": same, "ms_per_step": ms, "kernel_ms": tm,
-                     "info_bits_per_s": ok * tb_bytes * 8 / (ms * 1e-3), "dematch_in_decoder": bool(plan.info()[1])})
+        newly = ok - (rows[-1]["tb_crc_ok"] if rows else 0)  # transport blocks this transmission recovered (the later ones only combine and skip)
+        rows.append({"transmission": k, "rv": rv, "tb_crc_ok": ok, "tb_newly_recovered": newly, "transport_blocks_recovered": same, "ms_per_step": ms,
+                     "kernel_ms": tm, "info_bits_per_s": newly * tb_bytes * 8 / (ms * 1e-3), "dematch_in_decoder": bool(plan.info()[1])})
         plan.close()
         del s0, c0, m0
     ok_leg = rows[0]["tb_crc_ok"] == 0 and all(r["tb_crc_ok"] == n_tb and r["transport_blocks_recovered"] for r in rows[1:])
